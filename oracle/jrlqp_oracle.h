@@ -1,0 +1,205 @@
+/*
+ * jrlqp_oracle.h -- CPU oracle for the dense Goldfarb-Idnani hot path and the structured
+ * block-arrow / block-tridiagonal Cholesky family.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or executed by the product
+ * (jrl-qp_amd/, include/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker / the timed CPU baseline.
+ *
+ * It is a plain-C restatement of the reference algorithm (jrl-umi3218/jrl-qp):
+ *   src/DualSolver.cpp:91-168, :200-244           generic GI loop
+ *   src/GoldfarbIdnaniSolver.cpp:56-338           dense hooks
+ *   include/jrl-qp/internal/ConstraintNormal.h:81-123
+ *   src/internal/ActiveSet.cpp:45-168
+ *   src/decomposition/blockArrowLLT.cpp, triBlockDiagLLT.cpp
+ * The arithmetic the reference delegates to Eigen (not vendored, absent from this image, so the
+ * reference itself cannot be built here -- see DESIGN.md "Oracle") is restated with ONE canonical
+ * rounding order, documented in oracle/README.md ("CANON rules"), that the HIP kernels reproduce
+ * bit for bit.  Parity pinning: tests/test_oracle_*.py check this file against the reference's own
+ * known answers and fixtures (GI-paper example, MultiIK fixtures, planted-solution problems, dense
+ * identities for the structured family, the ActiveSet integer sequence).
+ */
+#ifndef JRLQP_ORACLE_H
+#define JRLQP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enums.h:15-37 of the reference; numeric values are part of the contract */
+enum
+{
+  ORC_INACTIVE = 0,
+  ORC_LOWER = 1,
+  ORC_UPPER = 2,
+  ORC_EQUALITY = 3,
+  ORC_LOWER_BOUND = 4,
+  ORC_UPPER_BOUND = 5,
+  ORC_FIXED = 6
+};
+enum
+{
+  ORC_SUCCESS = 0,
+  ORC_INCONSISTENT_INPUT = 1,
+  ORC_NON_POS_HESSIAN = 2,
+  ORC_INFEASIBLE = 3,
+  ORC_MAX_ITER_REACHED = 4,
+  ORC_LINEAR_DEPENDENCY_DETECTED = 5,
+  ORC_OVERCONSTRAINED_PROBLEM = 6,
+  ORC_UNKNOWN = 7
+};
+
+/* One trace record per pass of the GI loop (DualSolver.cpp:103-166). */
+typedef struct
+{
+  int p;      /* selected constraint index (Step 1) */
+  int status; /* its activation status */
+  int l;      /* position of the blocking constraint (ratio test) */
+  int kind;   /* 0 = full step + add, 1 = partial step + drop, 2 = dual-only step + drop */
+  double t1, t2;
+} orc_trace_rec;
+
+/* Workspace size in doubles for orc_gi_solve (n*n J + n*n R + vectors). */
+long orc_gi_work_doubles(int n, int m, int nb);
+
+/*
+ * Dense GI solve.  Mirrors GoldfarbIdnaniSolver::solve (GoldfarbIdnaniSolver.cpp:18-54).
+ *   G   n x n col-major, ld ldg, SPD; lower triangle overwritten by its Cholesky factor
+ *   a   n
+ *   C   n x m col-major, ld ldc: one constraint per column
+ *   bl,bu  m;  xl,xu  nb (nb == n or 0)
+ * Outputs (any may be NULL except x):
+ *   x n; u m+nb sign-expanded multipliers (DualSolver.cpp:38-69); status m+nb activation status;
+ *   active (<= n entries) ordered active list; *nactive; *iters; *f objective value.
+ *   trace/trace_cap: optional per-iteration records.
+ * work: orc_gi_work_doubles doubles, or NULL (then malloc'ed internally).
+ * Returns a TerminationStatus value.
+ */
+int orc_gi_solve(int n,
+                 int m,
+                 int nb,
+                 double * G,
+                 int ldg,
+                 const double * a,
+                 const double * C,
+                 int ldc,
+                 const double * bl,
+                 const double * bu,
+                 const double * xl,
+                 const double * xu,
+                 int max_iter,
+                 double big_bnd,
+                 double * x,
+                 double * u,
+                 int * status,
+                 int * active,
+                 int * nactive,
+                 int * iters,
+                 double * f,
+                 orc_trace_rec * trace,
+                 int trace_cap,
+                 double * work);
+
+/*
+ * Batch of independent dense problems, packed contiguously (problem b at base + b*stride):
+ * G: n*n, a: n, C: n*m, bl/bu: m, xl/xu: nb; outputs x: n, u: m+nb, status: m+nb, term/iters: 1, f: 1.
+ * G is NOT preserved (as in the reference).  nthreads <= 1 -> serial.  Used by tests and as bench.py's cpu_baseline.
+ */
+void orc_gi_solve_batch(int B,
+                        int n,
+                        int m,
+                        int nb,
+                        double * G,
+                        const double * a,
+                        const double * C,
+                        const double * bl,
+                        const double * bu,
+                        const double * xl,
+                        const double * xu,
+                        int max_iter,
+                        double big_bnd,
+                        double * x,
+                        double * u,
+                        int * status,
+                        int * term,
+                        int * iters,
+                        double * f,
+                        int nthreads);
+
+/* Canonical primitives, exported so tests can pin them one by one. */
+int orc_llt(int n, double * A, int lda);                         /* -1 ok, else failing column (Eigen llt_inplace) */
+void orc_inv_lt(int n, const double * L, int ldl, double * J, int ldj); /* J = L^-T, dense n x n */
+void orc_givens(double p, double q, double * c, double * s, double * r);
+double orc_dot(int n, const double * a, const double * b);
+
+/* ActiveSet restatement (ActiveSet.cpp:45-168) driven through a flat API for the integer-sequence test. */
+typedef struct orc_active_set orc_active_set;
+orc_active_set * orc_as_new(int ncstr, int nbnd);
+void orc_as_free(orc_active_set *);
+void orc_as_reset(orc_active_set *);
+void orc_as_activate(orc_active_set *, int idx, int status);
+void orc_as_deactivate(orc_active_set *, int pos);
+int orc_as_status(const orc_active_set *, int idx);
+int orc_as_at(const orc_active_set *, int pos);
+/* counters[8] = {nbActive, me, mi, ml, mu, mb, mbl, mbu}; returns mbe */
+int orc_as_counters(const orc_active_set *, int * counters);
+
+/*
+ * Structured family.  Blocks are described by flat arrays of pointers/sizes:
+ *   diag[i]: ni x ni col-major with ld ldd[i]; side[i]: see blockArrowLLT.h:13-68 of the reference.
+ * blockArrow: nblk diagonal blocks, nblk-1 side blocks.
+ *   up == 0: side[i] is n_last x n_i (last block row);  up == 1: side[i] is n_{i+1} x n_0 (first block column).
+ * Return 1 on success, 0 on failure (with the reference's ret>0 quirk, blockArrowLLT.cpp:65,80).
+ */
+int orc_block_arrow_llt(int nblk, const int * bs, double ** diag, const int * ldd, double ** side, const int * lds, int up);
+void orc_block_arrow_lsolve(int nblk,
+                            const int * bs,
+                            double ** diag,
+                            const int * ldd,
+                            double ** side,
+                            const int * lds,
+                            int up,
+                            double * M,
+                            int ldm,
+                            int nrhs,
+                            int start,
+                            int end);
+void orc_block_arrow_ltsolve(int nblk,
+                             const int * bs,
+                             double ** diag,
+                             const int * ldd,
+                             double ** side,
+                             const int * lds,
+                             int up,
+                             double * M,
+                             int ldm,
+                             int nrhs,
+                             int start,
+                             int end);
+/* triBlockDiag: sub[i] is n_{i+1} x n_i (triBlockDiagLLT.h:13-39). */
+int orc_tri_block_diag_llt(int nblk, const int * bs, double ** diag, const int * ldd, double ** sub, const int * lds);
+void orc_tri_block_diag_lsolve(int nblk,
+                               const int * bs,
+                               double ** diag,
+                               const int * ldd,
+                               double ** sub,
+                               const int * lds,
+                               double * M,
+                               int ldm,
+                               int nrhs,
+                               int start);
+void orc_tri_block_diag_ltsolve(int nblk,
+                                const int * bs,
+                                double ** diag,
+                                const int * ldd,
+                                double ** sub,
+                                const int * lds,
+                                double * M,
+                                int ldm,
+                                int nrhs,
+                                int end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

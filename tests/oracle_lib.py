@@ -1,0 +1,223 @@
+"""ctypes binding of the CPU oracle (oracle/libjrlqp_oracle.so).  Test infrastructure only:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product."""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libjrlqp_oracle.so")
+
+c_dp = ct.POINTER(ct.c_double)
+c_ip = ct.POINTER(ct.c_int)
+
+
+class TraceRec(ct.Structure):
+    _fields_ = [("p", ct.c_int), ("status", ct.c_int), ("l", ct.c_int), ("kind", ct.c_int), ("t1", ct.c_double), ("t2", ct.c_double)]
+
+
+def build_oracle(force: bool = False) -> str:
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("jrlqp_oracle.c", "structured_oracle.c", "jrlqp_oracle.h", "Makefile")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libjrlqp_oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_ip) if a is not None else None
+
+
+@dataclass
+class OracleResult:
+    term: int
+    x: np.ndarray
+    u: np.ndarray
+    status: np.ndarray
+    active: np.ndarray
+    iters: int
+    f: float
+    trace: list
+    L: np.ndarray  # G after the solve (lower triangle = Cholesky factor)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = ct.CDLL(build_oracle())
+        L = self.lib
+        L.orc_gi_work_doubles.restype = ct.c_long
+        L.orc_gi_solve.restype = ct.c_int
+        L.orc_gi_solve.argtypes = [ct.c_int, ct.c_int, ct.c_int, c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_dp, c_dp, c_dp, c_dp,
+                                   ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp, ct.POINTER(TraceRec), ct.c_int, c_dp]
+        L.orc_gi_solve_batch.restype = None
+        L.orc_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
+                                         ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_dp, ct.c_int]
+        L.orc_llt.restype = ct.c_int
+        L.orc_llt.argtypes = [ct.c_int, c_dp, ct.c_int]
+        L.orc_inv_lt.restype = None
+        L.orc_inv_lt.argtypes = [ct.c_int, c_dp, ct.c_int, c_dp, ct.c_int]
+        L.orc_givens.restype = None
+        L.orc_givens.argtypes = [ct.c_double, ct.c_double, c_dp, c_dp, c_dp]
+        L.orc_dot.restype = ct.c_double
+        L.orc_dot.argtypes = [ct.c_int, c_dp, c_dp]
+        L.orc_as_new.restype = ct.c_void_p
+        L.orc_as_new.argtypes = [ct.c_int, ct.c_int]
+        for nm in ("orc_as_free", "orc_as_reset"):
+            getattr(L, nm).restype = None
+            getattr(L, nm).argtypes = [ct.c_void_p]
+        L.orc_as_activate.restype = None
+        L.orc_as_activate.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
+        L.orc_as_deactivate.restype = None
+        L.orc_as_deactivate.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_as_status.restype = ct.c_int
+        L.orc_as_status.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_as_at.restype = ct.c_int
+        L.orc_as_at.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_as_counters.restype = ct.c_int
+        L.orc_as_counters.argtypes = [ct.c_void_p, c_ip]
+        pp = ct.POINTER(c_dp)
+        blk = [ct.c_int, c_ip, pp, c_ip, pp, c_ip]
+        L.orc_block_arrow_llt.restype = ct.c_int
+        L.orc_block_arrow_llt.argtypes = blk + [ct.c_int]
+        for nm in ("orc_block_arrow_lsolve", "orc_block_arrow_ltsolve"):
+            getattr(L, nm).restype = None
+            getattr(L, nm).argtypes = blk + [ct.c_int, c_dp, ct.c_int, ct.c_int, ct.c_int, ct.c_int]
+        L.orc_tri_block_diag_llt.restype = ct.c_int
+        L.orc_tri_block_diag_llt.argtypes = blk
+        for nm in ("orc_tri_block_diag_lsolve", "orc_tri_block_diag_ltsolve"):
+            getattr(L, nm).restype = None
+            getattr(L, nm).argtypes = blk + [c_dp, ct.c_int, ct.c_int, ct.c_int]
+
+    # ---- dense GI ------------------------------------------------------------------------------
+    def solve(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, trace_cap=0) -> OracleResult:
+        """G n x n, C n x m (one constraint per column); inputs are copied (G is clobbered by the solver)."""
+        Gf = np.array(G, dtype=np.float64, order="F", copy=True)
+        n = Gf.shape[0]
+        Cf = np.asfortranarray(np.asarray(C, dtype=np.float64).reshape(n, -1))
+        m = Cf.shape[1]
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        bl = np.ascontiguousarray(bl, dtype=np.float64)
+        bu = np.ascontiguousarray(bu, dtype=np.float64)
+        nb = 0 if xl is None else len(xl)
+        xl = np.ascontiguousarray(xl, dtype=np.float64) if nb else None
+        xu = np.ascontiguousarray(xu, dtype=np.float64) if nb else None
+        x = np.zeros(n)
+        u = np.zeros(m + nb)
+        status = np.zeros(m + nb, dtype=np.int32)
+        active = np.zeros(m + nb + 1, dtype=np.int32)
+        nact = ct.c_int(0)
+        iters = ct.c_int(0)
+        f = ct.c_double(0.0)
+        tr = (TraceRec * max(trace_cap, 1))()
+        term = self.lib.orc_gi_solve(n, m, nb, _dp(Gf), max(n, 1), _dp(a), _dp(Cf), max(n, 1), _dp(bl), _dp(bu), _dp(xl), _dp(xu),
+                                     max_iter, big_bnd, _dp(x), _dp(u), _ip(status), _ip(active), ct.byref(nact), ct.byref(iters),
+                                     ct.byref(f), tr, trace_cap, None)
+        trace = [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in tr[: min(trace_cap, iters.value)]]
+        return OracleResult(term, x, u, status, active[: nact.value].copy(), iters.value, f.value, trace, Gf)
+
+    def solve_batch(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, nthreads=1):
+        """Packed batch (see jrl-qp_amd/problems.py PackedBatch).  G is copied."""
+        B, n, _ = G.shape
+        m = C.shape[1]
+        nb = 0 if xl is None or xl.shape[1] == 0 else xl.shape[1]
+        Gc = np.ascontiguousarray(G, dtype=np.float64).copy()
+        a = np.ascontiguousarray(a)
+        C = np.ascontiguousarray(C)
+        bl = np.ascontiguousarray(bl)
+        bu = np.ascontiguousarray(bu)
+        xlc = np.ascontiguousarray(xl) if nb else None
+        xuc = np.ascontiguousarray(xu) if nb else None
+        x = np.zeros((B, n))
+        u = np.zeros((B, m + nb))
+        status = np.zeros((B, m + nb), dtype=np.int32)
+        term = np.zeros(B, dtype=np.int32)
+        iters = np.zeros(B, dtype=np.int32)
+        f = np.zeros(B)
+        self.lib.orc_gi_solve_batch(B, n, m, nb, _dp(Gc), _dp(a), _dp(C), _dp(bl), _dp(bu), _dp(xlc), _dp(xuc), max_iter, big_bnd,
+                                    _dp(x), _dp(u), _ip(status), _ip(term), _ip(iters), _dp(f), nthreads)
+        return dict(x=x, u=u, status=status, term=term, iters=iters, f=f, L=Gc)
+
+    # ---- primitives ----------------------------------------------------------------------------
+    def llt(self, A):
+        Af = np.array(A, dtype=np.float64, order="F", copy=True)
+        ret = self.lib.orc_llt(Af.shape[0], _dp(Af), max(Af.shape[0], 1))
+        return ret, Af
+
+    def inv_lt(self, L):
+        Lf = np.asfortranarray(L, dtype=np.float64)
+        n = Lf.shape[0]
+        J = np.zeros((n, n), order="F")
+        self.lib.orc_inv_lt(n, _dp(Lf), n, _dp(J), n)
+        return J
+
+    def givens(self, p, q):
+        c, s, r = ct.c_double(), ct.c_double(), ct.c_double()
+        self.lib.orc_givens(p, q, ct.byref(c), ct.byref(s), ct.byref(r))
+        return c.value, s.value, r.value
+
+    def dot(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        return self.lib.orc_dot(len(a), _dp(a), _dp(b))
+
+    # ---- structured ----------------------------------------------------------------------------
+    @staticmethod
+    def _blocks(blocks):
+        """blocks: list of Fortran-ordered 2-D views (possibly into one big matrix)."""
+        k = len(blocks)
+        ptrs = (c_dp * max(k, 1))()
+        lds = np.zeros(max(k, 1), dtype=np.int32)
+        for i, b in enumerate(blocks):
+            assert b.dtype == np.float64 and b.strides[0] == 8, "blocks must be col-major views"
+            ptrs[i] = ct.cast(b.ctypes.data, c_dp)
+            lds[i] = b.strides[1] // 8 if b.shape[1] > 1 else max(b.shape[0], 1)
+        return ptrs, lds
+
+    def block_arrow_llt(self, diag, side, up=False):
+        bs = np.array([d.shape[0] for d in diag], dtype=np.int32)
+        dp, dl = self._blocks(diag)
+        sp, sl = self._blocks(side)
+        return bool(self.lib.orc_block_arrow_llt(len(diag), _ip(bs), dp, _ip(dl), sp, _ip(sl), int(up)))
+
+    def block_arrow_solve(self, diag, side, up, M, start=0, end=-1, transpose=False):
+        bs = np.array([d.shape[0] for d in diag], dtype=np.int32)
+        dp, dl = self._blocks(diag)
+        sp, sl = self._blocks(side)
+        assert M.flags.f_contiguous
+        fn = self.lib.orc_block_arrow_ltsolve if transpose else self.lib.orc_block_arrow_lsolve
+        fn(len(diag), _ip(bs), dp, _ip(dl), sp, _ip(sl), int(up), _dp(M), M.shape[0], M.shape[1], start, end)
+
+    def tri_block_diag_llt(self, diag, sub):
+        bs = np.array([d.shape[0] for d in diag], dtype=np.int32)
+        dp, dl = self._blocks(diag)
+        sp, sl = self._blocks(sub)
+        return bool(self.lib.orc_tri_block_diag_llt(len(diag), _ip(bs), dp, _ip(dl), sp, _ip(sl)))
+
+    def tri_block_diag_solve(self, diag, sub, M, start=0, end=-1, transpose=False):
+        bs = np.array([d.shape[0] for d in diag], dtype=np.int32)
+        dp, dl = self._blocks(diag)
+        sp, sl = self._blocks(sub)
+        assert M.flags.f_contiguous
+        if transpose:
+            self.lib.orc_tri_block_diag_ltsolve(len(diag), _ip(bs), dp, _ip(dl), sp, _ip(sl), _dp(M), M.shape[0], M.shape[1], end)
+        else:
+            self.lib.orc_tri_block_diag_lsolve(len(diag), _ip(bs), dp, _ip(dl), sp, _ip(sl), _dp(M), M.shape[0], M.shape[1], start)
+
+
+_ORACLE = None
+
+
+def get_oracle() -> Oracle:
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = Oracle()
+    return _ORACLE
