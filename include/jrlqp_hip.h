@@ -1,0 +1,162 @@
+/*
+ * jrlqp_hip.h -- C ABI of the MI355X-native Goldfarb-Idnani hot path (libjrlqp_hip.so).
+ *
+ * This is the drop-in boundary.  The reference (jrl-umi3218/jrl-qp) has no FFI: its extension
+ * point is the C++ class jrl::qp::DualSolver with eight protected virtual hooks (include/jrl-qp/DualSolver.h:101-121)
+ * filled in by jrl::qp::GoldfarbIdnaniSolver (src/GoldfarbIdnaniSolver.cpp).  Each entry point below states the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++/torch types; every function returns a
+ * jrlqp_status (0 = ok) and never throws.  All matrix arguments are column-major fp64, exactly as the reference's
+ * Eigen::Ref<MatrixXd> views (include/jrl-qp/defs.h:11-14).  Pointers named d* are DEVICE pointers (HBM).
+ *
+ * Rounding contract: the kernels follow the CANON rules of DESIGN.md §4 (in-order fma chains, correctly rounded
+ * / and sqrt, no contraction), so results are bit-identical to the CPU oracle in oracle/ on the same inputs.
+ */
+#ifndef JRLQP_HIP_H
+#define JRLQP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JRLQP_ABI_VERSION 1
+
+/* jrl::qp::ActivationStatus, include/jrl-qp/enums.h:15-23 (same numeric values) */
+enum jrlqp_activation
+{
+  JRLQP_INACTIVE = 0,
+  JRLQP_LOWER = 1,
+  JRLQP_UPPER = 2,
+  JRLQP_EQUALITY = 3,
+  JRLQP_LOWER_BOUND = 4,
+  JRLQP_UPPER_BOUND = 5,
+  JRLQP_FIXED = 6
+};
+
+/* jrl::qp::TerminationStatus, include/jrl-qp/enums.h:26-37 (same numeric values) */
+enum jrlqp_termination
+{
+  JRLQP_SUCCESS = 0,
+  JRLQP_INCONSISTENT_INPUT = 1,
+  JRLQP_NON_POS_HESSIAN = 2,
+  JRLQP_INFEASIBLE = 3,
+  JRLQP_MAX_ITER_REACHED = 4,
+  JRLQP_LINEAR_DEPENDENCY_DETECTED = 5,
+  JRLQP_OVERCONSTRAINED_PROBLEM = 6,
+  JRLQP_UNKNOWN = 7
+};
+
+/* error codes of the ABI itself (not solver outcomes) */
+enum jrlqp_status
+{
+  JRLQP_OK = 0,
+  JRLQP_ERR_INVALID_ARGUMENT = -1,
+  JRLQP_ERR_UNSUPPORTED_SIZE = -2, /* batched path: n > JRLQP_BATCH_MAX_N or LDS budget exceeded */
+  JRLQP_ERR_NO_DEVICE = -3,
+  JRLQP_ERR_HIP = -4,          /* a HIP runtime call failed; see jrlqp_last_hip_error() */
+  JRLQP_ERR_WORKSPACE = -5
+};
+
+#define JRLQP_BATCH_MAX_N 64
+
+/* jrl::qp::SolverOptions, include/jrl-qp/SolverOptions.h:16-20 (maxIter_ = 500, bigBnd_ = 1e100).  warmStart_ and
+ * the logging fields have no GPU counterpart: the production solver resets the active set anyway
+ * (GoldfarbIdnaniSolver.cpp:75). */
+typedef struct jrlqp_options
+{
+  int max_iter;
+  double big_bnd;
+} jrlqp_options;
+
+/* per-iteration record (debug aid; the counterpart of the reference's LogFlags::ACTIVE_SET log lines,
+ * DualSolver.cpp:116,138,153,159) */
+typedef struct jrlqp_trace_rec
+{
+  int p, status, l, kind; /* kind: 0 full step + add, 1 partial step + drop, 2 dual-only step + drop */
+  double t1, t2;
+} jrlqp_trace_rec;
+
+int jrlqp_abi_version(void);
+const char * jrlqp_status_string(int status);
+int jrlqp_last_hip_error(void);
+/* number of visible devices; <= 0 when there is none (the library still loads on a CPU-only box) */
+int jrlqp_device_count(void);
+void jrlqp_default_options(jrlqp_options * opts);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Mode B -- device-resident batch: B independent dense QPs, one workgroup per QP, the whole GI state machine
+ * on-device.  Replaces B calls of
+ *     TerminationStatus GoldfarbIdnaniSolver::solve(G, a, C, bl, bu, xl, xu)   (GoldfarbIdnaniSolver.h:27-33,
+ *                                                                              GoldfarbIdnaniSolver.cpp:18-54)
+ * followed by solution() / multipliers() / objectiveValue() / iterations() / activeSet()
+ * (DualSolver.h:40-57, DualSolver.cpp:33-84).
+ *
+ * Packed layout, problem b at offset b*stride:
+ *   dG  [B][n*n]   col-major SPD; READ ONLY here (the reference clobbers G with its Cholesky factor; pass dL to get it)
+ *   da  [B][n]
+ *   dC  [B][n*m]   n x m col-major: column i = normal of constraint i
+ *   dbl,dbu [B][m];  dxl,dxu [B][nb], nb == n or 0 (then they may be NULL)
+ * Outputs:
+ *   dx [B][n]; du [B][m+nb] sign-expanded multipliers (DualSolver.cpp:38-69); dstatus [B][m+nb] int32 activation
+ *   status; dterm [B] int32 TerminationStatus; diters [B] int32; df [B] objective value.
+ *   dL   optional [B][n*n]: lower triangle receives the Cholesky factor of G (what the reference leaves in G).
+ *   dtrace optional [B][trace_cap] records.
+ * No allocation, no host synchronisation: the call enqueues one kernel on `stream` (a hipStream_t, may be NULL).
+ * Requires 1 <= n <= JRLQP_BATCH_MAX_N.
+ */
+int jrlqp_gi_solve_batch(int n,
+                         int m,
+                         int nb,
+                         int B,
+                         const double * dG,
+                         const double * da,
+                         const double * dC,
+                         const double * dbl,
+                         const double * dbu,
+                         const double * dxl,
+                         const double * dxu,
+                         const jrlqp_options * opts,
+                         double * dx,
+                         double * du,
+                         int * dstatus,
+                         int * dterm,
+                         int * diters,
+                         double * df,
+                         double * dL,
+                         jrlqp_trace_rec * dtrace,
+                         int trace_cap,
+                         void * stream);
+
+/* LDS bytes one workgroup of the batched kernel uses for (n, m, nb), and whether C is staged in LDS (1) or streamed
+ * from L2/HBM (0); -1 if unsupported.  Lets a caller reason about occupancy (163840 B of LDS per CU). */
+long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Self-tests of the arithmetic contract (no reference counterpart; used by tests/ to prove that device /, sqrt,
+ * fma and the Givens generator are bit-identical to the host's IEEE-754 results, and to pin the accumulation
+ * order of v_mfma_f64_16x16x4_f64).  Arrays of n doubles on the device:
+ *   ddiv = a/b, dsqrt = sqrt(|a|), dfma = fma(a,b,c), (dgc,dgs,dgr) = makeGivens(a,b).
+ */
+int jrlqp_selftest_arith(int n,
+                         const double * da,
+                         const double * db,
+                         const double * dc,
+                         double * ddiv,
+                         double * dsqrt,
+                         double * dfma,
+                         double * dgc,
+                         double * dgs,
+                         double * dgr,
+                         void * stream);
+/* Diagnostic: when dprof != NULL, following jrlqp_gi_solve_batch calls run an instrumented build of the kernel that
+ * accumulates shader-clock cycles per phase into dprof[b*16 + slot] (device int64, zero it first; slots are listed
+ * in jrl-qp_amd/csrc/gi_batch.hip).  Pass NULL to return to the production kernel.  Never used for quoted times. */
+int jrlqp_debug_set_profile(long long * dprof);
+/* D(16x16) = A(16x4) * B(4x16) + C(16x16), row-major, one MFMA instruction on one wave */
+int jrlqp_selftest_mfma_f64(const double * dA, const double * dB, const double * dC, double * dD, void * stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,29 @@
+// gi_batch.h -- launch interface of the batched GI kernel (internal to libjrlqp_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/jrlqp_hip.h"
+
+namespace jrlqp
+{
+struct BatchArgs
+{
+  int n, m, nb, B;
+  int ld; // n | 1: leading dimension (in doubles) of every n-row matrix staged in LDS
+  int max_iter;
+  int trace_cap;
+  double big_bnd;
+  const double *G, *a, *C, *bl, *bu, *xl, *xu;
+  double *x, *u;
+  int *status, *term, *iters;
+  double * f;
+  double * Lout;
+  jrlqp_trace_rec * trace;
+  long long * prof; // diagnostic only: 16 int64 per QP, or nullptr
+};
+
+constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
+
+long batch_lds_bytes(int n, int m, int nb, bool c_lds);
+hipError_t launch_gi_batch(const BatchArgs & a, bool c_lds, hipStream_t stream);
+} // namespace jrlqp

@@ -1,0 +1,75 @@
+// selftest.hip -- device-side probes of the arithmetic contract: correctly rounded fp64 division,
+// square root and fma, the Givens generator, and the accumulation order of v_mfma_f64_16x16x4_f64.  The GPU
+// tests compare these with the host's IEEE results bit for bit; they exist because the batched solver's
+// bit-exact parity with the CPU oracle rests on them.
+#include <hip/hip_runtime.h>
+
+#include "selftest.h"
+
+namespace jrlqp
+{
+namespace
+{
+__device__ __forceinline__ void make_givens_ref(double p, double q, double & c, double & s, double & r)
+{
+  if(q == 0.0) { c = p < 0.0 ? -1.0 : 1.0; s = 0.0; r = fabs(p); }
+  else if(p == 0.0) { c = 0.0; s = q < 0.0 ? 1.0 : -1.0; r = fabs(q); }
+  else if(fabs(p) > fabs(q))
+  {
+    double t = q / p;
+    double u = __builtin_sqrt(__builtin_fma(t, t, 1.0));
+    if(p < 0.0) u = -u;
+    c = 1.0 / u; s = -t * c; r = p * u;
+  }
+  else
+  {
+    double t = p / q;
+    double u = __builtin_sqrt(__builtin_fma(t, t, 1.0));
+    if(q < 0.0) u = -u;
+    s = -1.0 / u; c = -t * s; r = q * u;
+  }
+}
+
+__global__ void arith_kernel(int n, const double * a, const double * b, const double * c, double * odiv, double * osqrt,
+                             double * ofma, double * gc, double * gs, double * gr)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n) return;
+  odiv[i] = a[i] / b[i];
+  osqrt[i] = __builtin_sqrt(fabs(a[i]));
+  ofma[i] = __builtin_fma(a[i], b[i], c[i]);
+  double cc, ss, rr;
+  make_givens_ref(a[i], b[i], cc, ss, rr);
+  gc[i] = cc; gs[i] = ss; gr[i] = rr;
+}
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// one wave: D(16x16) = A(16x4) * B(4x16) + C, all row-major in memory.
+// fragment layout (cdna_hip_programming.md §3): a = A[l&15][l>>4], b = B[l>>4][l&15]; c/d reg r: row (l>>4)+4r, col l&15
+__global__ void mfma_f64_kernel(const double * A, const double * B, const double * C, double * D)
+{
+  int l = threadIdx.x;
+  double a = A[(l & 15) * 4 + (l >> 4)];
+  double b = B[(l >> 4) * 16 + (l & 15)];
+  double4_t acc;
+  for(int r = 0; r < 4; ++r) acc[r] = C[((l >> 4) + 4 * r) * 16 + (l & 15)];
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  for(int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+} // namespace
+
+hipError_t launch_selftest_arith(int n, const double * a, const double * b, const double * c, double * odiv, double * osqrt,
+                                 double * ofma, double * gc, double * gs, double * gr, hipStream_t stream)
+{
+  if(n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(arith_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, a, b, c, odiv, osqrt, ofma, gc, gs, gr);
+  return hipGetLastError();
+}
+
+hipError_t launch_selftest_mfma_f64(const double * A, const double * B, const double * C, double * D, hipStream_t stream)
+{
+  hipLaunchKernelGGL(mfma_f64_kernel, dim3(1), dim3(64), 0, stream, A, B, C, D);
+  return hipGetLastError();
+}
+} // namespace jrlqp

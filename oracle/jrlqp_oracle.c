@@ -408,6 +408,7 @@ int orc_gi_solve(int n,
   S.A.active = (int *)malloc(sizeof(int) * (size_t)(m + nb + 1));
   orc_as_reset(&S.A);
   for(int i = 0; i < m + nb + 2; ++i) S.u[i] = S.r[i] = 0.0;
+  for(int i = 0; i < n; ++i) S.x[i] = 0.0; /* defined output when init_ fails (the reference leaves x untouched) */
   double *x = S.x, *z = S.z, *u = S.u, *r = S.r;
 
   /* ---- init_ (GoldfarbIdnaniSolver.cpp:56-82) ---- */

@@ -1,0 +1,68 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/jrlqp_hip.h declares; argument validation returns error codes (no compute is launched)."""
+import ctypes as ct
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "jrlqp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jrlqp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    import jrl_qp_amd.capi as capi
+
+    lib = capi.load_library()
+    decl = declared_symbols()
+    assert decl, "no declarations found in the header"
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/jrlqp_hip.h but not exported"
+    assert sorted(capi.EXPORTED) == decl
+    assert lib.jrlqp_abi_version() == 1
+
+
+def test_defaults_and_lds_budget(pkg):
+    import jrl_qp_amd.capi as capi
+
+    lib = capi.load_library()
+    o = capi.Options()
+    lib.jrlqp_default_options(ct.byref(o))
+    assert o.max_iter == 500 and o.big_bnd == 1e100  # reference include/jrl-qp/SolverOptions.h:16-17
+    c = ct.c_int(-1)
+    lds = lib.jrlqp_gi_batch_lds_bytes(50, 200, 0, ct.byref(c))
+    assert 0 < lds <= 163840 and c.value == 1  # BASELINE config c3 fits one CU's LDS with C staged
+    lds = lib.jrlqp_gi_batch_lds_bytes(10, 20, 0, ct.byref(c))
+    assert 0 < lds < 16384 and c.value == 1
+    lds = lib.jrlqp_gi_batch_lds_bytes(50, 2000, 50, ct.byref(c))
+    assert 0 < lds <= 163840 and c.value == 0  # too many constraints: C is streamed
+    assert lib.jrlqp_gi_batch_lds_bytes(65, 10, 0, ct.byref(c)) == -1
+    assert lib.jrlqp_gi_batch_lds_bytes(10, 10, 5, ct.byref(c)) == -1  # nb must be 0 or n
+
+
+def test_argument_validation_without_gpu(pkg):
+    import jrl_qp_amd.capi as capi
+
+    lib = capi.load_library()
+    args = [None] * 7 + [None] + [None] * 8 + [0, None]
+    assert lib.jrlqp_gi_solve_batch(0, 1, 0, 1, *args) == -1  # n < 1
+    assert lib.jrlqp_gi_solve_batch(4, 1, 3, 1, *args) == -1  # nb not in {0, n}
+    assert lib.jrlqp_gi_solve_batch(4, 1, 0, 0, *args) == 0  # empty batch is a no-op
+    assert lib.jrlqp_gi_solve_batch(4, 1, 0, 1, *args) == -1  # null pointers
+    assert lib.jrlqp_status_string(-2).decode().startswith("problem size")
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must not import, link or execute anything under oracle/ (only tests/, smoke() and
+    bench.py's cpu_baseline may)."""
+    pk = os.path.join(ROOT, "jrl-qp_amd")
+    for dp, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_lib" not in text and "libjrlqp_oracle" not in text and "jrlqp_oracle.h" not in text, f
+    text = open(os.path.join(ROOT, "include", "jrlqp_hip.h")).read()
+    assert "jrlqp_oracle" not in text

@@ -1,0 +1,147 @@
+"""GPU parity tests proper: the batched HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs -- BIT-exact on termination status, iteration count, active-set vector AND on x, u, f (the CANON rounding
+contract makes the floating-point results identical, so the stated fp64 tolerance is 0 ulp)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(capi, pb, use_bounds=False, max_iter=500, trace_cap=0, want_factor=False):
+    import torch
+
+    dev = capi.to_device(pb, "cuda:0")
+    s = capi.BatchSolver(pb.n, pb.m, use_bounds, pb.B, device="cuda:0", max_iter=max_iter, trace_cap=trace_cap, want_factor=want_factor)
+    r = s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"], dev["xl"] if use_bounds else None, dev["xu"] if use_bounds else None)
+    torch.cuda.synchronize()
+    out = dict(x=r.x.cpu().numpy(), u=r.u.cpu().numpy(), status=r.status.cpu().numpy(), term=r.term.cpu().numpy(),
+               iters=r.iters.cpu().numpy(), f=r.f.cpu().numpy())
+    if want_factor:
+        out["L"] = r.L.cpu().numpy()
+    if trace_cap:
+        out["trace"] = s.trace_numpy()
+    return out
+
+
+def assert_bit_identical(gpu, ref, what=""):
+    for k in ("term", "iters", "status"):
+        bad = np.nonzero(np.any(np.atleast_2d(gpu[k] != ref[k]).reshape(len(ref["term"]), -1), axis=1))[0]
+        assert bad.size == 0, f"{what}: {k} differs for problems {bad[:10]} ({bad.size} of {len(ref['term'])})"
+    for k in ("x", "u", "f"):
+        same = (gpu[k] == ref[k]) | (np.isnan(gpu[k]) & np.isnan(ref[k]))
+        if not same.all():
+            bad = np.nonzero(~same.reshape(len(ref["term"]), -1).all(axis=1))[0]
+            err = np.nanmax(np.abs(gpu[k] - ref[k]))
+            raise AssertionError(f"{what}: {k} not bit-identical for problems {bad[:10]} ({bad.size}); max abs diff {err:.3e}")
+
+
+@pytest.fixture(scope="module")
+def capi(pkg):
+    import jrl_qp_amd.capi as capi
+
+    return capi
+
+
+@pytest.fixture(scope="module")
+def P(pkg):
+    import jrl_qp_amd.problems as problems
+
+    return problems
+
+
+def test_c1_small_problems(capi, P, oracle):
+    """BASELINE config c1 shape (n=10, m=20, ma=3), 512 problems."""
+    pb = P.generate_batch(512, P.benchmark_characteristics(10, 20))
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=8)
+    gpu = run_gpu(capi, pb, want_factor=True)
+    assert_bit_identical(gpu, ref, "c1")
+    assert np.all(ref["term"] == 0)
+    assert np.array_equal(np.tril(gpu["L"].transpose(0, 2, 1)), np.tril(ref["L"].transpose(0, 2, 1)))  # Cholesky factor too
+
+
+def test_c3_robotics_size(capi, P, oracle, pkg):
+    """BASELINE config c3 shape (n=50, m=200, ma=15), 256 problems; also KKT and planted-solution checks."""
+    import jrl_qp_amd.kkt as kkt
+
+    pb = P.generate_batch(256, P.benchmark_characteristics(50, 200))
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=8)
+    gpu = run_gpu(capi, pb)
+    assert_bit_identical(gpu, ref, "c3")
+    assert np.all(gpu["term"] == 0)
+    assert np.max(np.linalg.norm(gpu["x"] - pb.x_star, axis=1)) <= 1e-6
+    for b in range(0, 256, 16):
+        assert kkt.test_kkt(gpu["x"][b], gpu["u"][b], pb.G[b], pb.a[b], pb.C[b].T, pb.bl[b], pb.bu[b])
+
+
+@pytest.mark.parametrize("ma", [0, 25, 40])
+def test_c3_other_active_fractions(capi, P, oracle, ma):
+    pb = P.generate_batch(64, P.benchmark_characteristics(50, 200, ma), first_index=10000 + ma)
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=8)
+    gpu = run_gpu(capi, pb)
+    assert_bit_identical(gpu, ref, f"ma={ma}")
+
+
+CASES = [
+    dict(nVar=5, nObj=5),
+    dict(nVar=5, nObj=5, nEq=2),
+    dict(nVar=5, nObj=5, nIneq=8, nStrongActIneq=4),
+    dict(nVar=5, nObj=5, nEq=2, nIneq=6, nStrongActIneq=3),
+    dict(nVar=5, nObj=5, nEq=2, nIneq=6, nStrongActIneq=1, bounds=True, nStrongActBounds=2),
+    dict(nVar=6, nObj=6, nIneq=10, nStrongActIneq=3, doubleSidedIneq=True),
+    dict(nVar=8, nObj=8, bounds=True, nStrongActBounds=3),
+    dict(nVar=10, nObj=10, nEq=3, nIneq=20, nStrongActIneq=3, bounds=True, nStrongActBounds=2, doubleSidedIneq=True),
+    dict(nVar=33, nObj=33, nEq=5, nIneq=70, nStrongActIneq=10, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
+    dict(nVar=64, nObj=64, nIneq=100, nStrongActIneq=20),
+    dict(nVar=1, nObj=1, nIneq=3, nStrongActIneq=1),
+    dict(nVar=50, nObj=50, nIneq=900, nStrongActIneq=10),  # C does not fit LDS: streamed variant
+]
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_reference_characteristic_sets(capi, P, oracle, ci):
+    """The reference's "Random problems" characteristic sets (tests/GoldfarbIdnaniSolverTest.cpp:75-99) and wider
+    ones: equalities (K12), bounds, double-sided constraints, n = 1, n = 64, C streamed from HBM."""
+    ch = P.Characteristics(**CASES[ci])
+    pb = P.generate_batch(48, ch, first_index=500 * ci)
+    hb = ch.bounds
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl if hb else None, pb.xu if hb else None, nthreads=8)
+    gpu = run_gpu(capi, pb, use_bounds=hb)
+    assert_bit_identical(gpu, ref, f"case {ci}")
+    assert np.all(ref["term"] == 0)
+
+
+def test_termination_codes_and_edge_cases(capi, P, oracle):
+    """NON_POS_HESSIAN, INFEASIBLE, MAX_ITER_REACHED, OVERCONSTRAINED and a no-constraint problem in one batch."""
+    n, m = 4, 6
+    B = 6
+    rng = np.random.default_rng(5)
+    G = np.tile(np.eye(n), (B, 1, 1))
+    a = rng.standard_normal((B, n))
+    C = rng.standard_normal((B, m, n))
+    bl = np.full((B, m), -np.inf)
+    bu = np.full((B, m), 10.0)
+    G[0, 2, 2] = -1.0  # not positive definite
+    C[1, 0] = [1, 0, 0, 0]
+    C[1, 1] = [-1, 0, 0, 0]
+    bu[1, 0] = -1.0
+    bu[1, 1] = -1.0  # x0 <= -1 and -x0 <= -1: infeasible
+    bu[2] = -5.0  # many violated constraints; with max_iter = 2 -> MAX_ITER_REACHED for all that need more
+    bl[3] = bu[3] = 0.5  # six equalities for four unknowns: over-constrained
+    G[4, 0, 0] = 0.0  # failure at column 0
+    pb = P.PackedBatch(n=n, m=m, nb=0, G=G, a=a, C=C, bl=bl, bu=bu, xl=np.zeros((B, 0)), xu=np.zeros((B, 0)),
+                       x_star=np.zeros((B, n)), lam_star=np.zeros((B, m)))
+    ref = oracle.solve_batch(G, a, C, bl, bu, max_iter=2)
+    gpu = run_gpu(capi, pb, max_iter=2)
+    assert_bit_identical(gpu, ref, "edge cases")
+    assert ref["term"][0] == 2 and ref["term"][1] == 3 and ref["term"][3] == 6 and ref["term"][4] == 2
+    assert 4 in ref["term"]
+
+
+def test_trace_matches_oracle(capi, P, oracle):
+    pb = P.generate_batch(8, P.benchmark_characteristics(50, 200), first_index=31)
+    gpu = run_gpu(capi, pb, trace_cap=128)
+    for b in range(8):
+        r = oracle.solve(pb.G[b], pb.a[b], pb.C[b].T, pb.bl[b], pb.bu[b], trace_cap=128)
+        tr = gpu["trace"][b][: r.iters]
+        got = [(int(t["p"]), int(t["status"]), int(t["l"]), int(t["kind"]), float(t["t1"]), float(t["t2"])) for t in tr]
+        assert got == r.trace

@@ -1,0 +1,40 @@
+"""First timing probe of the batched kernel (not the judged bench): c3 workload, B QPs, HIP-event timing."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from __graft_entry__ import load_package
+pkg = load_package()
+import jrl_qp_amd.capi as capi, jrl_qp_amd.problems as P
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+n, m = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (50, 200)
+t = time.time(); base = P.generate_batch(min(B, 512), P.benchmark_characteristics(n, m)); print("gen", time.time() - t, flush=True)
+rep = (B + base.B - 1) // base.B
+tile = lambda a: np.ascontiguousarray(np.concatenate([a] * rep)[:B])
+pb = P.PackedBatch(n=base.n, m=base.m, nb=0, G=tile(base.G), a=tile(base.a), C=tile(base.C), bl=tile(base.bl), bu=tile(base.bu),
+                   xl=tile(base.xl), xu=tile(base.xu), x_star=tile(base.x_star), lam_star=tile(base.lam_star))
+dev = capi.to_device(pb)
+s = capi.BatchSolver(n, m, False, B)
+print("lds bytes", s.lds_bytes, "C in LDS", s.c_in_lds)
+for _ in range(2):
+    s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"])
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ts = []
+for _ in range(5):
+    e0.record(); r = s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"]); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+ms = min(ts)
+it = r.iters.cpu().numpy()
+print(f"B={B} n={n} m={m}: {ms:.3f} ms  -> {B / ms * 1e3:.0f} solves/s ; mean iters {it.mean():.2f}; term ok {int((r.term == 0).sum())}/{B}")
+print("all times ms", ts)
+# ---- phase profile (diagnostic build)
+prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
+capi.load_library().jrlqp_debug_set_profile(prof.data_ptr())
+s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"]); torch.cuda.synchronize()
+capi.load_library().jrlqp_debug_set_profile(None)
+pr = prof.cpu().numpy().astype(np.float64)
+names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)"]
+tot = pr[:, :10].sum(axis=1)
+print("mean cycles per solve", tot.mean(), " mean realtime us", pr[:, 12].mean() / 100.0, " => clock GHz", tot.mean() / (pr[:, 12].mean() / 100.0) / 1e3)
+for i, nm in enumerate(names):
+    print(f"  {nm:18s} {pr[:, i].mean():12.1f}  ({100 * pr[:, i].mean() / tot.mean():5.1f} %)")
