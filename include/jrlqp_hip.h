@@ -128,9 +128,10 @@ int jrlqp_gi_solve_batch(int n,
                          int trace_cap,
                          void * stream);
 
-/* LDS bytes one workgroup of the batched kernel uses for (n, m, nb), and whether C is staged in LDS (1) or streamed
- * from L2/HBM (0); -1 if unsupported.  Lets a caller reason about occupancy (163840 B of LDS per CU). */
-long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds);
+/* LDS bytes one workgroup of the batched kernel uses for (n, m, nb), and where the constraint matrix lives during the
+ * solve: *c_placement = 2 one column per thread in registers, 1 staged in LDS, 0 streamed from L2/HBM; returns -1 if
+ * unsupported.  Lets a caller reason about occupancy (163840 B of LDS per CU). */
+long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_placement);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Self-tests of the arithmetic contract (no reference counterpart; used by tests/ to prove that device /, sqrt,

@@ -121,7 +121,7 @@ class BatchSolver:
         lds = self.lib.jrlqp_gi_batch_lds_bytes(n, m, self.nb, ct.byref(c))
         if lds < 0:
             raise JrlqpError(f"batched path does not support n={n}, m={m}")
-        self.lds_bytes, self.c_in_lds = int(lds), bool(c.value)
+        self.lds_bytes, self.c_placement = int(lds), int(c.value)  # 2 registers, 1 LDS, 0 streamed
         self.opts = Options(max_iter, big_bnd)
         mt = m + self.nb
         f64, i32 = torch.float64, torch.int32

@@ -62,16 +62,10 @@ void jrlqp_default_options(jrlqp_options * o)
 long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds)
 {
   if(n < 1 || n > JRLQP_BATCH_MAX_N || m < 0 || (nb != 0 && nb != n)) return -1;
-  long with_c = jrlqp::batch_lds_bytes(n, m, nb, true);
-  if(with_c <= jrlqp::kLdsPerCU)
-  {
-    if(c_in_lds) *c_in_lds = 1;
-    return with_c;
-  }
-  long without = jrlqp::batch_lds_bytes(n, m, nb, false);
-  if(without > jrlqp::kLdsPerCU) return -1;
-  if(c_in_lds) *c_in_lds = 0;
-  return without;
+  int cmode = jrlqp::batch_pick_cmode(n, m, nb);
+  if(cmode < 0) return -1;
+  if(c_in_lds) *c_in_lds = cmode;
+  return jrlqp::batch_lds_bytes(n, m, nb, cmode);
 }
 
 int jrlqp_gi_solve_batch(int n,
@@ -105,8 +99,8 @@ int jrlqp_gi_solve_batch(int n,
   if(nb > 0 && (!dxl || !dxu)) return JRLQP_ERR_INVALID_ARGUMENT;
   if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
   if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
-  int c_lds = 0;
-  if(jrlqp_gi_batch_lds_bytes(n, m, nb, &c_lds) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  const int cmode = jrlqp::batch_pick_cmode(n, m, nb);
+  if(cmode < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
 
   jrlqp_options o;
   jrlqp_default_options(&o);
@@ -123,7 +117,7 @@ int jrlqp_gi_solve_batch(int n,
   a.Lout = dL;
   a.trace = dtrace;
   a.prof = g_prof.load();
-  hipError_t e = jrlqp::launch_gi_batch(a, c_lds != 0, static_cast<hipStream_t>(stream));
+  hipError_t e = jrlqp::launch_gi_batch(a, cmode, static_cast<hipStream_t>(stream));
   if(e != hipSuccess) return hip_fail(e);
   return JRLQP_OK;
 }

@@ -24,6 +24,9 @@ struct BatchArgs
 
 constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
 
-long batch_lds_bytes(int n, int m, int nb, bool c_lds);
-hipError_t launch_gi_batch(const BatchArgs & a, bool c_lds, hipStream_t stream);
+// cmode: where the constraint matrix lives during the solve: 0 = streamed from global memory, 1 = staged in LDS,
+// 2 = one column per thread in registers (specialised compile-time-n instantiations)
+long batch_lds_bytes(int n, int m, int nb, int cmode);
+int batch_pick_cmode(int n, int m, int nb); // -1 if unsupported
+hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream);
 } // namespace jrlqp

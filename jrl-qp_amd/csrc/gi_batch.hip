@@ -1,8 +1,7 @@
 // gi_batch.hip -- Mode B: device-resident batched Goldfarb-Idnani solver for gfx950 (MI355X).
 //
 // One 256-thread workgroup (4 wave64) solves one dense QP end to end: the complete dual active-set state
-// machine of the reference runs on-device out of LDS, inputs are read from HBM exactly once with coalesced
-// loads and the results written once.
+// machine of the reference runs on-device, inputs are read from HBM exactly once and the results written once.
 //
 //   reference path restated here (jrl-umi3218/jrl-qp):
 //     DualSolver::solve                      src/DualSolver.cpp:91-168
@@ -18,10 +17,21 @@
 // (one lane per output element), so the parallel kernel reproduces the sequential CPU oracle bit for bit;
 // divisions and square roots are the correctly rounded IEEE ones; this file is compiled with -ffp-contract=off.
 //
-// LDS map per workgroup (doubles, ld = n|1 odd so that both "lane = row" and "lane = column" accesses of the
-// n x n factors are bank-conflict free with ds_read_b64):
-//   J[n*ld] | R[n*ld] (holds L during init) | x[n] z[n] d[n] u[n+2] r[n+2] | (C[m*ld] bl[m] bu[m] if staged)
-//   | control block | active list int[n+1] | status bytes[m+nb]
+// Data placement per workgroup:
+//   LDS  (doubles, ld = n|1 odd => "lane = row" and "lane = column" accesses of the n x n factors are both
+//         bank-conflict free with ds_read_b64):
+//         J[n*ld] | R[n*ld] (holds L during init) | x z d np [n each] | u r [n+2 each] | (C[m*ld] bl bu if CMODE==1)
+//         | control block | active list int[n+2] | status bytes[m+nb]
+//   VGPR (CMODE==2, compile-time n): thread i keeps column i of C (n doubles) and bl_i, bu_i in registers, so the
+//         per-iteration constraint scan (K4, the largest streaming term) touches neither LDS nor HBM for C and
+//         three workgroups fit one CU.
+//   HBM  CMODE==0: C streamed from L2/HBM every scan (only when m is too large for the other two).
+//
+// Latency structure: the serial scalar chains (Givens coefficients, back-substitution pivots) set the critical
+// path (216 cycles per Givens step is the measured floor for one wave: 27 dependent fp64 ops x 8 cycles).  The
+// kernel therefore (i) software-pipelines every chain so that LDS latency, the 1/u division and the rotation of J
+// run in the shadow of the coefficient chain, and (ii) runs the next iteration's constraint scan on waves 1-3 while
+// wave 0 is inside the Givens sweep.
 #include <hip/hip_runtime.h>
 
 #include "gi_batch.h"
@@ -31,6 +41,7 @@ namespace jrlqp
 namespace
 {
 constexpr int WG = 256;
+constexpr int NONE = 0x7fffffff;
 
 enum : int
 {
@@ -61,20 +72,22 @@ struct Ctl
   int info;
   int l;
   int eq_next;
-  int pad;
+  int cnt;
 };
+
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
 
 // ---- wave-level helpers ---------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync()
 {
-  // single-wave producer/consumer through LDS: LDS executes one wave's accesses in order, so only the
+  // single-wave producer/consumer through LDS: the LDS executes one wave's accesses in order, so only the
   // compiler has to be told not to move accesses across this point.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// value of v in lane `src` (src must be wave-uniform): two v_readlane_b32, no LDS
+// value of v in lane `src` (src wave-uniform): two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double bcast_lane(double v, int src)
 {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -102,7 +115,27 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
   return __hiloint2double(hi, lo);
 }
 
-// lexicographic (value, index) minimum over the wave; every lane gets the winner
+__device__ __forceinline__ double wave_min_d(double v);
+
+// Lexicographic (value, index) minimum over the wave when the candidate index is monotone in the lane id
+// (idx == NONE marks "no candidate" and must come with val == +big).  Butterfly min on the value, then one
+// ballot picks the first lane holding it.  Every lane gets the winner.
+__device__ __forceinline__ void wave_argmin_monotone(double & val, int & idx, int & aux)
+{
+  const double mn = wave_min_d(val);
+  unsigned long long msk = __ballot(idx != NONE && val == mn);
+  if(msk == 0)
+  {
+    idx = NONE;
+    return;
+  }
+  int src = __builtin_ctzll(msk);
+  val = mn;
+  idx = __builtin_amdgcn_readlane(idx, src);
+  aux = __builtin_amdgcn_readlane(aux, src);
+}
+
+// general version (index not monotone in the lane id)
 __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
 {
 #pragma unroll
@@ -121,57 +154,180 @@ __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
   }
 }
 
-// Eigen JacobiRotation::makeGivens, real case (oracle orc_givens)
-__device__ __forceinline__ void make_givens(double p, double q, double & c, double & s, double & r)
+// Eigen JacobiRotation::makeGivens, real case (oracle orc_givens), split in two so that the
+// part the NEXT rotation depends on (r) is separated from the part only the application needs (c, s).
+// Branch-free: both operand orders share one instruction stream; the special cases are selects.
+struct GivensHalf
 {
-  if(q == 0.0)
-  {
-    c = p < 0.0 ? -1.0 : 1.0;
-    s = 0.0;
-    r = fabs(p);
-  }
-  else if(p == 0.0)
+  double t, u; // quotient and signed sqrt(1 + t^2)
+  double p, q; // inputs (for the special cases)
+  bool big_p;  // |p| > |q|
+};
+
+__device__ __forceinline__ double givens_r(double p, double q, GivensHalf & h)
+{
+  h.p = p;
+  h.q = q;
+  h.big_p = fabs(p) > fabs(q);
+  const double den = h.big_p ? p : q;
+  const double num = h.big_p ? q : p;
+  h.t = num / den;
+  double u = __builtin_sqrt(FMA(h.t, h.t, 1.0));
+  h.u = (den < 0.0) ? -u : u;
+  double r = den * h.u;
+  r = (p == 0.0) ? fabs(q) : r;
+  r = (q == 0.0) ? fabs(p) : r;
+  return r;
+}
+
+__device__ __forceinline__ void givens_cs(const GivensHalf & h, double & c, double & s)
+{
+  const double w = 1.0 / h.u; // 1/u
+  const double tw = h.t * w;
+  // |p|>|q|: c = 1/u, s = -t*c ;  else: s = -1/u, c = -t*s = t*(1/u)   (negations are exact)
+  c = h.big_p ? w : tw;
+  s = h.big_p ? -tw : -w;
+  if(h.p == 0.0)
   {
     c = 0.0;
-    s = q < 0.0 ? 1.0 : -1.0;
-    r = fabs(q);
+    s = (h.q < 0.0) ? 1.0 : -1.0;
   }
-  else if(fabs(p) > fabs(q))
+  if(h.q == 0.0)
   {
-    double t = q / p;
-    double u = __builtin_sqrt(__builtin_fma(t, t, 1.0));
-    if(p < 0.0) u = -u;
-    c = 1.0 / u;
-    s = -t * c;
-    r = p * u;
-  }
-  else
-  {
-    double t = p / q;
-    double u = __builtin_sqrt(__builtin_fma(t, t, 1.0));
-    if(q < 0.0) u = -u;
-    s = -1.0 / u;
-    c = -t * s;
-    r = q * u;
+    c = (h.p < 0.0) ? -1.0 : 1.0;
+    s = 0.0;
   }
 }
 
-#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+// sqrt(x) for x in [1, 2] (x = 1 + t^2, |t| <= 1): the Goldschmidt sequence hipcc expands __builtin_sqrt(double)
+// into, minus its range scaling (ldexp by 0 here) and its inf/zero class fix-up -- bit-identical on this range,
+// 9 dependent ops instead of 16 and no VALU->SALU round trip.
+__device__ __forceinline__ double sqrt_1to2(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = FMA(-h, g, 0.5);
+  g = FMA(g, r, g);
+  h = FMA(h, r, h);
+  double d = FMA(-g, g, x);
+  g = FMA(d, h, g);
+  d = FMA(-g, g, x);
+  g = FMA(d, h, g);
+  return g;
+}
 
-// ---- the kernel ------------------------------------------------------------------------------------------
+// r of makeGivens(p, q) alone -- what the NEXT rotation of a sweep depends on.  r = |den| * sqrt(1 + t^2) with
+// |t| = min(|p|,|q|) / max(|p|,|q|): the signs of t and u cancel in den*u and t enters only squared, so working on
+// magnitudes gives the same bits as the signed formula; p == 0 or q == 0 fall out exactly (t = 0, sqrt = 1).
+__device__ __forceinline__ double givens_r_only(double p, double q)
+{
+  const double a = fabs(p), b = fabs(q);
+  const double hi = fmax(a, b), lo = fmin(a, b);
+  const double t = lo / hi;
+  const double r = hi * sqrt_1to2(FMA(t, t, 1.0));
+  return (hi == 0.0) ? 0.0 : r;
+}
+
+// keeps a wave-uniform value in a VGPR and hides its provenance from the compiler: without this hipcc
+// scalarises parts of the coefficient chain and every select costs a VALU->SALU->VALU round trip
+__device__ __forceinline__ double opaque_v(double v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// minimum over the 64 lanes, every lane gets it: four DPP exchanges inside each row of 16, then the four row
+// minima through readlane -- no LDS crossbar (ds_bpermute) round trips
+template<int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+  double o;
+  o = dpp_move<0xB1>(v); // quad_perm [1,0,3,2]
+  v = (o < v) ? o : v;
+  o = dpp_move<0x4E>(v); // quad_perm [2,3,0,1]
+  v = (o < v) ? o : v;
+  o = dpp_move<0x141>(v); // row_half_mirror
+  v = (o < v) ? o : v;
+  o = dpp_move<0x140>(v); // row_mirror
+  v = (o < v) ? o : v;
+  double r0 = bcast_lane(v, 0), r1 = bcast_lane(v, 16), r2 = bcast_lane(v, 32), r3 = bcast_lane(v, 48);
+  double m01 = (r1 < r0) ? r1 : r0;
+  double m23 = (r3 < r2) ? r3 : r2;
+  return (m23 < m01) ? m23 : m01;
+}
+
+// acc <- chain over k = k0 .. k1-1 (ascending) of fma(a[k*sa], b[k*sb], acc); loads are issued a chunk ahead so
+// that LDS latency is paid once per chunk instead of once per step.
+template<int CH = 8>
+__device__ __forceinline__ double chain_up(const double * __restrict__ a, int sa, const double * __restrict__ b, int sb,
+                                           int k0, int k1, double acc)
+{
+  int k = k0;
+#pragma unroll 1
+  for(; k + CH <= k1; k += CH)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      av[u] = a[(k + u) * sa];
+      bv[u] = b[(k + u) * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH; ++u) acc = FMA(av[u], bv[u], acc);
+  }
+#pragma unroll 1
+  for(; k < k1; ++k) acc = FMA(a[k * sa], b[k * sb], acc);
+  return acc;
+}
+
+// same with the first operand negated and indices descending: k = k1-1 .. k0
+template<int CH = 8>
+__device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, int sa, const double * __restrict__ b, int sb,
+                                                 int k0, int k1, double acc)
+{
+  int k = k1 - 1;
+#pragma unroll 1
+  for(; k - CH + 1 >= k0; k -= CH)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      av[u] = a[(k - u) * sa];
+      bv[u] = b[(k - u) * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH; ++u) acc = FMA(-av[u], bv[u], acc);
+  }
+#pragma unroll 1
+  for(; k >= k0; --k) acc = FMA(-a[k * sa], b[k * sb], acc);
+  return acc;
+}
+
 // PROF: diagnostic build only -- thread 0 accumulates shader-clock cycles per phase into A.prof[b*16 + slot]
-// (slots: 0 load, 1 LLT, 2 J/x0, 3 scan, 4 d=J^T n, 5 trsv||z, 6 step+update, 7 add, 8 drop, 9 store,
-//  10 #adds, 11 #drops, 12 s_memrealtime ticks (100 MHz) for the whole solve).  Never used for a quoted time.
-#define STAMP(slot)                                 \
-  if(PROF && tid == 0)                              \
-  {                                                 \
-    long long now_ = clock64();                     \
+// (slots: 0 load, 1 LLT, 2 J/x0, 3 scan (not overlapped), 4 d=J^T n, 5 trsv||z, 6 step+update, 7 add (+overlapped scan),
+//  8 drop, 9 store, 10 #adds, 11 #drops, 12 s_memrealtime ticks (100 MHz) for the whole solve).
+#define STAMP(slot)                                  \
+  if(PROF && tid == 0)                               \
+  {                                                  \
+    long long now_ = clock64();                      \
     A.prof[(size_t)b * 16 + (slot)] += now_ - last_; \
-    last_ = now_;                                   \
+    last_ = now_;                                    \
   }
 
-template<bool C_LDS, bool PROF>
-__global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
+// ---- the kernel ------------------------------------------------------------------------------------------
+// NT    : compile-time n (0 = runtime n)
+// CMODE : 0 = C streamed from global memory, 1 = C staged in LDS, 2 = C in registers (needs NT > 0, m <= 256)
+template<int NT, int CMODE, bool PROF>
+__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 2 : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0;
   if(PROF)
@@ -184,22 +340,26 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
   const int b = blockIdx.x;
-  const int n = A.n, m = A.m, nb = A.nb, ld = A.ld;
+  const int n = NT ? NT : A.n;
+  const int ld = NT ? (NT | 1) : A.ld;
+  const int m = A.m, nb = A.nb;
   const int mt = m + nb;
+  constexpr int NR = NT ? NT : 1;
 
-  // LDS carve-up (must match jrlqp::batch_lds_layout in gi_batch_host.cpp)
+  // LDS carve-up (must match batch_lds_bytes below)
   double * J = smem;
   double * R = J + n * ld;
   double * xs = R + n * ld;
   double * zs = xs + n;
   double * ds = zs + n;
-  double * us = ds + n;
+  double * nps = ds + n;
+  double * us = nps + n;
   double * rs = us + (n + 2);
   double * tail = rs + (n + 2);
   double * Cs = tail;
   double * bls = tail;
   double * bus = tail;
-  if(C_LDS)
+  if(CMODE == 1)
   {
     bls = Cs + (size_t)m * ld;
     bus = bls + m;
@@ -217,6 +377,19 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
   const double * xlg = nb ? A.xl + (size_t)b * nb : nullptr;
   const double * xug = nb ? A.xu + (size_t)b * nb : nullptr;
 
+  // ---------------------------------------------------------------- C column -> registers (CMODE 2)
+  double creg[NR];
+  double my_bl = 0.0, my_bu = 0.0;
+  if(CMODE == 2)
+  {
+    const bool own = tid < m;
+    const double * ci = Cg + (size_t)(own ? tid : 0) * n;
+#pragma unroll
+    for(int k = 0; k < NR; ++k) creg[k] = own ? ci[k] : 0.0;
+    my_bl = own ? blg[tid] : 0.0;
+    my_bu = own ? bug[tid] : 0.0;
+  }
+
   // ---------------------------------------------------------------- load G (coalesced) -> R region, status = 0
   for(int e = tid; e < n * n; e += WG)
   {
@@ -229,7 +402,8 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
   {
     ctl->info = -1;
     ctl->f = 0.0;
-    ctl->eq_next = 0x7fffffff;
+    ctl->eq_next = NONE;
+    ctl->cnt = 0;
   }
   __syncthreads();
   STAMP(0)
@@ -242,10 +416,24 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
     for(int j = 0; j < n; ++j)
     {
       double acc = 0.0;
+      // ascending k (CANON C1): acc = G_ij - sum_{k<j} L_ik L_jk
       if(lane >= j && lane < n)
       {
         acc = L[lane + j * ld];
-        for(int k = 0; k < j; ++k) acc = FMA(-L[lane + k * ld], L[j + k * ld], acc);
+        int k = 0;
+        for(; k + 8 <= j; k += 8)
+        {
+          double av[8], bv[8];
+#pragma unroll
+          for(int u = 0; u < 8; ++u)
+          {
+            av[u] = L[lane + (k + u) * ld];
+            bv[u] = L[j + (k + u) * ld];
+          }
+#pragma unroll
+          for(int u = 0; u < 8; ++u) acc = FMA(-av[u], bv[u], acc);
+        }
+        for(; k < j; ++k) acc = FMA(-L[lane + k * ld], L[j + k * ld], acc);
       }
       double piv = bcast_lane(acc, j);
       if(piv <= 0.0)
@@ -264,7 +452,7 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
   }
   else
   {
-    if(C_LDS)
+    if(CMODE == 1)
     {
       for(int e = tid - 64; e < n * m; e += WG - 64)
       {
@@ -278,13 +466,21 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
       }
     }
     // equalities / fixed variables present?  (GoldfarbIdnaniSolver.cpp:268-287)
-    int first = 0x7fffffff;
+    int first = NONE, cnt = 0;
     for(int i = tid - 64; i < mt; i += WG - 64)
     {
       bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
-      if(eq && i < first) first = i;
+      if(eq)
+      {
+        ++cnt;
+        if(i < first) first = i;
+      }
     }
-    if(first != 0x7fffffff) atomicMin(&ctl->eq_next, first);
+    if(first != NONE)
+    {
+      atomicMin(&ctl->eq_next, first);
+      atomicAdd(&ctl->cnt, cnt);
+    }
   }
   __syncthreads();
   STAMP(1)
@@ -320,8 +516,8 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
           double v = 0.0;
           if(c >= i)
           {
-            double acc = (c == i) ? 1.0 : 0.0;
-            for(int k = c; k > i; --k) acc = FMA(-L[k + i * ld], J[k + c * ld], acc);
+            // J_ic = (delta_ic - sum_{k=c..i+1, descending} L_ki J_kc) / L_ii
+            double acc = chain_down_neg(L + i * ld, 1, J + c * ld, 1, i + 1, c + 1, (c == i) ? 1.0 : 0.0);
             v = acc / L[i + i * ld];
           }
           J[i + c * ld] = v;
@@ -332,21 +528,28 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
     {
       double xi = (lane < n) ? ag[lane] : 0.0;
       const double ai = xi;
+      const double dg = (lane < n) ? L[lane + lane * ld] : 1.0;
+      double col = (lane > 0 && lane < n) ? L[lane] : 0.0; // column 0
       for(int k = 0; k < n; ++k) // x = L.solve(a)
       {
-        double v = bcast_lane(xi, k) / L[k + k * ld];
+        double coln = (k + 1 < n && lane > k + 1 && lane < n) ? L[lane + (k + 1) * ld] : 0.0;
+        double v = bcast_lane(xi, k) / bcast_lane(dg, k);
         if(lane == k)
           xi = v;
         else if(lane > k && lane < n)
-          xi = FMA(-L[lane + k * ld], v, xi);
+          xi = FMA(-col, v, xi);
+        col = coln;
       }
+      col = (lane < n - 1) ? L[(n - 1) + lane * ld] : 0.0; // row n-1 of L = column n-1 of L^T
       for(int k = n - 1; k >= 0; --k) // L^T.solveInPlace(x)
       {
-        double v = bcast_lane(xi, k) / L[k + k * ld];
+        double coln = (k > 0 && lane < k - 1) ? L[(k - 1) + lane * ld] : 0.0;
+        double v = bcast_lane(xi, k) / bcast_lane(dg, k);
         if(lane == k)
           xi = v;
         else if(lane < k)
-          xi = FMA(-L[k + lane * ld], v, xi);
+          xi = FMA(-col, v, xi);
+        col = coln;
       }
       xi = -xi;
       if(lane < n) xs[lane] = xi;
@@ -358,419 +561,565 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
     __syncthreads();
     STAMP(2)
 
-    // more equalities / fixed variables than unknowns is UB in the reference; reported (as the oracle does)
-    int mode = (ctl->eq_next != 0x7fffffff) ? 0 : 1; // 0: initActiveSet, 1: main loop
-    if(mode == 0)
-    {
-      int cnt = 0;
-      for(int i = tid; i < mt; i += WG)
-      {
-        bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
-        cnt += eq;
-      }
-      // block-wide sum through an LDS atomic on the (still unused) red_idx slot
-      if(tid == 0) ctl->red_idx[0] = 0;
-      __syncthreads();
-      if(cnt) atomicAdd(&ctl->red_idx[0], cnt);
-      __syncthreads();
-      if(ctl->red_idx[0] > n)
-      {
-        term = T_OVERCONSTRAINED;
-        mode = 2;
-      }
-      __syncthreads();
-    }
-    int eq_cursor = 0;
-    int skip = 0;
-    int p = -1, pstat = INACTIVE;
     const double big = A.big_bnd;
+    int p = -1, pstat = INACTIVE;
 
-    while(mode != 2)
-    {
-      // ============================================================ selection
-      if(mode == 0)
+    // ======================================================================================================
+    // device-local lambdas (all inlined); barriers only ever appear in the kernel body, never inside them
+    // ======================================================================================================
+
+    // K4 for the calling thread's share: candidate (value < 0, index, status); `excl` is treated as active
+    auto scan_local = [&](int excl, double & bval, int & bidx, int & bstat) {
+      bval = 0.0;
+      bidx = NONE;
+      bstat = INACTIVE;
+      if(CMODE == 2)
       {
-        // next constraint with bl == bu (then bounds with xl == xu), in index order
-        int first = 0x7fffffff;
-        for(int i = eq_cursor + tid; i < mt; i += WG)
+        if(tid < m && st[tid] == INACTIVE && tid != excl)
         {
-          bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
-          if(eq && i < first) first = i;
+          double cx = 0.0;
+          // static register indices need full unrolling; x is fetched ten values at a time so that the LDS
+          // latency is paid once per group, and the scheduling barrier keeps the groups from being merged
+          // (all 50 loads hoisted => spills)
+#pragma unroll
+          for(int k0 = 0; k0 < NR; k0 += 10)
+          {
+            double xv[10];
+#pragma unroll
+            for(int u = 0; u < 10; ++u)
+              if(k0 + u < NR) xv[u] = xs[k0 + u];
+#pragma unroll
+            for(int u = 0; u < 10; ++u)
+              if(k0 + u < NR) cx = FMA(creg[k0 + u], xv[u], cx);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          double sl = cx - my_bl;
+          double su = my_bu - cx;
+          if(sl < 0.0)
+          {
+            bval = sl;
+            bidx = tid;
+            bstat = LOWER;
+          }
+          else if(su < 0.0)
+          {
+            bval = su;
+            bidx = tid;
+            bstat = UPPER;
+          }
         }
-        if(tid == 0) ctl->eq_next = 0x7fffffff;
-        __syncthreads();
-        if(first != 0x7fffffff) atomicMin(&ctl->eq_next, first);
-        __syncthreads();
-        p = uniform(ctl->eq_next);
-        __syncthreads();
-        if(p == 0x7fffffff)
-        {
-          mode = 1;
-          continue;
-        }
-        pstat = (p < m) ? EQUALITY : FIXED;
-        eq_cursor = p + 1;
-        if(tid == 0) us[q] = 0.0;
       }
       else
       {
-        if(it >= A.max_iter)
+        for(int i = tid; i < m; i += WG)
         {
-          term = T_MAX_ITER;
-          break;
-        }
-        if(!skip)
-        {
-          // ---- K4: s_i = min(C_i^T x - bl_i, bu_i - C_i^T x), first-index arg-min below 0
-          double bval = 0.0;
-          int bidx = 0x7fffffff, bstat = INACTIVE;
-          for(int i = tid; i < m; i += WG)
+          if(st[i] != INACTIVE || i == excl) continue;
+          const double * ci = (CMODE == 1) ? (Cs + (size_t)i * ld) : (Cg + (size_t)i * n);
+          double cx = chain_up(ci, 1, xs, 1, 0, n, 0.0);
+          double sl = cx - ((CMODE == 1) ? bls[i] : blg[i]);
+          if(sl < bval)
           {
-            if(st[i] != INACTIVE) continue;
-            double cx = 0.0;
-            if(C_LDS)
+            bval = sl;
+            bidx = i;
+            bstat = LOWER;
+          }
+          else
+          {
+            double su = ((CMODE == 1) ? bus[i] : bug[i]) - cx;
+            if(su < bval)
             {
-              const double * ci = Cs + (size_t)i * ld;
-              for(int k = 0; k < n; ++k) cx = FMA(ci[k], xs[k], cx);
-            }
-            else
-            {
-              const double * ci = Cg + (size_t)i * n;
-              for(int k = 0; k < n; ++k) cx = FMA(ci[k], xs[k], cx);
-            }
-            double lo = C_LDS ? bls[i] : blg[i];
-            double sl = cx - lo;
-            if(sl < bval)
-            {
-              bval = sl;
+              bval = su;
               bidx = i;
-              bstat = LOWER;
-            }
-            else
-            {
-              double hi = C_LDS ? bus[i] : bug[i];
-              double su = hi - cx;
-              if(su < bval)
-              {
-                bval = su;
-                bidx = i;
-                bstat = UPPER;
-              }
+              bstat = UPPER;
             }
           }
-          for(int i = tid; i < nb; i += WG)
-          {
-            if(st[m + i] != INACTIVE) continue;
-            double xi = xs[i];
-            double sl = xi - xlg[i];
-            if(sl < bval)
-            {
-              bval = sl;
-              bidx = m + i;
-              bstat = LOWER_BOUND;
-            }
-            else
-            {
-              double su = xug[i] - xi;
-              if(su < bval)
-              {
-                bval = su;
-                bidx = m + i;
-                bstat = UPPER_BOUND;
-              }
-            }
-          }
-          wave_argmin(bval, bidx, bstat);
-          if(lane == 0)
-          {
-            ctl->red_val[wave] = bval;
-            ctl->red_idx[wave] = bidx;
-            ctl->red_stat[wave] = bstat;
-          }
-          __syncthreads();
-          {
-            double v = ctl->red_val[0];
-            int ix = ctl->red_idx[0], sx = ctl->red_stat[0];
-#pragma unroll
-            for(int w = 1; w < 4; ++w)
-            {
-              double ov = ctl->red_val[w];
-              int oi = ctl->red_idx[w];
-              if(ov < v || (ov == v && oi < ix))
-              {
-                v = ov;
-                ix = oi;
-                sx = ctl->red_stat[w];
-              }
-            }
-            p = uniform((ix == 0x7fffffff) ? -1 : ix);
-            pstat = uniform(sx);
-          }
-          if(p < 0)
-          {
-            term = T_SUCCESS; // DualSolver.cpp:114
-            break;
-          }
-          if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
         }
       }
-      STAMP(3)
+      for(int i = tid; i < nb; i += WG)
+      {
+        if(st[m + i] != INACTIVE || (m + i) == excl) continue;
+        double xi = xs[i];
+        double sl = xi - xlg[i];
+        if(sl < bval)
+        {
+          bval = sl;
+          bidx = m + i;
+          bstat = LOWER_BOUND;
+        }
+        else
+        {
+          double su = xug[i] - xi;
+          if(su < bval)
+          {
+            bval = su;
+            bidx = m + i;
+            bstat = UPPER_BOUND;
+          }
+        }
+      }
+    };
 
-      // ============================================================ K5: d = J^T n+   (wave 0, lane = column of J)
-      const bool general = (p < m);
-      const int pb = p - m;
-      const double * cp = C_LDS ? (Cs + (size_t)(general ? p : 0) * ld) : (Cg + (size_t)(general ? p : 0) * n);
-      if(wave == 0 && lane < n)
+    // wave-level reduction of the scan candidates + hand-off of the wave's winner
+    auto scan_publish = [&](double bval, int bidx, int bstat) {
+      if(CMODE == 2 && nb == 0)
+      {
+        if(bidx == NONE) bval = 1.0; // candidates are < 0
+        wave_argmin_monotone(bval, bidx, bstat);
+      }
+      else
+        wave_argmin(bval, bidx, bstat);
+      if(lane == 0)
+      {
+        ctl->red_val[wave] = bval;
+        ctl->red_idx[wave] = bidx;
+        ctl->red_stat[wave] = bstat;
+      }
+    };
+
+    // after a barrier: every thread combines the four wave winners (first index wins ties)
+    auto scan_combine = [&](int & pp, int & ps) {
+      double v = ctl->red_val[0];
+      int ix = ctl->red_idx[0], sx = ctl->red_stat[0];
+#pragma unroll
+      for(int w = 1; w < 4; ++w)
+      {
+        double ov = ctl->red_val[w];
+        int oi = ctl->red_idx[w];
+        bool take = (oi != NONE) && (ix == NONE || ov < v || (ov == v && oi < ix));
+        if(take)
+        {
+          v = ov;
+          ix = oi;
+          sx = ctl->red_stat[w];
+        }
+      }
+      pp = uniform((ix == NONE) ? -1 : ix);
+      ps = uniform(sx);
+    };
+
+    // n+ of the selected general constraint -> LDS vector np (a pointer into staged C when CMODE == 1)
+    auto publish_np = [&](int pp) {
+      if(pp >= m) return;
+      if(CMODE == 2)
+      {
+        if(tid == pp)
+        {
+#pragma unroll
+          for(int k = 0; k < NR; ++k) nps[k] = creg[k];
+        }
+      }
+      else if(CMODE == 0)
+      {
+        if(tid < n) nps[tid] = Cg[(size_t)pp * n + tid];
+      }
+    };
+    auto np_ptr = [&](int pp) -> const double * {
+      if(CMODE == 1) return Cs + (size_t)((pp < m) ? pp : 0) * ld;
+      return nps;
+    };
+
+    // K5 (wave 0): d = +-J^T n+ (general) or +-row of J (bound)
+    auto compute_d = [&](int pp, int ps) {
+      if(lane < n)
       {
         double dj;
-        if(general)
-        {
-          dj = 0.0;
-          for(int k = 0; k < n; ++k) dj = FMA(J[k + lane * ld], cp[k], dj);
-        }
+        if(pp < m)
+          dj = chain_up(J + lane * ld, 1, np_ptr(pp), 1, 0, n, 0.0);
         else
-          dj = J[pb + lane * ld];
-        if(pstat == UPPER || pstat == UPPER_BOUND) dj = -dj;
+          dj = J[(pp - m) + lane * ld];
+        if(ps == UPPER || ps == UPPER_BOUND) dj = -dj;
         ds[lane] = dj;
       }
-      __syncthreads();
-      STAMP(4)
+    };
 
-      // ============================================================ K7 + ratio test (wave 0) || K6 + dots (wave 1)
-      if(wave == 0)
+    // K7 + ratio test (wave 0)
+    auto trsv_ratio = [&]() {
+      double rk = (lane < q) ? ds[lane] : 0.0;
+      const double dg = (lane < q) ? R[lane + lane * ld] : 1.0;
+      double col = (q > 0 && lane < q - 1) ? R[lane + (q - 1) * ld] : 0.0;
+      for(int k = q - 1; k >= 0; --k)
       {
-        double rk = (lane < q) ? ds[lane] : 0.0;
-        for(int k = q - 1; k >= 0; --k)
+        double coln = (k > 0 && lane < k - 1) ? R[lane + (k - 1) * ld] : 0.0; // prefetch the next column
+        double v = bcast_lane(rk, k) / bcast_lane(dg, k);
+        if(lane == k)
+          rk = v;
+        else if(lane < k)
+          rk = FMA(-col, v, rk);
+        col = coln;
+      }
+      if(lane < q) rs[lane] = rk;
+      // t1 = min u_k / r_k over r_k > 0 (not EQUALITY/FIXED; status looked up by POSITION, GoldfarbIdnaniSolver.cpp:162)
+      double tk = big;
+      int kk = NONE, dummy = 0;
+      if(lane < q)
+      {
+        int sk = st[lane];
+        if(sk != EQUALITY && sk != FIXED && rk > 0.0)
         {
-          double v = bcast_lane(rk, k) / R[k + k * ld];
-          if(lane == k)
-            rk = v;
-          else if(lane < k)
-            rk = FMA(-R[lane + k * ld], v, rk);
-        }
-        if(lane < q) rs[lane] = rk;
-        // t1 = min u_k / r_k over r_k > 0 (not EQUALITY/FIXED; status looked up by POSITION, GoldfarbIdnaniSolver.cpp:162)
-        double tk = big;
-        int kk = 0x7fffffff, dummy = 0;
-        if(lane < q)
-        {
-          int sk = st[lane];
-          if(sk != EQUALITY && sk != FIXED && rk > 0.0)
+          double tt = us[lane] / rk;
+          if(tt < big)
           {
-            double tt = us[lane] / rk;
-            if(tt < big)
-            {
-              tk = tt;
-              kk = lane;
-            }
+            tk = tt;
+            kk = lane;
           }
-        }
-        wave_argmin(tk, kk, dummy);
-        if(lane == 0)
-        {
-          ctl->t1 = tk;
-          ctl->l = (kk == 0x7fffffff) ? 0 : kk;
         }
       }
-      else if(wave == 1)
+      wave_argmin_monotone(tk, kk, dummy);
+      if(lane == 0)
       {
-        double zi = 0.0;
-        if(lane < n)
-        {
-          for(int j = q; j < n; ++j) zi = FMA(J[lane + j * ld], ds[j], zi);
-          zs[lane] = zi;
-        }
-        wave_sync();
-        // three in-order chains in three lanes: z.z, c_p.z, c_p.x
-        if(lane < 3)
-        {
-          double acc = 0.0;
-          if(general)
-          {
-            const double * pa = (lane == 0) ? zs : cp;
-            const double * pv = (lane == 2) ? xs : zs;
-            for(int k = 0; k < n; ++k) acc = FMA(pa[k], pv[k], acc);
-          }
-          else
-          {
-            if(lane == 0)
-              for(int k = 0; k < n; ++k) acc = FMA(zs[k], zs[k], acc);
-            else
-              acc = (lane == 1) ? zs[pb] : xs[pb];
-          }
-          if(lane == 0) ctl->zz = acc;
-          if(lane == 1) ctl->cz = acc;
-          if(lane == 2) ctl->cx = acc;
-        }
+        ctl->t1 = (kk == NONE) ? big : tk;
+        ctl->l = (kk == NONE) ? 0 : kk;
       }
-      __syncthreads();
-      STAMP(5)
+    };
 
-      // ============================================================ K8/K9: step length and primal/dual update
-      const double cz = uniform_d(ctl->cz);
-      const double zz = uniform_d(ctl->zz);
-      const double cxp = uniform_d(ctl->cx);
-      const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
-      double t, t1 = big, t2 = big;
-      int l = 0;
-      if(mode == 0)
+    // K6 + the three scalar products of K8 (wave 1)
+    auto z_and_dots = [&](int pp) {
+      const bool general = pp < m;
+      if(lane < n) zs[lane] = chain_up(J + lane, ld, ds, 1, q, n, 0.0);
+      wave_sync();
+      if(lane < 3)
       {
-        // addInitialConstraint (GoldfarbIdnaniSolver.cpp:295-338): full step, no ratio test
-        t = 0.0;
-        if(__builtin_sqrt(zz) > 1e-14)
+        double acc;
+        if(general)
         {
-          double bb = uniform_d(general ? (C_LDS ? bls[p] : blg[p]) : xlg[pb]);
-          t = (bb - cxp) / cz;
-        }
-      }
-      else
-      {
-        t1 = uniform_d(ctl->t1);
-        l = uniform(ctl->l);
-        if(__builtin_sqrt(zz) > 1e-14)
-        {
-          double bb;
-          if(pstat == LOWER)
-            bb = C_LDS ? bls[p] : blg[p];
-          else if(pstat == UPPER)
-            bb = C_LDS ? bus[p] : bug[p];
-          else if(pstat == LOWER_BOUND)
-            bb = xlg[pb];
-          else
-            bb = xug[pb];
-          t2 = (uniform_d(bb) - cxp) / cz;
-        }
-        t = (t2 < t1) ? t2 : t1;
-        if(A.trace && tid == 0 && it < A.trace_cap)
-        {
-          jrlqp_trace_rec * tr = A.trace + (size_t)b * A.trace_cap + it;
-          tr->p = p;
-          tr->status = pstat;
-          tr->l = l;
-          tr->kind = (t2 >= big) ? 2 : ((t == t2) ? 0 : 1);
-          tr->t1 = t1;
-          tr->t2 = t2;
-        }
-        if(t >= big)
-        {
-          term = T_INFEASIBLE; // DualSolver.cpp:131
-          break;
-        }
-      }
-      const bool dual_only = (mode == 1) && (t2 >= big);
-      const bool do_add = (mode == 0) || (!dual_only && t == t2);
-
-      if(wave == 0)
-      {
-        if(!dual_only)
-        {
-          if(lane < n) xs[lane] = FMA(t, zs[lane], xs[lane]);
-          if(lane == 0) ctl->f = FMA(t * dotsc, 0.5 * t + us[q], ctl->f); // uses u[q] BEFORE its update
-        }
-        wave_sync();
-        if(lane < q) us[lane] = FMA(-t, rs[lane], us[lane]);
-        if(lane == 0) us[q] = us[q] + t;
-        wave_sync();
-        STAMP(6)
-
-        if(do_add)
-        {
-          // ---- K10: addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237); lane = row of J
-          double carry = (lane < n) ? J[lane + (n - 1) * ld] : 0.0;
-          double dprev = ds[n - 1];
-          for(int i = n - 2; i >= q; --i)
-          {
-            double c, s, rho;
-            make_givens(ds[i], dprev, c, s, rho);
-            dprev = rho;
-            if(lane < n)
-            {
-              double xv = J[lane + i * ld];
-              J[lane + (i + 1) * ld] = FMA(s, xv, c * carry);
-              carry = FMA(c, xv, -(s * carry));
-            }
-          }
-          if(lane < n) J[lane + q * ld] = carry;
-          // R.col(q).head(q+1) = d.head(q+1)
-          if(lane < q)
-            R[lane + q * ld] = ds[lane];
-          else if(lane == q)
-            R[q + q * ld] = dprev;
-          if(lane == 0)
-          {
-            act[q] = p;
-            st[p] = (unsigned char)pstat;
-          }
-          STAMP(7)
-          if(PROF && tid == 0) A.prof[(size_t)b * 16 + 10] += 1;
+          const double * cp = np_ptr(pp);
+          const double * pa = (lane == 0) ? zs : cp;
+          const double * pv = (lane == 2) ? xs : zs;
+          acc = chain_up(pa, 1, pv, 1, 0, n, 0.0);
         }
         else
         {
-          // ---- K11: removeConstraint (DualSolver.cpp:237-244, GoldfarbIdnaniSolver.cpp:239-256)
-          double uv = (lane >= l && lane < q) ? us[lane + 1] : 0.0;
-          int av = (lane >= l && lane < q - 1) ? act[lane + 1] : 0;
-          int gone = act[l];
-          wave_sync();
-          if(lane >= l && lane < q) us[lane] = uv;
-          if(lane >= l && lane < q - 1) act[lane] = av;
-          if(lane == 0) st[gone] = INACTIVE;
-          const int qn = q - 1;
-          const bool mine = (lane >= l && lane < qn); // lane = NEW column index; old column = lane + 1
-          for(int rr = 0; rr < l; ++rr)
-          {
-            double v = mine ? R[rr + (lane + 1) * ld] : 0.0;
-            wave_sync();
-            if(mine) R[rr + lane * ld] = v;
-          }
-          double carry = mine ? R[l + (lane + 1) * ld] : 0.0;
-          wave_sync();
-          for(int i = l; i < qn; ++i)
-          {
-            double y = (lane >= i && lane < qn) ? R[(i + 1) + (lane + 1) * ld] : 0.0;
-            double c, s, rho;
-            make_givens(bcast_lane(carry, i), bcast_lane(y, i), c, s, rho);
-            if(lane == 0)
-            {
-              ds[i] = c; // d and z are dead here: reuse them to hand (c, s) to the J sweep
-              zs[i] = s;
-            }
-            if(lane == i)
-              R[i + i * ld] = rho;
-            else if(lane > i && lane < qn)
-            {
-              R[i + lane * ld] = FMA(c, carry, -(s * y));
-              carry = FMA(s, carry, c * y);
-            }
-            wave_sync();
-          }
-          if(lane < n && qn > l)
-          {
-            double jc = J[lane + l * ld];
-            for(int i = l; i < qn; ++i)
-            {
-              double c = ds[i], s = zs[i];
-              double y = J[lane + (i + 1) * ld];
-              J[lane + i * ld] = FMA(c, jc, -(s * y));
-              jc = FMA(s, jc, c * y);
-            }
-            J[lane + qn * ld] = jc;
-          }
-          STAMP(8)
-          if(PROF && tid == 0) A.prof[(size_t)b * 16 + 11] += 1;
+          if(lane == 0)
+            acc = chain_up(zs, 1, zs, 1, 0, n, 0.0);
+          else
+            acc = (lane == 1) ? zs[pp - m] : xs[pp - m];
         }
+        if(lane == 0) ctl->zz = acc;
+        if(lane == 1) ctl->cz = acc;
+        if(lane == 2) ctl->cx = acc;
       }
-      if(do_add)
+    };
+
+    // K9 (wave 0): primal/dual update
+    auto apply_step = [&](double t, double dotsc, bool dual_only) {
+      if(!dual_only)
       {
-        q = uniform(q + 1);
-        skip = 0;
+        if(lane < n) xs[lane] = FMA(t, zs[lane], xs[lane]);
+        if(lane == 0) ctl->f = FMA(t * dotsc, 0.5 * t + us[q], ctl->f); // uses u[q] BEFORE its update
+      }
+      wave_sync();
+      if(lane < q) us[lane] = FMA(-t, rs[lane], us[lane]);
+      if(lane == 0) us[q] = us[q] + t;
+      wave_sync();
+    };
+
+    // K10 (wave 0): addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237).
+    // Three phases so that only the irreducible recurrence r_i = f(d_i, r_{i+1}) is serial:
+    //   1. coefficient chain: every lane runs the recurrence (uniform values); lane i keeps r_{i+1}
+    //   2. lane i recomputes rotation i from (d_i, r_{i+1}) -- same function, same bits -- and derives (c_i, s_i):
+    //      all the 1/u divisions happen at once instead of inside the chain
+    //   3. lane = row of J: sweep i = n-2 .. q applying the rotations, operands prefetched one step ahead
+    auto do_add = [&](int pp, int ps) {
+      const int rl = (lane < n) ? lane : (n - 1); // lanes >= n shadow row n-1 (same values, same addresses)
+      const double dreg = ds[rl];
+      double rho = opaque_v(bcast_lane(dreg, n - 1));
+      double kq = 0.0;
+      for(int i = n - 2; i >= q; --i)
+      {
+        const double p_i = opaque_v(bcast_lane(dreg, i));
+        kq = (lane == i) ? rho : kq;
+        rho = givens_r_only(p_i, rho);
+      }
+      STAMP(13)
+      if(n - 2 >= q)
+      {
+        GivensHalf h;
+        (void)givens_r(dreg, kq, h);
+        double cl, sl;
+        givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
+        double carry = J[rl + (n - 1) * ld];
+        int i = n - 2;
+#pragma unroll 1
+        for(; i - 3 >= q; i -= 4)
+        {
+          double xv[4];
+#pragma unroll
+          for(int u = 0; u < 4; ++u) xv[u] = J[rl + (i - u) * ld];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for(int u = 0; u < 4; ++u)
+          {
+            const double c2 = bcast_lane(cl, i - u), s2 = bcast_lane(sl, i - u);
+            J[rl + (i - u + 1) * ld] = FMA(s2, xv[u], c2 * carry);
+            carry = FMA(c2, xv[u], -(s2 * carry));
+          }
+        }
+#pragma unroll 1
+        for(; i >= q; --i)
+        {
+          const double xv = J[rl + i * ld];
+          const double c2 = bcast_lane(cl, i), s2 = bcast_lane(sl, i);
+          J[rl + (i + 1) * ld] = FMA(s2, xv, c2 * carry);
+          carry = FMA(c2, xv, -(s2 * carry));
+        }
+        J[rl + q * ld] = carry;
+      }
+      STAMP(14)
+      // R.col(q).head(q+1) = d.head(q+1)
+      if(lane < q)
+        R[lane + q * ld] = dreg;
+      else if(lane == q)
+        R[q + q * ld] = rho;
+      if(lane == 0)
+      {
+        act[q] = pp;
+        st[pp] = (unsigned char)ps;
+      }
+    };
+
+    // K11 (wave 0): removeConstraint (DualSolver.cpp:237-244, GoldfarbIdnaniSolver.cpp:239-256)
+    auto do_drop = [&](int l) {
+      double uv = (lane >= l && lane < q) ? us[lane + 1] : 0.0;
+      int av = (lane >= l && lane < q - 1) ? act[lane + 1] : 0;
+      int gone = act[l];
+      wave_sync();
+      if(lane >= l && lane < q) us[lane] = uv;
+      if(lane >= l && lane < q - 1) act[lane] = av;
+      if(lane == 0) st[gone] = INACTIVE;
+      const int qn = q - 1;
+      const bool mine = (lane >= l && lane < qn); // lane = NEW column index; old column = lane + 1
+      for(int rr = 0; rr < l; ++rr)
+      {
+        double v = mine ? R[rr + (lane + 1) * ld] : 0.0;
+        wave_sync();
+        if(mine) R[rr + lane * ld] = v;
+      }
+      double carry = mine ? R[l + (lane + 1) * ld] : 0.0;
+      wave_sync();
+      double y = (lane >= l && lane < qn) ? R[(l + 1) + (lane + 1) * ld] : 0.0;
+      for(int i = l; i < qn; ++i)
+      {
+        double ynext = (i + 1 < qn && lane >= i + 1 && lane < qn) ? R[(i + 2) + (lane + 1) * ld] : 0.0;
+        GivensHalf h;
+        double rho = givens_r(bcast_lane(carry, i), bcast_lane(y, i), h);
+        double c, s;
+        givens_cs(h, c, s);
+        if(lane == 0)
+        {
+          ds[i] = c; // d and z are dead here: reuse them to hand (c, s) to the J sweep
+          zs[i] = s;
+        }
+        if(lane == i)
+          R[i + i * ld] = rho;
+        else if(lane > i && lane < qn)
+        {
+          R[i + lane * ld] = FMA(c, carry, -(s * y));
+          carry = FMA(s, carry, c * y);
+        }
+        y = ynext;
+      }
+      wave_sync();
+      if(lane < n && qn > l)
+      {
+        double jc = J[lane + l * ld];
+        double ynext = J[lane + (l + 1) * ld];
+        for(int i = l; i < qn; ++i)
+        {
+          double c = ds[i], s = zs[i];
+          double yy = ynext;
+          if(i + 1 < qn) ynext = J[lane + (i + 2) * ld];
+          J[lane + i * ld] = FMA(c, jc, -(s * yy));
+          jc = FMA(s, jc, c * yy);
+        }
+        J[lane + qn * ld] = jc;
+      }
+    };
+
+    // ======================================================================================================
+    // K12: initActiveSet -- equalities (bl == bu) then fixed variables (xl == xu), in index order, full step each
+    // ======================================================================================================
+    if(ctl->eq_next != NONE)
+    {
+      if(ctl->cnt > n)
+      {
+        term = T_OVERCONSTRAINED; // UB in the reference; reported (as the oracle does)
       }
       else
       {
-        q = uniform(q - 1);
-        skip = 1;
+        int cursor = 0;
+        for(;;)
+        {
+          int first = NONE;
+          for(int i = cursor + tid; i < mt; i += WG)
+          {
+            bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
+            if(eq && i < first) first = i;
+          }
+          __syncthreads();
+          if(tid == 0) ctl->eq_next = NONE;
+          __syncthreads();
+          if(first != NONE) atomicMin(&ctl->eq_next, first);
+          __syncthreads();
+          p = uniform(ctl->eq_next);
+          if(p == NONE) break;
+          pstat = (p < m) ? EQUALITY : FIXED;
+          cursor = p + 1;
+          publish_np(p);
+          if(tid == 0) us[q] = 0.0;
+          __syncthreads();
+          if(wave == 0) compute_d(p, pstat);
+          __syncthreads();
+          if(wave == 0)
+            trsv_ratio();
+          else if(wave == 1)
+            z_and_dots(p);
+          __syncthreads();
+          // addInitialConstraint (GoldfarbIdnaniSolver.cpp:295-338): full step, no ratio test
+          const double cz = uniform_d(ctl->cz);
+          double t = 0.0;
+          if(__builtin_sqrt(uniform_d(ctl->zz)) > 1e-14)
+          {
+            double bb = uniform_d((p < m) ? blg[p] : xlg[p - m]);
+            t = (bb - uniform_d(ctl->cx)) / cz;
+          }
+          if(wave == 0)
+          {
+            apply_step(t, cz, false);
+            do_add(p, pstat);
+          }
+          q = uniform(q + 1);
+          __syncthreads();
+        }
       }
-      if(mode == 1) ++it;
-      __syncthreads();
+    }
+
+    // ======================================================================================================
+    // main loop (DualSolver.cpp:103-166)
+    // ======================================================================================================
+    if(term == T_SUCCESS)
+    {
+      if(A.max_iter <= 0)
+        term = T_MAX_ITER;
+      else
+      {
+        // Step 1 for the first pass: everybody scans
+        {
+          double bv;
+          int bi, bs;
+          scan_local(-1, bv, bi, bs);
+          scan_publish(bv, bi, bs);
+          __syncthreads();
+          scan_combine(p, pstat);
+          STAMP(3)
+        }
+        bool running = (p >= 0);
+        if(running)
+        {
+          publish_np(p);
+          if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
+        }
+        while(running)
+        {
+          // ---- selected constraint (p, pstat): n+ to LDS, u[q] = 0 only when it was freshly selected
+          // (callers below take care of u[q]); K5
+          __syncthreads();
+          if(wave == 0) compute_d(p, pstat);
+          __syncthreads();
+          STAMP(4)
+          if(wave == 0)
+            trsv_ratio();
+          else if(wave == 1)
+            z_and_dots(p);
+          __syncthreads();
+          STAMP(5)
+
+          // ---- K8: step length (uniform, every thread)
+          const bool general = p < m;
+          const int pb = p - m;
+          const double cz = uniform_d(ctl->cz);
+          const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
+          const double t1 = uniform_d(ctl->t1);
+          const int l = uniform(ctl->l);
+          double t2 = big;
+          if(__builtin_sqrt(uniform_d(ctl->zz)) > 1e-14)
+          {
+            double bb;
+            if(pstat == LOWER)
+              bb = (CMODE == 1) ? bls[p] : blg[p];
+            else if(pstat == UPPER)
+              bb = (CMODE == 1) ? bus[p] : bug[p];
+            else if(pstat == LOWER_BOUND)
+              bb = xlg[pb];
+            else
+              bb = xug[pb];
+            t2 = (uniform_d(bb) - uniform_d(ctl->cx)) / cz;
+          }
+          (void)general;
+          const double t = (t2 < t1) ? t2 : t1;
+          if(A.trace && tid == 0 && it < A.trace_cap)
+          {
+            jrlqp_trace_rec * tr = A.trace + (size_t)b * A.trace_cap + it;
+            tr->p = p;
+            tr->status = pstat;
+            tr->l = l;
+            tr->kind = (t2 >= big) ? 2 : ((t == t2) ? 0 : 1);
+            tr->t1 = t1;
+            tr->t2 = t2;
+          }
+          if(t >= big)
+          {
+            term = T_INFEASIBLE; // DualSolver.cpp:131
+            break;
+          }
+          const bool dual_only = (t2 >= big);
+          const bool add = !dual_only && (t == t2);
+
+          if(wave == 0) apply_step(t, dotsc, dual_only);
+          STAMP(6)
+          if(add)
+          {
+            __syncthreads(); // x is final: waves 1-3 may scan for the NEXT pass while wave 0 sweeps
+            double bv;
+            int bi, bs;
+            if(wave == 0)
+            {
+              do_add(p, pstat);
+              wave_sync();
+            }
+            q = uniform(q + 1);
+            ++it;
+            scan_local(p, bv, bi, bs); // p is treated as active (wave 0 has it in st[] by now, the others exclude it)
+            scan_publish(bv, bi, bs);
+            STAMP(15)
+            if(wave == 0 && PROF && tid == 0) A.prof[(size_t)b * 16 + 10] += 1;
+            __syncthreads();
+            STAMP(7)
+            if(it >= A.max_iter)
+            {
+              term = T_MAX_ITER; // checked before the next selection (for(; it_ < maxIter_; ...), DualSolver.cpp:103)
+              break;
+            }
+            scan_combine(p, pstat);
+            if(p < 0) break; // SUCCESS (DualSolver.cpp:114)
+            publish_np(p);
+            if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
+          }
+          else
+          {
+            if(wave == 0) do_drop(l);
+            q = uniform(q - 1);
+            ++it;
+            if(PROF && tid == 0) A.prof[(size_t)b * 16 + 11] += 1;
+            STAMP(8)
+            if(it >= A.max_iter)
+            {
+              term = T_MAX_ITER;
+              break;
+            }
+            // skipStep1: same (p, pstat), u[q] keeps the shifted pending multiplier
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -801,32 +1150,48 @@ __global__ __launch_bounds__(WG) void gi_batch_kernel(const BatchArgs A)
   if(PROF && tid == 0) A.prof[(size_t)b * 16 + 12] += wall_clock64() - wall0_;
 }
 
+template<int NT, int CMODE, bool PROF>
+hipError_t launch_one(const BatchArgs & a, long lds, hipStream_t stream)
+{
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<NT, CMODE, PROF>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL((gi_batch_kernel<NT, CMODE, PROF>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
+  return hipGetLastError();
+}
+
+template<int NT, int CMODE>
+hipError_t launch_prof(const BatchArgs & a, long lds, hipStream_t stream)
+{
+  return a.prof ? launch_one<NT, CMODE, true>(a, lds, stream) : launch_one<NT, CMODE, false>(a, lds, stream);
+}
+
 } // namespace
 
-long batch_lds_bytes(int n, int m, int nb, bool c_lds)
+long batch_lds_bytes(int n, int m, int nb, int cmode)
 {
   const long ld = n | 1;
-  long dbl = 2L * n * ld + 3L * n + 2L * (n + 2);
-  if(c_lds) dbl += (long)m * ld + 2L * m;
+  long dbl = 2L * n * ld + 4L * n + 2L * (n + 2);
+  if(cmode == 1) dbl += (long)m * ld + 2L * m;
   long bytes = dbl * 8 + (long)sizeof(Ctl) + 4L * (n + 2) + (long)(m + nb);
   return (bytes + 15) & ~15L;
 }
 
-template<bool C_LDS, bool PROF>
-static hipError_t launch_one(const BatchArgs & a, long lds, hipStream_t stream)
+int batch_pick_cmode(int n, int m, int nb)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<C_LDS, PROF>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if(e != hipSuccess) return e;
-  hipLaunchKernelGGL((gi_batch_kernel<C_LDS, PROF>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
-  return hipGetLastError();
+  // registers: the specialised instantiations below; LDS when C fits beside the factors; else stream
+  if(n == 50 && m <= 256) return 2;
+  if(batch_lds_bytes(n, m, nb, 1) <= kLdsPerCU) return 1;
+  if(batch_lds_bytes(n, m, nb, 0) <= kLdsPerCU) return 0;
+  return -1;
 }
 
-hipError_t launch_gi_batch(const BatchArgs & a, bool c_lds, hipStream_t stream)
+hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)
 {
-  const long lds = batch_lds_bytes(a.n, a.m, a.nb, c_lds);
-  if(a.prof) return c_lds ? launch_one<true, true>(a, lds, stream) : launch_one<false, true>(a, lds, stream);
-  return c_lds ? launch_one<true, false>(a, lds, stream) : launch_one<false, false>(a, lds, stream);
+  const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode);
+  if(cmode == 2 && a.n == 50) return launch_prof<50, 2>(a, lds, stream);
+  if(cmode == 1) return launch_prof<0, 1>(a, lds, stream);
+  return launch_prof<0, 0>(a, lds, stream);
 }
 
 } // namespace jrlqp

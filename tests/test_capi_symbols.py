@@ -34,7 +34,7 @@ def test_defaults_and_lds_budget(pkg):
     assert o.max_iter == 500 and o.big_bnd == 1e100  # reference include/jrl-qp/SolverOptions.h:16-17
     c = ct.c_int(-1)
     lds = lib.jrlqp_gi_batch_lds_bytes(50, 200, 0, ct.byref(c))
-    assert 0 < lds <= 163840 and c.value == 1  # BASELINE config c3 fits one CU's LDS with C staged
+    assert 0 < lds <= 163840 // 3 and c.value == 2  # BASELINE config c3: C in registers, three workgroups per CU
     lds = lib.jrlqp_gi_batch_lds_bytes(10, 20, 0, ct.byref(c))
     assert 0 < lds < 16384 and c.value == 1
     lds = lib.jrlqp_gi_batch_lds_bytes(50, 2000, 50, ct.byref(c))

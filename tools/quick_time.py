@@ -14,7 +14,7 @@ pb = P.PackedBatch(n=base.n, m=base.m, nb=0, G=tile(base.G), a=tile(base.a), C=t
                    xl=tile(base.xl), xu=tile(base.xu), x_star=tile(base.x_star), lam_star=tile(base.lam_star))
 dev = capi.to_device(pb)
 s = capi.BatchSolver(n, m, False, B)
-print("lds bytes", s.lds_bytes, "C in LDS", s.c_in_lds)
+print("lds bytes", s.lds_bytes, "C placement", s.c_placement)
 for _ in range(2):
     s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"])
 torch.cuda.synchronize()
@@ -33,8 +33,8 @@ capi.load_library().jrlqp_debug_set_profile(prof.data_ptr())
 s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"]); torch.cuda.synchronize()
 capi.load_library().jrlqp_debug_set_profile(None)
 pr = prof.cpu().numpy().astype(np.float64)
-names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)"]
-tot = pr[:, :10].sum(axis=1)
+names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)", "add:chain", "add:cs+apply", "add:wave0 scan"]
+tot = pr[:, :10].sum(axis=1) + pr[:, 13:16].sum(axis=1)
 print("mean cycles per solve", tot.mean(), " mean realtime us", pr[:, 12].mean() / 100.0, " => clock GHz", tot.mean() / (pr[:, 12].mean() / 100.0) / 1e3)
 for i, nm in enumerate(names):
     print(f"  {nm:18s} {pr[:, i].mean():12.1f}  ({100 * pr[:, i].mean() / tot.mean():5.1f} %)")
