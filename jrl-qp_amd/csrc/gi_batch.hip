@@ -327,7 +327,7 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 // NT    : compile-time n (0 = runtime n)
 // CMODE : 0 = C streamed from global memory, 1 = C staged in LDS, 2 = C in registers (needs NT > 0, m <= 256)
 template<int NT, int CMODE, bool PROF>
-__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 2 : 1) void gi_batch_kernel(const BatchArgs A)
+__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0;
   if(PROF)
