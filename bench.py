@@ -27,30 +27,40 @@ def algorithmic_bytes_per_solve(n, m, nb):
     return 8 * (n * n + n + n * m + 2 * m + 2 * nb) + 8 * (n + m + nb) + 4 * (m + nb) + 16
 
 
-def cpu_baseline(pb, budget_s=15.0):
+def cpu_baseline(pb, budget_s=12.0):
     """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample of the same
-    workload.  Reported baseline, not the optimisation target."""
+    workload: the first `sample` QPs, solved round after round (G restored from a copy before every solve, as the
+    reference's own benchmark loop does, benchmarks/Solvers.cpp:447-453,:508-520) until about `budget_s` seconds
+    of wall time have passed.  Reported baseline, not the optimisation target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import get_oracle  # cpu_baseline leg only
 
     o = get_oracle()
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))  # the cores this process may actually use
+    except AttributeError:
+        cores = os.cpu_count() or 1
     probe = min(64, pb.B)
     t0 = time.perf_counter()
     o.solve_batch(pb.G[:probe], pb.a[:probe], pb.C[:probe], pb.bl[:probe], pb.bu[:probe], nthreads=1)
     per = (time.perf_counter() - t0) / probe
-    o.solve_batch(pb.G[:cores], pb.a[:cores], pb.C[:cores], pb.bl[:cores], pb.bu[:cores], nthreads=cores)  # spin up the pool
-    sample = int(min(pb.B, max(cores * 8, budget_s / per * cores)))
-    t0 = time.perf_counter()
-    o.solve_batch(pb.G[:sample], pb.a[:sample], pb.C[:sample], pb.bl[:sample], pb.bu[:sample], nthreads=cores)
-    dt = time.perf_counter() - t0
+    sample = pb.B
+    args = (pb.G[:sample], pb.a[:sample], pb.C[:sample], pb.bl[:sample], pb.bu[:sample])
+    o.solve_batch(*args, nthreads=cores)  # warm-up round: spins up the OpenMP pool, faults the pages in
+    rounds, t0 = 0, time.perf_counter()
+    while True:
+        o.solve_batch(*args, nthreads=cores)
+        rounds += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or rounds >= 2000:
+            break
     return {
-        "value": sample / dt,
+        "value": sample * rounds / dt,
         "unit": "solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {sample} QPs of the same workload, {cores} OpenMP threads, one workspace per thread; "
-                  f"single-thread probe {per * 1e6:.1f} us/solve",
+        "sample": f"{rounds} rounds over the first {sample} QPs of the same workload ({dt:.1f} s), {cores} OpenMP threads, "
+                  f"one workspace per thread, G restored before every solve; single-thread probe {per * 1e6:.1f} us/solve",
         "single_thread_us_per_solve": per * 1e6,
     }
 

@@ -283,8 +283,64 @@ __device__ __forceinline__ double chain_up(const double * __restrict__ a, int sa
 #pragma unroll
     for(int u = 0; u < CH; ++u) acc = FMA(av[u], bv[u], acc);
   }
+  const int rem = k1 - k; // < CH: one more batched group, fmas predicated (a select costs 8 cycles, an exposed LDS load ~130)
+  if(rem > 0)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH - 1; ++u)
+    {
+      const int kk = (u < rem) ? (k + u) : (k1 - 1);
+      av[u] = a[kk * sa];
+      bv[u] = b[kk * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH - 1; ++u)
+    {
+      const double nx = FMA(av[u], bv[u], acc);
+      acc = (u < rem) ? nx : acc;
+    }
+  }
+  return acc;
+}
+
+// ascending with the first operand negated (Cholesky updates)
+template<int CH = 8>
+__device__ __forceinline__ double chain_up_neg(const double * __restrict__ a, int sa, const double * __restrict__ b, int sb,
+                                               int k0, int k1, double acc)
+{
+  int k = k0;
 #pragma unroll 1
-  for(; k < k1; ++k) acc = FMA(a[k * sa], b[k * sb], acc);
+  for(; k + CH <= k1; k += CH)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      av[u] = a[(k + u) * sa];
+      bv[u] = b[(k + u) * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH; ++u) acc = FMA(-av[u], bv[u], acc);
+  }
+  const int rem = k1 - k;
+  if(rem > 0)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH - 1; ++u)
+    {
+      const int kk = (u < rem) ? (k + u) : (k1 - 1);
+      av[u] = a[kk * sa];
+      bv[u] = b[kk * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH - 1; ++u)
+    {
+      const double nx = FMA(-av[u], bv[u], acc);
+      acc = (u < rem) ? nx : acc;
+    }
+  }
   return acc;
 }
 
@@ -307,8 +363,24 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 #pragma unroll
     for(int u = 0; u < CH; ++u) acc = FMA(-av[u], bv[u], acc);
   }
-#pragma unroll 1
-  for(; k >= k0; --k) acc = FMA(-a[k * sa], b[k * sb], acc);
+  const int rem = k - k0 + 1; // < CH
+  if(rem > 0)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH - 1; ++u)
+    {
+      const int kk = (u < rem) ? (k - u) : k0;
+      av[u] = a[kk * sa];
+      bv[u] = b[kk * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH - 1; ++u)
+    {
+      const double nx = FMA(-av[u], bv[u], acc);
+      acc = (u < rem) ? nx : acc;
+    }
+  }
   return acc;
 }
 
@@ -319,7 +391,7 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
   if(PROF && tid == 0)                               \
   {                                                  \
     long long now_ = clock64();                      \
-    A.prof[(size_t)b * 16 + (slot)] += now_ - last_; \
+    A.prof[(size_t)b * 32 + (slot)] += now_ - last_; \
     last_ = now_;                                    \
   }
 
@@ -417,36 +489,21 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     {
       double acc = 0.0;
       // ascending k (CANON C1): acc = G_ij - sum_{k<j} L_ik L_jk
-      if(lane >= j && lane < n)
-      {
-        acc = L[lane + j * ld];
-        int k = 0;
-        for(; k + 8 <= j; k += 8)
-        {
-          double av[8], bv[8];
-#pragma unroll
-          for(int u = 0; u < 8; ++u)
-          {
-            av[u] = L[lane + (k + u) * ld];
-            bv[u] = L[j + (k + u) * ld];
-          }
-#pragma unroll
-          for(int u = 0; u < 8; ++u) acc = FMA(-av[u], bv[u], acc);
-        }
-        for(; k < j; ++k) acc = FMA(-L[lane + k * ld], L[j + k * ld], acc);
-      }
+      if(lane >= j && lane < n) acc = chain_up_neg(L + lane, ld, L + j, ld, 0, j, L[lane + j * ld]);
+      STAMP(18)
       double piv = bcast_lane(acc, j);
       if(piv <= 0.0)
       {
         info = j;
         break;
       }
-      double ljj = __builtin_sqrt(piv);
+      double ljj = __builtin_sqrt(opaque_v(piv));
       if(lane == j)
         L[j + j * ld] = ljj;
       else if(lane > j && lane < n)
         L[lane + j * ld] = acc / ljj;
       wave_sync();
+      STAMP(19)
     }
     if(lane == 0) ctl->info = info;
   }
@@ -526,29 +583,29 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     }
     else if(wave == 0)
     {
+      const int rl = (lane < n) ? lane : 0;
       double xi = (lane < n) ? ag[lane] : 0.0;
       const double ai = xi;
-      const double dg = (lane < n) ? L[lane + lane * ld] : 1.0;
-      double col = (lane > 0 && lane < n) ? L[lane] : 0.0; // column 0
-      for(int k = 0; k < n; ++k) // x = L.solve(a)
+      double dg = L[rl + rl * ld];
+      dg = (lane < n) ? dg : 1.0;
+      double col = L[rl]; // column 0
+      for(int k = 0; k < n; ++k) // x = L.solve(a), branch-free body
       {
-        double coln = (k + 1 < n && lane > k + 1 && lane < n) ? L[lane + (k + 1) * ld] : 0.0;
-        double v = bcast_lane(xi, k) / bcast_lane(dg, k);
-        if(lane == k)
-          xi = v;
-        else if(lane > k && lane < n)
-          xi = FMA(-col, v, xi);
+        const double coln = L[rl + ((k + 1 < n) ? (k + 1) : k) * ld];
+        const double v = opaque_v(bcast_lane(xi, k)) / opaque_v(bcast_lane(dg, k));
+        const double upd = FMA(-col, v, xi);
+        xi = (lane > k && lane < n) ? upd : xi;
+        xi = (lane == k) ? v : xi;
         col = coln;
       }
-      col = (lane < n - 1) ? L[(n - 1) + lane * ld] : 0.0; // row n-1 of L = column n-1 of L^T
+      col = L[(n - 1) + rl * ld]; // row n-1 of L = column n-1 of L^T
       for(int k = n - 1; k >= 0; --k) // L^T.solveInPlace(x)
       {
-        double coln = (k > 0 && lane < k - 1) ? L[(k - 1) + lane * ld] : 0.0;
-        double v = bcast_lane(xi, k) / bcast_lane(dg, k);
-        if(lane == k)
-          xi = v;
-        else if(lane < k)
-          xi = FMA(-col, v, xi);
+        const double coln = L[((k > 0) ? (k - 1) : 0) + rl * ld];
+        const double v = opaque_v(bcast_lane(xi, k)) / opaque_v(bcast_lane(dg, k));
+        const double upd = FMA(-col, v, xi);
+        xi = (lane < k) ? upd : xi;
+        xi = (lane == k) ? v : xi;
         col = coln;
       }
       xi = -xi;
@@ -732,22 +789,26 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
       }
     };
 
-    // K7 + ratio test (wave 0)
+    // K7 + ratio test (wave 0).  The loop body is branch-free on purpose: conditional LDS loads make hipcc wait
+    // with lgkmcnt(0) right after issuing the prefetch (measured 267 cycles per step instead of ~130).
     auto trsv_ratio = [&]() {
-      double rk = (lane < q) ? ds[lane] : 0.0;
-      const double dg = (lane < q) ? R[lane + lane * ld] : 1.0;
-      double col = (q > 0 && lane < q - 1) ? R[lane + (q - 1) * ld] : 0.0;
+      const int rl = (lane < n) ? lane : 0;
+      double rk = ds[rl];
+      rk = (lane < q) ? rk : 0.0;
+      double dg = R[rl + rl * ld];
+      dg = (lane < q) ? dg : 1.0;
+      double col = R[rl + ((q > 0) ? (q - 1) : 0) * ld];
       for(int k = q - 1; k >= 0; --k)
       {
-        double coln = (k > 0 && lane < k - 1) ? R[lane + (k - 1) * ld] : 0.0; // prefetch the next column
-        double v = bcast_lane(rk, k) / bcast_lane(dg, k);
-        if(lane == k)
-          rk = v;
-        else if(lane < k)
-          rk = FMA(-col, v, rk);
+        const double coln = R[rl + ((k > 0) ? (k - 1) : 0) * ld]; // prefetch the next column (always a valid address)
+        const double v = opaque_v(bcast_lane(rk, k)) / opaque_v(bcast_lane(dg, k));
+        const double upd = FMA(-col, v, rk);
+        rk = (lane < k) ? upd : rk;
+        rk = (lane == k) ? v : rk;
         col = coln;
       }
       if(lane < q) rs[lane] = rk;
+      STAMP(16)
       // t1 = min u_k / r_k over r_k > 0 (not EQUALITY/FIXED; status looked up by POSITION, GoldfarbIdnaniSolver.cpp:162)
       double tk = big;
       int kk = NONE, dummy = 0;
@@ -770,33 +831,32 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
         ctl->t1 = (kk == NONE) ? big : tk;
         ctl->l = (kk == NONE) ? 0 : kk;
       }
+      STAMP(17)
     };
 
-    // K6 + the three scalar products of K8 (wave 1)
+    // K6 + the scalar products of K8: wave 1 computes z, then z.z and c_p.z in two lanes; wave 2 computes c_p.x
+    // (which does not need z) at the same time
     auto z_and_dots = [&](int pp) {
       const bool general = pp < m;
+      if(wave == 2)
+      {
+        if(lane == 0) ctl->cx = general ? chain_up(np_ptr(pp), 1, xs, 1, 0, n, 0.0) : xs[pp - m];
+        return;
+      }
       if(lane < n) zs[lane] = chain_up(J + lane, ld, ds, 1, q, n, 0.0);
       wave_sync();
-      if(lane < 3)
+      if(lane < 2)
       {
         double acc;
-        if(general)
+        if(general || lane == 0)
         {
-          const double * cp = np_ptr(pp);
-          const double * pa = (lane == 0) ? zs : cp;
-          const double * pv = (lane == 2) ? xs : zs;
-          acc = chain_up(pa, 1, pv, 1, 0, n, 0.0);
+          const double * pa = (lane == 0) ? zs : np_ptr(pp);
+          acc = chain_up(pa, 1, zs, 1, 0, n, 0.0);
         }
         else
-        {
-          if(lane == 0)
-            acc = chain_up(zs, 1, zs, 1, 0, n, 0.0);
-          else
-            acc = (lane == 1) ? zs[pp - m] : xs[pp - m];
-        }
+          acc = zs[pp - m];
         if(lane == 0) ctl->zz = acc;
         if(lane == 1) ctl->cz = acc;
-        if(lane == 2) ctl->cx = acc;
       }
     };
 
@@ -971,7 +1031,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           __syncthreads();
           if(wave == 0)
             trsv_ratio();
-          else if(wave == 1)
+          else if(wave <= 2)
             z_and_dots(p);
           __syncthreads();
           // addInitialConstraint (GoldfarbIdnaniSolver.cpp:295-338): full step, no ratio test
@@ -1023,12 +1083,14 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           // ---- selected constraint (p, pstat): n+ to LDS, u[q] = 0 only when it was freshly selected
           // (callers below take care of u[q]); K5
           __syncthreads();
+          STAMP(20)
           if(wave == 0) compute_d(p, pstat);
+          STAMP(21)
           __syncthreads();
           STAMP(4)
           if(wave == 0)
             trsv_ratio();
-          else if(wave == 1)
+          else if(wave <= 2)
             z_and_dots(p);
           __syncthreads();
           STAMP(5)
@@ -1091,7 +1153,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
             scan_local(p, bv, bi, bs); // p is treated as active (wave 0 has it in st[] by now, the others exclude it)
             scan_publish(bv, bi, bs);
             STAMP(15)
-            if(wave == 0 && PROF && tid == 0) A.prof[(size_t)b * 16 + 10] += 1;
+            if(wave == 0 && PROF && tid == 0) A.prof[(size_t)b * 32 + 10] += 1;
             __syncthreads();
             STAMP(7)
             if(it >= A.max_iter)
@@ -1109,7 +1171,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
             if(wave == 0) do_drop(l);
             q = uniform(q - 1);
             ++it;
-            if(PROF && tid == 0) A.prof[(size_t)b * 16 + 11] += 1;
+            if(PROF && tid == 0) A.prof[(size_t)b * 32 + 11] += 1;
             STAMP(8)
             if(it >= A.max_iter)
             {
@@ -1147,7 +1209,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     A.f[b] = ctl->f;
   }
   STAMP(9)
-  if(PROF && tid == 0) A.prof[(size_t)b * 16 + 12] += wall_clock64() - wall0_;
+  if(PROF && tid == 0) A.prof[(size_t)b * 32 + 12] += wall_clock64() - wall0_;
 }
 
 template<int NT, int CMODE, bool PROF>

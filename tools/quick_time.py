@@ -28,13 +28,14 @@ it = r.iters.cpu().numpy()
 print(f"B={B} n={n} m={m}: {ms:.3f} ms  -> {B / ms * 1e3:.0f} solves/s ; mean iters {it.mean():.2f}; term ok {int((r.term == 0).sum())}/{B}")
 print("all times ms", ts)
 # ---- phase profile (diagnostic build)
-prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
+prof = torch.zeros((B, 32), dtype=torch.int64, device="cuda")
 capi.load_library().jrlqp_debug_set_profile(prof.data_ptr())
 s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"]); torch.cuda.synchronize()
 capi.load_library().jrlqp_debug_set_profile(None)
 pr = prof.cpu().numpy().astype(np.float64)
-names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)", "add:chain", "add:cs+apply", "add:wave0 scan"]
-tot = pr[:, :10].sum(axis=1) + pr[:, 13:16].sum(axis=1)
+names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)", "add:chain", "add:cs+apply", "add:wave0 scan", "trsv loop", "ratio", "llt chain", "llt pivot", "combine+np+barrier", "compute_d", "", "", "", "", "", "", "", "", "", ""]
+tot = pr[:, :10].sum(axis=1) + pr[:, 13:32].sum(axis=1)
 print("mean cycles per solve", tot.mean(), " mean realtime us", pr[:, 12].mean() / 100.0, " => clock GHz", tot.mean() / (pr[:, 12].mean() / 100.0) / 1e3)
 for i, nm in enumerate(names):
+    if nm == '': continue
     print(f"  {nm:18s} {pr[:, i].mean():12.1f}  ({100 * pr[:, i].mean() / tot.mean():5.1f} %)")
