@@ -134,6 +134,36 @@ int jrlqp_gi_solve_batch(int n,
 long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_placement);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Structured Cholesky family.  Replaces (include/jrl-qp/decomposition/blockArrowLLT.h:70-110, triBlockDiagLLT.h:41-72):
+ *     bool blockArrowLLT(diag, side, up);            void blockArrowLSolve(diag, side, up, M, start, end);
+ *     void blockArrowLTransposeSolve(diag, side, up, M, start, end);
+ *     bool triBlockDiagLLT(diag, subDiag);           void triBlockDiagLSolve(diag, subDiag, M, start);
+ *     void triBlockDiagLTransposeSolve(diag, subDiag, M, end);
+ * The reference passes std::vector<Eigen::Ref<MatrixXd>> views into caller-owned storage; here a PLAN object holds
+ * the same list as device pointers + leading dimensions (one list per problem of a batch of identically shaped
+ * problems), so that the compute calls allocate nothing.  Blocks stay in caller-owned device memory and are factored
+ * in place exactly like the reference does (diag[i] lower triangle <- L_i, side[i] <- B_i or B_i^T).
+ *   kind: 0 = block arrow pointing down (up = false), 1 = block arrow pointing up (up = true), 2 = block tridiagonal
+ *   block_sizes[nblk] (host); every block <= JRLQP_BLOCK_MAX rows (one wavefront, row per lane).
+ *   side block i: kind 0: n_last x n_i; kind 1: n_{i+1} x n_0; kind 2: n_{i+1} x n_i.
+ */
+#define JRLQP_BLOCK_MAX 64
+typedef struct jrlqp_blocks jrlqp_blocks;
+int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, int max_nrhs, jrlqp_blocks ** out);
+void jrlqp_blocks_destroy(jrlqp_blocks * plan);
+/* ddiag: host array [nprob*nblk] of device pointers (problem-major), ldd[nblk]; dside: [nprob*(nblk-1)], lds[nblk-1] */
+int jrlqp_blocks_bind(jrlqp_blocks * plan, double * const * ddiag, const int * ldd, double * const * dside, const int * lds, void * stream);
+/* the factorisation (asynchronous).  Failure semantics are the reference's, including its `ret > 0` quirk
+ * (blockArrowLLT.cpp:65, triBlockDiagLLT.cpp:19): query them with jrlqp_blocks_result. */
+int jrlqp_blocks_llt(jrlqp_blocks * plan, void * stream);
+/* synchronises the stream and writes the bool the reference returns, one per problem (1 = success) */
+int jrlqp_blocks_result(jrlqp_blocks * plan, int * ok_host, void * stream);
+/* in-place solve  P L X = M (transpose = 0)  or  L^T P^T X = M (transpose = 1); dM: device, N x nrhs column-major with
+ * leading dimension ldm, problem b at dM + b*mstride.  start/end: first non-zero row / first row of the trailing zero
+ * block (end < 0: none) -- the reference's zero-window arguments (tri-diagonal: start for L, end for L^T). */
+int jrlqp_blocks_solve(jrlqp_blocks * plan, int transpose, double * dM, int ldm, long mstride, int nrhs, int start, int end, void * stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Self-tests of the arithmetic contract (no reference counterpart; used by tests/ to prove that device /, sqrt,
  * fma and the Givens generator are bit-identical to the host's IEEE-754 results, and to pin the accumulation
  * order of v_mfma_f64_16x16x4_f64).  Arrays of n doubles on the device:

@@ -25,6 +25,12 @@ EXPORTED = [
     "jrlqp_default_options",
     "jrlqp_gi_solve_batch",
     "jrlqp_gi_batch_lds_bytes",
+    "jrlqp_blocks_create",
+    "jrlqp_blocks_destroy",
+    "jrlqp_blocks_bind",
+    "jrlqp_blocks_llt",
+    "jrlqp_blocks_result",
+    "jrlqp_blocks_solve",
     "jrlqp_debug_set_profile",
     "jrlqp_selftest_arith",
     "jrlqp_selftest_mfma_f64",
@@ -72,6 +78,18 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_gi_batch_lds_bytes.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_int)]
     lib.jrlqp_gi_solve_batch.restype = ct.c_int
     lib.jrlqp_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 7 + [ct.POINTER(Options)] + [c_dp] * 8 + [ct.c_int, c_dp]
+    lib.jrlqp_blocks_create.restype = ct.c_int
+    lib.jrlqp_blocks_create.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_int), ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p)]
+    lib.jrlqp_blocks_destroy.restype = None
+    lib.jrlqp_blocks_destroy.argtypes = [ct.c_void_p]
+    lib.jrlqp_blocks_bind.restype = ct.c_int
+    lib.jrlqp_blocks_bind.argtypes = [ct.c_void_p, ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_int), ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_int), c_dp]
+    lib.jrlqp_blocks_llt.restype = ct.c_int
+    lib.jrlqp_blocks_llt.argtypes = [ct.c_void_p, c_dp]
+    lib.jrlqp_blocks_result.restype = ct.c_int
+    lib.jrlqp_blocks_result.argtypes = [ct.c_void_p, ct.POINTER(ct.c_int), c_dp]
+    lib.jrlqp_blocks_solve.restype = ct.c_int
+    lib.jrlqp_blocks_solve.argtypes = [ct.c_void_p, ct.c_int, c_dp, ct.c_int, ct.c_long, ct.c_int, ct.c_int, ct.c_int, c_dp]
     lib.jrlqp_debug_set_profile.restype = ct.c_int
     lib.jrlqp_debug_set_profile.argtypes = [c_dp]
     lib.jrlqp_selftest_arith.restype = ct.c_int
@@ -160,6 +178,84 @@ class BatchSolver:
         raw = self.trace.cpu().numpy()
         dt = np.dtype([("p", "<i4"), ("status", "<i4"), ("l", "<i4"), ("kind", "<i4"), ("t1", "<f8"), ("t2", "<f8")])
         return raw.view(dt).reshape(self.B, self.trace_cap)
+
+
+class StructuredBlocks:
+    """Plan for the structured Cholesky family over `nprob` identically shaped problems stored as dense (N, N)
+    column-major matrices on the device (the usual case in the reference's tests: blocks are views into one big
+    matrix, tests/blockArrowLLTTest.cpp:46-47).  kind: "arrow_down", "arrow_up" or "tridiag".
+
+    H: float64 CUDA tensor of shape (nprob, N, N) holding each problem TRANSPOSED w.r.t. torch's row-major view,
+    i.e. H[b].T is the matrix (so that the memory is column-major with leading dimension N)."""
+
+    KINDS = {"arrow_down": 0, "arrow_up": 1, "tridiag": 2}
+
+    def __init__(self, kind, block_sizes, H, max_nrhs=8):
+        import torch
+
+        self.lib = load_library()
+        self.kind = self.KINDS[kind]
+        self.bs = [int(b) for b in block_sizes]
+        self.nblk = len(self.bs)
+        self.N = sum(self.bs)
+        assert H.is_cuda and H.dtype == torch.float64 and H.is_contiguous() and H.shape[1:] == (self.N, self.N)
+        self.H = H
+        self.nprob = H.shape[0]
+        self.max_nrhs = max_nrhs
+        h = ct.c_void_p()
+        arr = (ct.c_int * self.nblk)(*self.bs)
+        check(self.lib.jrlqp_blocks_create(self.kind, self.nblk, arr, self.nprob, max_nrhs, ct.byref(h)))
+        self.h = h
+        off = [0]
+        for b in self.bs:
+            off.append(off[-1] + b)
+        N, base, esz = self.N, H.data_ptr(), 8
+        diag, side = [], []
+        for p in range(self.nprob):
+            pbase = base + p * N * N * esz
+            for i in range(self.nblk):
+                diag.append(pbase + (off[i] + off[i] * N) * esz)  # element (off_i, off_i), column-major
+            for i in range(self.nblk - 1):
+                if self.kind == 0:  # last block row: rows off[-2].., columns off[i]..
+                    r, c = off[self.nblk - 1], off[i]
+                elif self.kind == 1:  # first block column: rows off[i+1].., columns 0..
+                    r, c = off[i + 1], 0
+                else:  # sub-diagonal: rows off[i+1].., columns off[i]..
+                    r, c = off[i + 1], off[i]
+                side.append(pbase + (r + c * N) * esz)
+        ns = max(self.nblk - 1, 1)
+        dptr = (ct.c_void_p * len(diag))(*diag)
+        sptr = (ct.c_void_p * max(len(side), 1))(*side) if side else (ct.c_void_p * 1)()
+        ldd = (ct.c_int * self.nblk)(*([N] * self.nblk))
+        lds = (ct.c_int * ns)(*([N] * ns))
+        check(self.lib.jrlqp_blocks_bind(self.h, dptr, ldd, sptr, lds, self._stream()))
+
+    def _stream(self):
+        import torch
+
+        return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def llt(self):
+        """In-place factorisation; returns a list of bools (the reference's return value, one per problem)."""
+        check(self.lib.jrlqp_blocks_llt(self.h, self._stream()))
+        ok = (ct.c_int * self.nprob)()
+        check(self.lib.jrlqp_blocks_result(self.h, ok, self._stream()))
+        return [bool(v) for v in ok]
+
+    def solve(self, M, transpose=False, start=0, end=-1):
+        """M: float64 CUDA tensor (nprob, nrhs, N): M[b].T is the N x nrhs right-hand side; solved in place."""
+        assert M.is_cuda and M.is_contiguous() and M.shape[0] == self.nprob and M.shape[2] == self.N
+        nrhs = M.shape[1]
+        check(self.lib.jrlqp_blocks_solve(self.h, int(transpose), _ptr(M), self.N, nrhs * self.N, nrhs, start, end, self._stream()))
+        return M
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jrlqp_blocks_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 def selftest_arith(a, b, c):

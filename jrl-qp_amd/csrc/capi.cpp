@@ -6,6 +6,10 @@
 #include "../../include/jrlqp_hip.h"
 #include "gi_batch.h"
 #include "selftest.h"
+#include "structured.h"
+
+#include <new>
+#include <vector>
 
 namespace
 {
@@ -18,6 +22,19 @@ int hip_fail(hipError_t e)
   return JRLQP_ERR_HIP;
 }
 } // namespace
+
+// plan object of the structured family: owns the device-side block descriptors, the failure flags and the scratch
+// used by the up-arrow row permutation, so that factorisations and solves allocate nothing
+struct jrlqp_blocks
+{
+  int kind = 0, nblk = 0, nprob = 0, max_nrhs = 0, maxb = 0, ntot = 0;
+  std::vector<int> h_bs, h_ldd, h_lds;
+  std::vector<double *> h_diag, h_side;
+  int *d_bs = nullptr, *d_ldd = nullptr, *d_lds = nullptr, *d_fail = nullptr;
+  double **d_diag = nullptr, **d_side = nullptr;
+  double * d_tmp = nullptr;
+  bool bound = false;
+};
 
 extern "C" {
 
@@ -120,6 +137,120 @@ int jrlqp_gi_solve_batch(int n,
   hipError_t e = jrlqp::launch_gi_batch(a, cmode, static_cast<hipStream_t>(stream));
   if(e != hipSuccess) return hip_fail(e);
   return JRLQP_OK;
+}
+
+#define HIP_TRY(x)                      \
+  do                                    \
+  {                                     \
+    hipError_t e_ = (x);                \
+    if(e_ != hipSuccess) return hip_fail(e_); \
+  } while(0)
+
+int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, int max_nrhs, jrlqp_blocks ** out)
+{
+  if(!out || !block_sizes || kind < 0 || kind > 2 || nblk < 1 || nprob < 1 || max_nrhs < 1) return JRLQP_ERR_INVALID_ARGUMENT;
+  int maxb = 0, ntot = 0;
+  for(int i = 0; i < nblk; ++i)
+  {
+    if(block_sizes[i] < 1) return JRLQP_ERR_INVALID_ARGUMENT;
+    if(block_sizes[i] > JRLQP_BLOCK_MAX) return JRLQP_ERR_UNSUPPORTED_SIZE;
+    maxb = block_sizes[i] > maxb ? block_sizes[i] : maxb;
+    ntot += block_sizes[i];
+  }
+  jrlqp_blocks * p = new(std::nothrow) jrlqp_blocks;
+  if(!p) return JRLQP_ERR_WORKSPACE;
+  p->kind = kind; p->nblk = nblk; p->nprob = nprob; p->max_nrhs = max_nrhs; p->maxb = maxb; p->ntot = ntot;
+  p->h_bs.assign(block_sizes, block_sizes + nblk);
+  const int ns = nblk > 1 ? nblk - 1 : 1;
+  hipError_t e = hipMalloc(&p->d_bs, sizeof(int) * nblk);
+  if(e == hipSuccess) e = hipMalloc(&p->d_ldd, sizeof(int) * nblk);
+  if(e == hipSuccess) e = hipMalloc(&p->d_lds, sizeof(int) * ns);
+  if(e == hipSuccess) e = hipMalloc(&p->d_fail, sizeof(int) * nprob);
+  if(e == hipSuccess) e = hipMalloc(&p->d_diag, sizeof(double *) * (size_t)nprob * nblk);
+  if(e == hipSuccess) e = hipMalloc(&p->d_side, sizeof(double *) * (size_t)nprob * ns);
+  if(e == hipSuccess) e = hipMalloc(&p->d_tmp, sizeof(double) * (size_t)nprob * ntot * max_nrhs);
+  if(e == hipSuccess) e = hipMemcpy(p->d_bs, block_sizes, sizeof(int) * nblk, hipMemcpyHostToDevice);
+  if(e != hipSuccess)
+  {
+    jrlqp_blocks_destroy(p);
+    return hip_fail(e);
+  }
+  *out = p;
+  return JRLQP_OK;
+}
+
+void jrlqp_blocks_destroy(jrlqp_blocks * p)
+{
+  if(!p) return;
+  (void)hipFree(p->d_bs); (void)hipFree(p->d_ldd); (void)hipFree(p->d_lds); (void)hipFree(p->d_fail);
+  (void)hipFree(p->d_diag); (void)hipFree(p->d_side); (void)hipFree(p->d_tmp);
+  delete p;
+}
+
+int jrlqp_blocks_bind(jrlqp_blocks * p, double * const * ddiag, const int * ldd, double * const * dside, const int * lds, void * stream)
+{
+  if(!p || !ddiag || !ldd || (p->nblk > 1 && (!dside || !lds))) return JRLQP_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ns = p->nblk - 1;
+  for(int i = 0; i < p->nblk; ++i)
+    if(ldd[i] < p->h_bs[i]) return JRLQP_ERR_INVALID_ARGUMENT;
+  p->h_ldd.assign(ldd, ldd + p->nblk);
+  p->h_lds.assign(lds ? lds : ldd, (lds ? lds : ldd) + (ns > 0 ? ns : 0));
+  p->h_diag.assign(ddiag, ddiag + (size_t)p->nprob * p->nblk);
+  if(ns > 0) p->h_side.assign(dside, dside + (size_t)p->nprob * ns);
+  HIP_TRY(hipMemcpyAsync(p->d_ldd, p->h_ldd.data(), sizeof(int) * p->nblk, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->d_diag, p->h_diag.data(), sizeof(double *) * p->h_diag.size(), hipMemcpyHostToDevice, st));
+  if(ns > 0)
+  {
+    HIP_TRY(hipMemcpyAsync(p->d_lds, p->h_lds.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_side, p->h_side.data(), sizeof(double *) * p->h_side.size(), hipMemcpyHostToDevice, st));
+  }
+  p->bound = true;
+  return JRLQP_OK;
+}
+
+static jrlqp::BlockDesc make_desc(const jrlqp_blocks * p, long mstride)
+{
+  jrlqp::BlockDesc d;
+  d.nblk = p->nblk;
+  d.up = (p->kind == 1) ? 1 : 0;
+  d.mstride = mstride;
+  d.bs = p->d_bs; d.ldd = p->d_ldd; d.lds = p->d_lds;
+  d.diag = p->d_diag; d.side = p->d_side; d.fail = p->d_fail;
+  d.h_bs = p->h_bs.data();
+  return d;
+}
+
+int jrlqp_blocks_llt(jrlqp_blocks * p, void * stream)
+{
+  if(!p || !p->bound) return JRLQP_ERR_INVALID_ARGUMENT;
+  jrlqp::BlockDesc d = make_desc(p, 0);
+  hipError_t e = (p->kind == 2) ? jrlqp::launch_tri_llt(d, p->nprob, p->maxb, static_cast<hipStream_t>(stream))
+                                : jrlqp::launch_block_arrow_llt(d, p->nprob, p->maxb, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? JRLQP_OK : hip_fail(e);
+}
+
+int jrlqp_blocks_result(jrlqp_blocks * p, int * ok_host, void * stream)
+{
+  if(!p || !ok_host) return JRLQP_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(ok_host, p->d_fail, sizeof(int) * p->nprob, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for(int i = 0; i < p->nprob; ++i) ok_host[i] = ok_host[i] ? 0 : 1;
+  return JRLQP_OK;
+}
+
+int jrlqp_blocks_solve(jrlqp_blocks * p, int transpose, double * dM, int ldm, long mstride, int nrhs, int start, int end, void * stream)
+{
+  if(!p || !p->bound || !dM || nrhs < 1 || nrhs > p->max_nrhs || ldm < p->ntot) return JRLQP_ERR_INVALID_ARGUMENT;
+  jrlqp::BlockDesc d = make_desc(p, mstride);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if(p->kind == 2)
+    e = jrlqp::launch_tri_solve(d, p->nprob, transpose != 0, dM, ldm, nrhs, transpose ? end : start, st);
+  else
+    e = jrlqp::launch_block_arrow_solve(d, p->nprob, transpose != 0, dM, ldm, nrhs, start, end, p->d_tmp, st);
+  return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }
 
 int jrlqp_debug_set_profile(long long * dprof)

@@ -1,0 +1,27 @@
+// structured.h -- launch interface of the structured Cholesky family (internal to libjrlqp_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace jrlqp
+{
+struct BlockDesc
+{
+  int nblk;
+  int up;          // block arrow pointing up (get<true> of blockArrowLLT.cpp:36-46)
+  long mstride;    // doubles between the right-hand sides of consecutive problems of a batch
+  const int * bs;  // [nblk]   block sizes (device)
+  const int * ldd; // [nblk]   leading dimensions of the diagonal blocks (device)
+  const int * lds; // [nblk-1] leading dimensions of the side / sub-diagonal blocks (device)
+  double ** diag;  // [nprob*nblk]     device pointers
+  double ** side;  // [nprob*(nblk-1)] device pointers
+  int * fail;      // [nprob] set to 1 when a factorisation fails
+  const int * h_bs; // host copy of bs (launch helpers only)
+};
+
+hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st);
+hipError_t launch_block_arrow_solve(const BlockDesc & d, int nprob, bool transpose, double * M, int ldm, int nrhs, int start,
+                                    int end, double * tmp, hipStream_t st);
+hipError_t launch_tri_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st);
+hipError_t launch_tri_solve(const BlockDesc & d, int nprob, bool transpose, double * M, int ldm, int nrhs, int start_or_end,
+                            hipStream_t st);
+} // namespace jrlqp

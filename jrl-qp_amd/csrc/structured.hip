@@ -1,0 +1,578 @@
+// structured.hip -- second kernel family: Cholesky factorisation and triangular solves of block-arrow and
+// block-tridiagonal SPD matrices given as lists of diagonal / off-diagonal blocks (gfx950).
+//
+//   reference (jrl-umi3218/jrl-qp):
+//     blockArrowLLT_              src/decomposition/blockArrowLLT.cpp:53-81
+//     blockArrowLSolve(_)         :92-176      blockArrowLTransposeSolve(_)  :179-277
+//     triBlockDiagLLT             src/decomposition/triBlockDiagLLT.cpp:9-35
+//     triBlockDiagLSolve          :37-96       triBlockDiagLTransposeSolve   :98-158
+//
+// Parallel structure: the b-1 off-head blocks of an arrow matrix are independent
+// (one workgroup each: LLT of D_i, B_i = S_i L_i^-T); the head block receives  D_b -= sum_i B_i B_i^T  -- under
+// the CANON rounding contract each ELEMENT of D_b owns one in-order fma chain over all blocks (that is what
+// makes the result bit-identical to the sequential reference order), so the head kernel gives one thread per
+// element and walks the blocks; the block-tridiagonal chain is inherently serial across blocks and runs in one
+// workgroup (parallelism comes from batching problems: grid.x = number of problems).
+//
+// Blocks are at most 64 x 64 (one wavefront row-per-lane); the substitutions keep the running column in
+// registers and move pivots with v_readlane, like the dense kernel.  -ffp-contract=off; every fma explicit.
+#include <hip/hip_runtime.h>
+
+#include "structured.h"
+
+namespace jrlqp
+{
+namespace
+{
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define AT(P, ld, i, j) (P)[(i) + (size_t)(j) * (ld)]
+
+__device__ __forceinline__ double bcast_lane(double v, int src)
+{
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- wave-level primitives on a block held in LDS (ld odd => conflict-free row-per-lane access) -----------
+// in-place lower Cholesky, lane = row; returns -1 or the failing column (Eigen llt_inplace semantics)
+__device__ int wave_llt(double * L, int ld, int n, int lane)
+{
+  for(int j = 0; j < n; ++j)
+  {
+    double acc = 0.0;
+    if(lane >= j && lane < n)
+    {
+      acc = AT(L, ld, lane, j);
+      for(int k = 0; k < j; ++k) acc = FMA(-AT(L, ld, lane, k), AT(L, ld, j, k), acc);
+    }
+    double piv = bcast_lane(acc, j);
+    if(piv <= 0.0) return j;
+    double ljj = __builtin_sqrt(piv);
+    if(lane == j)
+      AT(L, ld, j, j) = ljj;
+    else if(lane > j && lane < n)
+      AT(L, ld, lane, j) = acc / ljj;
+    wave_sync();
+  }
+  return -1;
+}
+
+// X (r x n, r <= 64) <- X L^-T : lane = row of X; column j becomes available in increasing j
+__device__ void wave_trsm_right_lt(const double * L, int ldl, int n, double * X, int ldx, int r, int lane)
+{
+  if(lane < r)
+    for(int j = 0; j < n; ++j)
+    {
+      double s = AT(X, ldx, lane, j);
+      for(int k = 0; k < j; ++k) s = FMA(-AT(X, ldx, lane, k), AT(L, ldl, j, k), s);
+      AT(X, ldx, lane, j) = s / AT(L, ldl, j, j);
+    }
+}
+
+// x (n) <- L^-1 x for one right-hand side held one element per lane (forward substitution, column oriented)
+__device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, double xi, int lane)
+{
+  for(int k = 0; k < n; ++k)
+  {
+    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
+    if(lane == k)
+      xi = v;
+    else if(lane > k && lane < n)
+      xi = FMA(-AT(L, ldl, lane, k), v, xi);
+  }
+  return xi;
+}
+// x <- L^-T x (backward substitution)
+__device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, double xi, int lane)
+{
+  for(int k = n - 1; k >= 0; --k)
+  {
+    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
+    if(lane == k)
+      xi = v;
+    else if(lane < k)
+      xi = FMA(-AT(L, ldl, k, lane), v, xi);
+  }
+  return xi;
+}
+
+__device__ __forceinline__ void load_block(double * dst, int ldd, const double * src, int lds_, int rows, int cols, int tid, int nthr)
+{
+  for(int e = tid; e < rows * cols; e += nthr)
+  {
+    int i = e % rows, j = e / rows;
+    AT(dst, ldd, i, j) = AT(src, lds_, i, j);
+  }
+}
+
+// logical diagonal block i of get<Up> (blockArrowLLT.cpp:22-46)
+__device__ __forceinline__ int dsel(int nblk, int up, int i)
+{
+  return up ? (i + 1) % nblk : i;
+}
+
+// =========================================================================================================
+// block arrow LLT, phase 1: one workgroup (one wave) per off-head block
+// =========================================================================================================
+__global__ __launch_bounds__(64) void arrow_block_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x; // logical block index < nblk - 1
+  const int pb = blockIdx.y; // problem in the batch
+  const int id = dsel(D.nblk, D.up, i), ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int ni = D.bs[id], nbk = D.bs[ib];
+  double * Dg = D.diag[(size_t)pb * D.nblk + id];
+  double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+  const int ldd = D.ldd[id], ldsg = D.lds[i];
+  const int ldl = ni | 1;
+  double * Ls = sm;
+  load_block(Ls, ldl, Dg, ldd, ni, ni, lane, 64);
+  wave_sync();
+  int ret = wave_llt(Ls, ldl, ni, lane);
+  if(ret > 0) // reference quirk: a failure at column 0 goes undetected (blockArrowLLT.cpp:65)
+  {
+    if(lane == 0) atomicExch(&D.fail[pb], 1);
+  }
+  // write the factor back (lower triangle only)
+  for(int e = lane; e < ni * ni; e += 64)
+  {
+    int r = e % ni, c = e / ni;
+    if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+  }
+  if(ret > 0) return;
+  if(!D.up)
+  {
+    // side[i] (nbk x ni) <- side[i] L_i^-T   (:71-72)
+    const int ldx = nbk | 1;
+    double * Xs = Ls + (size_t)ni * ldl;
+    load_block(Xs, ldx, Sg, ldsg, nbk, ni, lane, 64);
+    wave_sync();
+    wave_trsm_right_lt(Ls, ldl, ni, Xs, ldx, nbk, lane);
+    wave_sync();
+    for(int e = lane; e < nbk * ni; e += 64) AT(Sg, ldsg, e % nbk, e / nbk) = AT(Xs, ldx, e % nbk, e / nbk);
+  }
+  else
+  {
+    // side[i] (ni x nbk) <- L_i^-1 side[i]; it then stores B_i^T   (:68-70)
+    for(int c = 0; c < nbk; ++c)
+    {
+      double xi = (lane < ni) ? AT(Sg, ldsg, lane, c) : 0.0;
+      xi = wave_fwd(Ls, ldl, ni, xi, lane);
+      if(lane < ni) AT(Sg, ldsg, lane, c) = xi;
+    }
+  }
+}
+
+// =========================================================================================================
+// block arrow LLT, phase 2: head block.  D_b -= sum_i B_i B_i^T (one thread per lower-triangle element, blocks
+// walked in order: one fma chain per element), then LLT(D_b).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void arrow_head_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x;
+  const int pb = blockIdx.x;
+  const int ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int nbk = D.bs[ib];
+  double * Dg = D.diag[(size_t)pb * D.nblk + ib];
+  const int ldd = D.ldd[ib];
+  const int ldl = nbk | 1;
+  double * Ls = sm;
+  if(D.fail[pb]) return; // a block already failed: the reference returns false before touching D_b further
+  for(int e = tid; e < nbk * nbk; e += 256)
+  {
+    int r = e % nbk, c = e / nbk;
+    if(r < c) continue;
+    double acc = AT(Dg, ldd, r, c);
+    for(int i = 0; i < D.nblk - 1; ++i)
+    {
+      const int id = dsel(D.nblk, D.up, i);
+      const int ni = D.bs[id];
+      const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+      const int ldsg = D.lds[i];
+      if(!D.up)
+        for(int k = 0; k < ni; ++k) acc = FMA(-AT(Sg, ldsg, r, k), AT(Sg, ldsg, c, k), acc);
+      else
+        for(int k = 0; k < ni; ++k) acc = FMA(-AT(Sg, ldsg, k, r), AT(Sg, ldsg, k, c), acc);
+    }
+    AT(Ls, ldl, r, c) = acc;
+  }
+  __syncthreads();
+  if(tid < 64)
+  {
+    int ret = wave_llt(Ls, ldl, nbk, tid);
+    if(ret > 0 && tid == 0) atomicExch(&D.fail[pb], 1); // (:80) ret <= 0 is success
+  }
+  __syncthreads();
+  for(int e = tid; e < nbk * nbk; e += 256)
+  {
+    int r = e % nbk, c = e / nbk;
+    if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+  }
+}
+
+// =========================================================================================================
+// block arrow solves.  M is N x nrhs column-major (already permuted for the up variant).
+// =========================================================================================================
+// L X = M, phase 1: X_i = L_i^-1 M_i for the off-head blocks (window [start, end) of non-zero rows, :113-140)
+__global__ __launch_bounds__(64) void arrow_lsolve_blocks_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start, int end)
+{
+  const int lane = threadIdx.x, i = blockIdx.x, pb = blockIdx.y;
+  const int id = dsel(D.nblk, D.up, i);
+  const int ni = D.bs[id];
+  int n0 = 0;
+  for(int k = 0; k < i; ++k) n0 += D.bs[dsel(D.nblk, D.up, k)];
+  int s = max(start - n0, 0);
+  if(ni < s || end <= n0) return; // M_i is zero
+  const double * Dg = D.diag[(size_t)pb * D.nblk + id];
+  const int ldd = D.ldd[id];
+  const double * Lsub = Dg + s + (size_t)s * ldd; // bottomRightCorner(ni - s, ni - s)
+  double * Mp = M + (size_t)pb * D.mstride;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mi = Mp + n0 + s + (size_t)c * ldm;
+    double xi = (lane < ni - s) ? Mi[lane] : 0.0;
+    xi = wave_fwd(Lsub, ldd, ni - s, xi, lane);
+    if(lane < ni - s) Mi[lane] = xi;
+  }
+}
+
+// phase 2: M_b -= sum_i B_i(:, s:) X_i (one thread per (row, rhs) of M_b, blocks in order), then X_b = L_b^-1 M_b
+__global__ __launch_bounds__(64) void arrow_lsolve_head_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start, int end)
+{
+  const int lane = threadIdx.x, pb = blockIdx.x;
+  const int ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int nbk = D.bs[ib];
+  int ntot = 0;
+  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  double * Mp = M + (size_t)pb * D.mstride;
+  const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mb = Mp + (ntot - nbk) + (size_t)c * ldm;
+    double acc = (lane < nbk) ? Mb[lane] : 0.0;
+    int n0 = 0;
+    for(int i = 0; i < D.nblk - 1; ++i)
+    {
+      const int id = dsel(D.nblk, D.up, i);
+      const int ni = D.bs[id];
+      int s = max(start - n0, 0);
+      if(!(ni < s || end <= n0) && lane < nbk)
+      {
+        const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+        const int ldsg = D.lds[i];
+        const double * Xi = Mp + n0 + (size_t)c * ldm;
+        for(int k = s; k < ni; ++k)
+        {
+          double bv = D.up ? AT(Sg, ldsg, k, lane) : AT(Sg, ldsg, lane, k);
+          acc = FMA(-bv, Xi[k], acc);
+        }
+      }
+      n0 += ni;
+    }
+    acc = wave_fwd(Lb, D.ldd[ib], nbk, acc, lane);
+    if(lane < nbk) Mb[lane] = acc;
+  }
+}
+
+// L^T X = M, phase 1: head block X_b = L_b(0:r,0:r)^-T M_b(0:r) when end reaches into it (:203-212)
+__global__ __launch_bounds__(64) void arrow_ltsolve_head_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start, int end)
+{
+  const int lane = threadIdx.x, pb = blockIdx.x;
+  const int ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int nbk = D.bs[ib];
+  int ntot = 0;
+  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  if(!(end > ntot - nbk)) return;
+  const int r = end - ntot + nbk;
+  const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
+  double * Mp = M + (size_t)pb * D.mstride;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mb = Mp + (ntot - nbk) + (size_t)c * ldm;
+    double xi = (lane < r) ? Mb[lane] : 0.0;
+    xi = wave_bwd(Lb, D.ldd[ib], r, xi, lane);
+    if(lane < r) Mb[lane] = xi;
+  }
+}
+
+// phase 2: per off-head block  M_i -= B_i^T X_b (descending k), then L_i^T solve (:217-251)
+__global__ __launch_bounds__(64) void arrow_ltsolve_blocks_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start, int end)
+{
+  const int lane = threadIdx.x, i = blockIdx.x, pb = blockIdx.y;
+  const int ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int nbk = D.bs[ib];
+  int ntot = 0;
+  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const bool zero = !(end > ntot - nbk);
+  const int id = dsel(D.nblk, D.up, i);
+  const int ni = D.bs[id];
+  int n0 = 0;
+  for(int k = 0; k < i; ++k) n0 += D.bs[dsel(D.nblk, D.up, k)];
+  if(zero && start >= n0 + ni) return;
+  const double * Li = D.diag[(size_t)pb * D.nblk + id];
+  const int ldd = D.ldd[id];
+  const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+  const int ldsg = D.lds[i];
+  double * Mp = M + (size_t)pb * D.mstride;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mi = Mp + n0 + (size_t)c * ldm;
+    const double * Xb = Mp + (ntot - nbk) + (size_t)c * ldm;
+    double acc = (lane < ni) ? Mi[lane] : 0.0;
+    if(!zero && lane < ni)
+      for(int k = nbk - 1; k >= 0; --k)
+      {
+        double bv = D.up ? AT(Sg, ldsg, lane, k) : AT(Sg, ldsg, k, lane);
+        acc = FMA(-bv, Xb[k], acc);
+      }
+    if(end >= n0)
+    {
+      const int r = (end >= n0 + ni) ? ni : (end - n0);
+      double solved = wave_bwd(Li, ldd, r, acc, lane);
+      acc = (lane < r) ? solved : acc;
+    }
+    if(lane < ni) Mi[lane] = acc;
+  }
+}
+
+// up-arrow row permutation of the right-hand side (blockArrowLLT.cpp:163-170, :266-271), through a scratch copy
+__global__ void permute_rows_kernel(double * M, int ldm, int nrhs, int ntot, int n0, int backward, double * tmp, long mstride)
+{
+  double * Mp = M + (size_t)blockIdx.y * mstride;
+  double * tp = tmp + (size_t)blockIdx.y * (size_t)ntot * nrhs;
+  const int s = ntot - n0;
+  for(int e = blockIdx.x * blockDim.x + threadIdx.x; e < ntot * nrhs; e += gridDim.x * blockDim.x)
+  {
+    int r = e % ntot, c = e / ntot;
+    tp[e] = Mp[r + (size_t)c * ldm];
+  }
+  __syncthreads(); // single-block launch: gridDim.x == 1
+  for(int e = threadIdx.x; e < ntot * nrhs; e += blockDim.x)
+  {
+    int r = e % ntot, c = e / ntot;
+    int src;
+    if(!backward)
+      src = (r < s) ? (r + n0) : (r - s); // v.top(s) = tmp.bottom(s); v.bottom(n0) = tmp.top(n0)
+    else
+      src = (r < n0) ? (r + s) : (r - n0); // v.bottom(s) = tmp.top(s); v.top(n0) = tmp.bottom(n0)
+    Mp[r + (size_t)c * ldm] = tp[src + (size_t)c * ntot];
+  }
+}
+
+// =========================================================================================================
+// block tridiagonal: serial chain over blocks, one workgroup (one wave) per problem
+// =========================================================================================================
+__global__ __launch_bounds__(64) void tri_llt_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x, pb = blockIdx.x;
+  int maxb = 0;
+  for(int k = 0; k < D.nblk; ++k) maxb = max(maxb, D.bs[k]);
+  const int ldl = maxb | 1;
+  double * Ls = sm;                      // current diagonal block
+  double * Xs = Ls + (size_t)maxb * ldl; // current sub-diagonal block (n_{i+1} x n_i)
+  for(int i = 0; i < D.nblk; ++i)
+  {
+    const int ni = D.bs[i];
+    double * Dg = D.diag[(size_t)pb * D.nblk + i];
+    const int ldd = D.ldd[i];
+    load_block(Ls, ldl, Dg, ldd, ni, ni, lane, 64);
+    wave_sync();
+    int ret = wave_llt(Ls, ldl, ni, lane);
+    for(int e = lane; e < ni * ni; e += 64)
+    {
+      int r = e % ni, c = e / ni;
+      if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+    }
+    if(ret > 0) // triBlockDiagLLT.cpp:19,32
+    {
+      if(lane == 0) D.fail[pb] = 1;
+      return;
+    }
+    if(i == D.nblk - 1) break;
+    const int n1 = D.bs[i + 1];
+    double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+    const int ldsg = D.lds[i];
+    load_block(Xs, ldl, Sg, ldsg, n1, ni, lane, 64);
+    wave_sync();
+    wave_trsm_right_lt(Ls, ldl, ni, Xs, ldl, n1, lane); // S_i <- S_i L_i^-T
+    wave_sync();
+    for(int e = lane; e < n1 * ni; e += 64) AT(Sg, ldsg, e % n1, e / n1) = AT(Xs, ldl, e % n1, e / n1);
+    // D_{i+1} -= S_i S_i^T (lower)
+    double * Dn = D.diag[(size_t)pb * D.nblk + i + 1];
+    const int ldn = D.ldd[i + 1];
+    for(int e = lane; e < n1 * n1; e += 64)
+    {
+      int r = e % n1, c = e / n1;
+      if(r < c) continue;
+      double acc = AT(Dn, ldn, r, c);
+      for(int k = 0; k < ni; ++k) acc = FMA(-AT(Xs, ldl, r, k), AT(Xs, ldl, c, k), acc);
+      AT(Dn, ldn, r, c) = acc;
+    }
+    __threadfence_block();
+    wave_sync();
+  }
+}
+
+// triBlockDiagLSolve (triBlockDiagLLT.cpp:37-96): forward block substitution with the zero-window `start`
+__global__ __launch_bounds__(64) void tri_lsolve_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start)
+{
+  const int lane = threadIdx.x, pb = blockIdx.x;
+  double * Mp = M + (size_t)pb * D.mstride;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mc = Mp + (size_t)c * ldm;
+    int n = 0, l = 0, li = 0;
+    bool zero = true;
+    for(int i = 0; i < D.nblk; ++i)
+    {
+      const int ni = D.bs[i];
+      const double * Li = D.diag[(size_t)pb * D.nblk + i];
+      const int ldd = D.ldd[i];
+      if(n + ni >= start)
+      {
+        if(zero)
+        {
+          const int r = n + ni - start, off = ni - r;
+          double xi = (lane < r) ? Mc[start + lane] : 0.0;
+          xi = wave_fwd(Li + off + (size_t)off * ldd, ldd, r, xi, lane);
+          if(lane < r) Mc[start + lane] = xi;
+          zero = false;
+        }
+        else
+        {
+          const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i - 1];
+          const int ldsg = D.lds[i - 1];
+          double acc = (lane < ni) ? Mc[n + lane] : 0.0;
+          if(lane < ni)
+            for(int k = 0; k < li; ++k) acc = FMA(-AT(Sg, ldsg, lane, k), Mc[l + k], acc);
+          acc = wave_fwd(Li, ldd, ni, acc, lane);
+          if(lane < ni) Mc[n + lane] = acc;
+        }
+        __threadfence_block();
+        wave_sync();
+      }
+      l = n;
+      li = ni;
+      n += ni;
+    }
+  }
+}
+
+// triBlockDiagLTransposeSolve (triBlockDiagLLT.cpp:98-158)
+__global__ __launch_bounds__(64) void tri_ltsolve_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int end_in)
+{
+  const int lane = threadIdx.x, pb = blockIdx.x;
+  double * Mp = M + (size_t)pb * D.mstride;
+  int ntot = 0;
+  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int end = (end_in < 0) ? ntot : end_in;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mc = Mp + (size_t)c * ldm;
+    int n = ntot, l = 0, li = 0;
+    bool zero = true;
+    for(int i = D.nblk - 1; i >= 0; --i)
+    {
+      const int ni = D.bs[i];
+      const double * Li = D.diag[(size_t)pb * D.nblk + i];
+      const int ldd = D.ldd[i];
+      if(n - ni < end)
+      {
+        if(zero)
+        {
+          const int r = end - n + ni;
+          double xi = (lane < r) ? Mc[n - ni + lane] : 0.0;
+          xi = wave_bwd(Li, ldd, r, xi, lane);
+          if(lane < r) Mc[n - ni + lane] = xi;
+          zero = false;
+        }
+        else
+        {
+          const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+          const int ldsg = D.lds[i];
+          double acc = (lane < ni) ? Mc[n - ni + lane] : 0.0;
+          if(lane < ni)
+            for(int k = li - 1; k >= 0; --k) acc = FMA(-AT(Sg, ldsg, k, lane), Mc[(l - li) + k], acc);
+          acc = wave_bwd(Li, ldd, ni, acc, lane);
+          if(lane < ni) Mc[n - ni + lane] = acc;
+        }
+        __threadfence_block();
+        wave_sync();
+      }
+      l = n;
+      li = ni;
+      n -= ni;
+    }
+  }
+}
+
+inline size_t lds_arrow_block(int maxb)
+{
+  return sizeof(double) * 2 * (size_t)maxb * (maxb | 1);
+}
+} // namespace
+
+hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st)
+{
+  hipError_t e = hipMemsetAsync(d.fail, 0, sizeof(int) * nprob, st);
+  if(e != hipSuccess) return e;
+  if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(64), lds_arrow_block(maxb), st, d);
+  hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), sizeof(double) * (size_t)maxb * (maxb | 1), st, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_block_arrow_solve(const BlockDesc & d, int nprob, bool transpose, double * M, int ldm, int nrhs, int start,
+                                    int end, double * tmp, hipStream_t st)
+{
+  int ntot = 0;
+  for(int k = 0; k < d.nblk; ++k) ntot += d.h_bs[k];
+  if(end < 0) end = ntot;
+  const int n0 = d.h_bs[0];
+  if(!transpose)
+  {
+    if(d.up)
+    {
+      hipLaunchKernelGGL(permute_rows_kernel, dim3(1, nprob), dim3(256), 0, st, M, ldm, nrhs, ntot, n0, 0, tmp, d.mstride);
+      start = start - n0 > 0 ? start - n0 : 0;
+      end = end - n0 > 0 ? end - n0 : 0;
+    }
+    if(d.nblk > 1) hipLaunchKernelGGL(arrow_lsolve_blocks_kernel, dim3(d.nblk - 1, nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
+    hipLaunchKernelGGL(arrow_lsolve_head_kernel, dim3(nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
+  }
+  else
+  {
+    hipLaunchKernelGGL(arrow_ltsolve_head_kernel, dim3(nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
+    if(d.nblk > 1) hipLaunchKernelGGL(arrow_ltsolve_blocks_kernel, dim3(d.nblk - 1, nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
+    if(d.up) hipLaunchKernelGGL(permute_rows_kernel, dim3(1, nprob), dim3(256), 0, st, M, ldm, nrhs, ntot, n0, 1, tmp, d.mstride);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_tri_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st)
+{
+  hipError_t e = hipMemsetAsync(d.fail, 0, sizeof(int) * nprob, st);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL(tri_llt_kernel, dim3(nprob), dim3(64), lds_arrow_block(maxb), st, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_tri_solve(const BlockDesc & d, int nprob, bool transpose, double * M, int ldm, int nrhs, int start_or_end,
+                            hipStream_t st)
+{
+  if(!transpose)
+    hipLaunchKernelGGL(tri_lsolve_kernel, dim3(nprob), dim3(64), 0, st, d, M, ldm, nrhs, start_or_end);
+  else
+    hipLaunchKernelGGL(tri_ltsolve_kernel, dim3(nprob), dim3(64), 0, st, d, M, ldm, nrhs, start_or_end);
+  return hipGetLastError();
+}
+} // namespace jrlqp
