@@ -134,6 +134,43 @@ int jrlqp_gi_solve_batch(int n,
 long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_placement);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Mode A -- ONE large dense QP, state in HBM, the active-set state machine on the host.
+ *
+ * A handle plays the role of a pre-sized solver object (GoldfarbIdnaniSolver(nbVar, nbCstr, useBounds),
+ * GoldfarbIdnaniSolver.h:19): it owns J, R, d, z, x, u, r on the device; solve() allocates nothing.
+ * Two levels are exported:
+ *   (1) the eight hooks DualSolver calls (DualSolver.h:101-121), fused where the reference calls them back to back, so
+ *       that a jrl-qp maintainer can keep DualSolver::solve() as is and forward the hooks;
+ *   (2) jrlqp_dense_solve = GoldfarbIdnaniSolver::solve(G, a, C, bl, bu, xl, xu) (GoldfarbIdnaniSolver.cpp:18-54): the same
+ *       loop, run by the library's own host C++ restatement of DualSolver::solve.
+ * All data pointers are DEVICE pointers; G (ld ldg) is overwritten by its Cholesky factor (lower triangle, strictly
+ * upper part untouched) exactly like the reference; C is n x m column-major with leading dimension ldc.
+ * Requires n <= JRLQP_DENSE_MAX_N.
+ */
+#define JRLQP_DENSE_MAX_N 1024
+typedef struct jrlqp_dense jrlqp_dense;
+int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out);
+void jrlqp_dense_destroy(jrlqp_dense * h);
+int jrlqp_dense_last_hip_error(const jrlqp_dense * h);
+int jrlqp_dense_bind(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                     const double * dbu, const double * dxl, const double * dxu);
+/* init_ without the equality pre-activation: *llt_info = -1 or the failing column (Eigen llt_inplace), *f0 = a.x0/2 */
+int jrlqp_dense_init(jrlqp_dense * h, int * llt_info, double * f0, void * stream);
+/* selectViolatedConstraint_: *p = -1 and *status = JRLQP_INACTIVE when no constraint is violated */
+int jrlqp_dense_select(jrlqp_dense * h, int * p, int * status, void * stream);
+/* computeStep_ + computeStepLength_'s reductions + dot_: d, z, r stay on the device; returns t1, l, z.z, n.z, n.x, u[q] */
+int jrlqp_dense_step(jrlqp_dense * h, int p, int status, int q, double big_bnd, double * t1, int * l, double * zz, double * nz,
+                     double * nx, double * uq, void * stream);
+int jrlqp_dense_advance(jrlqp_dense * h, double t, int q, int primal, void * stream);
+int jrlqp_dense_add(jrlqp_dense * h, int p, int status, int q, void * stream);
+int jrlqp_dense_remove(jrlqp_dense * h, int l, int q, int index, void * stream);
+int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                      const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term,
+                      void * stream);
+/* host outputs: x[n], sign-expanded multipliers u[m+nb], activation status[m+nb], iterations, objective value */
+int jrlqp_dense_results(jrlqp_dense * h, double * x_host, double * u_host, int * status_host, int * iters, double * f, void * stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Structured Cholesky family.  Replaces (include/jrl-qp/decomposition/blockArrowLLT.h:70-110, triBlockDiagLLT.h:41-72):
  *     bool blockArrowLLT(diag, side, up);            void blockArrowLSolve(diag, side, up, M, start, end);
  *     void blockArrowLTransposeSolve(diag, side, up, M, start, end);

@@ -25,6 +25,18 @@ EXPORTED = [
     "jrlqp_default_options",
     "jrlqp_gi_solve_batch",
     "jrlqp_gi_batch_lds_bytes",
+    "jrlqp_dense_create",
+    "jrlqp_dense_destroy",
+    "jrlqp_dense_last_hip_error",
+    "jrlqp_dense_bind",
+    "jrlqp_dense_init",
+    "jrlqp_dense_select",
+    "jrlqp_dense_step",
+    "jrlqp_dense_advance",
+    "jrlqp_dense_add",
+    "jrlqp_dense_remove",
+    "jrlqp_dense_solve",
+    "jrlqp_dense_results",
     "jrlqp_blocks_create",
     "jrlqp_blocks_destroy",
     "jrlqp_blocks_bind",
@@ -78,6 +90,16 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_gi_batch_lds_bytes.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_int)]
     lib.jrlqp_gi_solve_batch.restype = ct.c_int
     lib.jrlqp_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 7 + [ct.POINTER(Options)] + [c_dp] * 8 + [ct.c_int, c_dp]
+    lib.jrlqp_dense_create.restype = ct.c_int
+    lib.jrlqp_dense_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p)]
+    lib.jrlqp_dense_destroy.restype = None
+    lib.jrlqp_dense_destroy.argtypes = [ct.c_void_p]
+    lib.jrlqp_dense_last_hip_error.restype = ct.c_int
+    lib.jrlqp_dense_last_hip_error.argtypes = [ct.c_void_p]
+    lib.jrlqp_dense_solve.restype = ct.c_int
+    lib.jrlqp_dense_solve.argtypes = [ct.c_void_p, c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_dp, c_dp, c_dp, c_dp, ct.POINTER(Options), ct.POINTER(ct.c_int), c_dp]
+    lib.jrlqp_dense_results.restype = ct.c_int
+    lib.jrlqp_dense_results.argtypes = [ct.c_void_p, c_dp, c_dp, c_dp, ct.POINTER(ct.c_int), ct.POINTER(ct.c_double), c_dp]
     lib.jrlqp_blocks_create.restype = ct.c_int
     lib.jrlqp_blocks_create.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_int), ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p)]
     lib.jrlqp_blocks_destroy.restype = None
@@ -178,6 +200,52 @@ class BatchSolver:
         raw = self.trace.cpu().numpy()
         dt = np.dtype([("p", "<i4"), ("status", "<i4"), ("l", "<i4"), ("kind", "<i4"), ("t1", "<f8"), ("t2", "<f8")])
         return raw.view(dt).reshape(self.B, self.trace_cap)
+
+
+class DenseSolver:
+    """Mode A: one (large) dense QP, state in HBM, host-driven active-set loop (jrlqp_dense_* of the C ABI).
+    Mirrors the reference's GoldfarbIdnaniSolver(nbVar, nbCstr, useBounds) + solve(G, a, C, bl, bu, xl, xu)."""
+
+    def __init__(self, n, m, use_bounds, max_iter=500, big_bnd=1e100):
+        self.lib = load_library()
+        self.n, self.m, self.nb = n, m, (n if use_bounds else 0)
+        self.opts = Options(max_iter, big_bnd)
+        h = ct.c_void_p()
+        check(self.lib.jrlqp_dense_create(n, m, self.nb, ct.byref(h)))
+        self.h = h
+
+    def solve(self, G, a, C, bl, bu, xl=None, xu=None):
+        """G (n,n) symmetric float64 CUDA tensor -- OVERWRITTEN by its Cholesky factor (lower triangle of the
+        column-major matrix, i.e. G.T's lower triangle in torch's row-major view); C (m,n): row i = constraint i."""
+        import torch
+
+        n, m = self.n, self.m
+        for t in (G, a, C, bl, bu, xl, xu):
+            if t is not None:
+                assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        term = ct.c_int(-1)
+        st = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = self.lib.jrlqp_dense_solve(self.h, _ptr(G), n, _ptr(a), _ptr(C) if m else None, n, _ptr(bl) if m else None,
+                                        _ptr(bu) if m else None, _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None,
+                                        ct.byref(self.opts), ct.byref(term), st)
+        if rc != 0:
+            raise JrlqpError(f"jrlqp_dense_solve failed: {rc} (hip {self.lib.jrlqp_dense_last_hip_error(self.h)})")
+        x = np.zeros(n)
+        u = np.zeros(m + self.nb)
+        status = np.zeros(m + self.nb, dtype=np.int32)
+        iters = ct.c_int(0)
+        f = ct.c_double(0.0)
+        check(self.lib.jrlqp_dense_results(self.h, x.ctypes.data_as(ct.c_void_p), u.ctypes.data_as(ct.c_void_p),
+                                           status.ctypes.data_as(ct.c_void_p), ct.byref(iters), ct.byref(f), st))
+        return dict(term=term.value, x=x, u=u, status=status, iters=iters.value, f=f.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jrlqp_dense_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class StructuredBlocks:

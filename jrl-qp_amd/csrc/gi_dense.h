@@ -1,0 +1,49 @@
+// gi_dense.h -- Mode A (one large dense QP, host-driven hooks): shared types and launchers (internal)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace jrlqp
+{
+// host-visible (pinned, mapped) scalar hand-off between the hook kernels and the host state machine
+struct Mailbox
+{
+  int p, pstatus;       // selectViolatedConstraint_
+  int l, pad;           // computeStepLength_
+  double t1, zz, cz, cx; // t1, z.z, n.z, n.x
+  double uq;            // u[q] before the update (needed by the f update on the host)
+  double f0;            // init_
+  int llt_info, pad2;
+};
+
+// the caller's problem (device pointers; GoldfarbIdnaniSolver::Problem, GoldfarbIdnaniSolver.h:35-58)
+struct DenseViews
+{
+  int n, m, nb;
+  double * G;
+  int ldg;
+  const double * a;
+  const double * C;
+  int ldc;
+  const double *bl, *bu, *xl, *xu;
+};
+
+// solver-owned device state (work_J_, work_R_, work_d_, work_x_, work_z_, work_u_, work_r_; DualSolver.h:128-141)
+struct DenseState
+{
+  double *J, *R, *d, *z, *x, *u, *r, *cc, *ss;
+  unsigned char * st; // activation status per constraint / bound
+  double * pval;      // select partials
+  int *pidx, *pstat;
+  int * info;         // LLT info (device)
+  Mailbox * mb;       // device view of the mailbox
+};
+
+hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st);
+hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st);
+hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st);
+hipError_t dense_select(const DenseViews & v, DenseState & s, hipStream_t st);
+hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st);
+hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st);
+hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st);
+hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st);
+} // namespace jrlqp

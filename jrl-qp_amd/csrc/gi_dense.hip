@@ -1,0 +1,823 @@
+// gi_dense.hip -- Mode A: kernels behind the eight DualSolver hooks for ONE large dense QP whose state
+// (J, R, C, x, ...) lives in HBM (gfx950).  The host keeps the active-set state machine (gi_dense_host.cpp).
+//
+//   hook (include/jrl-qp/DualSolver.h:101-121)      reference implementation            kernels here
+//   init_                    GoldfarbIdnaniSolver.cpp:56-82    llt_panel / llt_update (MFMA) / jinv_block / x0
+//   selectViolatedConstraint_                     :84-134      select_partial + select_final
+//   computeStep_ + computeStepLength_ + dot_      :136-219     jtn (or row gather), z_rows, step_tail
+//   (primal/dual update)   DualSolver.cpp:133-150              advance
+//   addConstraint_                                :221-237     add_chain + rot_apply
+//   removeConstraint_ (+ u shift, DualSolver.cpp:237-244) :239-256   remove_r + rot_apply
+//
+// CANON rounding contract: every output element owns one in-order fma chain, so the parallelism is
+// across outputs (constraints, columns of J, rows of J, elements of the trailing matrix).  The only matrix-core
+// use is the blocked-LLT trailing update: v_mfma_f64_16x16x4_f64 accumulates k-ordered fma chains
+// (tests/test_gpu_arith.py), so feeding it the panel in increasing k keeps every element's chain exactly the
+// oracle's.  Matrices are column-major; J and R have leading dimension n (Workspace.h, GoldfarbIdnaniSolver.cpp:140-141).
+#include <hip/hip_runtime.h>
+
+#include "gi_dense.h"
+
+namespace jrlqp
+{
+namespace
+{
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define AT(P, ld, i, j) (P)[(size_t)(i) + (size_t)(j) * (size_t)(ld)]
+constexpr int NONE = 0x7fffffff;
+enum : int { INACTIVE = 0, LOWER = 1, UPPER = 2, EQUALITY = 3, LOWER_BOUND = 4, UPPER_BOUND = 5, FIXED = 6 };
+
+__device__ __forceinline__ double bcast_lane(double v, int src)
+{
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int mask)
+{
+  int lo = __shfl_xor(__double2loint(v), mask);
+  int hi = __shfl_xor(__double2hiint(v), mask);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// lexicographic (value, index) minimum over the wave (general index order)
+__device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
+{
+#pragma unroll
+  for(int off = 32; off >= 1; off >>= 1)
+  {
+    double ov = shfl_xor_d(val, off);
+    int oi = __shfl_xor(idx, off);
+    int oa = __shfl_xor(aux, off);
+    bool take = (oi != NONE) && (idx == NONE || ov < val || (ov == val && oi < idx));
+    if(take)
+    {
+      val = ov;
+      idx = oi;
+      aux = oa;
+    }
+  }
+}
+
+// Eigen makeGivens (real), as in the batched kernel / oracle orc_givens
+__device__ __forceinline__ void make_givens(double p, double q, double & c, double & s, double & r)
+{
+  if(q == 0.0) { c = p < 0.0 ? -1.0 : 1.0; s = 0.0; r = fabs(p); }
+  else if(p == 0.0) { c = 0.0; s = q < 0.0 ? 1.0 : -1.0; r = fabs(q); }
+  else if(fabs(p) > fabs(q))
+  {
+    double t = q / p;
+    double u = __builtin_sqrt(FMA(t, t, 1.0));
+    if(p < 0.0) u = -u;
+    c = 1.0 / u; s = -t * c; r = p * u;
+  }
+  else
+  {
+    double t = p / q;
+    double u = __builtin_sqrt(FMA(t, t, 1.0));
+    if(q < 0.0) u = -u;
+    s = -1.0 / u; c = -t * s; r = q * u;
+  }
+}
+
+// sqrt on [1,2] and the radius-only Givens recurrence: identical to gi_batch.hip (see the comments there)
+__device__ __forceinline__ double sqrt_1to2(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = FMA(-h, g, 0.5);
+  g = FMA(g, r, g);
+  h = FMA(h, r, h);
+  double d = FMA(-g, g, x);
+  g = FMA(d, h, g);
+  d = FMA(-g, g, x);
+  g = FMA(d, h, g);
+  return g;
+}
+__device__ __forceinline__ double givens_r_only(double p, double q)
+{
+  const double a = fabs(p), b = fabs(q);
+  const double hi = fmax(a, b), lo = fmin(a, b);
+  const double t = lo / hi;
+  const double r = hi * sqrt_1to2(FMA(t, t, 1.0));
+  return (hi == 0.0) ? 0.0 : r;
+}
+__device__ __forceinline__ double opaque_v(double v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// ============================================================================================================
+// K1  blocked right-looking Cholesky
+// ============================================================================================================
+constexpr int NB = 32; // panel width
+
+// Panel j0, step 1: factor the diagonal block A11 (nb x nb) in LDS (one wave, lane = row), write it back.
+__global__ __launch_bounds__(64) void llt_diag_kernel(double * G, int ldg, int n, int j0, int * info)
+{
+  __shared__ double L11[NB * (NB + 1)];
+  const int lane = threadIdx.x;
+  const int nb = min(NB, n - j0);
+  const int ld1 = NB + 1;
+  if(*info >= 0) return;
+  for(int e = lane; e < nb * nb; e += 64)
+  {
+    int i = e % nb, j = e / nb;
+    L11[i + j * ld1] = AT(G, ldg, j0 + i, j0 + j);
+  }
+  wave_sync();
+  for(int j = 0; j < nb; ++j)
+  {
+    double acc = 0.0;
+    if(lane >= j && lane < nb)
+    {
+      acc = L11[lane + j * ld1];
+      for(int k = 0; k < j; ++k) acc = FMA(-L11[lane + k * ld1], L11[j + k * ld1], acc);
+    }
+    double piv = bcast_lane(acc, j);
+    if(piv <= 0.0)
+    {
+      if(lane == 0) *info = j0 + j; // Eigen llt_inplace: index of the first non-positive pivot
+      return;                       // nothing is written at or after that column
+    }
+    double ljj = __builtin_sqrt(piv);
+    if(lane == j)
+    {
+      L11[j + j * ld1] = ljj;
+      AT(G, ldg, j0 + j, j0 + j) = ljj;
+    }
+    else if(lane > j && lane < nb)
+    {
+      double v = acc / ljj;
+      L11[lane + j * ld1] = v;
+      AT(G, ldg, j0 + lane, j0 + j) = v;
+    }
+    wave_sync();
+  }
+}
+
+// Panel j0, step 2: L21 = A21 L11^-T, 64 rows per workgroup, row per lane (L11 staged in LDS)
+__global__ __launch_bounds__(64) void llt_panel_kernel(double * G, int ldg, int n, int j0, const int * info)
+{
+  __shared__ double L11[NB * (NB + 1)];
+  __shared__ double X[64 * (NB + 1)];
+  const int lane = threadIdx.x;
+  const int nb = min(NB, n - j0);
+  const int ld1 = NB + 1;
+  if(*info >= 0) return;
+  for(int e = lane; e < nb * nb; e += 64)
+  {
+    int i = e % nb, j = e / nb;
+    L11[i + j * ld1] = AT(G, ldg, j0 + i, j0 + j);
+  }
+  wave_sync();
+  const int row = j0 + nb + blockIdx.x * 64 + lane;
+  if(row < n)
+  {
+    // X is row-major per lane (stride NB+1, odd: conflict-free): X[lane][j]
+    for(int j = 0; j < nb; ++j) X[lane * ld1 + j] = AT(G, ldg, row, j0 + j);
+    for(int j = 0; j < nb; ++j)
+    {
+      double s = X[lane * ld1 + j];
+      for(int k = 0; k < j; ++k) s = FMA(-X[lane * ld1 + k], L11[j + k * ld1], s);
+      s = s / L11[j + j * ld1];
+      X[lane * ld1 + j] = s;
+      AT(G, ldg, row, j0 + j) = s;
+    }
+  }
+}
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// Trailing update A22 -= L21 L21^T (lower triangle) with v_mfma_f64_16x16x4_f64: one wave per 16 x 16 tile,
+// k in increasing order (4 per instruction): per element acc = fma(-L_ik, L_jk, acc), k ascending -- CANON C1.
+__global__ __launch_bounds__(64) void llt_update_kernel(double * G, int ldg, int n, int j0, const int * info)
+{
+  if(*info >= 0) return;
+  const int nb = min(NB, n - j0);
+  const int base = j0 + nb;
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if(tj > ti) return;
+  const int l = threadIdx.x;
+  const int i0 = base + ti * 16, c0 = base + tj * 16;
+  if(i0 >= n || c0 >= n) return;
+  const int col = c0 + (l & 15);
+  double4_t acc;
+#pragma unroll
+  for(int r = 0; r < 4; ++r)
+  {
+    const int row = i0 + (l >> 4) + 4 * r;
+    acc[r] = (row < n && col < n) ? AT(G, ldg, row, col) : 0.0;
+  }
+  const int arow = i0 + (l & 15); // A operand: A[i = l&15][k = l>>4]
+  const int brow = c0 + (l & 15); // B operand: B[k = l>>4][j = l&15] = L21[c0 + j, k]
+  for(int k = 0; k < nb; k += 4)
+  {
+    const int kk = k + (l >> 4);
+    const bool kin = kk < nb;
+    double a = (kin && arow < n) ? -AT(G, ldg, arow, j0 + kk) : 0.0;
+    double b = (kin && brow < n) ? AT(G, ldg, brow, j0 + kk) : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for(int r = 0; r < 4; ++r)
+  {
+    const int row = i0 + (l >> 4) + 4 * r;
+    if(row < n && col < n && row >= col) AT(G, ldg, row, col) = acc[r]; // strictly-upper part stays untouched
+  }
+}
+
+// ============================================================================================================
+// K2  J = L^-T (upper triangular), block row I = [i0, i0+NB) from the bottom up.  Lane = column c of J.
+//     acc[r] for the NB rows of the block are NB independent chains per lane:
+//       acc_i = delta_ic - sum_{k = c .. i0+NB, descending} L_ki J_kc      (rows below the block)
+//     then the in-block back substitution.  J must be zero below its diagonal on entry (memset).
+// ============================================================================================================
+__global__ __launch_bounds__(64) void jinv_block_kernel(const double * __restrict__ L, int ldl, double * __restrict__ J, int ldj, int n, int i0)
+{
+  __shared__ double Ls[64 * (NB + 1)]; // staged rows of L: Ls[kk][r] = L[k0 - kk, i0 + r]
+  __shared__ double Ld[NB * (NB + 1)]; // the diagonal block of L
+  const int lane = threadIdx.x;
+  const int nbk = min(NB, n - i0);
+  const int c = i0 + blockIdx.x * 64 + lane; // this lane's column
+  const int cmax = min(n - 1, i0 + blockIdx.x * 64 + 63);
+  const bool live = c < n;
+  double acc[NB];
+#pragma unroll
+  for(int r = 0; r < NB; ++r) acc[r] = (live && c == i0 + r) ? 1.0 : 0.0;
+  for(int e = lane; e < nbk * nbk; e += 64)
+  {
+    int i = e % nbk, j = e / nbk;
+    Ld[i + j * (NB + 1)] = AT(L, ldl, i0 + i, i0 + j);
+  }
+  // rows below the block, descending k, staged 64 at a time
+  for(int khi = cmax; khi >= i0 + nbk; khi -= 64)
+  {
+    const int cnt = min(64, khi - (i0 + nbk) + 1);
+    wave_sync();
+    for(int e = lane; e < cnt * nbk; e += 64)
+    {
+      int kk = e % cnt, r = e / cnt;
+      Ls[kk * (NB + 1) + r] = AT(L, ldl, khi - kk, i0 + r);
+    }
+    wave_sync();
+    for(int kk = 0; kk < cnt; ++kk)
+    {
+      const int k = khi - kk;
+      const double jk = (live && k <= c) ? AT(J, ldj, k, c) : 0.0;
+#pragma unroll
+      for(int r = 0; r < NB; ++r)
+        if(r < nbk) acc[r] = FMA(-Ls[kk * (NB + 1) + r], jk, acc[r]);
+    }
+  }
+  wave_sync();
+  // in-block back substitution (descending i), all columns of this tile at once
+#pragma unroll
+  for(int ri = NB - 1; ri >= 0; --ri)
+  {
+    if(ri < nbk)
+    {
+      const double v = acc[ri] / Ld[ri + ri * (NB + 1)];
+      if(live) AT(J, ldj, i0 + ri, c) = v;
+#pragma unroll
+      for(int r = 0; r < NB; ++r)
+        if(r < ri) acc[r] = FMA(-Ld[ri + r * (NB + 1)], v, acc[r]);
+    }
+  }
+}
+
+// ============================================================================================================
+// K3  x0 = -G^-1 a, f0 = a.x0 / 2: one workgroup, thread = row (strided), pivots through LDS
+// ============================================================================================================
+__global__ __launch_bounds__(1024) void x0_kernel(const double * __restrict__ L, int ldl, int n, const double * __restrict__ a, double * x, double * f0)
+{
+  extern __shared__ double xs[]; // n
+  __shared__ double piv;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for(int i = tid; i < n; i += nt) xs[i] = a[i];
+  __syncthreads();
+  for(int k = 0; k < n; ++k)
+  {
+    if(tid == 0)
+    {
+      piv = xs[k] / AT(L, ldl, k, k);
+      xs[k] = piv;
+    }
+    __syncthreads();
+    const double v = piv;
+    for(int i = k + 1 + tid; i < n; i += nt) xs[i] = FMA(-AT(L, ldl, i, k), v, xs[i]);
+    __syncthreads();
+  }
+  for(int k = n - 1; k >= 0; --k)
+  {
+    if(tid == 0)
+    {
+      piv = xs[k] / AT(L, ldl, k, k);
+      xs[k] = piv;
+    }
+    __syncthreads();
+    const double v = piv;
+    for(int i = tid; i < k; i += nt) xs[i] = FMA(-AT(L, ldl, k, i), v, xs[i]);
+    __syncthreads();
+  }
+  for(int i = tid; i < n; i += nt)
+  {
+    xs[i] = -xs[i];
+    x[i] = xs[i];
+  }
+  __syncthreads();
+  if(tid == 0)
+  {
+    double acc = 0.0;
+    for(int k = 0; k < n; ++k) acc = FMA(a[k], xs[k], acc);
+    *f0 = 0.5 * acc;
+  }
+}
+
+// ============================================================================================================
+// column dots: out[j] = sign * sum_k M[k + j*ld] v[k]   (K4 with M = C, v = x; K5 with M = J, v = C[:,p])
+// lane = column; the vector is staged in LDS; per lane the column is a contiguous stream.
+// ============================================================================================================
+__device__ __forceinline__ double column_dot(const double * __restrict__ col, const double * vs, int n)
+{
+  double acc = 0.0;
+  int k = 0;
+  for(; k + 8 <= n; k += 8)
+  {
+    double cv[8];
+#pragma unroll
+    for(int u = 0; u < 8; ++u) cv[u] = col[k + u];
+#pragma unroll
+    for(int u = 0; u < 8; ++u) acc = FMA(cv[u], vs[k + u], acc);
+  }
+  for(; k < n; ++k) acc = FMA(col[k], vs[k], acc);
+  return acc;
+}
+
+__global__ __launch_bounds__(64) void jtn_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign, double * out)
+{
+  extern __shared__ double vs[];
+  const int lane = threadIdx.x;
+  for(int i = lane; i < n; i += 64) vs[i] = v[i];
+  wave_sync();
+  const int j = blockIdx.x * 64 + lane;
+  if(j < ncols)
+  {
+    double acc = column_dot(M + (size_t)j * ld, vs, n);
+    out[j] = (sign < 0.0) ? -acc : acc;
+  }
+}
+
+// bound constraint: d = +-row pb of J
+__global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb, double sign, double * out)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if(j < n)
+  {
+    double v = AT(J, ld, pb, j);
+    out[j] = (sign < 0.0) ? -v : v;
+  }
+}
+
+// K4 partial: per 64 constraints the first-index arg-min of min(c.x - bl, bu - c.x) below 0
+__global__ __launch_bounds__(64) void select_partial_kernel(const double * __restrict__ C, int ldc, int n, int m, const double * __restrict__ x,
+                                                            const double * __restrict__ bl, const double * __restrict__ bu,
+                                                            const unsigned char * __restrict__ st, double * pval, int * pidx, int * pstat)
+{
+  extern __shared__ double vs[];
+  const int lane = threadIdx.x;
+  for(int i = lane; i < n; i += 64) vs[i] = x[i];
+  wave_sync();
+  const int i = blockIdx.x * 64 + lane;
+  double bval = 0.0;
+  int bidx = NONE, bstat = INACTIVE;
+  if(i < m && st[i] == INACTIVE)
+  {
+    double cx = column_dot(C + (size_t)i * ldc, vs, n);
+    double sl = cx - bl[i];
+    if(sl < 0.0)
+    {
+      bval = sl;
+      bidx = i;
+      bstat = LOWER;
+    }
+    else
+    {
+      double su = bu[i] - cx;
+      if(su < 0.0)
+      {
+        bval = su;
+        bidx = i;
+        bstat = UPPER;
+      }
+    }
+  }
+  wave_argmin(bval, bidx, bstat);
+  if(lane == 0)
+  {
+    pval[blockIdx.x] = bval;
+    pidx[blockIdx.x] = bidx;
+    pstat[blockIdx.x] = bstat;
+  }
+}
+
+// K4 final: combine the partials (in index order) and scan the bounds; result to the host-visible mailbox
+__global__ __launch_bounds__(256) void select_final_kernel(int nparts, const double * pval, const int * pidx, const int * pstat, int m, int nb,
+                                                          const double * __restrict__ x, const double * __restrict__ xl,
+                                                          const double * __restrict__ xu, const unsigned char * __restrict__ st, Mailbox * mb)
+{
+  __shared__ double sv[4];
+  __shared__ int si[4], ss[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double bval = 0.0;
+  int bidx = NONE, bstat = INACTIVE;
+  for(int k = tid; k < nparts; k += 256)
+  {
+    int oi = pidx[k];
+    double ov = pval[k];
+    if(oi != NONE && (bidx == NONE || ov < bval || (ov == bval && oi < bidx)))
+    {
+      bval = ov;
+      bidx = oi;
+      bstat = pstat[k];
+    }
+  }
+  for(int i = tid; i < nb; i += 256)
+  {
+    if(st[m + i] != INACTIVE) continue;
+    double xi = x[i];
+    double sl = xi - xl[i];
+    double cand;
+    int cs;
+    if(sl < 0.0) { cand = sl; cs = LOWER_BOUND; }
+    else
+    {
+      double su = xu[i] - xi;
+      if(!(su < 0.0)) continue;
+      cand = su;
+      cs = UPPER_BOUND;
+    }
+    // general constraints (index < m) win ties against bounds; bounds among themselves: first index
+    if(bidx == NONE || cand < bval || (cand == bval && (m + i) < bidx))
+    {
+      bval = cand;
+      bidx = m + i;
+      bstat = cs;
+    }
+  }
+  wave_argmin(bval, bidx, bstat);
+  if(lane == 0)
+  {
+    sv[wave] = bval;
+    si[wave] = bidx;
+    ss[wave] = bstat;
+  }
+  __syncthreads();
+  if(tid == 0)
+  {
+    double v = sv[0];
+    int ix = si[0], sx = ss[0];
+    for(int w = 1; w < 4; ++w)
+      if(si[w] != NONE && (ix == NONE || sv[w] < v || (sv[w] == v && si[w] < ix)))
+      {
+        v = sv[w];
+        ix = si[w];
+        sx = ss[w];
+      }
+    mb->p = (ix == NONE) ? -1 : ix;
+    mb->pstatus = sx;
+  }
+}
+
+// K6  z = J2 d2: lane = row of J (coalesced), in-order chain over columns q .. n-1
+__global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ J, int ld, int n, int q, const double * __restrict__ d, double * z)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if(i >= n) return;
+  double acc = 0.0;
+  int j = q;
+  for(; j + 8 <= n; j += 8)
+  {
+    double jv[8];
+#pragma unroll
+    for(int u = 0; u < 8; ++u) jv[u] = AT(J, ld, i, j + u);
+#pragma unroll
+    for(int u = 0; u < 8; ++u) acc = FMA(jv[u], d[j + u], acc);
+  }
+  for(; j < n; ++j) acc = FMA(AT(J, ld, i, j), d[j], acc);
+  z[i] = acc;
+}
+
+// K7 + K8: one workgroup of 4 waves.  wave 0: r = R^-1 d1 (blocked back substitution, 64-column blocks) and the
+// ratio test; waves 1-3: z.z, n.z, n.x as three in-order chains.  Results to the mailbox.
+__global__ __launch_bounds__(256) void step_tail_kernel(const double * __restrict__ R, int ld, int n, int q, const double * __restrict__ d, double * r,
+                                                        const double * __restrict__ u, const unsigned char * __restrict__ st, double big,
+                                                        const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
+                                                        int pb, Mailbox * mb)
+{
+  extern __shared__ double rs[]; // q doubles: the running right-hand side
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if(wave == 0)
+  {
+    for(int i = lane; i < q; i += 64) rs[i] = d[i];
+    wave_sync();
+    for(int kb = ((q - 1) / 64) * 64; kb >= 0 && q > 0; kb -= 64)
+    {
+      const int cnt = min(64, q - kb);
+      // diagonal block: lane = row kb + lane
+      double rk = (lane < cnt) ? rs[kb + lane] : 0.0;
+      for(int k = cnt - 1; k >= 0; --k)
+      {
+        double v = bcast_lane(rk, k) / AT(R, ld, kb + k, kb + k);
+        if(lane == k)
+          rk = v;
+        else if(lane < k)
+          rk = FMA(-AT(R, ld, kb + lane, kb + k), v, rk);
+      }
+      if(lane < cnt) rs[kb + lane] = rk;
+      wave_sync();
+      // rows above the block: their chains take this block's columns in descending k
+      for(int i0 = 0; i0 < kb; i0 += 64)
+      {
+        const int i = i0 + lane;
+        if(i < kb)
+        {
+          double acc = rs[i];
+          for(int k = cnt - 1; k >= 0; --k) acc = FMA(-AT(R, ld, i, kb + k), rs[kb + k], acc);
+          rs[i] = acc;
+        }
+      }
+      wave_sync();
+    }
+    // ratio test: t1 = min u_k / r_k over r_k > 0 (status by POSITION k: GoldfarbIdnaniSolver.cpp:162)
+    double tk = big;
+    int kk = NONE, dummy = 0;
+    for(int k = lane; k < q; k += 64)
+    {
+      double rv = rs[k];
+      r[k] = rv;
+      int sk = st[k];
+      if(sk != EQUALITY && sk != FIXED && rv > 0.0)
+      {
+        double tt = u[k] / rv;
+        if(tt < tk)
+        {
+          tk = tt;
+          kk = k;
+        }
+      }
+    }
+    wave_argmin(tk, kk, dummy);
+    if(lane == 0)
+    {
+      mb->t1 = (kk == NONE) ? big : tk;
+      mb->l = (kk == NONE) ? 0 : kk;
+      mb->uq = u[q];
+    }
+  }
+  else if(lane == 0)
+  {
+    // wave 1: z.z   wave 2: n.z   wave 3: n.x   (n = C[:,p] for a general constraint, e_pb for a bound)
+    double acc = 0.0;
+    if(wave == 1)
+      for(int k = 0; k < n; ++k) acc = FMA(z[k], z[k], acc);
+    else if(cp)
+    {
+      const double * v = (wave == 2) ? z : x;
+      for(int k = 0; k < n; ++k) acc = FMA(cp[k], v[k], acc);
+    }
+    else
+      acc = (wave == 2) ? z[pb] : x[pb];
+    if(wave == 1) mb->zz = acc;
+    if(wave == 2) mb->cz = acc;
+    if(wave == 3) mb->cx = acc;
+  }
+}
+
+// K9  x += t z ; u[0:q] -= t r ; u[q] += t
+__global__ void advance_kernel(int n, int q, double t, int primal, const double * __restrict__ z, double * x, const double * __restrict__ r, double * u)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(primal && i < n) x[i] = FMA(t, z[i], x[i]);
+  if(i < q) u[i] = FMA(-t, r[i], u[i]);
+  if(i == q) u[q] = u[q] + t;
+}
+
+// K10 part 1 (one wave): the Givens coefficient recurrence on d (i = n-2 .. q), then all (c_i, s_i) in parallel;
+// R(:, q) = d(0:q) with the new diagonal; status byte of the activated constraint.
+__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, double * d, double * cc, double * ss, double * R, int ld, unsigned char * st, int p, int pstat)
+{
+  extern __shared__ double sm[]; // d (n) | rho (n)
+  double * dsm = sm;
+  double * rho = sm + n;
+  const int lane = threadIdx.x;
+  for(int i = lane; i < n; i += 64) dsm[i] = d[i];
+  wave_sync();
+  double r = opaque_v(dsm[n - 1]);
+  if(lane == 0) rho[n - 1] = r;
+  double dnext = (n - 2 >= q) ? dsm[n - 2] : 0.0;
+  for(int i = n - 2; i >= q; --i)
+  {
+    const double di = opaque_v(dnext);
+    dnext = dsm[(i - 1 >= 0) ? (i - 1) : 0]; // prefetch
+    r = givens_r_only(di, r);
+    if(lane == 0) rho[i] = r;
+  }
+  wave_sync();
+  for(int i = q + lane; i <= n - 2; i += 64)
+  {
+    double c, s, rn;
+    make_givens(dsm[i], rho[i + 1], c, s, rn);
+    cc[i] = c;
+    ss[i] = s;
+  }
+  for(int k = lane; k < q; k += 64) AT(R, ld, k, q) = dsm[k];
+  if(lane == 0)
+  {
+    AT(R, ld, q, q) = r;
+    st[p] = (unsigned char)pstat;
+  }
+}
+
+// K10 part 2 / K11 part 2: apply the rotation sequence to the columns of J, lane = row.
+//   descending (add):   i = i_hi .. i_lo, columns (i, i+1), carry = column i+1
+//   ascending (remove): i = i_lo .. i_hi, columns (i, i+1), carry = column i
+__global__ __launch_bounds__(64) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
+                                                       const double * __restrict__ ss)
+{
+  const int row = blockIdx.x * 64 + threadIdx.x;
+  if(row >= n || i_hi < i_lo) return;
+  if(descending)
+  {
+    double carry = AT(J, ld, row, i_hi + 1);
+    for(int i = i_hi; i >= i_lo; --i)
+    {
+      const double c = cc[i], s = ss[i];
+      const double xv = AT(J, ld, row, i);
+      AT(J, ld, row, i + 1) = FMA(s, xv, c * carry);
+      carry = FMA(c, xv, -(s * carry));
+    }
+    AT(J, ld, row, i_lo) = carry;
+  }
+  else
+  {
+    double carry = AT(J, ld, row, i_lo);
+    for(int i = i_lo; i <= i_hi; ++i)
+    {
+      const double c = cc[i], s = ss[i];
+      const double y = AT(J, ld, row, i + 1);
+      AT(J, ld, row, i) = FMA(c, carry, -(s * y));
+      carry = FMA(s, carry, c * y);
+    }
+    AT(J, ld, row, i_hi + 1) = carry;
+  }
+}
+
+// K11 part 1 (one workgroup, thread = NEW column index of R): delete column l of R, restore triangularity with
+// q' - l rotations (q' = q - 1), record (c_i, s_i); shift u; clear the status byte.
+__global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int q, int l, double * cc, double * ss, double * u, unsigned char * st, int gone)
+{
+  __shared__ double gc, gs;
+  const int tid = threadIdx.x;
+  const int qn = q - 1;
+  // u.segment(l, q-l) = u.tail(q-l)   (u has q+1 entries)
+  double uv = 0.0;
+  const bool ush = (tid >= l && tid < q);
+  // columns are handled by threads l .. qn-1 (requires qn - l <= blockDim.x - l; host guarantees q <= 1024)
+  const bool mine = (tid >= l && tid < qn);
+  if(ush) uv = u[tid + 1];
+  __syncthreads();
+  if(ush) u[tid] = uv;
+  if(tid == 0) st[gone] = INACTIVE;
+  // head rows 0..l-1 of new column k come from old column k+1 (no rotation touches them): thread = row, columns
+  // shifted left one after the other (a row is private to its thread: no barrier needed)
+  double carry = mine ? AT(R, ld, l, tid + 1) : 0.0;
+  for(int rr = tid; rr < l; rr += blockDim.x)
+    for(int k = l; k < qn; ++k) AT(R, ld, rr, k) = AT(R, ld, rr, k + 1);
+  __syncthreads();
+  for(int i = l; i < qn; ++i)
+  {
+    double y = (tid >= i && tid < qn) ? AT(R, ld, i + 1, tid + 1) : 0.0;
+    if(tid == i)
+    {
+      double c, s, rho;
+      make_givens(carry, y, c, s, rho);
+      gc = c;
+      gs = s;
+      cc[i] = c;
+      ss[i] = s;
+      AT(R, ld, i, i) = rho;
+    }
+    __syncthreads();
+    const double c = gc, s = gs;
+    if(tid > i && tid < qn)
+    {
+      AT(R, ld, i, tid) = FMA(c, carry, -(s * y));
+      carry = FMA(s, carry, c * y);
+    }
+    __syncthreads();
+  }
+}
+
+} // namespace
+
+// ============================================================================================================
+// host-side launchers
+// ============================================================================================================
+hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st)
+{
+  for(int j0 = 0; j0 < n; j0 += NB)
+  {
+    const int nb = (n - j0 < NB) ? (n - j0) : NB;
+    const int rows = n - j0 - nb;
+    hipLaunchKernelGGL(llt_diag_kernel, dim3(1), dim3(64), 0, st, G, ldg, n, j0, d_info);
+    if(rows > 0)
+    {
+      hipLaunchKernelGGL(llt_panel_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, G, ldg, n, j0, d_info);
+      const int t = (rows + 15) / 16;
+      hipLaunchKernelGGL(llt_update_kernel, dim3(t, t), dim3(64), 0, st, G, ldg, n, j0, d_info);
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st)
+{
+  hipError_t e = hipMemsetAsync(J, 0, sizeof(double) * (size_t)n * n, st);
+  if(e != hipSuccess) return e;
+  const int nblk = (n + NB - 1) / NB;
+  for(int b = nblk - 1; b >= 0; --b)
+  {
+    const int i0 = b * NB;
+    const int cols = n - i0;
+    hipLaunchKernelGGL(jinv_block_kernel, dim3((cols + 63) / 64), dim3(64), 0, st, L, ldl, J, n, n, i0);
+  }
+  return hipGetLastError();
+}
+
+hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st)
+{
+  hipLaunchKernelGGL(x0_kernel, dim3(1), dim3(1024), sizeof(double) * n, st, L, ldl, n, a, x, f0);
+  return hipGetLastError();
+}
+
+hipError_t dense_select(const DenseViews & v, DenseState & s, hipStream_t st)
+{
+  const int parts = (v.m + 63) / 64;
+  if(parts > 0)
+    hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * v.n, st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
+                       s.pval, s.pidx, s.pstat);
+  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, s.mb);
+  return hipGetLastError();
+}
+
+hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st)
+{
+  const int n = v.n;
+  const double sign = (pstat == UPPER || pstat == UPPER_BOUND) ? -1.0 : 1.0;
+  const double * cp = nullptr;
+  if(p < v.m)
+  {
+    cp = v.C + (size_t)p * v.ldc;
+    hipLaunchKernelGGL(jtn_kernel, dim3((n + 63) / 64), dim3(64), sizeof(double) * n, st, s.J, n, n, n, cp, sign, s.d);
+  }
+  else
+    hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d);
+  hipLaunchKernelGGL(z_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
+  hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (q > 0 ? q : 1), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
+                     p - v.m, s.mb);
+  return hipGetLastError();
+}
+
+hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st)
+{
+  const int cnt = (v.n > q + 1) ? v.n : (q + 1);
+  hipLaunchKernelGGL(advance_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, v.n, q, t, primal ? 1 : 0, s.z, s.x, s.r, s.u);
+  return hipGetLastError();
+}
+
+hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st)
+{
+  const int n = v.n;
+  hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), sizeof(double) * 2 * n, st, n, q, s.d, s.cc, s.ss, s.R, n, s.st, p, pstat);
+  if(n - 2 >= q) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, n - 2, 1, s.cc, s.ss);
+  return hipGetLastError();
+}
+
+hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st)
+{
+  const int n = v.n;
+  hipLaunchKernelGGL(remove_r_kernel, dim3(1), dim3(1024), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
+  const int qn = q - 1;
+  if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
+  return hipGetLastError();
+}
+
+} // namespace jrlqp

@@ -1,0 +1,368 @@
+// gi_dense_host.cpp -- Mode A host side: the DualSolver state machine (src/DualSolver.cpp:91-168) and the
+// GoldfarbIdnaniSolver equality pre-activation (src/GoldfarbIdnaniSolver.cpp:268-338) in host C++17, driving the
+// hook kernels of gi_dense.hip through the same entry points the C ABI exports.  Only scalars cross back per
+// iteration (p, status, t1, l, three dot products, u[q]) through a pinned, mapped mailbox; J, R, C, x, z, d, u, r
+// never leave HBM.  No allocation inside solve(): everything is sized in jrlqp_dense_create.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/jrlqp_hip.h"
+#include "gi_dense.h"
+
+using namespace jrlqp;
+
+struct jrlqp_dense
+{
+  int n = 0, m = 0, nb = 0;
+  DenseViews v{};
+  DenseState s{};
+  Mailbox * h_mb = nullptr; // pinned host memory, mapped into the device address space
+  bool bound = false;
+  // host mirror of internal::ActiveSet (src/internal/ActiveSet.cpp): status per constraint + ordered active list
+  std::vector<int> status, active;
+  std::vector<double> h_bl, h_bu, h_xl, h_xu, h_u;
+  int it = 0, term = JRLQP_UNKNOWN;
+  double f = 0.0;
+  int last_hip = 0;
+};
+
+namespace
+{
+#define TRY(x)                                   \
+  do                                             \
+  {                                              \
+    hipError_t e_ = (x);                         \
+    if(e_ != hipSuccess)                         \
+    {                                            \
+      h->last_hip = (int)e_;                     \
+      return JRLQP_ERR_HIP;                      \
+    }                                            \
+  } while(0)
+
+template<class T>
+hipError_t dmalloc(T *& p, size_t count)
+{
+  return hipMalloc(reinterpret_cast<void **>(&p), sizeof(T) * (count ? count : 1));
+}
+} // namespace
+
+extern "C" {
+
+int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
+{
+  if(!out || n < 1 || m < 0 || (nb != 0 && nb != n)) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(n > JRLQP_DENSE_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  jrlqp_dense * h = new(std::nothrow) jrlqp_dense;
+  if(!h) return JRLQP_ERR_WORKSPACE;
+  h->n = n; h->m = m; h->nb = nb;
+  const size_t mt = (size_t)m + nb;
+  DenseState & s = h->s;
+  hipError_t e = dmalloc(s.J, (size_t)n * n);
+  if(e == hipSuccess) e = dmalloc(s.R, (size_t)n * n);
+  if(e == hipSuccess) e = dmalloc(s.d, n);
+  if(e == hipSuccess) e = dmalloc(s.z, n);
+  if(e == hipSuccess) e = dmalloc(s.x, n);
+  if(e == hipSuccess) e = dmalloc(s.u, mt + 2);
+  if(e == hipSuccess) e = dmalloc(s.r, mt + 2);
+  if(e == hipSuccess) e = dmalloc(s.cc, n);
+  if(e == hipSuccess) e = dmalloc(s.ss, n);
+  if(e == hipSuccess) e = dmalloc(s.st, mt);
+  const size_t parts = ((size_t)m + 63) / 64;
+  if(e == hipSuccess) e = dmalloc(s.pval, parts);
+  if(e == hipSuccess) e = dmalloc(s.pidx, parts);
+  if(e == hipSuccess) e = dmalloc(s.pstat, parts);
+  if(e == hipSuccess) e = dmalloc(s.info, 1);
+  if(e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h->h_mb), sizeof(Mailbox), hipHostMallocMapped);
+  if(e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s.mb), h->h_mb, 0);
+  if(e != hipSuccess)
+  {
+    jrlqp_dense_destroy(h);
+    return JRLQP_ERR_HIP;
+  }
+  h->status.assign(mt, 0);
+  h->active.reserve(n + 1);
+  h->h_bl.resize(m); h->h_bu.resize(m); h->h_xl.resize(nb); h->h_xu.resize(nb); h->h_u.resize(n + 2);
+  *out = h;
+  return JRLQP_OK;
+}
+
+void jrlqp_dense_destroy(jrlqp_dense * h)
+{
+  if(!h) return;
+  DenseState & s = h->s;
+  (void)hipFree(s.J); (void)hipFree(s.R); (void)hipFree(s.d); (void)hipFree(s.z); (void)hipFree(s.x);
+  (void)hipFree(s.u); (void)hipFree(s.r); (void)hipFree(s.cc); (void)hipFree(s.ss); (void)hipFree(s.st);
+  (void)hipFree(s.pval); (void)hipFree(s.pidx); (void)hipFree(s.pstat); (void)hipFree(s.info);
+  if(h->h_mb) (void)hipHostFree(h->h_mb);
+  delete h;
+}
+
+int jrlqp_dense_last_hip_error(const jrlqp_dense * h)
+{
+  return h ? h->last_hip : 0;
+}
+
+// ---- hook-level entry points ---------------------------------------------------------------------------------
+int jrlqp_dense_bind(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                     const double * dbu, const double * dxl, const double * dxu)
+{
+  if(!h || !dG || !da || ldg < h->n) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(h->m > 0 && (!dC || !dbl || !dbu || ldc < h->n)) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(h->nb > 0 && (!dxl || !dxu)) return JRLQP_ERR_INVALID_ARGUMENT;
+  DenseViews & v = h->v;
+  v.n = h->n; v.m = h->m; v.nb = h->nb;
+  v.G = dG; v.ldg = ldg; v.a = da; v.C = dC; v.ldc = ldc; v.bl = dbl; v.bu = dbu; v.xl = dxl; v.xu = dxu;
+  h->bound = true;
+  return JRLQP_OK;
+}
+
+// init_ (GoldfarbIdnaniSolver.cpp:56-74): LLT, J = L^-T, x0, f0, empty active set.  Synchronises the stream.
+int jrlqp_dense_init(jrlqp_dense * h, int * llt_info, double * f0, void * stream)
+{
+  if(!h || !h->bound) return JRLQP_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const DenseViews & v = h->v;
+  DenseState & s = h->s;
+  TRY(hipMemsetAsync(s.info, 0xff, sizeof(int), st)); // -1
+  TRY(hipMemsetAsync(s.st, 0, (size_t)v.m + v.nb, st));
+  TRY(hipMemsetAsync(s.u, 0, sizeof(double) * ((size_t)v.m + v.nb + 2), st));
+  TRY(hipMemsetAsync(s.x, 0, sizeof(double) * v.n, st));
+  TRY(dense_llt(v.G, v.ldg, v.n, s.info, st));
+  int info = -1;
+  TRY(hipMemcpyAsync(&info, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  TRY(hipStreamSynchronize(st));
+  if(llt_info) *llt_info = info;
+  std::fill(h->status.begin(), h->status.end(), 0);
+  h->active.clear();
+  h->f = 0.0;
+  if(info >= 0)
+  {
+    if(f0) *f0 = 0.0;
+    return JRLQP_OK;
+  }
+  TRY(dense_jinv(v.G, v.ldg, s.J, v.n, st));
+  TRY(dense_x0(v.G, v.ldg, v.n, v.a, s.x, &s.mb->f0, st));
+  TRY(hipStreamSynchronize(st));
+  h->f = h->h_mb->f0;
+  if(f0) *f0 = h->f;
+  return JRLQP_OK;
+}
+
+// selectViolatedConstraint_ (GoldfarbIdnaniSolver.cpp:84-134).  p = -1 / status INACTIVE when none is violated.
+int jrlqp_dense_select(jrlqp_dense * h, int * p, int * status, void * stream)
+{
+  if(!h || !h->bound || !p || !status) return JRLQP_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TRY(dense_select(h->v, h->s, st));
+  TRY(hipStreamSynchronize(st));
+  *p = h->h_mb->p;
+  *status = h->h_mb->pstatus;
+  return JRLQP_OK;
+}
+
+// computeStep_ + the device part of computeStepLength_ and dot_ (GoldfarbIdnaniSolver.cpp:136-219, :289-293):
+// leaves d, z, r on the device and returns t1, l, z.z, n.z, n.x and u[q] (n = C[:,p] or e_{p-m}, unsigned).
+int jrlqp_dense_step(jrlqp_dense * h, int p, int status, int q, double big_bnd, double * t1, int * l, double * zz, double * nz,
+                     double * nx, double * uq, void * stream)
+{
+  if(!h || !h->bound || p < 0 || p >= h->m + h->nb || q < 0 || q > h->n) return JRLQP_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TRY(dense_step(h->v, h->s, p, status, q, big_bnd, st));
+  TRY(hipStreamSynchronize(st));
+  const Mailbox & mb = *h->h_mb;
+  if(t1) *t1 = mb.t1;
+  if(l) *l = mb.l;
+  if(zz) *zz = mb.zz;
+  if(nz) *nz = mb.cz;
+  if(nx) *nx = mb.cx;
+  if(uq) *uq = mb.uq;
+  return JRLQP_OK;
+}
+
+// x += t z (if primal), u[0:q] -= t r, u[q] += t   (DualSolver.cpp:136-137, :146-150)
+int jrlqp_dense_advance(jrlqp_dense * h, double t, int q, int primal, void * stream)
+{
+  if(!h || !h->bound) return JRLQP_ERR_INVALID_ARGUMENT;
+  TRY(dense_advance(h->v, h->s, t, q, primal != 0, static_cast<hipStream_t>(stream)));
+  return JRLQP_OK;
+}
+
+// addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237); q = number of active constraints BEFORE the addition
+int jrlqp_dense_add(jrlqp_dense * h, int p, int status, int q, void * stream)
+{
+  if(!h || !h->bound || q >= h->n) return JRLQP_ERR_INVALID_ARGUMENT;
+  TRY(dense_add(h->v, h->s, p, status, q, static_cast<hipStream_t>(stream)));
+  return JRLQP_OK;
+}
+
+// removeConstraint (DualSolver.cpp:237-244) + removeConstraint_ (GoldfarbIdnaniSolver.cpp:239-256); q = number of
+// active constraints BEFORE the removal, `index` = constraint index of the l-th active constraint
+int jrlqp_dense_remove(jrlqp_dense * h, int l, int q, int index, void * stream)
+{
+  if(!h || !h->bound || l < 0 || l >= q || q > 1024) return JRLQP_ERR_INVALID_ARGUMENT;
+  TRY(dense_remove(h->v, h->s, l, q, index, static_cast<hipStream_t>(stream)));
+  return JRLQP_OK;
+}
+
+// ---- the complete solve: DualSolver::solve (src/DualSolver.cpp:91-168) on the host ----------------------------
+int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                      const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term_out,
+                      void * stream)
+{
+  int rc = jrlqp_dense_bind(h, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu);
+  if(rc != JRLQP_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  jrlqp_options o;
+  jrlqp_default_options(&o);
+  if(opts) o = *opts;
+  const int n = h->n, m = h->m, nb = h->nb;
+  const double big = o.big_bnd;
+  enum { INACTIVE = 0, LOWER, UPPER, EQUALITY, LOWER_BOUND, UPPER_BOUND, FIXED };
+
+  // bounds are needed on the host for t2 and for the equality detection
+  if(m) TRY(hipMemcpyAsync(h->h_bl.data(), dbl, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+  if(m) TRY(hipMemcpyAsync(h->h_bu.data(), dbu, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+  if(nb) TRY(hipMemcpyAsync(h->h_xl.data(), dxl, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+  if(nb) TRY(hipMemcpyAsync(h->h_xu.data(), dxu, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+
+  h->it = 0;
+  h->term = JRLQP_UNKNOWN;
+  int info = -1;
+  rc = jrlqp_dense_init(h, &info, nullptr, stream);
+  if(rc != JRLQP_OK) return rc;
+  auto finish = [&](int term) {
+    h->term = term;
+    if(term_out) *term_out = term;
+    return JRLQP_OK;
+  };
+  if(info >= 0) return finish(JRLQP_NON_POS_HESSIAN);
+
+  auto bound_value = [&](int p, int status) -> double {
+    switch(status)
+    {
+      case LOWER: case EQUALITY: return h->h_bl[p];
+      case UPPER: return h->h_bu[p];
+      case LOWER_BOUND: case FIXED: return h->h_xl[p - m];
+      default: return h->h_xu[p - m];
+    }
+  };
+  auto activate = [&](int p, int status) {
+    h->active.push_back(p);
+    h->status[p] = status;
+  };
+
+  // initActiveSet (GoldfarbIdnaniSolver.cpp:268-287)
+  {
+    int neq = 0;
+    for(int i = 0; i < m; ++i) neq += (h->h_bl[i] == h->h_bu[i]);
+    for(int i = 0; i < nb; ++i) neq += (h->h_xl[i] == h->h_xu[i]);
+    if(neq > n) return finish(JRLQP_OVERCONSTRAINED_PROBLEM);
+    for(int i = 0; i < m + nb; ++i)
+    {
+      const bool eq = (i < m) ? (h->h_bl[i] == h->h_bu[i]) : (h->h_xl[i - m] == h->h_xu[i - m]);
+      if(!eq) continue;
+      const int status = (i < m) ? EQUALITY : FIXED;
+      const int q = (int)h->active.size();
+      TRY(hipMemsetAsync(h->s.u + q, 0, sizeof(double), st)); // u[q] = 0
+      double t1, zz, nz, nx, uq;
+      int l;
+      rc = jrlqp_dense_step(h, i, status, q, big, &t1, &l, &zz, &nz, &nx, &uq, stream);
+      if(rc != JRLQP_OK) return rc;
+      double t = 0.0;
+      if(std::sqrt(zz) > 1e-14) t = (bound_value(i, status) - nx) / nz; // addInitialConstraint :309-322
+      rc = jrlqp_dense_advance(h, t, q, 1, stream);
+      if(rc != JRLQP_OK) return rc;
+      h->f = std::fma(t * nz, 0.5 * t + uq, h->f);
+      rc = jrlqp_dense_add(h, i, status, q, stream);
+      if(rc != JRLQP_OK) return rc;
+      activate(i, status);
+    }
+  }
+
+  bool skip = false;
+  int p = -1, pstat = INACTIVE;
+  for(; h->it < o.max_iter; ++h->it)
+  {
+    const int q = (int)h->active.size();
+    if(!skip)
+    {
+      rc = jrlqp_dense_select(h, &p, &pstat, stream);
+      if(rc != JRLQP_OK) return rc;
+      if(p < 0 || pstat == INACTIVE) return finish(JRLQP_SUCCESS);
+      TRY(hipMemsetAsync(h->s.u + q, 0, sizeof(double), st)); // u[q] = 0 (DualSolver.cpp:121)
+    }
+    double t1, zz, nz, nx, uq;
+    int l;
+    rc = jrlqp_dense_step(h, p, pstat, q, big, &t1, &l, &zz, &nz, &nx, &uq, stream);
+    if(rc != JRLQP_OK) return rc;
+    double t2 = big;
+    if(std::sqrt(zz) > 1e-14) t2 = (bound_value(p, pstat) - nx) / nz;
+    const double t = (t2 < t1) ? t2 : t1;
+    if(t >= big) return finish(JRLQP_INFEASIBLE);
+    const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -nz : nz;
+    if(t2 >= big)
+    {
+      rc = jrlqp_dense_advance(h, t, q, 0, stream);
+      if(rc != JRLQP_OK) return rc;
+      rc = jrlqp_dense_remove(h, l, q, h->active[l], stream);
+      if(rc != JRLQP_OK) return rc;
+      h->status[h->active[l]] = INACTIVE;
+      h->active.erase(h->active.begin() + l);
+      skip = true;
+    }
+    else
+    {
+      rc = jrlqp_dense_advance(h, t, q, 1, stream);
+      if(rc != JRLQP_OK) return rc;
+      h->f = std::fma(t * dotsc, 0.5 * t + uq, h->f);
+      if(t == t2)
+      {
+        rc = jrlqp_dense_add(h, p, pstat, q, stream);
+        if(rc != JRLQP_OK) return rc;
+        activate(p, pstat);
+        skip = false;
+      }
+      else
+      {
+        rc = jrlqp_dense_remove(h, l, q, h->active[l], stream);
+        if(rc != JRLQP_OK) return rc;
+        h->status[h->active[l]] = INACTIVE;
+        h->active.erase(h->active.begin() + l);
+        skip = true;
+      }
+    }
+  }
+  return finish(JRLQP_MAX_ITER_REACHED);
+}
+
+// solution(), multipliers() (sign-expanded, DualSolver.cpp:38-69), activeSet(), iterations(), objectiveValue()
+int jrlqp_dense_results(jrlqp_dense * h, double * x_host, double * u_host, int * status_host, int * iters, double * f, void * stream)
+{
+  if(!h) return JRLQP_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int q = (int)h->active.size();
+  if(x_host) TRY(hipMemcpyAsync(x_host, h->s.x, sizeof(double) * h->n, hipMemcpyDeviceToHost, st));
+  if(u_host && q) TRY(hipMemcpyAsync(h->h_u.data(), h->s.u, sizeof(double) * q, hipMemcpyDeviceToHost, st));
+  TRY(hipStreamSynchronize(st));
+  const int mt = h->m + h->nb;
+  if(u_host)
+  {
+    for(int i = 0; i < mt; ++i) u_host[i] = 0.0;
+    for(int k = 0; k < q; ++k)
+    {
+      const int i = h->active[k];
+      const int s = h->status[i];
+      u_host[i] = (s == 2 || s == 5) ? h->h_u[k] : -h->h_u[k];
+    }
+  }
+  if(status_host) for(int i = 0; i < mt; ++i) status_host[i] = h->status[i];
+  if(iters) *iters = h->it;
+  if(f) *f = h->f;
+  return JRLQP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,118 @@
+"""GPU parity tests of Mode A (one dense QP, state in HBM, host-driven hooks: jrlqp_dense_* of the C ABI) against
+the CPU oracle, bit for bit: termination status, iterations, active set, x, u, f and the Cholesky factor left in G
+(blocked LLT with the MFMA trailing update)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi(pkg):
+    import jrl_qp_amd.capi as capi
+
+    return capi
+
+
+@pytest.fixture(scope="module")
+def P(pkg):
+    import jrl_qp_amd.problems as problems
+
+    return problems
+
+
+def solve_gpu(capi, pb, b, use_bounds, max_iter=500):
+    import torch
+
+    n, m = pb.n, pb.m
+    G = torch.from_numpy(np.ascontiguousarray(pb.G[b])).cuda()
+    a = torch.from_numpy(np.ascontiguousarray(pb.a[b])).cuda()
+    C = torch.from_numpy(np.ascontiguousarray(pb.C[b])).cuda()
+    bl = torch.from_numpy(np.ascontiguousarray(pb.bl[b])).cuda()
+    bu = torch.from_numpy(np.ascontiguousarray(pb.bu[b])).cuda()
+    xl = torch.from_numpy(np.ascontiguousarray(pb.xl[b])).cuda() if use_bounds else None
+    xu = torch.from_numpy(np.ascontiguousarray(pb.xu[b])).cuda() if use_bounds else None
+    s = capi.DenseSolver(n, m, use_bounds, max_iter=max_iter)
+    r = s.solve(G, a, C, bl, bu, xl, xu)
+    torch.cuda.synchronize()
+    r["L"] = G.cpu().numpy().T  # column-major view
+    return r
+
+
+def check(gpu, ref, what):
+    assert gpu["term"] == ref.term, what
+    assert gpu["iters"] == ref.iters, what
+    assert np.array_equal(gpu["status"], ref.status), what
+    assert np.array_equal(gpu["x"], ref.x), f"{what}: x max diff {np.max(np.abs(gpu['x'] - ref.x)):.3e}"
+    assert np.array_equal(gpu["u"], ref.u), what
+    assert gpu["f"] == ref.f, what
+
+
+CASES = [
+    dict(nVar=10, nObj=10, nIneq=20, nStrongActIneq=3),  # BASELINE c1
+    dict(nVar=50, nObj=50, nIneq=200, nStrongActIneq=15),  # c3 shape through the host-driven path
+    dict(nVar=33, nObj=33, nEq=5, nIneq=70, nStrongActIneq=10, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
+    dict(nVar=100, nObj=100, nIneq=260, nStrongActIneq=30),  # several LLT panels, partial MFMA tiles (100 = 3*32 + 4)
+    dict(nVar=129, nObj=129, nEq=7, nIneq=150, nStrongActIneq=40, bounds=True, nStrongActBounds=9),
+    dict(nVar=5, nObj=5),
+    dict(nVar=1, nObj=1, nIneq=3, nStrongActIneq=1),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_dense_path_matches_oracle(capi, P, oracle, ci):
+    ch = P.Characteristics(**CASES[ci])
+    pb = P.generate_batch(3, ch, first_index=900 + 10 * ci)
+    hb = ch.bounds
+    for b in range(pb.B):
+        ref = oracle.solve(pb.G[b], pb.a[b], pb.C[b].T, pb.bl[b], pb.bu[b], pb.xl[b] if hb else None, pb.xu[b] if hb else None)
+        gpu = solve_gpu(capi, pb, b, hb)
+        check(gpu, ref, f"case {ci} problem {b}")
+        assert ref.term == 0
+        n = pb.n
+        assert np.array_equal(np.tril(gpu["L"]), np.tril(ref.L))  # factor left in G, lower triangle
+        assert np.array_equal(np.triu(gpu["L"], 1), np.triu(pb.G[b], 1))  # strictly upper part untouched
+
+
+def test_dense_n300(capi, P, oracle):
+    """A mid-size problem: 10 LLT panels, hundreds of iterations, drops included."""
+    ch = P.benchmark_characteristics(300, 600)
+    pb = P.generate_batch(1, ch, first_index=4242)
+    ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], max_iter=5000)
+    gpu = solve_gpu(capi, pb, 0, False, max_iter=5000)
+    check(gpu, ref, "n=300")
+    assert ref.term == 0 and np.linalg.norm(gpu["x"] - pb.x_star[0]) <= 1e-6
+
+
+def test_dense_status_codes(capi, P, oracle):
+    n, m = 4, 6
+    rng = np.random.default_rng(5)
+    G = np.eye(n)
+    a = rng.standard_normal(n)
+    C = rng.standard_normal((m, n))
+    bl = np.full(m, -np.inf)
+    bu = np.full(m, -5.0)
+    mk = lambda G_, bl_, bu_: P.PackedBatch(n=n, m=m, nb=0, G=G_[None], a=a[None], C=C[None], bl=bl_[None], bu=bu_[None], xl=np.zeros((1, 0)),
+                                            xu=np.zeros((1, 0)), x_star=np.zeros((1, n)), lam_star=np.zeros((1, m)))
+    # MAX_ITER_REACHED
+    pb = mk(G, bl, bu)
+    ref = oracle.solve(G, a, C.T, bl, bu, max_iter=2)
+    check(solve_gpu(capi, pb, 0, False, max_iter=2), ref, "max iter")
+    # NON_POS_HESSIAN at column 2 and at column 0
+    for col in (2, 0):
+        Gb = np.eye(n)
+        Gb[col, col] = -1.0
+        ref = oracle.solve(Gb, a, C.T, bl, bu)
+        g = solve_gpu(capi, mk(Gb, bl, bu), 0, False)
+        assert g["term"] == ref.term == 2
+    # INFEASIBLE
+    C2 = C.copy()
+    C2[0] = [1, 0, 0, 0]
+    C2[1] = [-1, 0, 0, 0]
+    bu2 = np.full(m, 10.0)
+    bu2[0] = bu2[1] = -1.0
+    pb2 = P.PackedBatch(n=n, m=m, nb=0, G=G[None], a=a[None], C=C2[None], bl=bl[None], bu=bu2[None], xl=np.zeros((1, 0)), xu=np.zeros((1, 0)),
+                        x_star=np.zeros((1, n)), lam_star=np.zeros((1, m)))
+    ref = oracle.solve(G, a, C2.T, bl, bu2)
+    check(solve_gpu(capi, pb2, 0, False), ref, "infeasible")
+    assert ref.term == 3
