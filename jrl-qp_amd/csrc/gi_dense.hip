@@ -240,55 +240,73 @@ __global__ __launch_bounds__(64) void llt_update_kernel(double * G, int ldg, int
 //       acc_i = delta_ic - sum_{k = c .. i0+NB, descending} L_ki J_kc      (rows below the block)
 //     then the in-block back substitution.  J must be zero below its diagonal on entry (memset).
 // ============================================================================================================
-__global__ __launch_bounds__(64) void jinv_block_kernel(const double * __restrict__ L, int ldl, double * __restrict__ J, int ldj, int n, int i0)
+__global__ __launch_bounds__(256) void jinv_block_kernel(const double * __restrict__ L, int ldl, double * __restrict__ J, int ldj, int n, int i0)
 {
-  __shared__ double Ls[64 * (NB + 1)]; // staged rows of L: Ls[kk][r] = L[k0 - kk, i0 + r]
+  // 4 waves share one tile of 64 columns: wave w accumulates rows 8w .. 8w+7 of the block (8 independent chains per
+  // lane instead of 32), the in-block substitution is done by wave 0 after the partial chains met in LDS
+  __shared__ double Ls[64 * (NB + 1)]; // staged rows of L:  Ls[k - klo][r] = L[k, i0 + r]
+  __shared__ double Jt[64 * 65];       // staged tile of J:  Jt[k - klo][c - c0] (coalesced loads, conflict-free reads)
   __shared__ double Ld[NB * (NB + 1)]; // the diagonal block of L
-  const int lane = threadIdx.x;
+  __shared__ double As[NB * 65];       // accumulators handed to wave 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nbk = min(NB, n - i0);
-  const int c = i0 + blockIdx.x * 64 + lane; // this lane's column
-  const int cmax = min(n - 1, i0 + blockIdx.x * 64 + 63);
+  const int c0 = i0 + blockIdx.x * 64;
+  const int c = c0 + lane; // this lane's column
+  const int cmax = min(n - 1, c0 + 63);
+  const int ncol = cmax - c0 + 1;
   const bool live = c < n;
-  double acc[NB];
+  constexpr int RW = NB / 4; // rows per wave
+  const int rbase = wave * RW;
+  double acc[RW];
 #pragma unroll
-  for(int r = 0; r < NB; ++r) acc[r] = (live && c == i0 + r) ? 1.0 : 0.0;
-  for(int e = lane; e < nbk * nbk; e += 64)
+  for(int r = 0; r < RW; ++r) acc[r] = (live && c == i0 + rbase + r) ? 1.0 : 0.0;
+  for(int e = tid; e < nbk * nbk; e += 256)
   {
     int i = e % nbk, j = e / nbk;
     Ld[i + j * (NB + 1)] = AT(L, ldl, i0 + i, i0 + j);
   }
-  // rows below the block, descending k, staged 64 at a time
+  // rows below the block, descending k, staged 64 at a time (J is zero below its diagonal, so rows k > c add nothing)
   for(int khi = cmax; khi >= i0 + nbk; khi -= 64)
   {
     const int cnt = min(64, khi - (i0 + nbk) + 1);
-    wave_sync();
-    for(int e = lane; e < cnt * nbk; e += 64)
+    const int klo = khi - cnt + 1;
+    __syncthreads();
+    for(int e = tid; e < cnt * nbk; e += 256)
     {
       int kk = e % cnt, r = e / cnt;
-      Ls[kk * (NB + 1) + r] = AT(L, ldl, khi - kk, i0 + r);
+      Ls[kk * (NB + 1) + r] = AT(L, ldl, klo + kk, i0 + r);
     }
-    wave_sync();
-    for(int kk = 0; kk < cnt; ++kk)
+    for(int e = tid; e < cnt * ncol; e += 256)
     {
-      const int k = khi - kk;
-      const double jk = (live && k <= c) ? AT(J, ldj, k, c) : 0.0;
+      int kk = e % cnt, cc = e / cnt;
+      Jt[kk * 65 + cc] = AT(J, ldj, klo + kk, c0 + cc);
+    }
+    __syncthreads();
+    for(int kk = cnt - 1; kk >= 0; --kk)
+    {
+      const double jk = live ? Jt[kk * 65 + lane] : 0.0;
 #pragma unroll
-      for(int r = 0; r < NB; ++r)
-        if(r < nbk) acc[r] = FMA(-Ls[kk * (NB + 1) + r], jk, acc[r]);
+      for(int r = 0; r < RW; ++r) acc[r] = FMA(-Ls[kk * (NB + 1) + rbase + r], jk, acc[r]);
     }
   }
-  wave_sync();
+#pragma unroll
+  for(int r = 0; r < RW; ++r) As[(rbase + r) * 65 + lane] = acc[r];
+  __syncthreads();
+  if(wave != 0) return;
   // in-block back substitution (descending i), all columns of this tile at once
+  double a2[NB];
+#pragma unroll
+  for(int r = 0; r < NB; ++r) a2[r] = As[r * 65 + lane];
 #pragma unroll
   for(int ri = NB - 1; ri >= 0; --ri)
   {
     if(ri < nbk)
     {
-      const double v = acc[ri] / Ld[ri + ri * (NB + 1)];
+      const double v = a2[ri] / Ld[ri + ri * (NB + 1)];
       if(live) AT(J, ldj, i0 + ri, c) = v;
 #pragma unroll
       for(int r = 0; r < NB; ++r)
-        if(r < ri) acc[r] = FMA(-Ld[ri + r * (NB + 1)], v, acc[r]);
+        if(r < ri) a2[r] = FMA(-Ld[ri + r * (NB + 1)], v, a2[r]);
     }
   }
 }
@@ -345,34 +363,65 @@ __global__ __launch_bounds__(1024) void x0_kernel(const double * __restrict__ L,
 // column dots: out[j] = sign * sum_k M[k + j*ld] v[k]   (K4 with M = C, v = x; K5 with M = J, v = C[:,p])
 // lane = column; the vector is staged in LDS; per lane the column is a contiguous stream.
 // ============================================================================================================
-__device__ __forceinline__ double column_dot(const double * __restrict__ col, const double * vs, int n)
+// Tile geometry of the streaming column-dot kernels: a workgroup (one wave) owns CT = 16 columns; the matrix is
+// streamed in tiles of KT = 64 rows x 16 columns.  ALL 64 lanes load (each column's 64 rows are 512 contiguous bytes:
+// full cache lines), the tile lands in LDS, and lanes 0..15 run the 16 in-order chains out of LDS.  Compared with one
+// lane per column streaming its own column, the matrix is spread over 4x as many CUs and every load is coalesced.
+constexpr int CT = 16, KT = 64;
+
+__device__ __forceinline__ double tile_column_dot(const double * __restrict__ M, int ld, int n, int col0, int ncols, const double * vs, double * tile,
+                                                  int lane)
 {
   double acc = 0.0;
-  int k = 0;
-  for(; k + 8 <= n; k += 8)
+  const int kk = lane; // row inside the tile this lane loads
+  // software pipeline: the global loads of tile t+1 are in flight while the chains consume tile t out of LDS
+  double nxt[CT];
+#pragma unroll
+  for(int c = 0; c < CT; ++c) nxt[c] = (c < ncols && kk < n) ? M[(size_t)(col0 + c) * ld + kk] : 0.0;
+  for(int k0 = 0; k0 < n; k0 += KT)
   {
-    double cv[8];
+    const int cnt = min(KT, n - k0);
+    wave_sync();
 #pragma unroll
-    for(int u = 0; u < 8; ++u) cv[u] = col[k + u];
+    for(int c = 0; c < CT; ++c) tile[c * (KT + 1) + kk] = nxt[c];
+    wave_sync();
+    const int k1 = k0 + KT;
 #pragma unroll
-    for(int u = 0; u < 8; ++u) acc = FMA(cv[u], vs[k + u], acc);
+    for(int c = 0; c < CT; ++c) nxt[c] = (c < ncols && k1 + kk < n) ? M[(size_t)(col0 + c) * ld + k1 + kk] : 0.0;
+    if(lane < ncols)
+    {
+      const double * tc = tile + lane * (KT + 1);
+      const double * vv = vs + k0;
+      int k = 0;
+      for(; k + 8 <= cnt; k += 8)
+      {
+        double cv[8], xv[8];
+#pragma unroll
+        for(int u = 0; u < 8; ++u)
+        {
+          cv[u] = tc[k + u];
+          xv[u] = vv[k + u];
+        }
+#pragma unroll
+        for(int u = 0; u < 8; ++u) acc = FMA(cv[u], xv[u], acc);
+      }
+      for(; k < cnt; ++k) acc = FMA(tc[k], vv[k], acc);
+    }
   }
-  for(; k < n; ++k) acc = FMA(col[k], vs[k], acc);
   return acc;
 }
 
 __global__ __launch_bounds__(64) void jtn_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign, double * out)
 {
-  extern __shared__ double vs[];
+  extern __shared__ double sh[]; // vector (n) | tile (CT x (KT+1))
+  double * vs = sh;
+  double * tile = sh + n;
   const int lane = threadIdx.x;
   for(int i = lane; i < n; i += 64) vs[i] = v[i];
-  wave_sync();
-  const int j = blockIdx.x * 64 + lane;
-  if(j < ncols)
-  {
-    double acc = column_dot(M + (size_t)j * ld, vs, n);
-    out[j] = (sign < 0.0) ? -acc : acc;
-  }
+  const int col0 = blockIdx.x * CT;
+  const int nc = min(CT, ncols - col0);
+  double acc = tile_column_dot(M, ld, n, col0, nc, vs, tile, lane);
+  if(lane < nc) out[col0 + lane] = (sign < 0.0) ? -acc : acc;
 }
 
 // bound constraint: d = +-row pb of J
@@ -386,21 +435,24 @@ __global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb
   }
 }
 
-// K4 partial: per 64 constraints the first-index arg-min of min(c.x - bl, bu - c.x) below 0
+// K4 partial: per CT constraints the first-index arg-min of min(c.x - bl, bu - c.x) below 0
 __global__ __launch_bounds__(64) void select_partial_kernel(const double * __restrict__ C, int ldc, int n, int m, const double * __restrict__ x,
                                                             const double * __restrict__ bl, const double * __restrict__ bu,
                                                             const unsigned char * __restrict__ st, double * pval, int * pidx, int * pstat)
 {
-  extern __shared__ double vs[];
+  extern __shared__ double sh[];
+  double * vs = sh;
+  double * tile = sh + n;
   const int lane = threadIdx.x;
   for(int i = lane; i < n; i += 64) vs[i] = x[i];
-  wave_sync();
-  const int i = blockIdx.x * 64 + lane;
+  const int col0 = blockIdx.x * CT;
+  const int nc = min(CT, m - col0);
+  const double cx = tile_column_dot(C, ldc, n, col0, nc, vs, tile, lane);
+  const int i = col0 + lane;
   double bval = 0.0;
   int bidx = NONE, bstat = INACTIVE;
-  if(i < m && st[i] == INACTIVE)
+  if(lane < nc && st[i] == INACTIVE)
   {
-    double cx = column_dot(C + (size_t)i * ldc, vs, n);
     double sl = cx - bl[i];
     if(sl < 0.0)
     {
@@ -496,23 +548,61 @@ __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const dou
   }
 }
 
-// K6  z = J2 d2: lane = row of J (coalesced), in-order chain over columns q .. n-1
+// K6  z = J2 d2.  A workgroup (one wave) owns 16 rows; all 64 lanes load (lane = (column offset, row): 4 columns x 16
+// rows per instruction, 128 contiguous bytes per column), the 16 x 64 tile lands in LDS, lanes 0..15 run the
+// in-order chains over columns q .. n-1.
 __global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ J, int ld, int n, int q, const double * __restrict__ d, double * z)
 {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if(i >= n) return;
+  __shared__ double tile[64 * 17]; // [column in tile][row], padded
+  __shared__ double dsm[64];
+  const int lane = threadIdx.x;
+  const int r0 = blockIdx.x * 16;
+  const int rr = lane & 15, cg = lane >> 4; // row in tile, column group
+  const bool rin = r0 + rr < n;
   double acc = 0.0;
-  int j = q;
-  for(; j + 8 <= n; j += 8)
+  double nxt[16], dn;
+#pragma unroll
+  for(int t = 0; t < 16; ++t)
   {
-    double jv[8];
-#pragma unroll
-    for(int u = 0; u < 8; ++u) jv[u] = AT(J, ld, i, j + u);
-#pragma unroll
-    for(int u = 0; u < 8; ++u) acc = FMA(jv[u], d[j + u], acc);
+    const int jc = q + t * 4 + cg;
+    nxt[t] = (rin && jc < n) ? AT(J, ld, r0 + rr, jc) : 0.0;
   }
-  for(; j < n; ++j) acc = FMA(AT(J, ld, i, j), d[j], acc);
-  z[i] = acc;
+  dn = (q + lane < n) ? d[q + lane] : 0.0;
+  for(int j0 = q; j0 < n; j0 += 64)
+  {
+    const int cnt = min(64, n - j0);
+    wave_sync();
+#pragma unroll
+    for(int t = 0; t < 16; ++t) tile[(t * 4 + cg) * 17 + rr] = nxt[t];
+    dsm[lane] = dn;
+    wave_sync();
+    const int j1 = j0 + 64;
+#pragma unroll
+    for(int t = 0; t < 16; ++t)
+    {
+      const int jc = j1 + t * 4 + cg;
+      nxt[t] = (rin && jc < n) ? AT(J, ld, r0 + rr, jc) : 0.0;
+    }
+    dn = (j1 + lane < n) ? d[j1 + lane] : 0.0;
+    if(lane < 16)
+    {
+      int j = 0;
+      for(; j + 8 <= cnt; j += 8)
+      {
+        double jv[8], dv[8];
+#pragma unroll
+        for(int u = 0; u < 8; ++u)
+        {
+          jv[u] = tile[(j + u) * 17 + lane];
+          dv[u] = dsm[j + u];
+        }
+#pragma unroll
+        for(int u = 0; u < 8; ++u) acc = FMA(jv[u], dv[u], acc);
+      }
+      for(; j < cnt; ++j) acc = FMA(tile[j * 17 + lane], dsm[j], acc);
+    }
+  }
+  if(lane < 16 && r0 + lane < n) z[r0 + lane] = acc;
 }
 
 // K7 + K8: one workgroup of 4 waves.  wave 0: r = R^-1 d1 (blocked back substitution, 64-column blocks) and the
@@ -522,35 +612,47 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const double * __restric
                                                         const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
                                                         int pb, Mailbox * mb)
 {
-  extern __shared__ double rs[]; // q doubles: the running right-hand side
+  extern __shared__ double rs[]; // q doubles (the running right-hand side) | 64 x 65 staging block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if(wave == 0)
   {
+    double * Rb = rs + ((q + 1) & ~1);
     for(int i = lane; i < q; i += 64) rs[i] = d[i];
     wave_sync();
     for(int kb = ((q - 1) / 64) * 64; kb >= 0 && q > 0; kb -= 64)
     {
       const int cnt = min(64, q - kb);
-      // diagonal block: lane = row kb + lane
+      // stage the diagonal block (coalesced column reads) so that the substitution chain runs out of LDS
+      for(int k = 0; k < cnt; ++k) Rb[lane + k * 65] = (lane < cnt) ? AT(R, ld, kb + lane, kb + k) : 0.0;
+      wave_sync();
       double rk = (lane < cnt) ? rs[kb + lane] : 0.0;
+      const double dg = (lane < cnt) ? Rb[lane + lane * 65] : 1.0;
       for(int k = cnt - 1; k >= 0; --k)
       {
-        double v = bcast_lane(rk, k) / AT(R, ld, kb + k, kb + k);
-        if(lane == k)
-          rk = v;
-        else if(lane < k)
-          rk = FMA(-AT(R, ld, kb + lane, kb + k), v, rk);
+        const double v = bcast_lane(rk, k) / bcast_lane(dg, k);
+        const double upd = FMA(-Rb[lane + k * 65], v, rk);
+        rk = (lane < k) ? upd : rk;
+        rk = (lane == k) ? v : rk;
       }
       if(lane < cnt) rs[kb + lane] = rk;
       wave_sync();
-      // rows above the block: their chains take this block's columns in descending k
+      // rows above the block: their chains take this block's columns in descending k (8 loads in flight)
       for(int i0 = 0; i0 < kb; i0 += 64)
       {
         const int i = i0 + lane;
         if(i < kb)
         {
           double acc = rs[i];
-          for(int k = cnt - 1; k >= 0; --k) acc = FMA(-AT(R, ld, i, kb + k), rs[kb + k], acc);
+          int k = cnt - 1;
+          for(; k - 7 >= 0; k -= 8)
+          {
+            double rv[8];
+#pragma unroll
+            for(int u = 0; u < 8; ++u) rv[u] = AT(R, ld, i, kb + k - u);
+#pragma unroll
+            for(int u = 0; u < 8; ++u) acc = FMA(-rv[u], rs[kb + k - u], acc);
+          }
+          for(; k >= 0; --k) acc = FMA(-AT(R, ld, i, kb + k), rs[kb + k], acc);
           rs[i] = acc;
         }
       }
@@ -586,12 +688,24 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const double * __restric
   {
     // wave 1: z.z   wave 2: n.z   wave 3: n.x   (n = C[:,p] for a general constraint, e_pb for a bound)
     double acc = 0.0;
-    if(wave == 1)
-      for(int k = 0; k < n; ++k) acc = FMA(z[k], z[k], acc);
-    else if(cp)
+    if(wave == 1 || cp)
     {
-      const double * v = (wave == 2) ? z : x;
-      for(int k = 0; k < n; ++k) acc = FMA(cp[k], v[k], acc);
+      const double * pa = (wave == 1) ? z : cp;
+      const double * pv = (wave == 3) ? x : z;
+      int k = 0;
+      for(; k + 8 <= n; k += 8)
+      {
+        double av[8], bv[8];
+#pragma unroll
+        for(int u = 0; u < 8; ++u)
+        {
+          av[u] = pa[k + u];
+          bv[u] = pv[k + u];
+        }
+#pragma unroll
+        for(int u = 0; u < 8; ++u) acc = FMA(av[u], bv[u], acc);
+      }
+      for(; k < n; ++k) acc = FMA(pa[k], pv[k], acc);
     }
     else
       acc = (wave == 2) ? z[pb] : x[pb];
@@ -654,10 +768,25 @@ __global__ __launch_bounds__(64) void rot_apply_kernel(double * J, int ld, int n
 {
   const int row = blockIdx.x * 64 + threadIdx.x;
   if(row >= n || i_hi < i_lo) return;
+  constexpr int U = 8; // columns fetched per group: the loads of a group are in flight together
   if(descending)
   {
     double carry = AT(J, ld, row, i_hi + 1);
-    for(int i = i_hi; i >= i_lo; --i)
+    int i = i_hi;
+    for(; i - (U - 1) >= i_lo; i -= U)
+    {
+      double xv[U];
+#pragma unroll
+      for(int u = 0; u < U; ++u) xv[u] = AT(J, ld, row, i - u);
+#pragma unroll
+      for(int u = 0; u < U; ++u)
+      {
+        const double c = cc[i - u], s = ss[i - u];
+        AT(J, ld, row, i - u + 1) = FMA(s, xv[u], c * carry);
+        carry = FMA(c, xv[u], -(s * carry));
+      }
+    }
+    for(; i >= i_lo; --i)
     {
       const double c = cc[i], s = ss[i];
       const double xv = AT(J, ld, row, i);
@@ -669,7 +798,21 @@ __global__ __launch_bounds__(64) void rot_apply_kernel(double * J, int ld, int n
   else
   {
     double carry = AT(J, ld, row, i_lo);
-    for(int i = i_lo; i <= i_hi; ++i)
+    int i = i_lo;
+    for(; i + (U - 1) <= i_hi; i += U)
+    {
+      double yv[U];
+#pragma unroll
+      for(int u = 0; u < U; ++u) yv[u] = AT(J, ld, row, i + u + 1);
+#pragma unroll
+      for(int u = 0; u < U; ++u)
+      {
+        const double c = cc[i + u], s = ss[i + u];
+        AT(J, ld, row, i + u) = FMA(c, carry, -(s * yv[u]));
+        carry = FMA(s, carry, c * yv[u]);
+      }
+    }
+    for(; i <= i_hi; ++i)
     {
       const double c = cc[i], s = ss[i];
       const double y = AT(J, ld, row, i + 1);
@@ -757,7 +900,7 @@ hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t 
   {
     const int i0 = b * NB;
     const int cols = n - i0;
-    hipLaunchKernelGGL(jinv_block_kernel, dim3((cols + 63) / 64), dim3(64), 0, st, L, ldl, J, n, n, i0);
+    hipLaunchKernelGGL(jinv_block_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, L, ldl, J, n, n, i0);
   }
   return hipGetLastError();
 }
@@ -770,9 +913,9 @@ hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double *
 
 hipError_t dense_select(const DenseViews & v, DenseState & s, hipStream_t st)
 {
-  const int parts = (v.m + 63) / 64;
+  const int parts = (v.m + CT - 1) / CT;
   if(parts > 0)
-    hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * v.n, st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
+    hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * (v.n + CT * (KT + 1)), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
                        s.pval, s.pidx, s.pstat);
   hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, s.mb);
   return hipGetLastError();
@@ -786,12 +929,12 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   if(p < v.m)
   {
     cp = v.C + (size_t)p * v.ldc;
-    hipLaunchKernelGGL(jtn_kernel, dim3((n + 63) / 64), dim3(64), sizeof(double) * n, st, s.J, n, n, n, cp, sign, s.d);
+    hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, cp, sign, s.d);
   }
   else
     hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d);
-  hipLaunchKernelGGL(z_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
-  hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (q > 0 ? q : 1), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
+  hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
+  hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (((q + 1) & ~1) + 64 * 65 + 2), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
                      p - v.m, s.mb);
   return hipGetLastError();
 }

@@ -71,7 +71,7 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = dmalloc(s.cc, n);
   if(e == hipSuccess) e = dmalloc(s.ss, n);
   if(e == hipSuccess) e = dmalloc(s.st, mt);
-  const size_t parts = ((size_t)m + 63) / 64;
+  const size_t parts = ((size_t)m + 15) / 16; // select_partial_kernel: one partial per 16 constraints
   if(e == hipSuccess) e = dmalloc(s.pval, parts);
   if(e == hipSuccess) e = dmalloc(s.pidx, parts);
   if(e == hipSuccess) e = dmalloc(s.pstat, parts);
