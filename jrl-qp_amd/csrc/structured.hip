@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void arrow_block_kernel(const BlockDesc D)
 // =========================================================================================================
 __global__ __launch_bounds__(256) void arrow_head_kernel(const BlockDesc D)
 {
-  extern __shared__ double sm[];
+  extern __shared__ double sm[]; // Ls (nbk x ldl) | Bs (64 x 65): the current side block, staged with coalesced loads
   const int tid = threadIdx.x;
   const int pb = blockIdx.x;
   const int ib = dsel(D.nblk, D.up, D.nblk - 1);
@@ -186,24 +186,71 @@ __global__ __launch_bounds__(256) void arrow_head_kernel(const BlockDesc D)
   const int ldd = D.ldd[ib];
   const int ldl = nbk | 1;
   double * Ls = sm;
+  double * Bs = sm + (size_t)nbk * ldl;
   if(D.fail[pb]) return; // a block already failed: the reference returns false before touching D_b further
-  for(int e = tid; e < nbk * nbk; e += 256)
+  // each thread owns up to 16 lower-triangle elements (r, c) of D_b: e = tid + 256*s
+  constexpr int SL = 16;
+  double acc[SL];
+#pragma unroll
+  for(int s = 0; s < SL; ++s)
   {
-    int r = e % nbk, c = e / nbk;
-    if(r < c) continue;
-    double acc = AT(Dg, ldd, r, c);
-    for(int i = 0; i < D.nblk - 1; ++i)
+    const int e = tid + 256 * s;
+    const int r = e % nbk, c = e / nbk;
+    acc[s] = (e < nbk * nbk && r >= c) ? AT(Dg, ldd, r, c) : 0.0;
+  }
+  // software pipeline over the blocks: the next block travels from L2 to registers while this one is consumed
+  double nxt[SL];
+  auto fetch = [&](int i) {
+    const int id = dsel(D.nblk, D.up, i);
+    const int ni = D.bs[id];
+    const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+    const int ldsg = D.lds[i];
+    const int rows = D.up ? ni : nbk, cols = D.up ? nbk : ni; // stored shape of side[i]
+#pragma unroll
+    for(int s = 0; s < SL; ++s)
     {
-      const int id = dsel(D.nblk, D.up, i);
-      const int ni = D.bs[id];
-      const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
-      const int ldsg = D.lds[i];
-      if(!D.up)
-        for(int k = 0; k < ni; ++k) acc = FMA(-AT(Sg, ldsg, r, k), AT(Sg, ldsg, c, k), acc);
-      else
-        for(int k = 0; k < ni; ++k) acc = FMA(-AT(Sg, ldsg, k, r), AT(Sg, ldsg, k, c), acc);
+      const int e = tid + 256 * s;
+      nxt[s] = (e < rows * cols) ? AT(Sg, ldsg, e % rows, e / rows) : 0.0;
     }
-    AT(Ls, ldl, r, c) = acc;
+  };
+  if(D.nblk > 1) fetch(0);
+  for(int i = 0; i < D.nblk - 1; ++i)
+  {
+    const int id = dsel(D.nblk, D.up, i);
+    const int ni = D.bs[id];
+    const int rows = D.up ? ni : nbk, cols = D.up ? nbk : ni;
+    __syncthreads();
+#pragma unroll
+    for(int s = 0; s < SL; ++s)
+    {
+      const int e = tid + 256 * s;
+      if(e < rows * cols) Bs[(e % rows) + (e / rows) * 65] = nxt[s];
+    }
+    __syncthreads();
+    if(i + 1 < D.nblk - 1) fetch(i + 1);
+#pragma unroll
+    for(int s = 0; s < SL; ++s)
+    {
+      const int e = tid + 256 * s;
+      const int r = e % nbk, c = e / nbk;
+      if(e < nbk * nbk && r >= c)
+      {
+        double a = acc[s];
+        if(!D.up)
+          for(int k = 0; k < ni; ++k) a = FMA(-Bs[r + k * 65], Bs[c + k * 65], a); // B_i(r,k) B_i(c,k)
+        else
+          for(int k = 0; k < ni; ++k) a = FMA(-Bs[k + r * 65], Bs[k + c * 65], a); // side stores B_i^T
+        acc[s] = a;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for(int s = 0; s < SL; ++s)
+  {
+    const int e = tid + 256 * s;
+    const int r = e % nbk, c = e / nbk;
+    if(e < nbk * nbk && r >= c) AT(Ls, ldl, r, c) = acc[s];
   }
   __syncthreads();
   if(tid < 64)
@@ -527,7 +574,7 @@ hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipS
   hipError_t e = hipMemsetAsync(d.fail, 0, sizeof(int) * nprob, st);
   if(e != hipSuccess) return e;
   if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(64), lds_arrow_block(maxb), st, d);
-  hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), sizeof(double) * (size_t)maxb * (maxb | 1), st, d);
+  hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), sizeof(double) * ((size_t)maxb * (maxb | 1) + 64 * 65), st, d);
   return hipGetLastError();
 }
 
