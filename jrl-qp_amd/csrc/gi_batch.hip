@@ -73,6 +73,8 @@ struct Ctl
   int l;
   int eq_next;
   int cnt;
+  int flag; // sequence number of the last add whose (c, s) coefficients are published (wave 0 -> wave 1 hand-off)
+  int pad;
 };
 
 #define FMA(a, b, c) __builtin_fma((a), (b), (c))
@@ -227,6 +229,40 @@ __device__ __forceinline__ double givens_r_only(double p, double q)
   const double t = lo / hi;
   const double r = hi * sqrt_1to2(FMA(t, t, 1.0));
   return (hi == 0.0) ? 0.0 : r;
+}
+
+// Division with the denominator-only part hoisted.  hipcc expands a/b (f64) into
+//   s0 = div_scale(b,b,a); r = rcp(s0); two Newton steps on r; s1 = div_scale(a,b,a); q0 = s1*r; e = fma(-s0,q0,s1);
+//   q = div_fmas(e, r, q0); div_fixup(q, b, a)
+// and div_scale / div_fmas / div_fixup are identities unless an operand is zero/denormal/huge (exponent beyond
+// +-768 or so).  Inside the safe range below the quotient is therefore exactly fma(e, r, q0) with r depending on the
+// DENOMINATOR ONLY: a substitution chain can precompute r for all its pivots at once (one lane per pivot) and keep
+// three dependent ops per step instead of thirteen.  Outside the safe range the caller falls back to a/b, so the
+// result is bit-identical to the plain division in every case.
+__device__ __forceinline__ double recip_refined(double den)
+{
+  double r = __builtin_amdgcn_rcp(den);
+  double e = FMA(-den, r, 1.0);
+  r = FMA(r, e, r);
+  e = FMA(-den, r, 1.0);
+  r = FMA(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_pre(double num, double den, double rinv)
+{
+  const double q0 = num * rinv;
+  const double e = FMA(-den, q0, num);
+  return FMA(e, rinv, q0);
+}
+__device__ __forceinline__ bool div_safe_den(double d)
+{
+  const double a = fabs(d);
+  return a > 0x1p-400 && a < 0x1p400;
+}
+__device__ __forceinline__ bool div_safe_num(double v)
+{
+  const double a = fabs(v);
+  return (a > 0x1p-400 && a < 0x1p400) || v == 0.0;
 }
 
 // keeps a wave-uniform value in a VGPR and hides its provenance from the compiler: without this hipcc
@@ -387,13 +423,17 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 // PROF: diagnostic build only -- thread 0 accumulates shader-clock cycles per phase into A.prof[b*16 + slot]
 // (slots: 0 load, 1 LLT, 2 J/x0, 3 scan (not overlapped), 4 d=J^T n, 5 trsv||z, 6 step+update, 7 add (+overlapped scan),
 //  8 drop, 9 store, 10 #adds, 11 #drops, 12 s_memrealtime ticks (100 MHz) for the whole solve).
-#define STAMP(slot)                                  \
-  if(PROF && tid == 0)                               \
-  {                                                  \
-    long long now_ = clock64();                      \
-    A.prof[(size_t)b * 32 + (slot)] += now_ - last_; \
-    last_ = now_;                                    \
+// The accumulators live in LDS (ds_add_u64, fire-and-forget) and are copied out once at the end: accumulating
+// straight into global memory costs a load round trip per stamp and distorts every phase by 1-2 k cycles.
+#define STAMP(slot)                                                                     \
+  if(PROF && tid == 0)                                                                  \
+  {                                                                                     \
+    long long now_ = clock64();                                                         \
+    atomicAdd(&prof_lds[(slot)], (unsigned long long)(now_ - last_));                   \
+    last_ = clock64();                                                                  \
   }
+#define PROF_COUNT(slot)                                   \
+  if(PROF && tid == 0) atomicAdd(&prof_lds[(slot)], 1ull);
 
 // ---- the kernel ------------------------------------------------------------------------------------------
 // NT    : compile-time n (0 = runtime n)
@@ -408,6 +448,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     wall0_ = wall_clock64();
   }
   extern __shared__ double smem[];
+  __shared__ unsigned long long prof_lds[PROF ? 32 : 1];
+  if(PROF && threadIdx.x < 32) prof_lds[threadIdx.x] = 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
@@ -476,6 +518,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     ctl->f = 0.0;
     ctl->eq_next = NONE;
     ctl->cnt = 0;
+    ctl->flag = 0;
   }
   __syncthreads();
   STAMP(0)
@@ -588,25 +631,40 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
       const double ai = xi;
       double dg = L[rl + rl * ld];
       dg = (lane < n) ? dg : 1.0;
-      double col = L[rl]; // column 0
-      for(int k = 0; k < n; ++k) // x = L.solve(a), branch-free body
+      const double rinv = recip_refined(dg);
+      const bool den_safe = __all(div_safe_den(dg));
+      for(int pass = 0; pass < 2; ++pass)
       {
-        const double coln = L[rl + ((k + 1 < n) ? (k + 1) : k) * ld];
-        const double v = opaque_v(bcast_lane(xi, k)) / opaque_v(bcast_lane(dg, k));
-        const double upd = FMA(-col, v, xi);
-        xi = (lane > k && lane < n) ? upd : xi;
-        xi = (lane == k) ? v : xi;
-        col = coln;
-      }
-      col = L[(n - 1) + rl * ld]; // row n-1 of L = column n-1 of L^T
-      for(int k = n - 1; k >= 0; --k) // L^T.solveInPlace(x)
-      {
-        const double coln = L[((k > 0) ? (k - 1) : 0) + rl * ld];
-        const double v = opaque_v(bcast_lane(xi, k)) / opaque_v(bcast_lane(dg, k));
-        const double upd = FMA(-col, v, xi);
-        xi = (lane < k) ? upd : xi;
-        xi = (lane == k) ? v : xi;
-        col = coln;
+        // pass 0: hoisted reciprocals (div_pre); pass 1 (only if an operand left the safe range): plain a/b
+        bool safe = den_safe;
+        xi = ai;
+        double col = L[rl]; // column 0
+        for(int k = 0; k < n; ++k) // x = L.solve(a), branch-free body
+        {
+          const double coln = L[rl + ((k + 1 < n) ? (k + 1) : k) * ld];
+          const double num = opaque_v(bcast_lane(xi, k));
+          const double den = bcast_lane(dg, k);
+          const double v = (pass == 0) ? div_pre(num, den, bcast_lane(rinv, k)) : num / opaque_v(den);
+          safe = safe && div_safe_num(num);
+          const double upd = FMA(-col, v, xi);
+          xi = (lane > k && lane < n) ? upd : xi;
+          xi = (lane == k) ? v : xi;
+          col = coln;
+        }
+        col = L[(n - 1) + rl * ld]; // row n-1 of L = column n-1 of L^T
+        for(int k = n - 1; k >= 0; --k) // L^T.solveInPlace(x)
+        {
+          const double coln = L[((k > 0) ? (k - 1) : 0) + rl * ld];
+          const double num = opaque_v(bcast_lane(xi, k));
+          const double den = bcast_lane(dg, k);
+          const double v = (pass == 0) ? div_pre(num, den, bcast_lane(rinv, k)) : num / opaque_v(den);
+          safe = safe && div_safe_num(num);
+          const double upd = FMA(-col, v, xi);
+          xi = (lane < k) ? upd : xi;
+          xi = (lane == k) ? v : xi;
+          col = coln;
+        }
+        if(safe) break;
       }
       xi = -xi;
       if(lane < n) xs[lane] = xi;
@@ -620,6 +678,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
 
     const double big = A.big_bnd;
     int p = -1, pstat = INACTIVE;
+    int addno = 0; // number of constraints added so far: the hand-off token of add_chain / add_apply
 
     // ======================================================================================================
     // device-local lambdas (all inlined); barriers only ever appear in the kernel body, never inside them
@@ -797,15 +856,41 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
       rk = (lane < q) ? rk : 0.0;
       double dg = R[rl + rl * ld];
       dg = (lane < q) ? dg : 1.0;
-      double col = R[rl + ((q > 0) ? (q - 1) : 0) * ld];
+      const double rk0 = rk;
+      const double rinv = recip_refined(dg); // every pivot's reciprocal at once (lane = pivot)
+      bool safe = __all(div_safe_den(dg));
+      // columns are fetched FOUR steps ahead (the LDS is shared with 11 other waves: a one-step prefetch still
+      // exposes most of its latency on this chain)
+      auto colat = [&](int k) { return R[rl + ((k > 0) ? k : 0) * ld]; };
+      double c0 = colat(q - 1), c1 = colat(q - 2), c2 = colat(q - 3), c3 = colat(q - 4);
       for(int k = q - 1; k >= 0; --k)
       {
-        const double coln = R[rl + ((k > 0) ? (k - 1) : 0) * ld]; // prefetch the next column (always a valid address)
-        const double v = opaque_v(bcast_lane(rk, k)) / opaque_v(bcast_lane(dg, k));
+        const double col = c0;
+        c0 = c1;
+        c1 = c2;
+        c2 = c3;
+        c3 = colat(k - 4);
+        const double num = opaque_v(bcast_lane(rk, k));
+        const double v = div_pre(num, bcast_lane(dg, k), bcast_lane(rinv, k));
+        safe = safe && div_safe_num(num);
         const double upd = FMA(-col, v, rk);
         rk = (lane < k) ? upd : rk;
         rk = (lane == k) ? v : rk;
-        col = coln;
+      }
+      if(!safe)
+      {
+        // an operand left the range in which the hoisted reciprocal is provably the compiler's own: redo with a/b
+        rk = rk0;
+        double col = R[rl + ((q > 0) ? (q - 1) : 0) * ld];
+        for(int k = q - 1; k >= 0; --k)
+        {
+          const double coln = R[rl + ((k > 0) ? (k - 1) : 0) * ld];
+          const double v = opaque_v(bcast_lane(rk, k)) / opaque_v(bcast_lane(dg, k));
+          const double upd = FMA(-col, v, rk);
+          rk = (lane < k) ? upd : rk;
+          rk = (lane == k) ? v : rk;
+          col = coln;
+        }
       }
       if(lane < q) rs[lane] = rk;
       STAMP(16)
@@ -879,8 +964,10 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     //   2. lane i recomputes rotation i from (d_i, r_{i+1}) -- same function, same bits -- and derives (c_i, s_i):
     //      all the 1/u divisions happen at once instead of inside the chain
     //   3. lane = row of J: sweep i = n-2 .. q applying the rotations, operands prefetched one step ahead
-    auto do_add = [&](int pp, int ps) {
-      const int rl = (lane < n) ? lane : (n - 1); // lanes >= n shadow row n-1 (same values, same addresses)
+    // wave 0: phases 1 and 2; publishes (c_i, s_i) in LDS (z and r are dead after the primal/dual update) and raises
+    // the flag wave 1 is waiting on; then the new column of R and the active-set bookkeeping
+    auto add_chain = [&](int pp, int ps, int token) {
+      const int rl = (lane < n) ? lane : (n - 1);
       const double dreg = ds[rl];
       double rho = opaque_v(bcast_lane(dreg, n - 1));
       double kq = 0.0;
@@ -897,33 +984,14 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
         (void)givens_r(dreg, kq, h);
         double cl, sl;
         givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
-        double carry = J[rl + (n - 1) * ld];
-        int i = n - 2;
-#pragma unroll 1
-        for(; i - 3 >= q; i -= 4)
+        if(lane >= q && lane <= n - 2)
         {
-          double xv[4];
-#pragma unroll
-          for(int u = 0; u < 4; ++u) xv[u] = J[rl + (i - u) * ld];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for(int u = 0; u < 4; ++u)
-          {
-            const double c2 = bcast_lane(cl, i - u), s2 = bcast_lane(sl, i - u);
-            J[rl + (i - u + 1) * ld] = FMA(s2, xv[u], c2 * carry);
-            carry = FMA(c2, xv[u], -(s2 * carry));
-          }
+          zs[lane] = cl;
+          rs[lane] = sl;
         }
-#pragma unroll 1
-        for(; i >= q; --i)
-        {
-          const double xv = J[rl + i * ld];
-          const double c2 = bcast_lane(cl, i), s2 = bcast_lane(sl, i);
-          J[rl + (i + 1) * ld] = FMA(s2, xv, c2 * carry);
-          carry = FMA(c2, xv, -(s2 * carry));
-        }
-        J[rl + q * ld] = carry;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if(lane == 0) __atomic_store_n(&ctl->flag, token, __ATOMIC_RELAXED);
       STAMP(14)
       // R.col(q).head(q+1) = d.head(q+1)
       if(lane < q)
@@ -935,6 +1003,45 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
         act[q] = pp;
         st[pp] = (unsigned char)ps;
       }
+    };
+
+    // wave 1: phase 3, lane = row of J (lanes >= n shadow row n-1: same values, same addresses); runs while wave 0
+    // scans its own constraints
+    auto add_apply = [&](int qa, int token) {
+      while(__atomic_load_n(&ctl->flag, __ATOMIC_RELAXED) != token) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if(n - 2 < qa) return;
+      const int rl = (lane < n) ? lane : (n - 1);
+      double carry = J[rl + (n - 1) * ld];
+      int i = n - 2;
+#pragma unroll 1
+      for(; i - 3 >= qa; i -= 4)
+      {
+        double xv[4], cv[4], sv[4];
+#pragma unroll
+        for(int u = 0; u < 4; ++u)
+        {
+          xv[u] = J[rl + (i - u) * ld];
+          cv[u] = zs[i - u];
+          sv[u] = rs[i - u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for(int u = 0; u < 4; ++u)
+        {
+          J[rl + (i - u + 1) * ld] = FMA(sv[u], xv[u], cv[u] * carry);
+          carry = FMA(cv[u], xv[u], -(sv[u] * carry));
+        }
+      }
+#pragma unroll 1
+      for(; i >= qa; --i)
+      {
+        const double xv = J[rl + i * ld];
+        const double c2 = zs[i], s2 = rs[i];
+        J[rl + (i + 1) * ld] = FMA(s2, xv, c2 * carry);
+        carry = FMA(c2, xv, -(s2 * carry));
+      }
+      J[rl + qa * ld] = carry;
     };
 
     // K11 (wave 0): removeConstraint (DualSolver.cpp:237-244, GoldfarbIdnaniSolver.cpp:239-256)
@@ -1042,11 +1149,14 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
             double bb = uniform_d((p < m) ? blg[p] : xlg[p - m]);
             t = (bb - uniform_d(ctl->cx)) / cz;
           }
+          ++addno;
           if(wave == 0)
           {
             apply_step(t, cz, false);
-            do_add(p, pstat);
+            add_chain(p, pstat, addno);
           }
+          else if(wave == 1)
+            add_apply(q, addno);
           q = uniform(q + 1);
           __syncthreads();
         }
@@ -1143,17 +1253,20 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
             __syncthreads(); // x is final: waves 1-3 may scan for the NEXT pass while wave 0 sweeps
             double bv;
             int bi, bs;
+            ++addno;
             if(wave == 0)
             {
-              do_add(p, pstat);
+              add_chain(p, pstat, addno);
               wave_sync();
             }
+            const int qa = q;
             q = uniform(q + 1);
             ++it;
             scan_local(p, bv, bi, bs); // p is treated as active (wave 0 has it in st[] by now, the others exclude it)
             scan_publish(bv, bi, bs);
             STAMP(15)
-            if(wave == 0 && PROF && tid == 0) A.prof[(size_t)b * 32 + 10] += 1;
+            if(wave == 1) add_apply(qa, addno); // overlaps wave 0's share of the scan
+            PROF_COUNT(10)
             __syncthreads();
             STAMP(7)
             if(it >= A.max_iter)
@@ -1171,7 +1284,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
             if(wave == 0) do_drop(l);
             q = uniform(q - 1);
             ++it;
-            if(PROF && tid == 0) A.prof[(size_t)b * 32 + 11] += 1;
+            PROF_COUNT(11)
             STAMP(8)
             if(it >= A.max_iter)
             {
@@ -1209,7 +1322,12 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     A.f[b] = ctl->f;
   }
   STAMP(9)
-  if(PROF && tid == 0) A.prof[(size_t)b * 32 + 12] += wall_clock64() - wall0_;
+  if(PROF)
+  {
+    __syncthreads();
+    if(tid < 32) A.prof[(size_t)b * 32 + tid] = (long long)prof_lds[tid];
+    if(tid == 0) A.prof[(size_t)b * 32 + 12] = wall_clock64() - wall0_;
+  }
 }
 
 template<int NT, int CMODE, bool PROF>
