@@ -479,6 +479,13 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     bus = bls + m;
     tail = bus + m;
   }
+  // CMODE 2: constraint i < 192 lives in the registers of thread 64 + i (waves 1-3: wave 0 owns no constraint, so
+  // the next pass's scan never lands on the wave that runs the serial chains); the m - 192 remaining columns are
+  // staged in LDS and scanned by wave 1 in a second, short pass
+  constexpr int CREG_MAX = WG - 64;
+  const int ne = (CMODE == 2 && m > CREG_MAX) ? (m - CREG_MAX) : 0;
+  double * Ce = tail;
+  if(CMODE == 2) tail = Ce + (size_t)ne * ld;
   Ctl * ctl = reinterpret_cast<Ctl *>(tail);
   int * act = reinterpret_cast<int *>(ctl + 1);
   unsigned char * st = reinterpret_cast<unsigned char *>(act + (n + 2));
@@ -494,14 +501,20 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
   // ---------------------------------------------------------------- C column -> registers (CMODE 2)
   double creg[NR];
   double my_bl = 0.0, my_bu = 0.0;
+  const int myc = (CMODE == 2) ? (tid - 64) : -1; // constraint held in this thread's registers
   if(CMODE == 2)
   {
-    const bool own = tid < m;
-    const double * ci = Cg + (size_t)(own ? tid : 0) * n;
+    const bool own = myc >= 0 && myc < m;
+    const double * ci = Cg + (size_t)(own ? myc : 0) * n;
 #pragma unroll
     for(int k = 0; k < NR; ++k) creg[k] = own ? ci[k] : 0.0;
-    my_bl = own ? blg[tid] : 0.0;
-    my_bu = own ? bug[tid] : 0.0;
+    my_bl = own ? blg[myc] : 0.0;
+    my_bu = own ? bug[myc] : 0.0;
+    for(int e = tid; e < ne * n; e += WG)
+    {
+      int k = e % n, i = e / n;
+      Ce[(size_t)i * ld + k] = Cg[(size_t)(CREG_MAX + i) * n + k];
+    }
   }
 
   // ---------------------------------------------------------------- load G (coalesced) -> R region, status = 0
@@ -691,7 +704,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
       bstat = INACTIVE;
       if(CMODE == 2)
       {
-        if(tid < m && st[tid] == INACTIVE && tid != excl)
+        if(myc >= 0 && myc < m && st[myc] == INACTIVE && myc != excl)
         {
           double cx = 0.0;
           // static register indices need full unrolling; x is fetched ten values at a time so that the LDS
@@ -714,13 +727,13 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           if(sl < 0.0)
           {
             bval = sl;
-            bidx = tid;
+            bidx = myc;
             bstat = LOWER;
           }
           else if(su < 0.0)
           {
             bval = su;
-            bidx = tid;
+            bidx = myc;
             bstat = UPPER;
           }
         }
@@ -751,8 +764,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           }
         }
       }
-      for(int i = tid; i < nb; i += WG)
+      for(int i = (CMODE == 2) ? (tid - 64) : tid; i < nb; i += (CMODE == 2) ? (WG - 64) : WG)
       {
+        if(i < 0) break; // CMODE 2: wave 0 takes no part in the scan
         if(st[m + i] != INACTIVE || (m + i) == excl) continue;
         double xi = xs[i];
         double sl = xi - xlg[i];
@@ -775,15 +789,60 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
       }
     };
 
-    // wave-level reduction of the scan candidates + hand-off of the wave's winner
-    auto scan_publish = [&](double bval, int bidx, int bstat) {
-      if(CMODE == 2 && nb == 0)
+    // wave-level reduction of the scan candidates + hand-off of the wave's winner.  CMODE 2: waves 1-3 publish slots
+    // 1-3; slot 0 (wave 0 holds no constraint) carries the winner among the LDS-staged extra columns, which wave 1
+    // scans in a second pass (lane e = extra column e).
+    auto scan_publish = [&](int excl, double bval, int bidx, int bstat) {
+      if(CMODE == 2)
       {
-        if(bidx == NONE) bval = 1.0; // candidates are < 0
-        wave_argmin_monotone(bval, bidx, bstat);
+        if(wave == 0) return;
+        if(nb == 0)
+        {
+          if(bidx == NONE) bval = 1.0; // candidates are < 0
+          wave_argmin_monotone(bval, bidx, bstat);
+        }
+        else
+          wave_argmin(bval, bidx, bstat);
+        if(lane == 0)
+        {
+          ctl->red_val[wave] = bval;
+          ctl->red_idx[wave] = bidx;
+          ctl->red_stat[wave] = bstat;
+        }
+        if(wave == 1)
+        {
+          double ev = 1.0;
+          int ei = NONE, es = INACTIVE;
+          const int i = CREG_MAX + lane;
+          if(lane < ne && st[i] == INACTIVE && i != excl)
+          {
+            const double cx = chain_up(Ce + (size_t)lane * ld, 1, xs, 1, 0, n, 0.0);
+            const double sl = cx - blg[i];
+            const double su = bug[i] - cx;
+            if(sl < 0.0)
+            {
+              ev = sl;
+              ei = i;
+              es = LOWER;
+            }
+            else if(su < 0.0)
+            {
+              ev = su;
+              ei = i;
+              es = UPPER;
+            }
+          }
+          if(ne > 0) wave_argmin_monotone(ev, ei, es);
+          if(lane == 0)
+          {
+            ctl->red_val[0] = ev;
+            ctl->red_idx[0] = ei;
+            ctl->red_stat[0] = es;
+          }
+        }
+        return;
       }
-      else
-        wave_argmin(bval, bidx, bstat);
+      wave_argmin(bval, bidx, bstat);
       if(lane == 0)
       {
         ctl->red_val[wave] = bval;
@@ -818,7 +877,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
       if(pp >= m) return;
       if(CMODE == 2)
       {
-        if(tid == pp)
+        if(myc == pp) // (extra columns are used in place: np_ptr)
         {
 #pragma unroll
           for(int k = 0; k < NR; ++k) nps[k] = creg[k];
@@ -831,6 +890,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     };
     auto np_ptr = [&](int pp) -> const double * {
       if(CMODE == 1) return Cs + (size_t)((pp < m) ? pp : 0) * ld;
+      if(CMODE == 2 && pp >= CREG_MAX && pp < m) return Ce + (size_t)(pp - CREG_MAX) * ld;
       return nps;
     };
 
@@ -1177,7 +1237,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           double bv;
           int bi, bs;
           scan_local(-1, bv, bi, bs);
-          scan_publish(bv, bi, bs);
+          scan_publish(-1, bv, bi, bs);
           __syncthreads();
           scan_combine(p, pstat);
           STAMP(3)
@@ -1263,7 +1323,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
             q = uniform(q + 1);
             ++it;
             scan_local(p, bv, bi, bs); // p is treated as active (wave 0 has it in st[] by now, the others exclude it)
-            scan_publish(bv, bi, bs);
+            scan_publish(p, bv, bi, bs);
             STAMP(15)
             if(wave == 1) add_apply(qa, addno); // overlaps wave 0's share of the scan
             PROF_COUNT(10)
@@ -1353,6 +1413,7 @@ long batch_lds_bytes(int n, int m, int nb, int cmode)
   const long ld = n | 1;
   long dbl = 2L * n * ld + 4L * n + 2L * (n + 2);
   if(cmode == 1) dbl += (long)m * ld + 2L * m;
+  if(cmode == 2 && m > WG - 64) dbl += (long)(m - (WG - 64)) * ld; // extra columns beyond the 192 register-resident ones
   long bytes = dbl * 8 + (long)sizeof(Ctl) + 4L * (n + 2) + (long)(m + nb);
   return (bytes + 15) & ~15L;
 }

@@ -94,6 +94,10 @@ CASES = [
     dict(nVar=64, nObj=64, nIneq=100, nStrongActIneq=20),
     dict(nVar=1, nObj=1, nIneq=3, nStrongActIneq=1),
     dict(nVar=50, nObj=50, nIneq=900, nStrongActIneq=10),  # C does not fit LDS: streamed variant
+    # the n = 50 register-resident specialisation: no LDS extras (m <= 192), all 64 extras (m = 256), bounds + equalities
+    dict(nVar=50, nObj=50, nIneq=150, nStrongActIneq=12),
+    dict(nVar=50, nObj=50, nIneq=256, nStrongActIneq=20),
+    dict(nVar=50, nObj=50, nEq=4, nIneq=196, nStrongActIneq=10, bounds=True, nStrongActBounds=5, doubleSidedIneq=True),
 ]
 
 
