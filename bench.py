@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--m", type=int, default=M_INEQ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-bytes", type=float, default=None, help="HBM bytes per launch from a separate rocprofv3 --pmc pass")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from separate rocprofv3 --pmc passes (default: profiles/r1_pmc_traffic.json if it matches)")
     args = ap.parse_args()
 
     import numpy as np
@@ -134,6 +135,12 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
         bytes_per_launch = algorithmic_bytes_per_solve(n, m, 0) * (hi - lo)
+        traffic = args.traffic_bytes
+        if traffic is None and (n, m, hi - lo) == (N_VAR, M_INEQ, BATCH):
+            try:  # measured once per round with two separate --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE), see profiles/
+                traffic = float(json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["traffic_bytes_per_launch"])
+            except Exception:
+                traffic = None
         avg_kernel_s = float(np.mean(kern_ms)) * 1e-3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         out = {
@@ -165,7 +172,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": args.traffic_bytes,
+                "traffic": traffic,
                 "kernel": "gi_batch_kernel",
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_kernel_s * 1e3,
