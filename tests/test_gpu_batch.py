@@ -141,6 +141,23 @@ def test_termination_codes_and_edge_cases(capi, P, oracle):
     assert 4 in ref["term"]
 
 
+def test_c3_full_bench_batch(capi, P, oracle, pkg):
+    """The full BASELINE workload (B = 4096, n = 50, m = 200): bit-exact against the oracle on every problem, and the
+    size-independent properties -- every solve reaches the planted optimum, the active set is the planted one, the
+    multipliers have the right signs."""
+    import os
+
+    pb = P.generate_batch(4096, P.benchmark_characteristics(50, 200))
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=min(64, len(os.sched_getaffinity(0))))
+    gpu = run_gpu(capi, pb)
+    assert_bit_identical(gpu, ref, "c3 x 4096")
+    assert np.all(gpu["term"] == 0)
+    assert np.max(np.linalg.norm(gpu["x"] - pb.x_star, axis=1)) <= 1e-6
+    assert np.array_equal(gpu["status"] == 2, pb.lam_star > 0)  # UPPER exactly where the planted multiplier is positive
+    assert np.all(gpu["u"] >= 0) and np.max(np.abs(gpu["u"] - pb.lam_star)) <= 1e-6
+    assert 25 < gpu["iters"].mean() < 40
+
+
 def test_trace_matches_oracle(capi, P, oracle):
     pb = P.generate_batch(8, P.benchmark_characteristics(50, 200), first_index=31)
     gpu = run_gpu(capi, pb, trace_cap=128)
