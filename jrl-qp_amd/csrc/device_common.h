@@ -1,0 +1,109 @@
+// device_common.h -- device-side helpers shared by every kernel file (gfx950, wave64).
+//
+// Everything here is part of the CANON rounding contract: explicit fmas, correctly rounded / and
+// sqrt, no contraction (the translation units are compiled with -ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace jrlqp
+{
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+// single-wave producer/consumer through LDS (or through memory the wave itself wrote): the hardware executes one
+// wave's accesses in order, so only the compiler has to be told not to move accesses across this point
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value of v in lane `src` (src wave-uniform): two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double bcast_lane(double v, int src)
+{
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int mask)
+{
+  int lo = __shfl_xor(__double2loint(v), mask);
+  int hi = __shfl_xor(__double2hiint(v), mask);
+  return __hiloint2double(hi, lo);
+}
+
+// keeps a wave-uniform value in a VGPR and hides its provenance from the compiler: without this hipcc scalarises
+// parts of a dependent chain and every select costs a VALU->SALU->VALU round trip
+__device__ __forceinline__ double opaque_v(double v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// Eigen JacobiRotation<double>::makeGivens(p, q, &r), real case (reference call sites GoldfarbIdnaniSolver.cpp:229,249;
+// oracle orc_givens):  [c -s; s c] [p; q] = [r; 0]
+__device__ __forceinline__ void make_givens(double p, double q, double & c, double & s, double & r)
+{
+  if(q == 0.0)
+  {
+    c = p < 0.0 ? -1.0 : 1.0;
+    s = 0.0;
+    r = fabs(p);
+  }
+  else if(p == 0.0)
+  {
+    c = 0.0;
+    s = q < 0.0 ? 1.0 : -1.0;
+    r = fabs(q);
+  }
+  else if(fabs(p) > fabs(q))
+  {
+    double t = q / p;
+    double u = __builtin_sqrt(FMA(t, t, 1.0));
+    if(p < 0.0) u = -u;
+    c = 1.0 / u;
+    s = -t * c;
+    r = p * u;
+  }
+  else
+  {
+    double t = p / q;
+    double u = __builtin_sqrt(FMA(t, t, 1.0));
+    if(q < 0.0) u = -u;
+    s = -1.0 / u;
+    c = -t * s;
+    r = q * u;
+  }
+}
+
+// sqrt(x) for x in [1, 2] (x = 1 + t^2, |t| <= 1): the Goldschmidt sequence hipcc expands __builtin_sqrt(double)
+// into, minus its range scaling (ldexp by 0 here) and its inf/zero class fix-up -- bit-identical on this range,
+// 9 dependent ops instead of 16 and no VALU->SALU round trip.
+__device__ __forceinline__ double sqrt_1to2(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = FMA(-h, g, 0.5);
+  g = FMA(g, r, g);
+  h = FMA(h, r, h);
+  double d = FMA(-g, g, x);
+  g = FMA(d, h, g);
+  d = FMA(-g, g, x);
+  g = FMA(d, h, g);
+  return g;
+}
+
+// r of makeGivens(p, q) alone -- what the NEXT rotation of a sweep depends on.  r = |den| * sqrt(1 + t^2) with
+// |t| = min(|p|,|q|) / max(|p|,|q|): the signs of t and u cancel in den*u and t enters only squared, so working on
+// magnitudes gives the same bits as the signed formula; p == 0 or q == 0 fall out exactly (t = 0, sqrt = 1).
+__device__ __forceinline__ double givens_r_only(double p, double q)
+{
+  const double a = fabs(p), b = fabs(q);
+  const double hi = fmax(a, b), lo = fmin(a, b);
+  const double t = lo / hi;
+  const double r = hi * sqrt_1to2(FMA(t, t, 1.0));
+  return (hi == 0.0) ? 0.0 : r;
+}
+} // namespace jrlqp

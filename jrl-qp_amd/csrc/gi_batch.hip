@@ -34,6 +34,7 @@
 // wave 0 is inside the Givens sweep.
 #include <hip/hip_runtime.h>
 
+#include "device_common.h"
 #include "gi_batch.h"
 
 namespace jrlqp
@@ -77,26 +78,7 @@ struct Ctl
   int pad;
 };
 
-#define FMA(a, b, c) __builtin_fma((a), (b), (c))
-
 // ---- wave-level helpers ---------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync()
-{
-  // single-wave producer/consumer through LDS: the LDS executes one wave's accesses in order, so only the
-  // compiler has to be told not to move accesses across this point.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// value of v in lane `src` (src wave-uniform): two v_readlane_b32, no LDS round trip
-__device__ __forceinline__ double bcast_lane(double v, int src)
-{
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ int uniform(int v)
 {
   return __builtin_amdgcn_readfirstlane(v);
@@ -107,13 +89,6 @@ __device__ __forceinline__ double uniform_d(double v)
 {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double shfl_xor_d(double v, int mask)
-{
-  int lo = __shfl_xor(__double2loint(v), mask);
-  int hi = __shfl_xor(__double2hiint(v), mask);
   return __hiloint2double(hi, lo);
 }
 
@@ -201,36 +176,6 @@ __device__ __forceinline__ void givens_cs(const GivensHalf & h, double & c, doub
   }
 }
 
-// sqrt(x) for x in [1, 2] (x = 1 + t^2, |t| <= 1): the Goldschmidt sequence hipcc expands __builtin_sqrt(double)
-// into, minus its range scaling (ldexp by 0 here) and its inf/zero class fix-up -- bit-identical on this range,
-// 9 dependent ops instead of 16 and no VALU->SALU round trip.
-__device__ __forceinline__ double sqrt_1to2(double x)
-{
-  double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  double h = y * 0.5;
-  double r = FMA(-h, g, 0.5);
-  g = FMA(g, r, g);
-  h = FMA(h, r, h);
-  double d = FMA(-g, g, x);
-  g = FMA(d, h, g);
-  d = FMA(-g, g, x);
-  g = FMA(d, h, g);
-  return g;
-}
-
-// r of makeGivens(p, q) alone -- what the NEXT rotation of a sweep depends on.  r = |den| * sqrt(1 + t^2) with
-// |t| = min(|p|,|q|) / max(|p|,|q|): the signs of t and u cancel in den*u and t enters only squared, so working on
-// magnitudes gives the same bits as the signed formula; p == 0 or q == 0 fall out exactly (t = 0, sqrt = 1).
-__device__ __forceinline__ double givens_r_only(double p, double q)
-{
-  const double a = fabs(p), b = fabs(q);
-  const double hi = fmax(a, b), lo = fmin(a, b);
-  const double t = lo / hi;
-  const double r = hi * sqrt_1to2(FMA(t, t, 1.0));
-  return (hi == 0.0) ? 0.0 : r;
-}
-
 // Division with the denominator-only part hoisted.  hipcc expands a/b (f64) into
 //   s0 = div_scale(b,b,a); r = rcp(s0); two Newton steps on r; s1 = div_scale(a,b,a); q0 = s1*r; e = fma(-s0,q0,s1);
 //   q = div_fmas(e, r, q0); div_fixup(q, b, a)
@@ -263,14 +208,6 @@ __device__ __forceinline__ bool div_safe_num(double v)
 {
   const double a = fabs(v);
   return (a > 0x1p-400 && a < 0x1p400) || v == 0.0;
-}
-
-// keeps a wave-uniform value in a VGPR and hides its provenance from the compiler: without this hipcc
-// scalarises parts of the coefficient chain and every select costs a VALU->SALU->VALU round trip
-__device__ __forceinline__ double opaque_v(double v)
-{
-  asm volatile("" : "+v"(v));
-  return v;
 }
 
 // minimum over the 64 lanes, every lane gets it: four DPP exchanges inside each row of 16, then the four row

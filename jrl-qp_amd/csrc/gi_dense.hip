@@ -16,35 +16,17 @@
 // oracle's.  Matrices are column-major; J and R have leading dimension n (Workspace.h, GoldfarbIdnaniSolver.cpp:140-141).
 #include <hip/hip_runtime.h>
 
+#include "device_common.h"
 #include "gi_dense.h"
 
 namespace jrlqp
 {
 namespace
 {
-#define FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define AT(P, ld, i, j) (P)[(size_t)(i) + (size_t)(j) * (size_t)(ld)]
 constexpr int NONE = 0x7fffffff;
 enum : int { INACTIVE = 0, LOWER = 1, UPPER = 2, EQUALITY = 3, LOWER_BOUND = 4, UPPER_BOUND = 5, FIXED = 6 };
 
-__device__ __forceinline__ double bcast_lane(double v, int src)
-{
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double shfl_xor_d(double v, int mask)
-{
-  int lo = __shfl_xor(__double2loint(v), mask);
-  int hi = __shfl_xor(__double2hiint(v), mask);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void wave_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 // lexicographic (value, index) minimum over the wave (general index order)
 __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
 {
@@ -62,56 +44,6 @@ __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
       aux = oa;
     }
   }
-}
-
-// Eigen makeGivens (real), as in the batched kernel / oracle orc_givens
-__device__ __forceinline__ void make_givens(double p, double q, double & c, double & s, double & r)
-{
-  if(q == 0.0) { c = p < 0.0 ? -1.0 : 1.0; s = 0.0; r = fabs(p); }
-  else if(p == 0.0) { c = 0.0; s = q < 0.0 ? 1.0 : -1.0; r = fabs(q); }
-  else if(fabs(p) > fabs(q))
-  {
-    double t = q / p;
-    double u = __builtin_sqrt(FMA(t, t, 1.0));
-    if(p < 0.0) u = -u;
-    c = 1.0 / u; s = -t * c; r = p * u;
-  }
-  else
-  {
-    double t = p / q;
-    double u = __builtin_sqrt(FMA(t, t, 1.0));
-    if(q < 0.0) u = -u;
-    s = -1.0 / u; c = -t * s; r = q * u;
-  }
-}
-
-// sqrt on [1,2] and the radius-only Givens recurrence: identical to gi_batch.hip (see the comments there)
-__device__ __forceinline__ double sqrt_1to2(double x)
-{
-  double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  double h = y * 0.5;
-  double r = FMA(-h, g, 0.5);
-  g = FMA(g, r, g);
-  h = FMA(h, r, h);
-  double d = FMA(-g, g, x);
-  g = FMA(d, h, g);
-  d = FMA(-g, g, x);
-  g = FMA(d, h, g);
-  return g;
-}
-__device__ __forceinline__ double givens_r_only(double p, double q)
-{
-  const double a = fabs(p), b = fabs(q);
-  const double hi = fmax(a, b), lo = fmin(a, b);
-  const double t = lo / hi;
-  const double r = hi * sqrt_1to2(FMA(t, t, 1.0));
-  return (hi == 0.0) ? 0.0 : r;
-}
-__device__ __forceinline__ double opaque_v(double v)
-{
-  asm volatile("" : "+v"(v));
-  return v;
 }
 
 // ============================================================================================================

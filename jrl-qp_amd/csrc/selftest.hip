@@ -4,32 +4,13 @@
 // bit-exact parity with the CPU oracle rests on them.
 #include <hip/hip_runtime.h>
 
+#include "device_common.h"
 #include "selftest.h"
 
 namespace jrlqp
 {
 namespace
 {
-__device__ __forceinline__ void make_givens_ref(double p, double q, double & c, double & s, double & r)
-{
-  if(q == 0.0) { c = p < 0.0 ? -1.0 : 1.0; s = 0.0; r = fabs(p); }
-  else if(p == 0.0) { c = 0.0; s = q < 0.0 ? 1.0 : -1.0; r = fabs(q); }
-  else if(fabs(p) > fabs(q))
-  {
-    double t = q / p;
-    double u = __builtin_sqrt(__builtin_fma(t, t, 1.0));
-    if(p < 0.0) u = -u;
-    c = 1.0 / u; s = -t * c; r = p * u;
-  }
-  else
-  {
-    double t = p / q;
-    double u = __builtin_sqrt(__builtin_fma(t, t, 1.0));
-    if(q < 0.0) u = -u;
-    s = -1.0 / u; c = -t * s; r = q * u;
-  }
-}
-
 __global__ void arith_kernel(int n, const double * a, const double * b, const double * c, double * odiv, double * osqrt,
                              double * ofma, double * gc, double * gs, double * gr)
 {
@@ -39,7 +20,7 @@ __global__ void arith_kernel(int n, const double * a, const double * b, const do
   osqrt[i] = __builtin_sqrt(fabs(a[i]));
   ofma[i] = __builtin_fma(a[i], b[i], c[i]);
   double cc, ss, rr;
-  make_givens_ref(a[i], b[i], cc, ss, rr);
+  make_givens(a[i], b[i], cc, ss, rr);
   gc[i] = cc; gs[i] = ss; gr[i] = rr;
 }
 

@@ -18,27 +18,14 @@
 // registers and move pivots with v_readlane, like the dense kernel.  -ffp-contract=off; every fma explicit.
 #include <hip/hip_runtime.h>
 
+#include "device_common.h"
 #include "structured.h"
 
 namespace jrlqp
 {
 namespace
 {
-#define FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define AT(P, ld, i, j) (P)[(i) + (size_t)(j) * (ld)]
-
-__device__ __forceinline__ double bcast_lane(double v, int src)
-{
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void wave_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // ---- wave-level primitives on a block held in LDS (ld odd => conflict-free row-per-lane access) -----------
 // in-place lower Cholesky, lane = row; returns -1 or the failing column (Eigen llt_inplace semantics)
