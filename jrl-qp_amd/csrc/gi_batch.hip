@@ -68,6 +68,7 @@ struct Ctl
   double red_val[4];
   double t1, zz, cz, cx;
   double f;
+  double bnd; // bound value b of the selected constraint (bl, bu, xl or xu by status): kept out of global memory on the step path
   int red_idx[4];
   int red_stat[4];
   int info;
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     // ======================================================================================================
 
     // K4 for the calling thread's share: candidate (value < 0, index, status); `excl` is treated as active
-    auto scan_local = [&](int excl, double & bval, int & bidx, int & bstat) {
+    auto scan_local = [&](int excl, double & bval, int & bidx, int & bstat) __attribute__((always_inline)) {
       bval = 0.0;
       bidx = NONE;
       bstat = INACTIVE;
@@ -809,21 +810,30 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
       ps = uniform(sx);
     };
 
-    // n+ of the selected general constraint -> LDS vector np (a pointer into staged C when CMODE == 1)
-    auto publish_np = [&](int pp) {
-      if(pp >= m) return;
+    // n+ of the selected general constraint -> LDS vector np (a pointer into staged C when CMODE == 1) and its bound
+    // value.  (always_inline: a lambda that is not inlined captures creg[] by address and pushes it to scratch.)
+    auto publish_np = [&](int pp, int ps) __attribute__((always_inline)) {
+      const bool lower = (ps == LOWER || ps == EQUALITY || ps == LOWER_BOUND || ps == FIXED);
       if(CMODE == 2)
       {
-        if(myc == pp) // (extra columns are used in place: np_ptr)
+        if(myc == pp) // the owner thread (extra columns are used in place: np_ptr)
         {
 #pragma unroll
           for(int k = 0; k < NR; ++k) nps[k] = creg[k];
+          ctl->bnd = lower ? my_bl : my_bu; // bounds come from the owner's registers: no global load on the step path
         }
       }
-      else if(CMODE == 0)
-      {
-        if(tid < n) nps[tid] = Cg[(size_t)pp * n + tid];
-      }
+      if(CMODE == 0 && pp < m && tid < n) nps[tid] = Cg[(size_t)pp * n + tid];
+    };
+    // b of the selected constraint: from LDS when its owner thread published it, else from memory
+    // (keeping every other case out of publish_np matters: a larger lambda there stops hipcc from keeping creg[] in
+    // registers -- it lands in scratch and the kernel runs 2x slower)
+    auto bound_of = [&](int pp, int ps) -> double {
+      const bool lower = (ps == LOWER || ps == EQUALITY || ps == LOWER_BOUND || ps == FIXED);
+      if(CMODE == 2 && pp < CREG_MAX && pp < m) return ctl->bnd;
+      if(pp >= m) return lower ? xlg[pp - m] : xug[pp - m];
+      if(CMODE == 1) return lower ? bls[pp] : bus[pp];
+      return lower ? blg[pp] : bug[pp];
     };
     auto np_ptr = [&](int pp) -> const double * {
       if(CMODE == 1) return Cs + (size_t)((pp < m) ? pp : 0) * ld;
@@ -1128,7 +1138,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           if(p == NONE) break;
           pstat = (p < m) ? EQUALITY : FIXED;
           cursor = p + 1;
-          publish_np(p);
+          publish_np(p, pstat);
           if(tid == 0) us[q] = 0.0;
           __syncthreads();
           if(wave == 0) compute_d(p, pstat);
@@ -1143,8 +1153,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           double t = 0.0;
           if(__builtin_sqrt(uniform_d(ctl->zz)) > 1e-14)
           {
-            double bb = uniform_d((p < m) ? blg[p] : xlg[p - m]);
-            t = (bb - uniform_d(ctl->cx)) / cz;
+            t = (uniform_d(bound_of(p, pstat)) - uniform_d(ctl->cx)) / cz;
           }
           ++addno;
           if(wave == 0)
@@ -1182,7 +1191,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
         bool running = (p >= 0);
         if(running)
         {
-          publish_np(p);
+          publish_np(p, pstat);
           if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
         }
         while(running)
@@ -1203,8 +1212,6 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           STAMP(5)
 
           // ---- K8: step length (uniform, every thread)
-          const bool general = p < m;
-          const int pb = p - m;
           const double cz = uniform_d(ctl->cz);
           const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
           const double t1 = uniform_d(ctl->t1);
@@ -1212,18 +1219,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           double t2 = big;
           if(__builtin_sqrt(uniform_d(ctl->zz)) > 1e-14)
           {
-            double bb;
-            if(pstat == LOWER)
-              bb = (CMODE == 1) ? bls[p] : blg[p];
-            else if(pstat == UPPER)
-              bb = (CMODE == 1) ? bus[p] : bug[p];
-            else if(pstat == LOWER_BOUND)
-              bb = xlg[pb];
-            else
-              bb = xug[pb];
-            t2 = (uniform_d(bb) - uniform_d(ctl->cx)) / cz;
+            t2 = (uniform_d(bound_of(p, pstat)) - uniform_d(ctl->cx)) / cz;
           }
-          (void)general;
           const double t = (t2 < t1) ? t2 : t1;
           if(A.trace && tid == 0 && it < A.trace_cap)
           {
@@ -1273,7 +1270,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
             }
             scan_combine(p, pstat);
             if(p < 0) break; // SUCCESS (DualSolver.cpp:114)
-            publish_np(p);
+            publish_np(p, pstat);
             if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
           }
           else
