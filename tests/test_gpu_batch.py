@@ -166,3 +166,29 @@ def test_trace_matches_oracle(capi, P, oracle):
         tr = gpu["trace"][b][: r.iters]
         got = [(int(t["p"]), int(t["status"]), int(t["l"]), int(t["kind"]), float(t["t1"]), float(t["t2"])) for t in tr]
         assert got == r.trace
+
+
+def test_randomised_shape_sweep(capi, P, oracle):
+    """Fuzz over shapes and constraint mixes (n = 1 .. 64, equalities, bounds, double-sided, weakly active =
+    degenerate problems on which the reference algorithm may legitimately stop with INFEASIBLE): whatever the
+    oracle does, the HIP path does bit for bit."""
+    rng = np.random.default_rng(20260301)
+    seen_terms = set()
+    for trial in range(40):
+        n = int(rng.choice([1, 2, 3, 7, 16, 17, 31, 32, 33, 48, 50, 63, 64]))
+        nEq = int(rng.integers(0, max(1, n // 4) + 1)) if rng.random() < 0.4 else 0
+        bounds = bool(rng.random() < 0.4)
+        nIneq = int(rng.integers(0, 4 * n + 8))
+        room = n - nEq
+        nSA = int(rng.integers(0, min(nIneq, room) + 1))
+        nSB = int(rng.integers(0, max(0, min(n, room - nSA)) + 1)) if bounds else 0
+        nWA = int(rng.integers(0, min(3, nIneq - nSA) + 1)) if rng.random() < 0.3 else 0
+        nWB = int(rng.integers(0, min(2, n - nSB) + 1)) if (bounds and rng.random() < 0.3) else 0
+        ch = P.Characteristics(nVar=n, nObj=n, nEq=nEq, nIneq=nIneq, nStrongActIneq=nSA, nWeakActIneq=nWA, bounds=bounds,
+                               nStrongActBounds=nSB, nWeakActBounds=nWB, doubleSidedIneq=bool(rng.random() < 0.5))
+        pb = P.generate_batch(24, ch, first_index=100000 + 50 * trial)
+        ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl if bounds else None, pb.xu if bounds else None, nthreads=8)
+        gpu = run_gpu(capi, pb, use_bounds=bounds)
+        assert_bit_identical(gpu, ref, f"trial {trial}: {ch}")
+        seen_terms |= set(ref["term"].tolist())
+    assert 0 in seen_terms
