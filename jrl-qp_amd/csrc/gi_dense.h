@@ -41,7 +41,7 @@ struct DenseState
 hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st);
 hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st);
 hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st);
-hipError_t dense_select(const DenseViews & v, DenseState & s, hipStream_t st);
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st);
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st);
 hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st);
 hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st);

@@ -370,7 +370,7 @@ __global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb
 // K4 partial: per CT constraints the first-index arg-min of min(c.x - bl, bu - c.x) below 0
 __global__ __launch_bounds__(64) void select_partial_kernel(const double * __restrict__ C, int ldc, int n, int m, const double * __restrict__ x,
                                                             const double * __restrict__ bl, const double * __restrict__ bu,
-                                                            const unsigned char * __restrict__ st, double * pval, int * pidx, int * pstat)
+                                                            const unsigned char * __restrict__ st, int excl, double * pval, int * pidx, int * pstat)
 {
   extern __shared__ double sh[];
   double * vs = sh;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64) void select_partial_kernel(const double * __res
   const int i = col0 + lane;
   double bval = 0.0;
   int bidx = NONE, bstat = INACTIVE;
-  if(lane < nc && st[i] == INACTIVE)
+  if(lane < nc && st[i] == INACTIVE && i != excl) // `excl`: a constraint being activated concurrently (its status byte may not be set yet)
   {
     double sl = cx - bl[i];
     if(sl < 0.0)
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void select_partial_kernel(const double * __res
 // K4 final: combine the partials (in index order) and scan the bounds; result to the host-visible mailbox
 __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const double * pval, const int * pidx, const int * pstat, int m, int nb,
                                                           const double * __restrict__ x, const double * __restrict__ xl,
-                                                          const double * __restrict__ xu, const unsigned char * __restrict__ st, Mailbox * mb)
+                                                          const double * __restrict__ xu, const unsigned char * __restrict__ st, int excl, Mailbox * mb)
 {
   __shared__ double sv[4];
   __shared__ int si[4], ss[4];
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const dou
   }
   for(int i = tid; i < nb; i += 256)
   {
-    if(st[m + i] != INACTIVE) continue;
+    if(st[m + i] != INACTIVE || (m + i) == excl) continue;
     double xi = x[i];
     double sl = xi - xl[i];
     double cand;
@@ -851,13 +851,13 @@ hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double *
   return hipGetLastError();
 }
 
-hipError_t dense_select(const DenseViews & v, DenseState & s, hipStream_t st)
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st)
 {
   const int parts = (v.m + CT - 1) / CT;
   if(parts > 0)
     hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * (v.n + CT * (KT + 1)), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
-                       s.pval, s.pidx, s.pstat);
-  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, s.mb);
+                       excl, s.pval, s.pidx, s.pstat);
+  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb);
   return hipGetLastError();
 }
 

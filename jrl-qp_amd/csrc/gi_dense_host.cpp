@@ -28,6 +28,8 @@ struct jrlqp_dense
   int it = 0, term = JRLQP_UNKNOWN;
   double f = 0.0;
   int last_hip = 0;
+  hipStream_t side = nullptr;          // runs the next pass's constraint scan beside the Givens sweep
+  hipEvent_t ev_x = nullptr, ev_sel = nullptr;
 };
 
 namespace
@@ -78,6 +80,9 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = dmalloc(s.info, 1);
   if(e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h->h_mb), sizeof(Mailbox), hipHostMallocMapped);
   if(e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s.mb), h->h_mb, 0);
+  if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming);
   if(e != hipSuccess)
   {
     jrlqp_dense_destroy(h);
@@ -98,6 +103,9 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   (void)hipFree(s.u); (void)hipFree(s.r); (void)hipFree(s.cc); (void)hipFree(s.ss); (void)hipFree(s.st);
   (void)hipFree(s.pval); (void)hipFree(s.pidx); (void)hipFree(s.pstat); (void)hipFree(s.info);
   if(h->h_mb) (void)hipHostFree(h->h_mb);
+  if(h->side) (void)hipStreamDestroy(h->side);
+  if(h->ev_x) (void)hipEventDestroy(h->ev_x);
+  if(h->ev_sel) (void)hipEventDestroy(h->ev_sel);
   delete h;
 }
 
@@ -157,7 +165,7 @@ int jrlqp_dense_select(jrlqp_dense * h, int * p, int * status, void * stream)
 {
   if(!h || !h->bound || !p || !status) return JRLQP_ERR_INVALID_ARGUMENT;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  TRY(dense_select(h->v, h->s, st));
+  TRY(dense_select(h->v, h->s, -1, st));
   TRY(hipStreamSynchronize(st));
   *p = h->h_mb->p;
   *status = h->h_mb->pstatus;
@@ -284,14 +292,25 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
   }
 
   bool skip = false;
+  bool prefetched = false; // the scan of this pass already ran on the side stream, beside the previous pass's sweep
   int p = -1, pstat = INACTIVE;
   for(; h->it < o.max_iter; ++h->it)
   {
     const int q = (int)h->active.size();
     if(!skip)
     {
-      rc = jrlqp_dense_select(h, &p, &pstat, stream);
-      if(rc != JRLQP_OK) return rc;
+      if(prefetched)
+      {
+        TRY(hipStreamSynchronize(h->side));
+        p = h->h_mb->p;
+        pstat = h->h_mb->pstatus;
+        prefetched = false;
+      }
+      else
+      {
+        rc = jrlqp_dense_select(h, &p, &pstat, stream);
+        if(rc != JRLQP_OK) return rc;
+      }
       if(p < 0 || pstat == INACTIVE) return finish(JRLQP_SUCCESS);
       TRY(hipMemsetAsync(h->s.u + q, 0, sizeof(double), st)); // u[q] = 0 (DualSolver.cpp:121)
     }
@@ -321,6 +340,16 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
       h->f = std::fma(t * dotsc, 0.5 * t + uq, h->f);
       if(t == t2)
       {
+        // x is final once `advance` has run: the next pass's constraint scan (which only reads C, x, bounds and the
+        // status bytes) runs on the side stream while the main stream does the Givens sweep; the constraint being
+        // activated is excluded explicitly because its status byte is written by the sweep's first kernel
+        if(h->it + 1 < o.max_iter)
+        {
+          TRY(hipEventRecord(h->ev_x, st));
+          TRY(hipStreamWaitEvent(h->side, h->ev_x, 0));
+          TRY(dense_select(h->v, h->s, p, h->side));
+          prefetched = true;
+        }
         rc = jrlqp_dense_add(h, p, pstat, q, stream);
         if(rc != JRLQP_OK) return rc;
         activate(p, pstat);
