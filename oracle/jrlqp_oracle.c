@@ -243,7 +243,7 @@ typedef struct
 
 long orc_gi_work_doubles(int n, int m, int nb)
 {
-  return 2L * n * n + 3L * n + 2L * (m + nb + 2) + m + 1;
+  return 2L * n * n + 3L * n + 2L * (m + nb + 2) + m + 1 + 4L * n; /* + b_act, hCoeffs, alpha, beta (warm start) */
 }
 
 /* ConstraintNormal::dot (ConstraintNormal.h:105-123) */
@@ -321,14 +321,12 @@ static void add_constraint(gi_state * S, int p, int status)
   for(int k = 0; k < q; ++k) S->R[k + (long)(q - 1) * n] = d[k];
 }
 
-/* removeConstraint (DualSolver.cpp:237-244) + removeConstraint_ (GoldfarbIdnaniSolver.cpp:239-256) */
-static void remove_constraint(gi_state * S, int l)
+/* removeConstraint_ (GoldfarbIdnaniSolver.cpp:239-256) preceded by A_.deactivate(l) */
+static void remove_constraint_raw(gi_state * S, int l)
 {
   const int n = S->n;
-  int q = S->A.nact;
-  for(int k = l; k < q; ++k) S->u[k] = S->u[k + 1]; /* u.segment(l,q-l) = u.tail(q-l), u has q+1 entries */
   orc_as_deactivate(&S->A, l);
-  q = S->A.nact; /* already counts the removal */
+  const int q = S->A.nact; /* already counts the removal */
   double *R = S->R, *J = S->J;
   for(int i = l; i < q; ++i)
   {
@@ -339,6 +337,14 @@ static void remove_constraint(gi_state * S, int l)
     double *ci = J + (long)i * n, *cj = J + (long)(i + 1) * n;
     for(int rr = 0; rr < n; ++rr) rot(c, s, &ci[rr], &cj[rr]);
   }
+}
+
+/* removeConstraint (DualSolver.cpp:237-244) + removeConstraint_ */
+static void remove_constraint(gi_state * S, int l)
+{
+  const int q = S->A.nact;
+  for(int k = l; k < q; ++k) S->u[k] = S->u[k + 1]; /* u.segment(l,q-l) = u.tail(q-l), u has q+1 entries */
+  remove_constraint_raw(S, l);
 }
 
 /* addInitialConstraint (GoldfarbIdnaniSolver.cpp:295-338) */
@@ -369,10 +375,210 @@ static void add_initial_constraint(gi_state * S, int p, int status)
   add_constraint(S, p, status);
 }
 
-int orc_gi_solve(int n,
-                 int m,
-                 int nb,
-                 double * G,
+/* ------------------------------------------------------------------------------------------- */
+/* warm start: experimental::GoldfarbIdnaniSolver (src/experimental/GoldfarbIdnaniSolver.cpp)   */
+/* ------------------------------------------------------------------------------------------- */
+
+/* processInitialActiveSet (experimental/GoldfarbIdnaniSolver.cpp:309-386): bounds first, then general constraints.
+ * Data equalities win over the guess; guesses on infinite bounds and FIXED guesses on non-fixed variables are
+ * ignored.  Guess entries the reference rules out with assert() (a bound status on a general constraint, a general
+ * status on a bound, values outside the enum) are ignored too.  as == NULL: no guess (the cold active set). */
+static int process_initial_active_set(gi_state * S, const int * as, double big_bnd)
+{
+  const int n = S->n, m = S->m, nb = S->nb;
+  orc_active_set * A = &S->A;
+  orc_as_reset(A);
+  for(int i = 0; i < nb; ++i)
+  {
+    const int bi = m + i;
+    if(S->xl[i] == S->xu[i])
+      orc_as_activate(A, bi, ORC_FIXED);
+    else if(as && as[bi] != ORC_INACTIVE)
+    {
+      const int s = as[bi];
+      if(s == ORC_LOWER_BOUND && !(S->xl[i] < -big_bnd)) orc_as_activate(A, bi, s);
+      if(s == ORC_UPPER_BOUND && !(S->xu[i] > +big_bnd)) orc_as_activate(A, bi, s);
+    }
+  }
+  for(int i = 0; i < m; ++i)
+  {
+    if(S->bl[i] == S->bu[i])
+      orc_as_activate(A, i, ORC_EQUALITY);
+    else if(as && as[i] != ORC_INACTIVE)
+    {
+      const int s = as[i];
+      if(s == ORC_LOWER && !(S->bl[i] < -big_bnd)) orc_as_activate(A, i, s);
+      if(s == ORC_UPPER && !(S->bu[i] > +big_bnd)) orc_as_activate(A, i, s);
+      if(s == ORC_EQUALITY) orc_as_activate(A, i, s); /* :357-371 only filters FIXED: an EQUALITY guess is taken as is */
+    }
+  }
+  if(A->nact > n)
+  {
+    if(A->me + A->mbe > n) return ORC_OVERCONSTRAINED_PROBLEM;
+    /* work backward, deactivating inequality constraints until n are left (:373-383) */
+    int i = A->nact;
+    while(A->nact > n)
+    {
+      --i;
+      for(;;)
+      {
+        int st = A->status[A->active[i]];
+        if(st == ORC_EQUALITY || st == ORC_FIXED) --i; else break;
+      }
+      orc_as_deactivate(A, i);
+    }
+  }
+  return ORC_SUCCESS;
+}
+
+/* initializeComputationData (experimental/GoldfarbIdnaniSolver.cpp:388-458).
+ * N -> S->R (n x q), b_act; J = L^-T; B = L^-1 N; B = Q R (Householder, unblocked: Eigen's blocked variant with
+ * block size 48 reduces to it for q <= 48; for larger q the CANON order below is still the definition); J = J Q.
+ * CANON for the Householder steps (Eigen/src/Householder/Householder.h makeHouseholder / applyHouseholderOnTheLeft /
+ * applyHouseholderOnTheRight): every sum an ascending fma chain; a*b+c one fma. */
+static void initialize_computation_data(gi_state * S, const double * L, int ldl, double * b_act, double * hco)
+{
+  const int n = S->n, m = S->m, q = S->A.nact;
+  double *N = S->R, *J = S->J;
+  for(int j = 0; j < q; ++j)
+  {
+    const int idx = S->A.active[j];
+    double * col = N + (long)j * n;
+    switch(S->A.status[idx])
+    {
+      case ORC_LOWER:
+      case ORC_EQUALITY:
+        for(int i = 0; i < n; ++i) col[i] = S->C[i + (long)idx * S->ldc];
+        b_act[j] = S->bl[idx];
+        break;
+      case ORC_UPPER:
+        for(int i = 0; i < n; ++i) col[i] = -S->C[i + (long)idx * S->ldc];
+        b_act[j] = -S->bu[idx];
+        break;
+      case ORC_LOWER_BOUND:
+      case ORC_FIXED:
+        for(int i = 0; i < n; ++i) col[i] = 0.0;
+        col[idx - m] = 1.0;
+        b_act[j] = S->xl[idx - m];
+        break;
+      case ORC_UPPER_BOUND:
+        for(int i = 0; i < n; ++i) col[i] = 0.0;
+        col[idx - m] = -1.0;
+        b_act[j] = -S->xu[idx - m];
+        break;
+      default: break;
+    }
+  }
+  orc_inv_lt(n, L, ldl, J, n); /* :421-423 */
+  /* B = L^-1 N (:426), forward substitution; per element: acc = N_ij; acc = fma(-L_ik, B_kj, acc), k ascending; / L_ii */
+  for(int j = 0; j < q; ++j)
+  {
+    double * col = N + (long)j * n;
+    for(int i = 0; i < n; ++i)
+    {
+      double acc = col[i];
+      for(int k = 0; k < i; ++k) acc = FMA(-L[i + (long)k * ldl], col[k], acc);
+      col[i] = acc / L[i + (long)i * ldl];
+    }
+  }
+  /* QR in place (:432-440) */
+  for(int k = 0; k < q; ++k)
+  {
+    double * v = N + (long)k * n; /* essential part: v[k+1 .. n-1] */
+    double tail = 0.0;
+    for(int i = k + 1; i < n; ++i) tail = FMA(v[i], v[i], tail);
+    const double c0 = v[k];
+    double tau, beta;
+    if(tail <= 2.2250738585072014e-308) /* numeric_limits<double>::min() */
+    {
+      tau = 0.0;
+      beta = c0;
+      for(int i = k + 1; i < n; ++i) v[i] = 0.0;
+    }
+    else
+    {
+      beta = sqrt(FMA(c0, c0, tail));
+      if(c0 >= 0.0) beta = -beta;
+      const double den = c0 - beta;
+      for(int i = k + 1; i < n; ++i) v[i] = v[i] / den;
+      tau = (beta - c0) / beta;
+    }
+    v[k] = beta;
+    hco[k] = tau;
+    if(tau != 0.0 && k + 1 < n)
+      for(int j = k + 1; j < q; ++j) /* applyHouseholderOnTheLeft on the trailing columns */
+      {
+        double * cj = N + (long)j * n;
+        double t = 0.0;
+        for(int i = k + 1; i < n; ++i) t = FMA(v[i], cj[i], t);
+        t = t + cj[k];
+        cj[k] = FMA(-tau, t, cj[k]);
+        const double st = tau * t;
+        for(int i = k + 1; i < n; ++i) cj[i] = FMA(-st, v[i], cj[i]);
+      }
+  }
+  /* J = J * Q,  Q = H_0 H_1 ... H_{q-1}  (:443-444): applyHouseholderOnTheRight on J.rightCols(n - k), k ascending */
+  for(int k = 0; k < q; ++k)
+  {
+    const double * v = N + (long)k * n;
+    const double tau = hco[k];
+    if(k + 1 == n)
+    {
+      for(int i = 0; i < n; ++i) J[i + (long)k * n] *= (1.0 - tau); /* single column: *this *= 1 - tau */
+      continue;
+    }
+    if(tau == 0.0) continue;
+    for(int i = 0; i < n; ++i)
+    {
+      double t = 0.0;
+      for(int j = k + 1; j < n; ++j) t = FMA(J[i + (long)j * n], v[j], t);
+      t = t + J[i + (long)k * n];
+      J[i + (long)k * n] = FMA(-tau, t, J[i + (long)k * n]);
+      const double st = tau * t;
+      for(int j = k + 1; j < n; ++j) J[i + (long)j * n] = FMA(-st, v[j], J[i + (long)j * n]);
+    }
+  }
+}
+
+/* initializePrimalDualPoints (experimental/GoldfarbIdnaniSolver.cpp:462-487) */
+static void initialize_primal_dual(gi_state * S, const double * a, const double * b_act, double * alpha, double * beta)
+{
+  const int n = S->n, q = S->A.nact;
+  const double *J = S->J, *R = S->R;
+  double *x = S->x, *u = S->u;
+  multi_dot(n, J, n, n, a, alpha); /* alpha = J^T a */
+  for(int k = 0; k < q; ++k) /* beta = R^-T b_act */
+  {
+    double acc = b_act[k];
+    for(int i = 0; i < k; ++i) acc = FMA(-R[i + (long)k * n], beta[i], acc);
+    beta[k] = acc / R[k + (long)k * n];
+  }
+  for(int i = 0; i < n; ++i) /* x = J1 beta - J2 alpha2 */
+  {
+    double acc = 0.0;
+    for(int k = 0; k < q; ++k) acc = FMA(J[i + (long)k * n], beta[k], acc);
+    for(int k = q; k < n; ++k) acc = FMA(-J[i + (long)k * n], alpha[k], acc);
+    x[i] = acc;
+  }
+  for(int k = 0; k < q; ++k) u[k] = alpha[k] + beta[k]; /* u = R^-1 (alpha1 + beta) */
+  for(int k = q - 1; k >= 0; --k)
+  {
+    double v = u[k] / R[k + (long)k * n];
+    u[k] = v;
+    for(int i = 0; i < k; ++i) u[i] = FMA(-R[i + (long)k * n], v, u[i]);
+  }
+  double f1 = 0.0, f2 = 0.0; /* f = beta.(0.5 beta + alpha1) - 0.5 |alpha2|^2 */
+  for(int k = 0; k < q; ++k) f1 = FMA(beta[k], FMA(0.5, beta[k], alpha[k]), f1);
+  for(int k = q; k < n; ++k) f2 = FMA(alpha[k], alpha[k], f2);
+  S->f = FMA(-0.5, f2, f1);
+}
+
+static int gi_solve_impl(int warm,
+                         const int * as_in,
+                         int n,
+                         int m,
+                         int nb,
+                         double * G,
                  int ldg,
                  const double * a,
                  const double * C,
@@ -411,6 +617,42 @@ int orc_gi_solve(int n,
   for(int i = 0; i < n; ++i) S.x[i] = 0.0; /* defined output when init_ fails (the reference leaves x untouched) */
   double *x = S.x, *z = S.z, *u = S.u, *r = S.r;
 
+  if(warm)
+  {
+    /* ---- experimental init_ (experimental/GoldfarbIdnaniSolver.cpp:65-112) ---- */
+    double * b_act = cxs + m + 1;
+    double * hco = b_act + n;
+    double * alpha = hco + n;
+    double * beta = alpha + n;
+    rc = process_initial_active_set(&S, as_in, big_bnd);
+    if(rc != ORC_SUCCESS) goto done;
+    if(orc_llt(n, G, ldg) >= 0) { rc = ORC_NON_POS_HESSIAN; goto done; }
+    initialize_computation_data(&S, G, ldg, b_act, hco);
+    initialize_primal_dual(&S, a, b_act, alpha, beta);
+    for(;;) /* constraints activated with u < 0 are deactivated (:78-109) */
+    {
+      const int q = S.A.nact;
+      double umin = -1e-14;
+      int lmin = -1;
+      for(int l = 0; l < q; ++l)
+      {
+        int st = S.A.status[S.A.active[l]];
+        if(S.u[l] < umin && st != ORC_FIXED && st != ORC_EQUALITY)
+        {
+          umin = S.u[l];
+          lmin = l;
+        }
+      }
+      if(lmin < 0) break;
+      ++it;
+      for(int k = lmin; k + 1 < q; ++k) b_act[k] = b_act[k + 1];
+      remove_constraint_raw(&S, lmin);
+      initialize_primal_dual(&S, a, b_act, alpha, beta);
+    }
+    S.u[S.A.nact] = 0.0;
+    goto main_loop;
+  }
+
   /* ---- init_ (GoldfarbIdnaniSolver.cpp:56-82) ---- */
   if(orc_llt(n, G, ldg) >= 0) { rc = ORC_NON_POS_HESSIAN; goto done; }
   orc_inv_lt(n, G, ldg, S.J, n);
@@ -443,6 +685,7 @@ int orc_gi_solve(int n,
     if(xl[i] == xu[i]) add_initial_constraint(&S, m + i, ORC_FIXED);
 
   /* ---- DualSolver::solve loop (DualSolver.cpp:96-167) ---- */
+main_loop:
   {
     int skip_step1 = 0, p = -1, pstatus = ORC_INACTIVE;
     rc = ORC_MAX_ITER_REACHED;
@@ -579,6 +822,25 @@ done:
   return rc;
 }
 
+int orc_gi_solve(int n, int m, int nb, double * G, int ldg, const double * a, const double * C, int ldc,
+                 const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
+                 double big_bnd, double * xout, double * uout, int * status_out, int * active_out, int * nactive_out,
+                 int * iters_out, double * f_out, orc_trace_rec * trace, int trace_cap, double * work)
+{
+  return gi_solve_impl(0, NULL, n, m, nb, G, ldg, a, C, ldc, bl, bu, xl, xu, max_iter, big_bnd, xout, uout, status_out,
+                       active_out, nactive_out, iters_out, f_out, trace, trace_cap, work);
+}
+
+int orc_gi_solve_warm(int n, int m, int nb, double * G, int ldg, const double * a, const double * C, int ldc,
+                      const double * bl, const double * bu, const double * xl, const double * xu, const int * as_in,
+                      int max_iter, double big_bnd, double * xout, double * uout, int * status_out, int * active_out,
+                      int * nactive_out, int * iters_out, double * f_out, orc_trace_rec * trace, int trace_cap,
+                      double * work)
+{
+  return gi_solve_impl(1, as_in, n, m, nb, G, ldg, a, C, ldc, bl, bu, xl, xu, max_iter, big_bnd, xout, uout, status_out,
+                       active_out, nactive_out, iters_out, f_out, trace, trace_cap, work);
+}
+
 void orc_gi_solve_batch(int B,
                         int n,
                         int m,
@@ -613,6 +875,32 @@ void orc_gi_solve_batch(int B,
                              big_bnd, x + (long)b * n, u + (long)b * (m + nb), status + (long)b * (m + nb), NULL, NULL,
                              iters + b, f + b, NULL, 0, work);
     }
+    free(work);
+  }
+}
+
+/* B warm-started solves; as_in: B x (m+nb) activation-status guesses (may be NULL: no guess). */
+void orc_gi_solve_batch_warm(int B, int n, int m, int nb, double * G, const double * a, const double * C,
+                             const double * bl, const double * bu, const double * xl, const double * xu,
+                             const int * as_in, int max_iter, double big_bnd, double * x, double * u, int * status,
+                             int * term, int * iters, double * f, int nthreads)
+{
+  if(nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    double * work = (double *)malloc(sizeof(double) * (size_t)orc_gi_work_doubles(n, m, nb));
+    int * as = (int *)malloc(sizeof(int) * (size_t)(m + nb + 1));
+#pragma omp for schedule(static)
+    for(int b = 0; b < B; ++b)
+    {
+      if(as_in) memcpy(as, as_in + (long)b * (m + nb), sizeof(int) * (size_t)(m + nb)); /* status may alias as_in */
+      term[b] = orc_gi_solve_warm(n, m, nb, G + (long)b * n * n, n, a + (long)b * n, C + (long)b * n * m, n,
+                                  bl + (long)b * m, bu + (long)b * m, nb ? xl + (long)b * nb : NULL,
+                                  nb ? xu + (long)b * nb : NULL, as_in ? as : NULL, max_iter, big_bnd, x + (long)b * n,
+                                  u + (long)b * (m + nb), status + (long)b * (m + nb), NULL, NULL, iters + b, f + b,
+                                  NULL, 0, work);
+    }
+    free(as);
     free(work);
   }
 }

@@ -126,6 +126,24 @@ void orc_gi_solve_batch(int B,
                         double * f,
                         int nthreads);
 
+/*
+ * Warm-started dense GI solve: experimental::GoldfarbIdnaniSolver::solve(..., as) with options.warmStart_ = true
+ * (src/experimental/GoldfarbIdnaniSolver.cpp:20-112, 309-487).  Same arguments as orc_gi_solve plus
+ *   as_in  m+nb activation-status guess (general constraints first, then bounds), or NULL for "no guess".
+ * Data equalities (bl == bu, xl == xu) are activated up front (bounds first), the guessed constraints after them;
+ * J and R come from a Householder QR of L^-1 N instead of one Givens sweep per constraint; constraints whose
+ * multiplier comes out < -1e-14 are dropped one at a time (each counts as one iteration) before the usual loop.
+ */
+int orc_gi_solve_warm(int n, int m, int nb, double * G, int ldg, const double * a, const double * C, int ldc,
+                      const double * bl, const double * bu, const double * xl, const double * xu, const int * as_in,
+                      int max_iter, double big_bnd, double * x, double * u, int * status, int * active, int * nactive,
+                      int * iters, double * f, orc_trace_rec * trace, int trace_cap, double * work);
+
+void orc_gi_solve_batch_warm(int B, int n, int m, int nb, double * G, const double * a, const double * C,
+                             const double * bl, const double * bu, const double * xl, const double * xu,
+                             const int * as_in, int max_iter, double big_bnd, double * x, double * u, int * status,
+                             int * term, int * iters, double * f, int nthreads);
+
 /* Canonical primitives, exported so tests can pin them one by one. */
 int orc_llt(int n, double * A, int lda);                         /* -1 ok, else failing column (Eigen llt_inplace) */
 void orc_inv_lt(int n, const double * L, int ldl, double * J, int ldj); /* J = L^-T, dense n x n */

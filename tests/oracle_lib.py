@@ -61,6 +61,12 @@ class Oracle:
         L.orc_gi_solve_batch.restype = None
         L.orc_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
                                          ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_dp, ct.c_int]
+        L.orc_gi_solve_warm.restype = ct.c_int
+        L.orc_gi_solve_warm.argtypes = [ct.c_int, ct.c_int, ct.c_int, c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_ip,
+                                        ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp, ct.POINTER(TraceRec), ct.c_int, c_dp]
+        L.orc_gi_solve_batch_warm.restype = None
+        L.orc_gi_solve_batch_warm.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip,
+                                              ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_dp, ct.c_int]
         L.orc_llt.restype = ct.c_int
         L.orc_llt.argtypes = [ct.c_int, c_dp, ct.c_int]
         L.orc_inv_lt.restype = None
@@ -98,8 +104,9 @@ class Oracle:
             getattr(L, nm).argtypes = blk + [c_dp, ct.c_int, ct.c_int, ct.c_int]
 
     # ---- dense GI ------------------------------------------------------------------------------
-    def solve(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, trace_cap=0) -> OracleResult:
-        """G n x n, C n x m (one constraint per column); inputs are copied (G is clobbered by the solver)."""
+    def solve(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, trace_cap=0, warm=False, guess=None) -> OracleResult:
+        """G n x n, C n x m (one constraint per column); inputs are copied (G is clobbered by the solver).
+        warm=True: experimental::GoldfarbIdnaniSolver with warmStart_, `guess` = activation-status vector or None."""
         Gf = np.array(G, dtype=np.float64, order="F", copy=True)
         n = Gf.shape[0]
         Cf = np.asfortranarray(np.asarray(C, dtype=np.float64).reshape(n, -1))
@@ -118,14 +125,21 @@ class Oracle:
         iters = ct.c_int(0)
         f = ct.c_double(0.0)
         tr = (TraceRec * max(trace_cap, 1))()
-        term = self.lib.orc_gi_solve(n, m, nb, _dp(Gf), max(n, 1), _dp(a), _dp(Cf), max(n, 1), _dp(bl), _dp(bu), _dp(xl), _dp(xu),
-                                     max_iter, big_bnd, _dp(x), _dp(u), _ip(status), _ip(active), ct.byref(nact), ct.byref(iters),
-                                     ct.byref(f), tr, trace_cap, None)
+        if warm:
+            g = None if guess is None else np.ascontiguousarray(guess, dtype=np.int32)
+            assert g is None or g.shape == (m + nb,)
+            term = self.lib.orc_gi_solve_warm(n, m, nb, _dp(Gf), max(n, 1), _dp(a), _dp(Cf), max(n, 1), _dp(bl), _dp(bu), _dp(xl),
+                                              _dp(xu), _ip(g), max_iter, big_bnd, _dp(x), _dp(u), _ip(status), _ip(active),
+                                              ct.byref(nact), ct.byref(iters), ct.byref(f), tr, trace_cap, None)
+        else:
+            term = self.lib.orc_gi_solve(n, m, nb, _dp(Gf), max(n, 1), _dp(a), _dp(Cf), max(n, 1), _dp(bl), _dp(bu), _dp(xl), _dp(xu),
+                                         max_iter, big_bnd, _dp(x), _dp(u), _ip(status), _ip(active), ct.byref(nact), ct.byref(iters),
+                                         ct.byref(f), tr, trace_cap, None)
         trace = [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in tr[: min(trace_cap, iters.value)]]
         return OracleResult(term, x, u, status, active[: nact.value].copy(), iters.value, f.value, trace, Gf)
 
-    def solve_batch(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, nthreads=1):
-        """Packed batch (see jrl-qp_amd/problems.py PackedBatch).  G is copied."""
+    def solve_batch(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, nthreads=1, warm=False, guess=None):
+        """Packed batch (see jrl-qp_amd/problems.py PackedBatch).  G is copied.  warm/guess: see solve()."""
         B, n, _ = G.shape
         m = C.shape[1]
         nb = 0 if xl is None or xl.shape[1] == 0 else xl.shape[1]
@@ -142,8 +156,14 @@ class Oracle:
         term = np.zeros(B, dtype=np.int32)
         iters = np.zeros(B, dtype=np.int32)
         f = np.zeros(B)
-        self.lib.orc_gi_solve_batch(B, n, m, nb, _dp(Gc), _dp(a), _dp(C), _dp(bl), _dp(bu), _dp(xlc), _dp(xuc), max_iter, big_bnd,
-                                    _dp(x), _dp(u), _ip(status), _ip(term), _ip(iters), _dp(f), nthreads)
+        if warm:
+            g = None if guess is None else np.ascontiguousarray(guess, dtype=np.int32)
+            assert g is None or g.shape == (B, m + nb)
+            self.lib.orc_gi_solve_batch_warm(B, n, m, nb, _dp(Gc), _dp(a), _dp(C), _dp(bl), _dp(bu), _dp(xlc), _dp(xuc), _ip(g),
+                                             max_iter, big_bnd, _dp(x), _dp(u), _ip(status), _ip(term), _ip(iters), _dp(f), nthreads)
+        else:
+            self.lib.orc_gi_solve_batch(B, n, m, nb, _dp(Gc), _dp(a), _dp(C), _dp(bl), _dp(bu), _dp(xlc), _dp(xuc), max_iter, big_bnd,
+                                        _dp(x), _dp(u), _ip(status), _ip(term), _ip(iters), _dp(f), nthreads)
         return dict(x=x, u=u, status=status, term=term, iters=iters, f=f, L=Gc)
 
     # ---- primitives ----------------------------------------------------------------------------
