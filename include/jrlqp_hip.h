@@ -128,10 +128,49 @@ int jrlqp_gi_solve_batch(int n,
                          int trace_cap,
                          void * stream);
 
+/* Warm-started variant.  Replaces B calls of
+ *     experimental::GoldfarbIdnaniSolver::solve(G, a, C, bl, bu, xl, xu, as)  with options.warmStart_ = true
+ *     (include/jrl-qp/experimental/GoldfarbIdnaniSolver.h, src/experimental/GoldfarbIdnaniSolver.cpp:20-112).
+ * das [B][m+nb] int32: the activation-status guess per problem, general constraints first, then bounds -- exactly
+ * what activeSet() returned for a previous solve (so a dstatus buffer can be passed back; das may alias dstatus:
+ * that is the reference's "as.empty(): reuse the solver's own active set").  NULL = no guess.  Data equalities
+ * (bl == bu, xl == xu) are activated whatever the guess says; guesses on infinite bounds (beyond +-big_bnd), FIXED
+ * guesses on free variables and entries the reference rejects with assert() are ignored; if more than n constraints
+ * come out active, inequality guesses are dropped from the back (src/experimental/GoldfarbIdnaniSolver.cpp:309-386).
+ * J and R then come from a Householder QR of L^-1 N (:388-458); constraints whose multiplier is < -1e-14 are dropped
+ * one at a time, each counting as one iteration (:78-109); then the same loop as the cold solver.
+ * Every other argument as for jrlqp_gi_solve_batch. */
+int jrlqp_gi_solve_batch_warm(int n,
+                              int m,
+                              int nb,
+                              int B,
+                              const double * dG,
+                              const double * da,
+                              const double * dC,
+                              const double * dbl,
+                              const double * dbu,
+                              const double * dxl,
+                              const double * dxu,
+                              const int * das,
+                              const jrlqp_options * opts,
+                              double * dx,
+                              double * du,
+                              int * dstatus,
+                              int * dterm,
+                              int * diters,
+                              double * df,
+                              double * dL,
+                              jrlqp_trace_rec * dtrace,
+                              int trace_cap,
+                              void * stream);
+
 /* LDS bytes one workgroup of the batched kernel uses for (n, m, nb), and where the constraint matrix lives during the
  * solve: *c_placement = 2 one column per thread in registers, 1 staged in LDS, 0 streamed from L2/HBM; returns -1 if
  * unsupported.  Lets a caller reason about occupancy (163840 B of LDS per CU). */
 long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_placement);
+
+/* the same for the warm-started kernel (it keeps N / the QR factors in LDS as well) */
+long jrlqp_gi_batch_warm_lds_bytes(int n, int m, int nb, int * c_placement);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Mode A -- ONE large dense QP, state in HBM, the active-set state machine on the host.

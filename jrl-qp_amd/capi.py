@@ -24,7 +24,9 @@ EXPORTED = [
     "jrlqp_device_count",
     "jrlqp_default_options",
     "jrlqp_gi_solve_batch",
+    "jrlqp_gi_solve_batch_warm",
     "jrlqp_gi_batch_lds_bytes",
+    "jrlqp_gi_batch_warm_lds_bytes",
     "jrlqp_dense_create",
     "jrlqp_dense_destroy",
     "jrlqp_dense_last_hip_error",
@@ -88,6 +90,11 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_default_options.argtypes = [ct.POINTER(Options)]
     lib.jrlqp_gi_batch_lds_bytes.restype = ct.c_long
     lib.jrlqp_gi_batch_lds_bytes.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_int)]
+    lib.jrlqp_gi_batch_warm_lds_bytes.restype = ct.c_long
+    lib.jrlqp_gi_batch_warm_lds_bytes.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_int)]
+    lib.jrlqp_gi_solve_batch_warm.restype = ct.c_int
+    lib.jrlqp_gi_solve_batch_warm.argtypes = ([ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 8 + [ct.POINTER(Options)] + [c_dp] * 8
+                                              + [ct.c_int, c_dp])
     lib.jrlqp_gi_solve_batch.restype = ct.c_int
     lib.jrlqp_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 7 + [ct.POINTER(Options)] + [c_dp] * 8 + [ct.c_int, c_dp]
     lib.jrlqp_dense_create.restype = ct.c_int
@@ -190,6 +197,35 @@ class BatchSolver:
         st = self.lib.jrlqp_gi_solve_batch(
             self.n, self.m, self.nb, self.B, _ptr(G), _ptr(a), _ptr(C), _ptr(bl), _ptr(bu),
             _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None, ct.byref(self.opts),
+            _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term), _ptr(self.iters), _ptr(self.f),
+            _ptr(self.L), _ptr(self.trace), self.trace_cap, ct.c_void_p(s.cuda_stream))
+        check(st)
+        return BatchResult(self.x, self.u, self.status, self.term, self.iters, self.f, self.L, self.trace)
+
+    def solve_warm(self, G, a, C, bl, bu, xl=None, xu=None, guess=None, stream=None) -> BatchResult:
+        """Warm-started solve (experimental::GoldfarbIdnaniSolver with warmStart_, jrlqp_gi_solve_batch_warm).
+        guess: (B, m+nb) int32 CUDA tensor of activation statuses, "previous" to reuse this solver's own last
+        active set in place (the reference's as.empty() case), or None for no guess."""
+        torch = self.torch
+        for t in (G, a, C, bl, bu, xl, xu):
+            if t is not None:
+                assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        assert G.shape == (self.B, self.n, self.n) and a.shape == (self.B, self.n)
+        assert C.shape == (self.B, self.m, self.n) and bl.shape == (self.B, self.m) and bu.shape == (self.B, self.m)
+        if self.nb:
+            assert xl.shape == (self.B, self.nb) and xu.shape == (self.B, self.nb)
+        if isinstance(guess, str):
+            assert guess == "previous"
+            guess = self.status
+        if guess is not None:
+            assert guess.is_cuda and guess.dtype == torch.int32 and guess.is_contiguous() and guess.shape == (self.B, self.m + self.nb)
+        c = ct.c_int(0)
+        if self.lib.jrlqp_gi_batch_warm_lds_bytes(self.n, self.m, self.nb, ct.byref(c)) < 0:
+            raise JrlqpError(f"warm-started batched path does not support n={self.n}, m={self.m}")
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        st = self.lib.jrlqp_gi_solve_batch_warm(
+            self.n, self.m, self.nb, self.B, _ptr(G), _ptr(a), _ptr(C), _ptr(bl), _ptr(bu),
+            _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None, _ptr(guess), ct.byref(self.opts),
             _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term), _ptr(self.iters), _ptr(self.f),
             _ptr(self.L), _ptr(self.trace), self.trace_cap, ct.c_void_p(s.cuda_stream))
         check(st)

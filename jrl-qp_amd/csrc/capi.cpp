@@ -85,28 +85,30 @@ long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds)
   return jrlqp::batch_lds_bytes(n, m, nb, cmode);
 }
 
-int jrlqp_gi_solve_batch(int n,
-                         int m,
-                         int nb,
-                         int B,
-                         const double * dG,
-                         const double * da,
-                         const double * dC,
-                         const double * dbl,
-                         const double * dbu,
-                         const double * dxl,
-                         const double * dxu,
-                         const jrlqp_options * opts,
-                         double * dx,
-                         double * du,
-                         int * dstatus,
-                         int * dterm,
-                         int * diters,
-                         double * df,
-                         double * dL,
-                         jrlqp_trace_rec * dtrace,
-                         int trace_cap,
-                         void * stream)
+static int gi_batch_common(int warm,
+                           const int * das,
+                           int n,
+                           int m,
+                           int nb,
+                           int B,
+                           const double * dG,
+                           const double * da,
+                           const double * dC,
+                           const double * dbl,
+                           const double * dbu,
+                           const double * dxl,
+                           const double * dxu,
+                           const jrlqp_options * opts,
+                           double * dx,
+                           double * du,
+                           int * dstatus,
+                           int * dterm,
+                           int * diters,
+                           double * df,
+                           double * dL,
+                           jrlqp_trace_rec * dtrace,
+                           int trace_cap,
+                           void * stream)
 {
   if(n < 1 || m < 0 || B < 0 || (nb != 0 && nb != n)) return JRLQP_ERR_INVALID_ARGUMENT;
   if(B == 0) return JRLQP_OK;
@@ -116,7 +118,7 @@ int jrlqp_gi_solve_batch(int n,
   if(nb > 0 && (!dxl || !dxu)) return JRLQP_ERR_INVALID_ARGUMENT;
   if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
   if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
-  const int cmode = jrlqp::batch_pick_cmode(n, m, nb);
+  const int cmode = jrlqp::batch_pick_cmode(n, m, nb, warm);
   if(cmode < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
 
   jrlqp_options o;
@@ -134,9 +136,39 @@ int jrlqp_gi_solve_batch(int n,
   a.Lout = dL;
   a.trace = dtrace;
   a.prof = g_prof.load();
+  a.warm = warm;
+  a.as_in = das;
   hipError_t e = jrlqp::launch_gi_batch(a, cmode, static_cast<hipStream_t>(stream));
   if(e != hipSuccess) return hip_fail(e);
   return JRLQP_OK;
+}
+
+long jrlqp_gi_batch_warm_lds_bytes(int n, int m, int nb, int * c_in_lds)
+{
+  if(n < 1 || n > JRLQP_BATCH_MAX_N || m < 0 || (nb != 0 && nb != n)) return -1;
+  int cmode = jrlqp::batch_pick_cmode(n, m, nb, 1);
+  if(cmode < 0) return -1;
+  if(c_in_lds) *c_in_lds = cmode;
+  return jrlqp::batch_lds_bytes(n, m, nb, cmode, 1);
+}
+
+int jrlqp_gi_solve_batch(int n, int m, int nb, int B, const double * dG, const double * da, const double * dC,
+                         const double * dbl, const double * dbu, const double * dxl, const double * dxu,
+                         const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm, int * diters,
+                         double * df, double * dL, jrlqp_trace_rec * dtrace, int trace_cap, void * stream)
+{
+  return gi_batch_common(0, nullptr, n, m, nb, B, dG, da, dC, dbl, dbu, dxl, dxu, opts, dx, du, dstatus, dterm, diters, df,
+                         dL, dtrace, trace_cap, stream);
+}
+
+int jrlqp_gi_solve_batch_warm(int n, int m, int nb, int B, const double * dG, const double * da, const double * dC,
+                              const double * dbl, const double * dbu, const double * dxl, const double * dxu,
+                              const int * das, const jrlqp_options * opts, double * dx, double * du, int * dstatus,
+                              int * dterm, int * diters, double * df, double * dL, jrlqp_trace_rec * dtrace,
+                              int trace_cap, void * stream)
+{
+  return gi_batch_common(1, das, n, m, nb, B, dG, da, dC, dbl, dbu, dxl, dxu, opts, dx, du, dstatus, dterm, diters, df, dL,
+                         dtrace, trace_cap, stream);
 }
 
 #define HIP_TRY(x)                      \

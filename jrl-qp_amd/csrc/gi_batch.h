@@ -20,13 +20,15 @@ struct BatchArgs
   double * Lout;
   jrlqp_trace_rec * trace;
   long long * prof; // diagnostic only: 16 int64 per QP, or nullptr
+  int warm;           // 1: warm-started solve (experimental::GoldfarbIdnaniSolver), as_in = activation-status guess
+  const int * as_in;  // B x (m+nb) guesses, or nullptr ("no guess"); may alias `status`
 };
 
 constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
 
 // cmode: where the constraint matrix lives during the solve: 0 = streamed from global memory, 1 = staged in LDS,
 // 2 = one column per thread in registers (specialised compile-time-n instantiations)
-long batch_lds_bytes(int n, int m, int nb, int cmode);
-int batch_pick_cmode(int n, int m, int nb); // -1 if unsupported
+long batch_lds_bytes(int n, int m, int nb, int cmode, int warm = 0);
+int batch_pick_cmode(int n, int m, int nb, int warm = 0); // -1 if unsupported
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream);
 } // namespace jrlqp

@@ -76,6 +76,8 @@ struct Ctl
   int eq_next;
   int cnt;
   int flag; // sequence number of the last add whose (c, s) coefficients are published (wave 0 -> wave 1 hand-off)
+  int nact; // WARM: size of the initial active set
+  int over; // WARM: more than n equalities / fixed variables activated
   int pad;
 };
 
@@ -376,8 +378,10 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 // ---- the kernel ------------------------------------------------------------------------------------------
 // NT    : compile-time n (0 = runtime n)
 // CMODE : 0 = C streamed from global memory, 1 = C staged in LDS, 2 = C in registers (needs NT > 0, m <= 256)
-template<int NT, int CMODE, bool PROF>
-__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_kernel(const BatchArgs A)
+// WARM  : warm-started solve (src/experimental/GoldfarbIdnaniSolver.cpp): the initial active set comes from the data
+//         equalities plus a guess, J and R from a Householder QR of L^-1 N; then the same loop
+template<int NT, int CMODE, bool PROF, bool WARM>
+__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0;
   if(PROF)
@@ -408,6 +412,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
   double * us = nps + n;
   double * rs = us + (n + 2);
   double * tail = rs + (n + 2);
+  // WARM: N -> B = L^-1 N -> its QR factors (n x q), b_act, Householder coefficients
+  double * Bw = tail;
+  double * bact = Bw + (WARM ? n * ld : 0);
+  double * hco = bact + (WARM ? n : 0);
+  tail = hco + (WARM ? n : 0);
   double * Cs = tail;
   double * bls = tail;
   double * bus = tail;
@@ -516,31 +525,115 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
         bus[i] = bug[i];
       }
     }
-    // equalities / fixed variables present?  (GoldfarbIdnaniSolver.cpp:268-287)
-    int first = NONE, cnt = 0;
-    for(int i = tid - 64; i < mt; i += WG - 64)
+    if constexpr(WARM)
     {
-      bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
-      if(eq)
+      // processInitialActiveSet, decision per constraint (experimental/GoldfarbIdnaniSolver.cpp:309-371): data
+      // equalities win over the guess; guesses on infinite bounds, FIXED guesses and ill-typed entries are ignored
+      const int * asg = A.as_in ? A.as_in + (size_t)b * mt : nullptr;
+      int neq = 0;
+      for(int i = tid - 64; i < mt; i += WG - 64)
       {
-        ++cnt;
-        if(i < first) first = i;
+        int s = INACTIVE;
+        const int g = asg ? asg[i] : INACTIVE;
+        if(i < m)
+        {
+          const double lo = blg[i], hi = bug[i];
+          if(lo == hi)
+            s = EQUALITY;
+          else if(g == LOWER && !(lo < -A.big_bnd))
+            s = LOWER;
+          else if(g == UPPER && !(hi > A.big_bnd))
+            s = UPPER;
+          else if(g == EQUALITY)
+            s = EQUALITY; // :357-371 only filters FIXED: an EQUALITY guess is taken as is
+        }
+        else
+        {
+          const double lo = xlg[i - m], hi = xug[i - m];
+          if(lo == hi)
+            s = FIXED;
+          else if(g == LOWER_BOUND && !(lo < -A.big_bnd))
+            s = LOWER_BOUND;
+          else if(g == UPPER_BOUND && !(hi > A.big_bnd))
+            s = UPPER_BOUND;
+        }
+        st[i] = (unsigned char)s;
+        neq += (s == EQUALITY || s == FIXED);
       }
+      if(neq) atomicAdd(&ctl->cnt, neq);
     }
-    if(first != NONE)
+    else
     {
-      atomicMin(&ctl->eq_next, first);
-      atomicAdd(&ctl->cnt, cnt);
+      // equalities / fixed variables present?  (GoldfarbIdnaniSolver.cpp:268-287)
+      int first = NONE, cnt = 0;
+      for(int i = tid - 64; i < mt; i += WG - 64)
+      {
+        bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
+        if(eq)
+        {
+          ++cnt;
+          if(i < first) first = i;
+        }
+      }
+      if(first != NONE)
+      {
+        atomicMin(&ctl->eq_next, first);
+        atomicAdd(&ctl->cnt, cnt);
+      }
     }
   }
   __syncthreads();
   STAMP(1)
 
+  if constexpr(WARM)
+  {
+    // activation ORDER (:319-371): bounds first, then general constraints, each by increasing index; if more than n
+    // came out, inequality entries are dropped from the back until n remain (:373-383) -- i.e. every equality stays
+    // and the first n - #eq inequality entries (in list order) stay
+    if(wave == 0)
+    {
+      const int neq = ctl->cnt;
+      const int budget = n - neq;
+      int base = 0, nrank = 0;
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      for(int part = 0; part < 2; ++part)
+      {
+        const int lo = (part == 0) ? m : 0, hi = (part == 0) ? mt : m;
+        for(int c0 = lo; c0 < hi; c0 += 64)
+        {
+          const int i = c0 + lane;
+          const int s = (i < hi) ? st[i] : INACTIVE;
+          const bool iseq = (s == EQUALITY || s == FIXED);
+          const bool isne = (s != INACTIVE) && !iseq;
+          const unsigned long long mne = __ballot(isne);
+          const int rank = nrank + __popcll(mne & lt);
+          const bool keep = iseq || (isne && rank < budget);
+          const unsigned long long mk = __ballot(keep);
+          const int pos = base + __popcll(mk & lt);
+          if(keep && pos < n) act[pos] = i;
+          if(isne && !keep && budget >= 0) st[i] = INACTIVE;
+          base += __popcll(mk);
+          nrank += __popcll(mne);
+        }
+      }
+      if(lane == 0)
+      {
+        ctl->nact = (base < n) ? base : n;
+        ctl->over = (neq > n);
+      }
+    }
+    __syncthreads();
+  }
+
   int term = T_SUCCESS;
   int it = 0;
   int q = 0;
 
-  if(ctl->info >= 0)
+  if(WARM && ctl->over)
+  {
+    term = T_OVERCONSTRAINED; // reported before the factorisation is looked at (:70-71)
+  }
+  else if(ctl->info >= 0)
   {
     term = T_NON_POS_HESSIAN;
   }
@@ -574,6 +667,39 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
           J[i + c * ld] = v;
         }
       }
+    }
+    else if constexpr(WARM)
+    {
+      // waves 0, 2, 3: N (+-C columns / +-unit vectors) and b_act in activation order (:393-418); a -> LDS
+      const int t3 = (wave == 0) ? lane : (tid - 64);
+      const int qn = ctl->nact;
+      for(int e = t3; e < qn * n; e += WG - 64)
+      {
+        const int j = e / n, i = e % n;
+        const int idx = act[j];
+        const int sj = st[idx];
+        double v;
+        if(idx < m)
+        {
+          const double c = Cg[(size_t)idx * n + i];
+          v = (sj == UPPER) ? -c : c;
+        }
+        else
+          v = (i == idx - m) ? ((sj == UPPER_BOUND) ? -1.0 : 1.0) : 0.0;
+        Bw[i + j * ld] = v;
+      }
+      for(int j = t3; j < qn; j += WG - 64)
+      {
+        const int idx = act[j];
+        const int sj = st[idx];
+        double bv;
+        if(idx < m)
+          bv = (sj == UPPER) ? -bug[idx] : blg[idx];
+        else
+          bv = (sj == UPPER_BOUND) ? -xug[idx - m] : xlg[idx - m];
+        bact[j] = bv;
+      }
+      if(t3 < n) nps[t3] = ag[t3];
     }
     else if(wave == 0)
     {
@@ -1112,7 +1238,200 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     // ======================================================================================================
     // K12: initActiveSet -- equalities (bl == bu) then fixed variables (xl == xu), in index order, full step each
     // ======================================================================================================
-    if(ctl->eq_next != NONE)
+    if constexpr(WARM)
+    {
+      // ==================================================================================================
+      // warm start: initializeComputationData + initializePrimalDualPoints + purge of the negative multipliers
+      // (experimental/GoldfarbIdnaniSolver.cpp:388-487, 78-109); J = L^-T and N are in place
+      // ==================================================================================================
+      q = uniform(ctl->nact);
+      // ---- B = L^-1 N (:426): wave w takes columns w, w+4, ...; lane = row, forward substitution as for x0
+      {
+        const int rl = (lane < n) ? lane : 0;
+        double dg = L[rl + rl * ld];
+        dg = (lane < n) ? dg : 1.0;
+        const double rinv = recip_refined(dg);
+        const bool den_safe = __all(div_safe_den(dg));
+        for(int j = wave; j < q; j += 4)
+        {
+          const double b0 = (lane < n) ? Bw[lane + j * ld] : 0.0;
+          double xi = b0;
+          for(int pass = 0; pass < 2; ++pass)
+          {
+            bool safe = den_safe;
+            xi = b0;
+            double col = L[rl];
+            for(int k = 0; k < n; ++k)
+            {
+              const double coln = L[rl + ((k + 1 < n) ? (k + 1) : k) * ld];
+              const double num = opaque_v(bcast_lane(xi, k));
+              const double den = bcast_lane(dg, k);
+              const double v = (pass == 0) ? div_pre(num, den, bcast_lane(rinv, k)) : num / opaque_v(den);
+              safe = safe && div_safe_num(num);
+              const double upd = FMA(-col, v, xi);
+              xi = (lane > k && lane < n) ? upd : xi;
+              xi = (lane == k) ? v : xi;
+              col = coln;
+            }
+            if(safe) break;
+          }
+          if(lane < n) Bw[lane + j * ld] = xi;
+        }
+      }
+      __syncthreads();
+      // ---- B = Q R, Householder, column by column (:432-440; Eigen makeHouseholder / applyHouseholderOnTheLeft) on
+      // wave 0; wave 1 applies each reflector to J from the right as soon as it exists (J = J Q, :443-444)
+      for(int k = 0; k < q; ++k)
+      {
+        if(wave == 0)
+        {
+          const double * vk = Bw + k * ld;
+          const double tailsq = chain_up(vk, 1, vk, 1, k + 1, n, 0.0); // every lane the same chain (LDS broadcast)
+          const double c0 = vk[k];
+          const bool zero = tailsq <= 2.2250738585072014e-308;
+          double beta = __builtin_sqrt(FMA(c0, c0, tailsq));
+          beta = (c0 >= 0.0) ? -beta : beta;
+          const double den = c0 - beta;
+          double tau = (beta - c0) / beta;
+          tau = zero ? 0.0 : tau;
+          beta = zero ? c0 : beta;
+          const double mine = (lane > k && lane < n) ? vk[lane] : 0.0;
+          wave_sync();
+          if(lane > k && lane < n) Bw[lane + k * ld] = zero ? 0.0 : mine / den;
+          if(lane == 0)
+          {
+            Bw[k + k * ld] = beta;
+            hco[k] = tau;
+          }
+        }
+        __syncthreads();
+        const double tau = uniform_d(hco[k]);
+        if(tau != 0.0 && k + 1 < n)
+        {
+          const double * v = Bw + k * ld;
+          if(wave == 0)
+          {
+            if(lane > k && lane < q) // lane = trailing column
+            {
+              double * cj = Bw + lane * ld;
+              double t = chain_up(v, 1, cj, 1, k + 1, n, 0.0);
+              const double top = cj[k];
+              t = t + top;
+              cj[k] = FMA(-tau, t, top);
+              const double stt = tau * t;
+              for(int i = k + 1; i < n; ++i) cj[i] = FMA(-stt, v[i], cj[i]);
+            }
+            wave_sync();
+          }
+          else if(wave == 1)
+          {
+            if(lane < n) // lane = row of J
+            {
+              double t = chain_up(J + lane, ld, v, 1, k + 1, n, 0.0);
+              const double jk = J[lane + k * ld];
+              t = t + jk;
+              J[lane + k * ld] = FMA(-tau, t, jk);
+              const double stt = tau * t;
+              for(int j = k + 1; j < n; ++j) J[lane + j * ld] = FMA(-stt, v[j], J[lane + j * ld]);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- R = upper triangle of the factored B (L is dead)
+      for(int e = tid; e < q * q; e += WG)
+      {
+        const int i = e % q, j = e / q;
+        if(i <= j) R[i + j * ld] = Bw[i + j * ld];
+      }
+      __syncthreads();
+      // ---- initializePrimalDualPoints (:462-487), repeated after every purge (:78-109)
+      for(;;)
+      {
+        if(wave == 1)
+        {
+          if(lane < n) ds[lane] = chain_up(J + lane * ld, 1, nps, 1, 0, n, 0.0); // alpha = J^T a
+        }
+        else if(wave == 0)
+        {
+          // beta = R^-T b_act: forward substitution, lane = component
+          const int cl = (lane < q) ? lane : 0;
+          double acc = (lane < q) ? bact[lane] : 0.0;
+          for(int i = 0; i < q; ++i)
+          {
+            const double v = opaque_v(bcast_lane(acc, i)) / opaque_v(R[i + i * ld]);
+            const double upd = FMA(-R[i + cl * ld], v, acc);
+            acc = (lane > i && lane < q) ? upd : acc;
+            acc = (lane == i) ? v : acc;
+          }
+          if(lane < q) rs[lane] = acc;
+        }
+        __syncthreads();
+        if(wave == 0)
+        {
+          if(lane < n) // x = J1 beta - J2 alpha2
+          {
+            double acc = chain_up(J + lane, ld, rs, 1, 0, q, 0.0);
+            acc = chain_up_neg(J + lane, ld, ds, 1, q, n, acc);
+            xs[lane] = acc;
+          }
+        }
+        else if(wave == 1)
+        {
+          // u = R^-1 (alpha1 + beta)
+          const int rl = (lane < q) ? lane : 0;
+          double uk = (lane < q) ? (ds[rl] + rs[rl]) : 0.0;
+          for(int k = q - 1; k >= 0; --k)
+          {
+            const double v = opaque_v(bcast_lane(uk, k)) / opaque_v(R[k + k * ld]);
+            const double upd = FMA(-R[rl + k * ld], v, uk);
+            uk = (lane < k) ? upd : uk;
+            uk = (lane == k) ? v : uk;
+          }
+          if(lane < q) us[lane] = uk;
+          // most negative multiplier of an inequality (first one on ties), threshold -1e-14 (:82-93)
+          double cand = 1.0;
+          int ci = NONE, dummy = 0;
+          if(lane < q)
+          {
+            const int sk = st[act[lane]];
+            if(uk < -1e-14 && sk != FIXED && sk != EQUALITY)
+            {
+              cand = uk;
+              ci = lane;
+            }
+          }
+          wave_argmin_monotone(cand, ci, dummy);
+          if(lane == 0) ctl->l = (ci == NONE) ? -1 : ci;
+        }
+        else if(wave == 2)
+        {
+          // f = beta.(0.5 beta + alpha1) - 0.5 |alpha2|^2
+          if(lane < q) zs[lane] = FMA(0.5, rs[lane], ds[lane]);
+          wave_sync();
+          if(lane == 0)
+          {
+            const double f1 = chain_up(rs, 1, zs, 1, 0, q, 0.0);
+            const double f2 = chain_up(ds, 1, ds, 1, q, n, 0.0);
+            ctl->f = FMA(-0.5, f2, f1);
+          }
+        }
+        __syncthreads();
+        const int lmin = uniform(ctl->l);
+        if(lmin < 0) break;
+        ++it;
+        if(wave == 0)
+        {
+          const double bv = (lane >= lmin && lane < q - 1) ? bact[lane + 1] : 0.0;
+          wave_sync();
+          if(lane >= lmin && lane < q - 1) bact[lane] = bv;
+          do_drop(lmin);
+        }
+        q = uniform(q - 1);
+        __syncthreads();
+      }
+    }
+    else if(ctl->eq_next != NONE)
     {
       if(ctl->cnt > n)
       {
@@ -1174,7 +1493,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
     // ======================================================================================================
     if(term == T_SUCCESS)
     {
-      if(A.max_iter <= 0)
+      if(it >= A.max_iter) // it > 0 only after a warm start purged constraints
         term = T_MAX_ITER;
       else
       {
@@ -1324,46 +1643,48 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? 3 : 1) void gi_batch_k
   }
 }
 
-template<int NT, int CMODE, bool PROF>
+template<int NT, int CMODE, bool PROF, bool WARM>
 hipError_t launch_one(const BatchArgs & a, long lds, hipStream_t stream)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<NT, CMODE, PROF>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<NT, CMODE, PROF, WARM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if(e != hipSuccess) return e;
-  hipLaunchKernelGGL((gi_batch_kernel<NT, CMODE, PROF>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
+  hipLaunchKernelGGL((gi_batch_kernel<NT, CMODE, PROF, WARM>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
   return hipGetLastError();
 }
 
 template<int NT, int CMODE>
 hipError_t launch_prof(const BatchArgs & a, long lds, hipStream_t stream)
 {
-  return a.prof ? launch_one<NT, CMODE, true>(a, lds, stream) : launch_one<NT, CMODE, false>(a, lds, stream);
+  if(a.warm) return launch_one<NT, CMODE, false, true>(a, lds, stream); // the phase profile covers the cold path only
+  return a.prof ? launch_one<NT, CMODE, true, false>(a, lds, stream) : launch_one<NT, CMODE, false, false>(a, lds, stream);
 }
 
 } // namespace
 
-long batch_lds_bytes(int n, int m, int nb, int cmode)
+long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
 {
   const long ld = n | 1;
   long dbl = 2L * n * ld + 4L * n + 2L * (n + 2);
+  if(warm) dbl += (long)n * ld + 2L * n;
   if(cmode == 1) dbl += (long)m * ld + 2L * m;
   if(cmode == 2 && m > WG - 64) dbl += (long)(m - (WG - 64)) * ld; // extra columns beyond the 192 register-resident ones
   long bytes = dbl * 8 + (long)sizeof(Ctl) + 4L * (n + 2) + (long)(m + nb);
   return (bytes + 15) & ~15L;
 }
 
-int batch_pick_cmode(int n, int m, int nb)
+int batch_pick_cmode(int n, int m, int nb, int warm)
 {
   // registers: the specialised instantiations below; LDS when C fits beside the factors; else stream
   if(n == 50 && m <= 256) return 2;
-  if(batch_lds_bytes(n, m, nb, 1) <= kLdsPerCU) return 1;
-  if(batch_lds_bytes(n, m, nb, 0) <= kLdsPerCU) return 0;
+  if(batch_lds_bytes(n, m, nb, 1, warm) <= kLdsPerCU) return 1;
+  if(batch_lds_bytes(n, m, nb, 0, warm) <= kLdsPerCU) return 0;
   return -1;
 }
 
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)
 {
-  const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode);
+  const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode, a.warm);
   if(cmode == 2 && a.n == 50) return launch_prof<50, 2>(a, lds, stream);
   if(cmode == 1) return launch_prof<0, 1>(a, lds, stream);
   return launch_prof<0, 0>(a, lds, stream);
