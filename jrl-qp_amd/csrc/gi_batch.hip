@@ -487,25 +487,64 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
   double * L = R;
   if(wave == 0)
   {
+    // Left-looking by blocks of LB columns, lane = row: the LB accumulators of a row stay in registers while the
+    // wave walks the columns k < j0 already factored (one lane-varying + LB broadcast LDS reads feed LB independent
+    // fma chains per k), then the LB x LB diagonal block and the panel below it are finished from registers with
+    // readlane.  Per element the updates still arrive in ascending k (CANON C1): bit-identical to the unblocked form.
+    constexpr int LB = 8;
     int info = -1;
-    for(int j = 0; j < n; ++j)
+    const int rl = (lane < n) ? lane : (n - 1); // lanes >= n shadow the last row (results discarded)
+    for(int j0 = 0; j0 < n && info < 0; j0 += LB)
     {
-      double acc = 0.0;
-      // ascending k (CANON C1): acc = G_ij - sum_{k<j} L_ik L_jk
-      if(lane >= j && lane < n) acc = chain_up_neg(L + lane, ld, L + j, ld, 0, j, L[lane + j * ld]);
-      STAMP(18)
-      double piv = bcast_lane(acc, j);
-      if(piv <= 0.0)
+      double acc[LB];
+#pragma unroll
+      for(int c = 0; c < LB; ++c) acc[c] = L[rl + ((j0 + c < n) ? (j0 + c) : (n - 1)) * ld];
+      // rows j0 .. j0+LB-1 of column k are LB consecutive doubles: one base address, immediate offsets.  In the last
+      // block j0+c may pass n: the read then lands on the first rows of column k+1 (k+1 <= j0 < n, still inside
+      // the factor's LDS region) and the accumulator it feeds is never used.
+      // (loads of two steps issued together, then the fmas: the scheduling barrier keeps hipcc from interleaving
+      // them one LDS round trip at a time to save registers)
+      int k = 0;
+#pragma unroll 1
+      for(; k + 2 <= j0; k += 2)
       {
-        info = j;
-        break;
+        double li[2], lj[2][LB];
+#pragma unroll
+        for(int u = 0; u < 2; ++u)
+        {
+          li[u] = L[rl + (k + u) * ld];
+#pragma unroll
+          for(int c = 0; c < LB; ++c) lj[u][c] = L[j0 + c + (k + u) * ld];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for(int u = 0; u < 2; ++u)
+#pragma unroll
+          for(int c = 0; c < LB; ++c) acc[c] = FMA(-li[u], lj[u][c], acc[c]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      double ljj = __builtin_sqrt(opaque_v(piv));
-      if(lane == j)
-        L[j + j * ld] = ljj;
-      else if(lane > j && lane < n)
-        L[lane + j * ld] = acc / ljj;
-      wave_sync();
+      static_assert(LB % 2 == 0, "j0 is a multiple of LB: the two-step loop leaves no remainder");
+      STAMP(18)
+#pragma unroll
+      for(int c = 0; c < LB; ++c)
+      {
+        const int j = j0 + c;
+        if(j < n && info < 0)
+        {
+          const double piv = bcast_lane(acc[c], j);
+          if(piv <= 0.0)
+            info = j;
+          else
+          {
+            const double ljj = __builtin_sqrt(opaque_v(piv));
+            const double lij = (lane == j) ? ljj : acc[c] / ljj;
+            if(lane >= j && lane < n) L[lane + j * ld] = lij;
+#pragma unroll
+            for(int c2 = c + 1; c2 < LB; ++c2)
+              if(j0 + c2 < n) acc[c2] = FMA(-lij, bcast_lane(lij, j0 + c2), acc[c2]);
+          }
+        }
+      }
       STAMP(19)
     }
     if(lane == 0) ctl->info = info;
@@ -652,19 +691,54 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     // ---------------------------------------------------------------- K2 (wave 1): J = L^-T ; K3 (wave 0): x0, f0
     if(wave == 1)
     {
-      const int c = lane;
-      for(int i = n - 1; i >= 0; --i)
+      // J = L^-T by blocks of JB rows from the bottom, lane = column c: J_ic = (delta_ic - sum_{k = c .. i+1,
+      // descending} L_ki J_kc) / L_ii.  The JB accumulators of a column stay in registers while the wave walks the
+      // rows k below the block; rows k > c contribute exact zeros (J_kc = +0), which leaves every accumulator bit
+      // for bit as the triangular loop would (x + (+-0) = x, and an accumulator is never -0 here).
+      constexpr int JB = 8;
+      const int cl = (lane < n) ? lane : (n - 1);
+      for(int i0 = ((n - 1) / JB) * JB; i0 >= 0; i0 -= JB)
       {
-        if(c < n)
+        double acc[JB];
+#pragma unroll
+        for(int r = 0; r < JB; ++r) acc[r] = (i0 + r == lane) ? 1.0 : 0.0;
+        // (the loop is empty for the bottom block, the only one whose rows can pass n: i0 + r < n below)
+        int k = n - 1;
+#pragma unroll 1
+        for(; k - 1 >= i0 + JB; k -= 2)
         {
-          double v = 0.0;
-          if(c >= i)
+          double jk[2], lk[2][JB];
+#pragma unroll
+          for(int u = 0; u < 2; ++u)
           {
-            // J_ic = (delta_ic - sum_{k=c..i+1, descending} L_ki J_kc) / L_ii
-            double acc = chain_down_neg(L + i * ld, 1, J + c * ld, 1, i + 1, c + 1, (c == i) ? 1.0 : 0.0);
-            v = acc / L[i + i * ld];
+            jk[u] = J[(k - u) + cl * ld];
+#pragma unroll
+            for(int r = 0; r < JB; ++r) lk[u][r] = L[(k - u) + (i0 + r) * ld];
           }
-          J[i + c * ld] = v;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for(int u = 0; u < 2; ++u)
+#pragma unroll
+            for(int r = 0; r < JB; ++r) acc[r] = FMA(-lk[u][r], jk[u], acc[r]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if(k >= i0 + JB) // odd count: one more step
+        {
+          const double jk = J[k + cl * ld];
+#pragma unroll
+          for(int r = 0; r < JB; ++r) acc[r] = FMA(-L[k + (i0 + r) * ld], jk, acc[r]);
+        }
+#pragma unroll
+        for(int r = JB - 1; r >= 0; --r)
+        {
+          const int i = i0 + r;
+          if(i < n)
+          {
+            const double v = acc[r] / L[i + i * ld];
+            if(lane < n) J[i + lane * ld] = v;
+#pragma unroll
+            for(int r2 = 0; r2 < r; ++r2) acc[r2] = FMA(-L[i + (i0 + r2) * ld], v, acc[r2]);
+          }
         }
       }
     }
