@@ -453,8 +453,22 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
   {
     const bool own = myc >= 0 && myc < m;
     const double * ci = Cg + (size_t)(own ? myc : 0) * n;
+    if((NR % 2 == 0) && ((reinterpret_cast<size_t>(Cg) & 15) == 0)) // a column is NR*8 bytes: 16-byte loads when aligned
+    {
+      const double2 * c2 = reinterpret_cast<const double2 *>(ci);
 #pragma unroll
-    for(int k = 0; k < NR; ++k) creg[k] = own ? ci[k] : 0.0;
+      for(int k = 0; k < NR / 2; ++k)
+      {
+        const double2 v = c2[k];
+        creg[2 * k] = own ? v.x : 0.0;
+        creg[2 * k + 1] = own ? v.y : 0.0;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for(int k = 0; k < NR; ++k) creg[k] = own ? ci[k] : 0.0;
+    }
     my_bl = own ? blg[myc] : 0.0;
     my_bu = own ? bug[myc] : 0.0;
     for(int e = tid; e < ne * n; e += WG)
