@@ -1079,25 +1079,38 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
       dg = (lane < q) ? dg : 1.0;
       const double rk0 = rk;
       const double rinv = recip_refined(dg); // every pivot's reciprocal at once (lane = pivot)
-      bool safe = __all(div_safe_den(dg));
-      // columns are fetched FOUR steps ahead (the LDS is shared with 11 other waves: a one-step prefetch still
-      // exposes most of its latency on this chain)
+      // Columns are fetched FOUR steps ahead (the LDS is shared with 11 other waves: a one-step prefetch still exposes
+      // most of its latency on this chain); the loop is unrolled by four so that the look-ahead registers need no
+      // rotation.  Each lane keeps the numerator of its own division (`pre`): the range check that licenses the
+      // hoisted reciprocals is made once, after the loop, instead of once per step.
       auto colat = [&](int k) { return R[rl + ((k > 0) ? k : 0) * ld]; };
-      double c0 = colat(q - 1), c1 = colat(q - 2), c2 = colat(q - 3), c3 = colat(q - 4);
-      for(int k = q - 1; k >= 0; --k)
-      {
-        const double col = c0;
-        c0 = c1;
-        c1 = c2;
-        c2 = c3;
-        c3 = colat(k - 4);
+      double pre = 0.0;
+      auto step = [&](int k, double col) __attribute__((always_inline)) {
         const double num = opaque_v(bcast_lane(rk, k));
         const double v = div_pre(num, bcast_lane(dg, k), bcast_lane(rinv, k));
-        safe = safe && div_safe_num(num);
         const double upd = FMA(-col, v, rk);
+        pre = (lane == k) ? rk : pre;
         rk = (lane < k) ? upd : rk;
         rk = (lane == k) ? v : rk;
+      };
+      int k = q - 1;
+      double c0 = colat(k), c1 = colat(k - 1), c2 = colat(k - 2), c3 = colat(k - 3);
+#pragma unroll 1
+      for(; k >= 3; k -= 4)
+      {
+        step(k, c0);
+        c0 = colat(k - 4);
+        step(k - 1, c1);
+        c1 = colat(k - 5);
+        step(k - 2, c2);
+        c2 = colat(k - 6);
+        step(k - 3, c3);
+        c3 = colat(k - 7);
       }
+      if(k >= 0) step(k, c0);
+      if(k >= 1) step(k - 1, c1);
+      if(k >= 2) step(k - 2, c2);
+      const bool safe = __all(div_safe_den(dg) && div_safe_num(pre));
       if(!safe)
       {
         // an operand left the range in which the hoisted reciprocal is provably the compiler's own: redo with a/b
