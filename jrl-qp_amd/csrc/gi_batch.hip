@@ -1078,6 +1078,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
       double dg = R[rl + rl * ld];
       dg = (lane < q) ? dg : 1.0;
       const double rk0 = rk;
+      const int sk_l = (lane < q) ? st[lane] : INACTIVE; // operands of the ratio test below
+      const double u_l = us[rl];
       const double rinv = recip_refined(dg); // every pivot's reciprocal at once (lane = pivot)
       // Columns are fetched FOUR steps ahead (the LDS is shared with 11 other waves: a one-step prefetch still exposes
       // most of its latency on this chain); the loop is unrolled by four so that the look-ahead registers need no
@@ -1129,21 +1131,12 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
       if(lane < q) rs[lane] = rk;
       STAMP(16)
       // t1 = min u_k / r_k over r_k > 0 (not EQUALITY/FIXED; status looked up by POSITION, GoldfarbIdnaniSolver.cpp:162)
-      double tk = big;
-      int kk = NONE, dummy = 0;
-      if(lane < q)
-      {
-        int sk = st[lane];
-        if(sk != EQUALITY && sk != FIXED && rk > 0.0)
-        {
-          double tt = us[lane] / rk;
-          if(tt < big)
-          {
-            tk = tt;
-            kk = lane;
-          }
-        }
-      }
+      // (u and the status byte were fetched before the substitution loop; the quotient is formed in every lane and
+      // selected afterwards: no LDS round trip and no divergent region on this path)
+      const double tt = u_l / ((rk > 0.0) ? rk : 1.0);
+      const bool cand = (lane < q) && sk_l != EQUALITY && sk_l != FIXED && rk > 0.0 && tt < big;
+      double tk = cand ? tt : big;
+      int kk = cand ? lane : NONE, dummy = 0;
       wave_argmin_monotone(tk, kk, dummy);
       if(lane == 0)
       {
