@@ -1005,20 +1005,25 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
 
     // after a barrier: every thread combines the four wave winners (first index wins ties)
     auto scan_combine = [&](int & pp, int & ps) {
-      double v = ctl->red_val[0];
-      int ix = ctl->red_idx[0], sx = ctl->red_stat[0];
+      // all twelve words are fetched up front (one LDS round trip), then selected in registers
+      double rv[4];
+      int ri[4], rst[4];
+#pragma unroll
+      for(int w = 0; w < 4; ++w)
+      {
+        rv[w] = ctl->red_val[w];
+        ri[w] = ctl->red_idx[w];
+        rst[w] = ctl->red_stat[w];
+      }
+      double v = rv[0];
+      int ix = ri[0], sx = rst[0];
 #pragma unroll
       for(int w = 1; w < 4; ++w)
       {
-        double ov = ctl->red_val[w];
-        int oi = ctl->red_idx[w];
-        bool take = (oi != NONE) && (ix == NONE || ov < v || (ov == v && oi < ix));
-        if(take)
-        {
-          v = ov;
-          ix = oi;
-          sx = ctl->red_stat[w];
-        }
+        const bool take = (ri[w] != NONE) && (ix == NONE || rv[w] < v || (rv[w] == v && ri[w] < ix));
+        v = take ? rv[w] : v;
+        ix = take ? ri[w] : ix;
+        sx = take ? rst[w] : sx;
       }
       pp = uniform((ix == NONE) ? -1 : ix);
       ps = uniform(sx);
@@ -1682,9 +1687,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
               break;
             }
             scan_combine(p, pstat);
+            STAMP(22)
             if(p < 0) break; // SUCCESS (DualSolver.cpp:114)
             publish_np(p, pstat);
             if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
+            STAMP(23)
           }
           else
           {
