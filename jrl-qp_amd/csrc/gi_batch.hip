@@ -69,6 +69,7 @@ struct Ctl
   double t1, zz, cz, cx;
   double f;
   double bnd; // bound value b of the selected constraint (bl, bu, xl or xu by status): kept out of global memory on the step path
+  double bndw[4]; // CMODE 2: the same per scanning wave (each wave's own winner), see scan_publish
   int red_idx[4];
   int red_stat[4];
   int info;
@@ -412,6 +413,10 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
   double * us = nps + n;
   double * rs = us + (n + 2);
   double * tail = rs + (n + 2);
+  // CMODE 2: one n-vector per scanning wave: the normal of that wave's most violated constraint, written by its owner
+  // thread during the (overlapped) scan, so that nothing has to be published once the winner among the waves is known
+  double * npw = tail;
+  if(CMODE == 2) tail = npw + 3 * n;
   // WARM: N -> B = L^-1 N -> its QR factors (n x q), b_act, Householder coefficients
   double * Bw = tail;
   double * bact = Bw + (WARM ? n * ld : 0);
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     // wave-level reduction of the scan candidates + hand-off of the wave's winner.  CMODE 2: waves 1-3 publish slots
     // 1-3; slot 0 (wave 0 holds no constraint) carries the winner among the LDS-staged extra columns, which wave 1
     // scans in a second pass (lane e = extra column e).
-    auto scan_publish = [&](int excl, double bval, int bidx, int bstat) {
+    auto scan_publish = [&](int excl, double bval, int bidx, int bstat) __attribute__((always_inline)) {
       if(CMODE == 2)
       {
         if(wave == 0) return;
@@ -960,6 +965,13 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
           ctl->red_val[wave] = bval;
           ctl->red_idx[wave] = bidx;
           ctl->red_stat[wave] = bstat;
+        }
+        if(myc == bidx && myc < m) // this wave's winner: n+ and its bound into the wave's slot
+        {
+          double * slot = npw + (wave - 1) * n;
+#pragma unroll
+          for(int k = 0; k < NR; ++k) slot[k] = creg[k];
+          ctl->bndw[wave] = (bstat == LOWER) ? my_bl : my_bu;
         }
         if(wave == 1)
         {
@@ -1031,15 +1043,16 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
 
     // n+ of the selected general constraint -> LDS vector np (a pointer into staged C when CMODE == 1) and its bound
     // value.  (always_inline: a lambda that is not inlined captures creg[] by address and pushes it to scratch.)
-    auto publish_np = [&](int pp, int ps) __attribute__((always_inline)) {
+    auto publish_np = [&](int pp, int ps, bool scanned) __attribute__((always_inline)) {
       const bool lower = (ps == LOWER || ps == EQUALITY || ps == LOWER_BOUND || ps == FIXED);
-      if(CMODE == 2)
+      if(CMODE == 2 && !scanned) // (a scan already left n+ and b in the owner wave's slot: scan_publish)
       {
-        if(myc == pp) // the owner thread (extra columns are used in place: np_ptr)
+        if(myc == pp && myc < m) // the owner thread (extra columns are used in place: np_ptr)
         {
+          double * slot = npw + (pp >> 6) * n;
 #pragma unroll
-          for(int k = 0; k < NR; ++k) nps[k] = creg[k];
-          ctl->bnd = lower ? my_bl : my_bu; // bounds come from the owner's registers: no global load on the step path
+          for(int k = 0; k < NR; ++k) slot[k] = creg[k];
+          ctl->bndw[1 + (pp >> 6)] = lower ? my_bl : my_bu;
         }
       }
       if(CMODE == 0 && pp < m && tid < n) nps[tid] = Cg[(size_t)pp * n + tid];
@@ -1049,7 +1062,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     // registers -- it lands in scratch and the kernel runs 2x slower)
     auto bound_of = [&](int pp, int ps) -> double {
       const bool lower = (ps == LOWER || ps == EQUALITY || ps == LOWER_BOUND || ps == FIXED);
-      if(CMODE == 2 && pp < CREG_MAX && pp < m) return ctl->bnd;
+      if(CMODE == 2 && pp < CREG_MAX && pp < m) return ctl->bndw[1 + (pp >> 6)];
       if(pp >= m) return lower ? xlg[pp - m] : xug[pp - m];
       if(CMODE == 1) return lower ? bls[pp] : bus[pp];
       return lower ? blg[pp] : bug[pp];
@@ -1057,6 +1070,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     auto np_ptr = [&](int pp) -> const double * {
       if(CMODE == 1) return Cs + (size_t)((pp < m) ? pp : 0) * ld;
       if(CMODE == 2 && pp >= CREG_MAX && pp < m) return Ce + (size_t)(pp - CREG_MAX) * ld;
+      if(CMODE == 2 && pp < m) return npw + (pp >> 6) * n; // constraint i is held by thread 64 + i: wave 1 + i/64
       return nps;
     };
 
@@ -1556,7 +1570,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
           if(p == NONE) break;
           pstat = (p < m) ? EQUALITY : FIXED;
           cursor = p + 1;
-          publish_np(p, pstat);
+          publish_np(p, pstat, false);
           if(tid == 0) us[q] = 0.0;
           __syncthreads();
           if(wave == 0) compute_d(p, pstat);
@@ -1609,7 +1623,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
         bool running = (p >= 0);
         if(running)
         {
-          publish_np(p, pstat);
+          publish_np(p, pstat, true);
           if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
         }
         while(running)
@@ -1689,7 +1703,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
             scan_combine(p, pstat);
             STAMP(22)
             if(p < 0) break; // SUCCESS (DualSolver.cpp:114)
-            publish_np(p, pstat);
+            publish_np(p, pstat, true);
             if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
             STAMP(23)
           }
@@ -1769,6 +1783,7 @@ long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
   long dbl = 2L * n * ld + 4L * n + 2L * (n + 2);
   if(warm) dbl += (long)n * ld + 2L * n;
   if(cmode == 1) dbl += (long)m * ld + 2L * m;
+  if(cmode == 2) dbl += 3L * n;                                    // per-wave n+ slots
   if(cmode == 2 && m > WG - 64) dbl += (long)(m - (WG - 64)) * ld; // extra columns beyond the 192 register-resident ones
   long bytes = dbl * 8 + (long)sizeof(Ctl) + 4L * (n + 2) + (long)(m + nb);
   return (bytes + 15) & ~15L;
