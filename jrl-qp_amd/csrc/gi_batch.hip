@@ -373,6 +373,14 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
     atomicAdd(&prof_lds[(slot)], (unsigned long long)(now_ - last_));                   \
     last_ = clock64();                                                                  \
   }
+// same for the first lane of wave 3 (the chain wave of the speculative path), with its own time base
+#define STAMP3(slot)                                                                    \
+  if(PROF && tid == 192)                                                                \
+  {                                                                                     \
+    long long now_ = clock64();                                                         \
+    atomicAdd(&prof_lds[(slot)], (unsigned long long)(now_ - last3_));                  \
+    last3_ = clock64();                                                                 \
+  }
 #define PROF_COUNT(slot)                                   \
   if(PROF && tid == 0) atomicAdd(&prof_lds[(slot)], 1ull);
 
@@ -384,7 +392,7 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 template<int NT, int CMODE, bool PROF, bool WARM>
 __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) void gi_batch_kernel(const BatchArgs A)
 {
-  long long last_ = 0, wall0_ = 0;
+  long long last_ = 0, wall0_ = 0, last3_ = 0;
   if(PROF)
   {
     last_ = clock64();
@@ -431,9 +439,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     bus = bls + m;
     tail = bus + m;
   }
-  // CMODE 2: constraint i < 192 lives in the registers of thread 64 + i (waves 1-3: wave 0 owns no constraint, so
-  // the next pass's scan never lands on the wave that runs the serial chains); the m - 192 remaining columns are
-  // staged in LDS and scanned by wave 1 in a second, short pass
+  // CMODE 2: constraint i < 192 lives in the registers of thread i (waves 0-2; wave 3 owns no constraint: it runs
+  // the Givens coefficient chain of an addition, speculatively, beside the other waves' work); the m - 192 remaining
+  // columns are staged in LDS and scanned by wave 1 in a second, short pass
   constexpr int CREG_MAX = WG - 64;
   const int ne = (CMODE == 2 && m > CREG_MAX) ? (m - CREG_MAX) : 0;
   double * Ce = tail;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
   // ---------------------------------------------------------------- C column -> registers (CMODE 2)
   double creg[NR];
   double my_bl = 0.0, my_bu = 0.0;
-  const int myc = (CMODE == 2) ? (tid - 64) : -1; // constraint held in this thread's registers
+  const int myc = (CMODE == 2 && tid < CREG_MAX) ? tid : -1; // constraint held in this thread's registers (waves 0-2)
   if(CMODE == 2)
   {
     const bool own = myc >= 0 && myc < m;
@@ -847,6 +855,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     STAMP(2)
 
     const double big = A.big_bnd;
+    constexpr bool SPEC = (CMODE == 2); // speculative Givens coefficient chain on wave 3 (which holds no constraint)
+    constexpr int SPEC_A0 = 10, SPEC_B = 8; // steps run beside trsv/ratio (plus q/2) and beside the primal/dual update
     int p = -1, pstat = INACTIVE;
     int addno = 0; // number of constraints added so far: the hand-off token of add_chain / add_apply
 
@@ -921,9 +931,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
           }
         }
       }
-      for(int i = (CMODE == 2) ? (tid - 64) : tid; i < nb; i += (CMODE == 2) ? (WG - 64) : WG)
+      for(int i = tid; i < nb; i += (CMODE == 2) ? CREG_MAX : WG)
       {
-        if(i < 0) break; // CMODE 2: wave 0 takes no part in the scan
+        if(CMODE == 2 && tid >= CREG_MAX) break; // CMODE 2: wave 3 takes no part in the scan
         if(st[m + i] != INACTIVE || (m + i) == excl) continue;
         double xi = xs[i];
         double sl = xi - xlg[i];
@@ -946,13 +956,13 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
       }
     };
 
-    // wave-level reduction of the scan candidates + hand-off of the wave's winner.  CMODE 2: waves 1-3 publish slots
-    // 1-3; slot 0 (wave 0 holds no constraint) carries the winner among the LDS-staged extra columns, which wave 1
+    // wave-level reduction of the scan candidates + hand-off of the wave's winner.  CMODE 2: waves 0-2 publish slots
+    // 0-2; slot 3 (wave 3 holds no constraint) carries the winner among the LDS-staged extra columns, which wave 1
     // scans in a second pass (lane e = extra column e).
     auto scan_publish = [&](int excl, double bval, int bidx, int bstat) __attribute__((always_inline)) {
       if(CMODE == 2)
       {
-        if(wave == 0) return;
+        if(wave == 3) return;
         if(nb == 0)
         {
           if(bidx == NONE) bval = 1.0; // candidates are < 0
@@ -968,7 +978,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
         }
         if(myc == bidx && myc < m) // this wave's winner: n+ and its bound into the wave's slot
         {
-          double * slot = npw + (wave - 1) * n;
+          double * slot = npw + wave * n;
 #pragma unroll
           for(int k = 0; k < NR; ++k) slot[k] = creg[k];
           ctl->bndw[wave] = (bstat == LOWER) ? my_bl : my_bu;
@@ -999,9 +1009,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
           if(ne > 0) wave_argmin_monotone(ev, ei, es);
           if(lane == 0)
           {
-            ctl->red_val[0] = ev;
-            ctl->red_idx[0] = ei;
-            ctl->red_stat[0] = es;
+            ctl->red_val[3] = ev;
+            ctl->red_idx[3] = ei;
+            ctl->red_stat[3] = es;
           }
         }
         return;
@@ -1052,7 +1062,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
           double * slot = npw + (pp >> 6) * n;
 #pragma unroll
           for(int k = 0; k < NR; ++k) slot[k] = creg[k];
-          ctl->bndw[1 + (pp >> 6)] = lower ? my_bl : my_bu;
+          ctl->bndw[pp >> 6] = lower ? my_bl : my_bu;
         }
       }
       if(CMODE == 0 && pp < m && tid < n) nps[tid] = Cg[(size_t)pp * n + tid];
@@ -1062,7 +1072,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     // registers -- it lands in scratch and the kernel runs 2x slower)
     auto bound_of = [&](int pp, int ps) -> double {
       const bool lower = (ps == LOWER || ps == EQUALITY || ps == LOWER_BOUND || ps == FIXED);
-      if(CMODE == 2 && pp < CREG_MAX && pp < m) return ctl->bndw[1 + (pp >> 6)];
+      if(CMODE == 2 && pp < CREG_MAX && pp < m) return ctl->bndw[pp >> 6];
       if(pp >= m) return lower ? xlg[pp - m] : xug[pp - m];
       if(CMODE == 1) return lower ? bls[pp] : bus[pp];
       return lower ? blg[pp] : bug[pp];
@@ -1070,7 +1080,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     auto np_ptr = [&](int pp) -> const double * {
       if(CMODE == 1) return Cs + (size_t)((pp < m) ? pp : 0) * ld;
       if(CMODE == 2 && pp >= CREG_MAX && pp < m) return Ce + (size_t)(pp - CREG_MAX) * ld;
-      if(CMODE == 2 && pp < m) return npw + (pp >> 6) * n; // constraint i is held by thread 64 + i: wave 1 + i/64
+      if(CMODE == 2 && pp < m) return npw + (pp >> 6) * n; // constraint i is held by thread i: wave i/64
       return nps;
     };
 
@@ -1212,22 +1222,34 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
     //   3. lane = row of J: sweep i = n-2 .. q applying the rotations, operands prefetched one step ahead
     // wave 0: phases 1 and 2; publishes (c_i, s_i) in LDS (z and r are dead after the primal/dual update) and raises
     // the flag wave 1 is waiting on; then the new column of R and the active-set bookkeeping
-    auto add_chain = [&](int pp, int ps, int token) {
+    // chain state (registers of the wave that runs it): d (lane i holds d_i), running radius, r_{i+1} kept by lane i,
+    // next rotation index
+    double gc_d = 0.0, gc_rho = 0.0, gc_kq = 0.0;
+    int gc_i = -1;
+    auto chain_begin = [&]() {
       const int rl = (lane < n) ? lane : (n - 1);
-      const double dreg = ds[rl];
-      double rho = opaque_v(bcast_lane(dreg, n - 1));
-      double kq = 0.0;
-      for(int i = n - 2; i >= q; --i)
+      gc_d = ds[rl];
+      gc_rho = opaque_v(bcast_lane(gc_d, n - 1));
+      gc_kq = 0.0;
+      gc_i = n - 2;
+    };
+    // up to `count` more steps of the coefficient recurrence (rotation indices n-2 .. q)
+    auto chain_steps = [&](int count) {
+      const int stop = (gc_i - count + 1 > q) ? (gc_i - count + 1) : q;
+      for(int i = gc_i; i >= stop; --i)
       {
-        const double p_i = opaque_v(bcast_lane(dreg, i));
-        kq = (lane == i) ? rho : kq;
-        rho = givens_r_only(p_i, rho);
+        const double p_i = opaque_v(bcast_lane(gc_d, i));
+        gc_kq = (lane == i) ? gc_rho : gc_kq;
+        gc_rho = givens_r_only(p_i, gc_rho);
       }
+      gc_i = (gc_i >= stop) ? (stop - 1) : gc_i;
+    };
+    auto chain_finish = [&](int pp, int ps, int token) {
       STAMP(13)
       if(n - 2 >= q)
       {
         GivensHalf h;
-        (void)givens_r(dreg, kq, h);
+        (void)givens_r(gc_d, gc_kq, h);
         double cl, sl;
         givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
         if(lane >= q && lane <= n - 2)
@@ -1241,21 +1263,29 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
       STAMP(14)
       // R.col(q).head(q+1) = d.head(q+1)
       if(lane < q)
-        R[lane + q * ld] = dreg;
+        R[lane + q * ld] = gc_d;
       else if(lane == q)
-        R[q + q * ld] = rho;
+        R[q + q * ld] = gc_rho;
       if(lane == 0)
       {
         act[q] = pp;
         st[pp] = (unsigned char)ps;
       }
     };
+    auto add_chain = [&](int pp, int ps, int token) {
+      chain_begin();
+      chain_steps(n);
+      chain_finish(pp, ps, token);
+    };
 
     // wave 1: phase 3, lane = row of J (lanes >= n shadow row n-1: same values, same addresses); runs while wave 0
     // scans its own constraints
     auto add_apply = [&](int qa, int token) {
-      while(__atomic_load_n(&ctl->flag, __ATOMIC_RELAXED) != token) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if(token >= 0) // coefficients published by another wave: wait for its flag
+      {
+        while(__atomic_load_n(&ctl->flag, __ATOMIC_RELAXED) != token) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
       if(n - 2 < qa) return;
       const int rl = (lane < n) ? lane : (n - 1);
       double carry = J[rl + (n - 1) * ld];
@@ -1636,12 +1666,28 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
           STAMP(21)
           __syncthreads();
           STAMP(4)
-          if(wave == 0)
+          // SPEC: d is all the coefficient recurrence of an addition needs, so wave 3 starts on it now, before the step
+          // length says whether this pass adds or drops; it runs as many steps as the other waves' work is expected
+          // to last (so that it neither holds the barrier up nor idles), and the result is simply discarded on a drop
+          if(SPEC && wave == 3)
+          {
+            STAMP3(24)
+            chain_begin();
+            chain_steps(SPEC_A0 + (q >> 1));
+            STAMP3(25)
+          }
+          else if(wave == 0)
             trsv_ratio();
           else if(wave <= 2)
             z_and_dots(p);
           __syncthreads();
           STAMP(5)
+          if(SPEC && wave == 3)
+          {
+            STAMP3(26)
+            chain_steps(SPEC_B); // beside the step-length computation and wave 0's primal/dual update
+            STAMP3(27)
+          }
 
           // ---- K8: step length (uniform, every thread)
           const double cz = uniform_d(ctl->cz);
@@ -1676,11 +1722,25 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
           STAMP(6)
           if(add)
           {
-            __syncthreads(); // x is final: waves 1-3 may scan for the NEXT pass while wave 0 sweeps
+            __syncthreads(); // x is final: the other waves may scan for the NEXT pass during the rest of the sweep
             double bv;
             int bi, bs;
             ++addno;
-            if(wave == 0)
+            if(SPEC)
+            {
+              if(wave == 3)
+              {
+                STAMP3(28)
+                chain_steps(n);
+                STAMP3(29)
+                chain_finish(p, pstat, addno);
+                wave_sync();
+                STAMP3(30)
+                add_apply(q, -1); // same wave: the sweep of J follows at once, beside the other waves' scan
+                STAMP3(31)
+              }
+            }
+            else if(wave == 0)
             {
               add_chain(p, pstat, addno);
               wave_sync();
@@ -1691,7 +1751,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
             scan_local(p, bv, bi, bs); // p is treated as active (wave 0 has it in st[] by now, the others exclude it)
             scan_publish(p, bv, bi, bs);
             STAMP(15)
-            if(wave == 1) add_apply(qa, addno); // overlaps wave 0's share of the scan
+            if(!SPEC && wave == 1) add_apply(qa, addno); // overlaps wave 0's share of the scan
             PROF_COUNT(10)
             __syncthreads();
             STAMP(7)
