@@ -396,6 +396,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) vo
   if(PROF)
   {
     last_ = clock64();
+    last3_ = last_;
     wall0_ = wall_clock64();
   }
   extern __shared__ double smem[];
