@@ -1,0 +1,129 @@
+"""Synthetic problems for the structured GI path (block-tridiagonal / block-arrow Hessian, block-diagonal constraints).
+
+Patterns follow the reference's own structured tests:
+  tests/BlockGISolverTest.in.cpp:27-68   biBlockDiagRandom / blockDiagAndOneColDiagRandom (G = A A^T or A^T A)
+  tests/BlockGISolverTest.in.cpp:70-170  per-block double-sided constraints taken from randomProblem(n_i, 0, 0, m_i)
+  SURVEY.md §8(d) c5                      MPC-style block arrow: 100 stages x 30 (+ head), 10 constraints per stage
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import problems as P
+
+
+@dataclass
+class StructuredQP:
+    kind: str  # "tri" | "arrow_up" | "arrow_down"
+    bs: list  # block sizes of G
+    G: np.ndarray  # dense n x n (Fortran order); the structured solvers factorise views of a COPY of it
+    a: np.ndarray
+    Cblocks: list  # block-diagonal C: list of n_i x m_i arrays (one constraint per column)
+    bl: np.ndarray
+    bu: np.ndarray
+    xl: np.ndarray | None = None
+    xu: np.ndarray | None = None
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n(self):
+        return int(sum(self.bs))
+
+    @property
+    def m(self):
+        return int(sum(c.shape[1] for c in self.Cblocks))
+
+    def dense_C(self):
+        C = np.zeros((self.n, self.m), order="F")
+        r = c = 0
+        for blk in self.Cblocks:
+            C[r : r + blk.shape[0], c : c + blk.shape[1]] = blk
+            r += blk.shape[0]
+            c += blk.shape[1]
+        return C
+
+
+def block_views(G, bs, kind):
+    """(diag, off) lists of col-major VIEWS into G, as the reference's tests pack them (BlockGISolverTest.in.cpp:78-81,
+    :130-133, :212-221, :293-302).  tri: off[i] = G[blk i+1, blk i]; arrow_up: off[i] = G[blk i+1, blk 0];
+    arrow_down: off[i] = G[blk last, blk i]."""
+    assert G.flags.f_contiguous
+    o = np.concatenate([[0], np.cumsum(bs)]).astype(int)
+    k = len(bs)
+    diag = [G[o[i] : o[i + 1], o[i] : o[i + 1]] for i in range(k)]
+    if kind == "tri":
+        off = [G[o[i + 1] : o[i + 2], o[i] : o[i + 1]] for i in range(k - 1)]
+    elif kind == "arrow_up":
+        off = [G[o[i + 1] : o[i + 2], o[0] : o[1]] for i in range(k - 1)]
+    elif kind == "arrow_down":
+        off = [G[o[k - 1] : o[k], o[i] : o[i + 1]] for i in range(k - 1)]
+    else:
+        raise ValueError(kind)
+    return diag, off
+
+
+def _pattern(rng, bs, kind):
+    """Random square factor A with the block pattern whose Gram matrix has the requested structure."""
+    o = np.concatenate([[0], np.cumsum(bs)]).astype(int)
+    n, k = int(o[-1]), len(bs)
+    A = np.zeros((n, n))
+    for i in range(k):
+        A[o[i] : o[i + 1], o[i] : o[i + 1]] = rng.uniform(-1, 1, (bs[i], bs[i]))
+        if kind == "tri" and i + 1 < k:
+            A[o[i + 1] : o[i + 2], o[i] : o[i + 1]] = rng.uniform(-1, 1, (bs[i + 1], bs[i]))
+        elif kind == "arrow_up":
+            A[o[i] : o[i + 1], o[0] : o[1]] = rng.uniform(-1, 1, (bs[i], bs[0]))
+        elif kind == "arrow_down":
+            A[o[i] : o[i + 1], o[k - 1] : o[k]] = rng.uniform(-1, 1, (bs[i], bs[-1]))
+    return A
+
+
+def random_structured_qp(kind, bs, mc, seed, double_sided=True, ridge=0.0) -> StructuredQP:
+    """G with the requested block structure (tri: A A^T, arrows: A^T A, as the reference's tests), a ~ U[-1,1],
+    per-block constraints C_i (n_i x mc[i]) from the planted-solution generator with no objective
+    (ProblemCharacteristics(n_i, 0, 0, m_i).doubleSidedIneq(true), BlockGISolverTest.in.cpp:93-101)."""
+    rng = np.random.default_rng(seed)
+    A = _pattern(rng, bs, kind)
+    G = A @ A.T if kind == "tri" else A.T @ A
+    n = G.shape[0]
+    if ridge:
+        G = G + ridge * np.eye(n)
+    G = np.asfortranarray(0.5 * (G + G.T))
+    a = rng.uniform(-1, 1, n)
+    Cb, bl, bu = [], [], []
+    for ni, mi in zip(bs, mc):
+        if mi == 0:
+            Cb.append(np.zeros((ni, 0), order="F"))
+            continue
+        ch = P.Characteristics(nVar=ni, nObj=0, nEq=0, nIneq=mi, doubleSidedIneq=double_sided)
+        pb = P.random_problem(ch, rng)
+        Cb.append(np.asfortranarray(pb.C.T))
+        bl.append(pb.l)
+        bu.append(pb.u)
+    return StructuredQP(kind, list(bs), G, a, Cb, np.concatenate(bl), np.concatenate(bu), meta=dict(seed=seed))
+
+
+def mpc_arrow_qp(nstage=100, nx=30, mc=10, seed=0, scale_a=4.0) -> StructuredQP:
+    """BASELINE config c5: block arrow (pointing down) with `nstage` stage blocks of size nx plus a head block of size nx
+    (G = M^T M, M with the arrow pattern of tests/blockArrowLLTTest.cpp:17-37), `mc` one-sided constraints per stage
+    block (block-diagonal C, pattern of BlockGISolverTest.in.cpp:85-101), none on the head.  `scale_a` pushes the
+    unconstrained optimum outside the feasible set so that a fraction of the constraints becomes active."""
+    rng = np.random.default_rng(0xC5 + seed)
+    bs = [nx] * nstage + [nx]
+    A = _pattern(rng, bs, "arrow_down")
+    G = np.asfortranarray(A.T @ A)
+    G = np.asfortranarray(0.5 * (G + G.T))
+    n = G.shape[0]
+    a = scale_a * rng.uniform(-1, 1, n)
+    Cb, bl, bu = [], [], []
+    for i in range(nstage):
+        Ci = rng.standard_normal((nx, mc))
+        x0 = rng.uniform(-1, 1, nx)
+        ub = Ci.T @ x0 + np.abs(rng.uniform(0, 1, mc))  # x0 strictly feasible
+        Cb.append(np.asfortranarray(Ci))
+        bl.append(np.full(mc, -np.inf))
+        bu.append(ub)
+    Cb.append(np.zeros((nx, 0), order="F"))
+    return StructuredQP("arrow_down", bs, G, a, Cb, np.concatenate(bl), np.concatenate(bu), meta=dict(seed=seed))

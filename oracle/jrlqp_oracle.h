@@ -217,6 +217,33 @@ void orc_tri_block_diag_ltsolve(int nblk,
                                 int nrhs,
                                 int end);
 
+/*
+ * Structured GI loop: experimental::BlockGISolver::solve (src/experimental/BlockGISolver.cpp:17-60) on a StructuredG
+ * (type 0 TriBlockDiagonal: off[i] = sub-diagonal block n_{i+1} x n_i; 1 BlockArrowUp; 2 BlockArrowDown: off = side,
+ * as for the decompositions above) and a block-diagonal StructuredC (ncb blocks, block i: cvar[i] x ccstr[i],
+ * col-major with ld cld[i], one constraint per column).  diag/off are factorised in place like the reference.
+ * Cold start without data equalities only -- the only configuration that is functional in the reference
+ * (assert at BlockGISolver.cpp:475); anything else returns INCONSISTENT_INPUT.  blockgi_oracle.c.
+ */
+int orc_blockgi_solve(int type, int nblk, const int * bs, double ** diag, const int * ldd, double ** off, const int * ldo,
+                      const double * a, int ncb, const int * cvar, const int * ccstr, const double ** cblk, const int * cld,
+                      const double * bl, const double * bu, const double * xl, const double * xu, int nb, int max_iter,
+                      double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * iters,
+                      double * f, orc_trace_rec * trace, int trace_cap);
+
+/* rule C4 (blockgi_oracle.c): sum a[i] b[i] as 1024 strided fma chains (element i has absolute index phase + i)
+ * combined by an adjacent-first pairwise tree */
+double orc_dot_tree(int n, const double * a, const double * b, int phase);
+
+/* OrthonormalSequence (src/internal/OrthonormalSequence.cpp) as a stand-alone object, for the identities of the
+ * reference's tests/InternalTest.cpp */
+typedef struct orc_oseq orc_oseq;
+orc_oseq * orc_oseq_new(int n);
+void orc_oseq_free(orc_oseq *);
+double orc_oseq_add_householder(orc_oseq *, int start, int len, const double * v); /* returns beta */
+void orc_oseq_add_givens(orc_oseq *, int start, int size, const double * c, const double * s);
+void orc_oseq_apply(const orc_oseq *, double * v, int transpose);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ class TraceRec(ct.Structure):
 
 
 def build_oracle(force: bool = False) -> str:
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("jrlqp_oracle.c", "structured_oracle.c", "jrlqp_oracle.h", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("jrlqp_oracle.c", "structured_oracle.c", "blockgi_oracle.c", "jrlqp_oracle.h", "Makefile")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libjrlqp_oracle.so"], stdout=subprocess.DEVNULL)
@@ -102,6 +102,22 @@ class Oracle:
         for nm in ("orc_tri_block_diag_lsolve", "orc_tri_block_diag_ltsolve"):
             getattr(L, nm).restype = None
             getattr(L, nm).argtypes = blk + [c_dp, ct.c_int, ct.c_int, ct.c_int]
+        L.orc_blockgi_solve.restype = ct.c_int
+        L.orc_blockgi_solve.argtypes = [ct.c_int] + blk + [c_dp, ct.c_int, c_ip, c_ip, pp, c_ip, c_dp, c_dp, c_dp, c_dp, ct.c_int,
+                                                           ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp,
+                                                           ct.POINTER(TraceRec), ct.c_int]
+        L.orc_dot_tree.restype = ct.c_double
+        L.orc_dot_tree.argtypes = [ct.c_int, c_dp, c_dp, ct.c_int]
+        L.orc_oseq_new.restype = ct.c_void_p
+        L.orc_oseq_new.argtypes = [ct.c_int]
+        L.orc_oseq_free.restype = None
+        L.orc_oseq_free.argtypes = [ct.c_void_p]
+        L.orc_oseq_add_householder.restype = ct.c_double
+        L.orc_oseq_add_householder.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, c_dp]
+        L.orc_oseq_add_givens.restype = None
+        L.orc_oseq_add_givens.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, c_dp, c_dp]
+        L.orc_oseq_apply.restype = None
+        L.orc_oseq_apply.argtypes = [ct.c_void_p, c_dp, ct.c_int]
 
     # ---- dense GI ------------------------------------------------------------------------------
     def solve(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, trace_cap=0, warm=False, guess=None) -> OracleResult:
@@ -197,6 +213,9 @@ class Oracle:
         ptrs = (c_dp * max(k, 1))()
         lds = np.zeros(max(k, 1), dtype=np.int32)
         for i, b in enumerate(blocks):
+            if b.size == 0:
+                lds[i] = max(b.shape[0], 1)
+                continue
             assert b.dtype == np.float64 and b.strides[0] == 8, "blocks must be col-major views"
             ptrs[i] = ct.cast(b.ctypes.data, c_dp)
             lds[i] = b.strides[1] // 8 if b.shape[1] > 1 else max(b.shape[0], 1)
@@ -231,6 +250,75 @@ class Oracle:
             self.lib.orc_tri_block_diag_ltsolve(len(diag), _ip(bs), dp, _ip(dl), sp, _ip(sl), _dp(M), M.shape[0], M.shape[1], end)
         else:
             self.lib.orc_tri_block_diag_lsolve(len(diag), _ip(bs), dp, _ip(dl), sp, _ip(sl), _dp(M), M.shape[0], M.shape[1], start)
+
+
+    # ---- structured GI loop (blockgi_oracle.c) ---------------------------------------------------
+    def blockgi_solve(self, kind, diag, off, a, Cblocks, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, trace_cap=0):
+        """experimental::BlockGISolver::solve.  kind: "tri" | "arrow_up" | "arrow_down"; diag/off: col-major views
+        (factorised IN PLACE); Cblocks: list of n_i x m_i col-major blocks of the block-diagonal C."""
+        typ = {"tri": 0, "arrow_up": 1, "arrow_down": 2}[kind]
+        bs = np.array([d.shape[0] for d in diag], dtype=np.int32)
+        n = int(bs.sum())
+        dp, dl = self._blocks(diag)
+        op, ol = self._blocks(off)
+        cv = np.array([c.shape[0] for c in Cblocks], dtype=np.int32)
+        cc = np.array([c.shape[1] for c in Cblocks], dtype=np.int32)
+        Cb = [np.asfortranarray(c, dtype=np.float64) for c in Cblocks]
+        cp, cl = self._blocks(Cb)
+        m = int(cc.sum())
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        bl = np.ascontiguousarray(bl, dtype=np.float64)
+        bu = np.ascontiguousarray(bu, dtype=np.float64)
+        nb = 0 if xl is None else len(xl)
+        xl = np.ascontiguousarray(xl, dtype=np.float64) if nb else None
+        xu = np.ascontiguousarray(xu, dtype=np.float64) if nb else None
+        x = np.zeros(n)
+        u = np.zeros(m + nb)
+        status = np.zeros(m + nb, dtype=np.int32)
+        active = np.zeros(m + nb + 1, dtype=np.int32)
+        nact, iters, f = ct.c_int(0), ct.c_int(0), ct.c_double(0.0)
+        tr = (TraceRec * max(trace_cap, 1))()
+        term = self.lib.orc_blockgi_solve(typ, len(diag), _ip(bs), dp, _ip(dl), op, _ip(ol), _dp(a), len(Cb), _ip(cv), _ip(cc), cp,
+                                          _ip(cl), _dp(bl), _dp(bu), _dp(xl), _dp(xu), nb, max_iter, big_bnd, _dp(x), _dp(u),
+                                          _ip(status), _ip(active), ct.byref(nact), ct.byref(iters), ct.byref(f), tr, trace_cap)
+        trace = [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in tr[: min(trace_cap, iters.value)]]
+        return OracleResult(term, x, u, status, active[: nact.value].copy(), iters.value, f.value, trace, None)
+
+    def dot_tree(self, a, b, phase=0):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        return self.lib.orc_dot_tree(len(a), _dp(a), _dp(b), phase)
+
+
+class OrthoSeq:
+    """OrthonormalSequence of the oracle (for the identities of the reference's tests/InternalTest.cpp)."""
+
+    def __init__(self, oracle, n):
+        self.lib, self.n = oracle.lib, n
+        self.h = self.lib.orc_oseq_new(n)
+
+    def add_householder(self, start, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        return self.lib.orc_oseq_add_householder(self.h, start, len(v), _dp(v))
+
+    def add_givens(self, start, c, s):
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        self.lib.orc_oseq_add_givens(self.h, start, len(c), _dp(c), _dp(s))
+
+    def apply(self, v, transpose=False):
+        w = np.array(v, dtype=np.float64).copy()
+        assert w.shape == (self.n,)
+        self.lib.orc_oseq_apply(self.h, _dp(w), int(transpose))
+        return w
+
+    def to_dense(self):
+        return np.stack([self.apply(e) for e in np.eye(self.n)], axis=1)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_oseq_free(self.h)
+            self.h = None
 
 
 _ORACLE = None
