@@ -240,6 +240,45 @@ int jrlqp_blocks_result(jrlqp_blocks * plan, int * ok_host, void * stream);
 int jrlqp_blocks_solve(jrlqp_blocks * plan, int transpose, double * dM, int ldm, long mstride, int nrhs, int start, int end, void * stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Structured GI solver.  Replaces experimental::BlockGISolver (include/jrl-qp/experimental/BlockGISolver.h:24-40):
+ *     BlockGISolver(int nbVar, int nbCstr, bool useBounds);
+ *     TerminationStatus solve(const structured::StructuredG & G, const VectorConstRef & a, const structured::StructuredC & C,
+ *                             const VectorConstRef & bl, const VectorConstRef & bu, const VectorConstRef & xl,
+ *                             const VectorConstRef & xu, const std::vector<ActivationStatus> & as = {});
+ * and, behind it, the hooks of src/experimental/BlockGISolver.cpp:62-288 with structured::StructuredG / StructuredC /
+ * StructuredJ / StructuredQR (src/structured/{StructuredG,StructuredC,StructuredJ,StructuredQR}.cpp) and
+ * internal::OrthonormalSequence (src/internal/OrthonormalSequence.cpp).  J = L^-T Q is never formed: L stays in the
+ * caller's blocks (factorised in place, like StructuredG::lltInPlace), Q is a growing sequence of Householder
+ * reflectors (one per added constraint) and Givens sequences (one per removed constraint), R is dense upper triangular.
+ *
+ * A PLAN describes a batch of `nprob` identically shaped problems:
+ *   StructuredG(Type, diag, offDiag)  -> kind / nblk / block_sizes as for jrlqp_blocks_create (kind 0 = BlockArrowDown,
+ *                                        1 = BlockArrowUp, 2 = TriBlockDiagonal) + jrlqp_blockgi_bind(ddiag, ldd, doff, ldo)
+ *   StructuredC(std::vector<MatrixConstRef>) (block diagonal, StructuredC.cpp:9-23)
+ *                                     -> ncb blocks, block i is cvar[i] x ccstr[i] column-major (one constraint per
+ *                                        column); sum cvar = nbVar; + jrlqp_blockgi_bind(dcblk, ldc)
+ * The whole active-set loop runs on the device (one workgroup per problem, one launch per batch); the orthonormal
+ * sequence grows by one element per iteration, so the plan's workspace is sized by `max_iter` at creation and
+ * options.max_iter must not exceed it.  n <= 3072 unknowns per problem (the vectors of unknowns live in LDS).
+ * As in the reference, only the cold start without data equalities / fixed variables is functional (the reference
+ * asserts in initializePrimalDualPoints, BlockGISolver.cpp:475): such inputs return INCONSISTENT_INPUT per problem.
+ * Outputs as jrlqp_gi_solve_batch: x [nprob*n], sign-expanded multipliers u and activation status [nprob*(m+nb)],
+ * term / iters / f [nprob].  da: [nprob*n]; dbl, dbu: [nprob*m]; dxl, dxu: [nprob*n] or NULL (plan without bounds).
+ */
+typedef struct jrlqp_blockgi jrlqp_blockgi;
+int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, const int * cvar, const int * ccstr, int use_bounds,
+                         int nprob, int max_iter, jrlqp_blockgi ** out);
+void jrlqp_blockgi_destroy(jrlqp_blockgi * plan);
+long long jrlqp_blockgi_workspace_bytes(const jrlqp_blockgi * plan);
+/* ddiag [nprob*nblk], doff [nprob*(nblk-1)], dcblk [nprob*ncb]: HOST arrays of DEVICE pointers (problem-major) */
+int jrlqp_blockgi_bind(jrlqp_blockgi * plan, double * const * ddiag, const int * ldd, double * const * doff, const int * ldo,
+                       const double * const * dcblk, const int * ldc, void * stream);
+/* factorises the bound blocks in place and solves (asynchronous on `stream`); dtrace: optional, trace_cap records per problem */
+int jrlqp_blockgi_solve(jrlqp_blockgi * plan, const double * da, const double * dbl, const double * dbu, const double * dxl,
+                        const double * dxu, const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm,
+                        int * diters, double * df, jrlqp_trace_rec * dtrace, int trace_cap, void * stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Self-tests of the arithmetic contract (no reference counterpart; used by tests/ to prove that device /, sqrt,
  * fma and the Givens generator are bit-identical to the host's IEEE-754 results, and to pin the accumulation
  * order of v_mfma_f64_16x16x4_f64).  Arrays of n doubles on the device:

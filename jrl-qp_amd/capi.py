@@ -45,6 +45,11 @@ EXPORTED = [
     "jrlqp_blocks_llt",
     "jrlqp_blocks_result",
     "jrlqp_blocks_solve",
+    "jrlqp_blockgi_create",
+    "jrlqp_blockgi_destroy",
+    "jrlqp_blockgi_workspace_bytes",
+    "jrlqp_blockgi_bind",
+    "jrlqp_blockgi_solve",
     "jrlqp_debug_set_profile",
     "jrlqp_selftest_arith",
     "jrlqp_selftest_mfma_f64",
@@ -119,6 +124,18 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_blocks_result.argtypes = [ct.c_void_p, ct.POINTER(ct.c_int), c_dp]
     lib.jrlqp_blocks_solve.restype = ct.c_int
     lib.jrlqp_blocks_solve.argtypes = [ct.c_void_p, ct.c_int, c_dp, ct.c_int, ct.c_long, ct.c_int, ct.c_int, ct.c_int, c_dp]
+    lib.jrlqp_blockgi_create.restype = ct.c_int
+    lib.jrlqp_blockgi_create.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_int), ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int),
+                                         ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p)]
+    lib.jrlqp_blockgi_destroy.restype = None
+    lib.jrlqp_blockgi_destroy.argtypes = [ct.c_void_p]
+    lib.jrlqp_blockgi_workspace_bytes.restype = ct.c_longlong
+    lib.jrlqp_blockgi_workspace_bytes.argtypes = [ct.c_void_p]
+    lib.jrlqp_blockgi_bind.restype = ct.c_int
+    lib.jrlqp_blockgi_bind.argtypes = [ct.c_void_p, ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_int), ct.POINTER(ct.c_void_p),
+                                       ct.POINTER(ct.c_int), ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_int), c_dp]
+    lib.jrlqp_blockgi_solve.restype = ct.c_int
+    lib.jrlqp_blockgi_solve.argtypes = [ct.c_void_p] + [c_dp] * 5 + [ct.POINTER(Options)] + [c_dp] * 6 + [c_dp, ct.c_int, c_dp]
     lib.jrlqp_debug_set_profile.restype = ct.c_int
     lib.jrlqp_debug_set_profile.argtypes = [c_dp]
     lib.jrlqp_selftest_arith.restype = ct.c_int
@@ -357,6 +374,113 @@ class StructuredBlocks:
         try:
             if getattr(self, "h", None):
                 self.lib.jrlqp_blocks_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+
+class BlockGISolver:
+    """Host-side mirror of experimental::BlockGISolver (include/jrl-qp/experimental/BlockGISolver.h:24-40) over a batch of
+    `nprob` identically shaped structured QPs.  kind: "tridiag" | "arrow_up" | "arrow_down" (StructuredG::Type);
+    block_sizes: diagonal blocks of G; c_shapes: [(n_i, m_i)] of the block-diagonal StructuredC.
+
+    solve(H, a, Cb, bl, bu, xl, xu):
+      H   (nprob, N, N) float64 CUDA tensor, H[b].T = G (column-major, leading dimension N); FACTORISED IN PLACE
+      Cb  (nprob, ctot) float64 CUDA tensor: the blocks of C back to back, block i stored column-major n_i x m_i
+      a (nprob, N); bl, bu (nprob, m); xl, xu (nprob, N) or None."""
+
+    def __init__(self, kind, block_sizes, c_shapes, use_bounds, nprob, max_iter=500, big_bnd=1e100, device="cuda"):
+        import torch
+
+        self.lib = load_library()
+        self.kind = StructuredBlocks.KINDS[kind]
+        self.bs = [int(b) for b in block_sizes]
+        self.nblk = len(self.bs)
+        self.N = sum(self.bs)
+        self.cshapes = [(int(r), int(c)) for r, c in c_shapes]
+        self.m = sum(c for _, c in self.cshapes)
+        self.nb = self.N if use_bounds else 0
+        self.nprob = nprob
+        self.device = torch.device(device)
+        self.opts = Options(max_iter, big_bnd)
+        h = ct.c_void_p()
+        bs = (ct.c_int * self.nblk)(*self.bs)
+        ncb = len(self.cshapes)
+        cv = (ct.c_int * max(ncb, 1))(*[r for r, _ in self.cshapes])
+        cc = (ct.c_int * max(ncb, 1))(*[c for _, c in self.cshapes])
+        check(self.lib.jrlqp_blockgi_create(self.kind, self.nblk, bs, ncb, cv, cc, int(bool(use_bounds)), nprob, max_iter, ct.byref(h)))
+        self.h = h
+        self.workspace_bytes = self.lib.jrlqp_blockgi_workspace_bytes(self.h)
+        B, N, m, nb = nprob, self.N, self.m, self.nb
+        dev = self.device
+        self.x = torch.zeros((B, N), dtype=torch.float64, device=dev)
+        self.u = torch.zeros((B, max(m + nb, 1)), dtype=torch.float64, device=dev)
+        self.status = torch.zeros((B, max(m + nb, 1)), dtype=torch.int32, device=dev)
+        self.term = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.f = torch.zeros(B, dtype=torch.float64, device=dev)
+        self._bound = None
+
+    def _bind(self, H, Cb):
+        key = (H.data_ptr(), Cb.data_ptr() if Cb is not None else 0)
+        if self._bound == key:
+            return
+        N, esz = self.N, 8
+        off = [0]
+        for b in self.bs:
+            off.append(off[-1] + b)
+        diag, side, cblk = [], [], []
+        ctot = sum(r * c for r, c in self.cshapes)
+        for p in range(self.nprob):
+            pbase = H.data_ptr() + p * N * N * esz
+            for i in range(self.nblk):
+                diag.append(pbase + (off[i] + off[i] * N) * esz)
+            for i in range(self.nblk - 1):
+                if self.kind == 0:
+                    r, c = off[self.nblk - 1], off[i]
+                elif self.kind == 1:
+                    r, c = off[i + 1], 0
+                else:
+                    r, c = off[i + 1], off[i]
+                side.append(pbase + (r + c * N) * esz)
+            o = 0
+            for r, c in self.cshapes:
+                cblk.append(Cb.data_ptr() + (p * ctot + o) * esz)
+                o += r * c
+        ns = max(self.nblk - 1, 1)
+        ncb = len(self.cshapes)
+        dptr = (ct.c_void_p * len(diag))(*diag)
+        sptr = (ct.c_void_p * max(len(side), 1))(*side) if side else (ct.c_void_p * 1)()
+        cptr = (ct.c_void_p * max(len(cblk), 1))(*cblk) if cblk else (ct.c_void_p * 1)()
+        ldd = (ct.c_int * self.nblk)(*([N] * self.nblk))
+        lds = (ct.c_int * ns)(*([N] * ns))
+        ldc = (ct.c_int * max(ncb, 1))(*[max(r, 1) for r, _ in self.cshapes])
+        check(self.lib.jrlqp_blockgi_bind(self.h, dptr, ldd, sptr, lds, cptr, ldc, self._stream()))
+        self._bound = key
+
+    def _stream(self):
+        import torch
+
+        return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def solve(self, H, a, Cb, bl, bu, xl=None, xu=None, trace_cap=0) -> BatchResult:
+        import torch
+
+        assert H.is_cuda and H.dtype == torch.float64 and H.is_contiguous() and H.shape == (self.nprob, self.N, self.N)
+        self._bind(H, Cb)
+        self.trace = None
+        if trace_cap:
+            self.trace = torch.zeros((self.nprob, trace_cap, ct.sizeof(TraceRec)), dtype=torch.uint8, device=self.device)
+        check(self.lib.jrlqp_blockgi_solve(self.h, _ptr(a), _ptr(bl), _ptr(bu), _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None,
+                                           ct.byref(self.opts), _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term),
+                                           _ptr(self.iters), _ptr(self.f), _ptr(self.trace) if trace_cap else None, trace_cap, self._stream()))
+        return BatchResult(self.x, self.u, self.status, self.term, self.iters, self.f, None)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.jrlqp_blockgi_destroy(self.h)
                 self.h = None
         except Exception:
             pass

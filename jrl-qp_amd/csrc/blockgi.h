@@ -1,0 +1,55 @@
+// blockgi.h -- launch interface of the structured GI kernel (internal to libjrlqp_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/jrlqp_hip.h"
+
+namespace jrlqp
+{
+// One batch of identically shaped structured QPs.  Every pointer is a DEVICE pointer.
+struct BgiArgs
+{
+  // StructuredG (shared shape; per-problem block pointers)
+  int kind;            // jrlqp_blocks numbering: 0 block arrow down, 1 block arrow up, 2 block tridiagonal
+  int nblk, n;
+  const int * bs;      // [nblk] block sizes
+  const int * boff;    // [nblk] first row of block b in the vector of unknowns
+  const int * ldd;     // [nblk]
+  const int * lds;     // [nblk-1]
+  double * const * diag; // [nprob*nblk]
+  double * const * side; // [nprob*(nblk-1)]
+  const int * fail;    // [nprob] set by the factorisation kernels
+  // StructuredC (block diagonal)
+  int m, nb, ncb;
+  const int *cvar, *ccstr; // [ncb] rows / columns of block i
+  const int *cum_var, *cum_cstr; // [ncb] prefix sums (StructuredC.cpp:13-21)
+  const int * to_block;    // [m] constraint -> block (toBlock_)
+  const int * cld;         // [ncb]
+  const double * const * cblk; // [nprob*ncb]
+  // problem vectors (problem b at base + b * length)
+  const double *a, *bl, *bu, *xl, *xu;
+  int max_iter;
+  double big_bnd;
+  // workspace, per problem
+  int n_pad;   // n rounded up to a multiple of 4
+  int qcap;    // capacity of the active list: min(n, m + nb) + 1, rounded up to a multiple of 4
+  int row_len; // doubles per sequence element: max(n_pad, 2 * qcap)
+  double * pool;  // [nprob * max_iter * row_len]   Householder vectors (absolute row index) / Givens (c | s)
+  double * Rp;    // [nprob * rlen]   R packed by columns: R(i,j) at i + j(j+1)/2
+  long rlen;
+  double * tau;   // [nprob * max_iter]
+  int * desc;     // [nprob * max_iter * 4]  {kind, start, size, 0}
+  int * active;   // [nprob * qcap]
+  // outputs
+  double *x, *u;
+  int *status, *term, *iters;
+  double * f;
+  jrlqp_trace_rec * trace;
+  int trace_cap;
+};
+
+constexpr int kBgiMaxN = 3072; // unknowns per structured QP (vectors live in LDS)
+
+long blockgi_lds_bytes(int n, int m, int nb);
+hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t stream);
+} // namespace jrlqp

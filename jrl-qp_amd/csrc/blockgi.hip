@@ -1,0 +1,1025 @@
+// blockgi.hip -- the STRUCTURED Goldfarb-Idnani inner loop on gfx950: one workgroup per QP, the whole state machine
+// on the device, one launch per batch.
+//
+//   reference (jrl-umi3218/jrl-qp):
+//     experimental::BlockGISolver      src/experimental/BlockGISolver.cpp:62-288, :446-483   hooks + init
+//     StructuredG / StructuredC        src/structured/StructuredG.cpp:45-113, StructuredC.cpp:59-77
+//     StructuredJ                      src/structured/StructuredJ.cpp:32-57     d = Q^T L^-1 n+,  z = L^-T Q [0; d2]
+//     StructuredQR                     src/structured/StructuredQR.cpp:64-102   R solve, Householder add, Givens remove
+//     OrthonormalSequence              src/internal/OrthonormalSequence.cpp:50-126, :189-207
+//     generic loop                     src/DualSolver.cpp:91-168, :231-244, :38-69
+//   oracle: oracle/blockgi_oracle.c (bit-identical results; rounding rules C1-C4 stated there and in DESIGN.md §4)
+//
+// Data placement: the vectors of unknowns (d, z, x) and the dual vectors (u, r) live in LDS; everything that grows
+// with the iteration count -- R (packed upper triangle), the Householder vectors / Givens coefficients of the
+// orthonormal sequence, the active list -- lives in a per-problem HBM workspace that stays L2-resident; the factor L
+// (the caller's blocks, factorised in place by the kernels of structured.hip just before this launch) and C are read
+// from where the caller put them.
+//
+// Parallel structure: J is never formed.  One iteration is a handful of O(n) vector passes:
+//   * L^-1 n+ touches only the blocks under the constraint's non-zero window (reference zero-window logic);
+//   * Q^T / Q applications are sequences of reflectors  v -= tau (E.v) E : the working vector stays in REGISTERS
+//     (element e on thread (e mod 1024) / VPT), one C4 tree reduction and one barrier per reflector;
+//   * L^-T is block parallel for the arrow shapes (one wave per off-head block), serial over blocks for the
+//     tridiagonal shape;
+//   * R^-1 d1 is a blocked back substitution (64-column diagonal blocks on one wave, pivots by v_readlane, row
+//     updates on all waves);
+//   * dropping a constraint pipelines the Givens rotations over the columns of R: one lane per column, one carried
+//     value per lane, (c, s) broadcast with v_readlane.
+#include "blockgi.h"
+
+#include "device_common.h"
+
+namespace jrlqp
+{
+namespace
+{
+#define RP(R, i, j) (R)[(size_t)(i) + (size_t)(j) * ((size_t)(j) + 1) / 2]
+
+constexpr int kTri = 64 * 65 / 2; // doubles of LDS scratch for one packed 64 x 64 upper triangle
+
+struct Ctx
+{
+  const BgiArgs * A;
+  int tid, lane, wave;
+  double * const * diag;
+  double * const * side;
+  const double * const * cblk;
+  double *d, *z, *x, *u, *r, *tri, *red;
+  int * ired;
+  int par; // parity of the reduction scratch slot (two slots: one barrier per reduction)
+  double *pool, *Rp, *tau;
+  int *desc, *active, *status;
+};
+
+// ---- C4 reduction over the workgroup -------------------------------------------------------------------------------
+template<int NT>
+__device__ __forceinline__ double block_sum(Ctx & K, double s)
+{
+  constexpr int NW = NT / 64;
+  s = wave_sum_tree(s);
+  if(NW == 1) return s;
+  double * slot = K.red + 16 * K.par;
+  K.par ^= 1;
+  if(K.lane == 0) slot[K.wave] = s;
+  __syncthreads();
+  double w[NW];
+#pragma unroll
+  for(int i = 0; i < NW; ++i) w[i] = slot[i];
+#pragma unroll
+  for(int st = 1; st < NW; st <<= 1)
+#pragma unroll
+    for(int i = 0; i < NW; i += 2 * st) w[i] = w[i] + w[i + st];
+  return w[0];
+}
+
+// sum over e in [lo, hi) of fa(e) * fb(e); chain (e mod 1024) lives on thread (e mod 1024) / VPT
+template<int NT, class FA, class FB>
+__device__ __forceinline__ double dot_tree(Ctx & K, int lo, int hi, FA fa, FB fb)
+{
+  constexpr int VPT = 1024 / NT;
+  double p[VPT];
+#pragma unroll
+  for(int i = 0; i < VPT; ++i) p[i] = 0.0;
+  const int t0 = K.tid * VPT;
+  for(int base = lo & ~1023; base < hi; base += 1024)
+  {
+#pragma unroll
+    for(int i = 0; i < VPT; ++i)
+    {
+      const int e = base + t0 + i;
+      if(e >= lo && e < hi) p[i] = FMA(fa(e), fb(e), p[i]);
+    }
+  }
+#pragma unroll
+  for(int st = 1; st < VPT; st <<= 1)
+#pragma unroll
+    for(int i = 0; i < VPT; i += 2 * st) p[i] = p[i] + p[i + st];
+  return block_sum<NT>(K, p[0]);
+}
+
+// ---- StructuredG::solveL / solveInPlaceLTranspose on a vector held in LDS --------------------------------------------
+// Block arrow, L v <- v with the non-zero window [start, end) of v (blockArrowLLT.cpp:92-176).  The up variant's row
+// permutation (:163-170) is a change of offsets only: logical block i sits at physical rows boff[dsel(i)].
+template<int NT>
+__device__ void arrow_lsolve(Ctx & K, double * v, int start, int end)
+{
+  const BgiArgs & A = *K.A;
+  constexpr int NW = NT / 64;
+  const int up = A.kind == 1, nblk = A.nblk, lane = K.lane;
+  const int ib = dsel(nblk, up, nblk - 1), nbk = A.bs[ib];
+  const int shift = up ? A.bs[0] : 0; // permuted row = physical row - shift for the off-head blocks
+  if(up)
+  {
+    start = max(0, start - shift);
+    end = max(0, end - shift);
+  }
+  for(int i = K.wave; i < nblk - 1; i += NW)
+  {
+    const int id = dsel(nblk, up, i), ni = A.bs[id], n0 = A.boff[id] - shift;
+    const int s = max(start - n0, 0);
+    if(ni < s || end <= n0) continue; // (:121-127)
+    const double * Dg = K.diag[id];
+    const int ldd = A.ldd[id];
+    double * vi = v + A.boff[id] + s;
+    double xi = (lane < ni - s) ? vi[lane] : 0.0;
+    xi = wave_fwd(Dg + s + (size_t)s * ldd, ldd, ni - s, xi, lane);
+    if(lane < ni - s) vi[lane] = xi;
+  }
+  __syncthreads();
+  if(K.wave == 0)
+  {
+    double * vb = v + A.boff[ib];
+    double acc = (lane < nbk) ? vb[lane] : 0.0;
+    for(int i = 0; i < nblk - 1; ++i)
+    {
+      const int id = dsel(nblk, up, i), ni = A.bs[id], n0 = A.boff[id] - shift;
+      const int s = max(start - n0, 0);
+      if(ni < s || end <= n0) continue;
+      if(lane < nbk)
+      {
+        const double * Sg = K.side[i];
+        const int ldsg = A.lds[i];
+        const double * Xi = v + A.boff[id];
+        for(int k = s; k < ni; ++k)
+        {
+          const double bv = up ? AT(Sg, ldsg, k, lane) : AT(Sg, ldsg, lane, k);
+          acc = FMA(-bv, Xi[k], acc);
+        }
+      }
+    }
+    acc = wave_fwd(K.diag[ib], A.ldd[ib], nbk, acc, lane);
+    if(lane < nbk) vb[lane] = acc;
+  }
+  __syncthreads();
+}
+
+// L^T v <- v, full vector (blockArrowLLT.cpp:179-277 with start = 0, end = n)
+template<int NT>
+__device__ void arrow_ltsolve(Ctx & K, double * v)
+{
+  const BgiArgs & A = *K.A;
+  constexpr int NW = NT / 64;
+  const int up = A.kind == 1, nblk = A.nblk, lane = K.lane;
+  const int ib = dsel(nblk, up, nblk - 1), nbk = A.bs[ib];
+  double * vb = v + A.boff[ib];
+  if(K.wave == 0)
+  {
+    double xi = (lane < nbk) ? vb[lane] : 0.0;
+    xi = wave_bwd(K.diag[ib], A.ldd[ib], nbk, xi, lane);
+    if(lane < nbk) vb[lane] = xi;
+  }
+  __syncthreads();
+  for(int i = K.wave; i < nblk - 1; i += NW)
+  {
+    const int id = dsel(nblk, up, i), ni = A.bs[id];
+    const double * Sg = K.side[i];
+    const int ldsg = A.lds[i];
+    double * vi = v + A.boff[id];
+    double acc = (lane < ni) ? vi[lane] : 0.0;
+    if(lane < ni)
+      for(int k = nbk - 1; k >= 0; --k)
+      {
+        const double bv = up ? AT(Sg, ldsg, lane, k) : AT(Sg, ldsg, k, lane);
+        acc = FMA(-bv, vb[k], acc);
+      }
+    const double solved = wave_bwd(K.diag[id], A.ldd[id], ni, acc, lane);
+    if(lane < ni) vi[lane] = solved;
+  }
+  __syncthreads();
+}
+
+// Block tridiagonal (triBlockDiagLLT.cpp:37-96): serial over the blocks, one wave
+__device__ void tri_lsolve(Ctx & K, double * v, int start)
+{
+  const BgiArgs & A = *K.A;
+  const int lane = K.lane;
+  if(K.wave == 0)
+  {
+    int n = 0, l = 0, li = 0;
+    bool zero = true;
+    for(int i = 0; i < A.nblk; ++i)
+    {
+      const int ni = A.bs[i];
+      const double * Li = K.diag[i];
+      const int ldd = A.ldd[i];
+      if(n + ni >= start)
+      {
+        if(zero)
+        {
+          const int rr = n + ni - start, off = ni - rr;
+          double xi = (lane < rr) ? v[start + lane] : 0.0;
+          xi = wave_fwd(Li + off + (size_t)off * ldd, ldd, rr, xi, lane);
+          if(lane < rr) v[start + lane] = xi;
+          zero = false;
+        }
+        else
+        {
+          const double * Sg = K.side[i - 1];
+          const int ldsg = A.lds[i - 1];
+          double acc = (lane < ni) ? v[n + lane] : 0.0;
+          if(lane < ni)
+            for(int k = 0; k < li; ++k) acc = FMA(-AT(Sg, ldsg, lane, k), v[l + k], acc);
+          acc = wave_fwd(Li, ldd, ni, acc, lane);
+          if(lane < ni) v[n + lane] = acc;
+        }
+        wave_sync();
+      }
+      l = n;
+      li = ni;
+      n += ni;
+    }
+  }
+  __syncthreads();
+}
+
+// triBlockDiagLTransposeSolve (triBlockDiagLLT.cpp:98-158), full vector
+__device__ void tri_ltsolve(Ctx & K, double * v)
+{
+  const BgiArgs & A = *K.A;
+  const int lane = K.lane;
+  if(K.wave == 0)
+  {
+    int n = A.n, l = 0, li = 0;
+    bool zero = true;
+    for(int i = A.nblk - 1; i >= 0; --i)
+    {
+      const int ni = A.bs[i];
+      const double * Li = K.diag[i];
+      const int ldd = A.ldd[i];
+      if(zero)
+      {
+        double xi = (lane < ni) ? v[n - ni + lane] : 0.0;
+        xi = wave_bwd(Li, ldd, ni, xi, lane);
+        if(lane < ni) v[n - ni + lane] = xi;
+        zero = false;
+      }
+      else
+      {
+        const double * Sg = K.side[i];
+        const int ldsg = A.lds[i];
+        double acc = (lane < ni) ? v[n - ni + lane] : 0.0;
+        if(lane < ni)
+          for(int k = li - 1; k >= 0; --k) acc = FMA(-AT(Sg, ldsg, k, lane), v[(l - li) + k], acc);
+        acc = wave_bwd(Li, ldd, ni, acc, lane);
+        if(lane < ni) v[n - ni + lane] = acc;
+      }
+      wave_sync();
+      l = n;
+      li = ni;
+      n -= ni;
+    }
+  }
+  __syncthreads();
+}
+
+// The up arrow's row permutation (blockArrowLLT.cpp:163-170, :266-271): blockArrowLSolve returns its result in the
+// PERMUTED order (first block moved last) and blockArrowLTransposeSolve expects its argument in that order -- d, and
+// with it the orthonormal sequence, live in permuted coordinates.  forward: v <- [v(n0:), v(:n0)]; backward: the inverse.
+template<int NT>
+__device__ void permute_up(Ctx & K, double * v, bool forward)
+{
+  constexpr int PER = kBgiMaxN / NT;
+  const int n = K.A->n, n0 = K.A->bs[0], s = n - n0;
+  double tmp[PER];
+#pragma unroll
+  for(int j = 0; j < PER; ++j)
+  {
+    const int e = K.tid + j * NT;
+    int src;
+    if(forward)
+      src = (e < s) ? e + n0 : e - s;
+    else
+      src = (e < n0) ? e + s : e - n0;
+    tmp[j] = (e < n) ? v[src] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for(int j = 0; j < PER; ++j)
+  {
+    const int e = K.tid + j * NT;
+    if(e < n) v[e] = tmp[j];
+  }
+  __syncthreads();
+}
+
+// StructuredG::solveL (StructuredG.cpp:67-113); permuted = false keeps the result in the original row order (only
+// valid when the matching sg_ltsolve call is told the same: the two permutations of the reference cancel)
+template<int NT>
+__device__ __forceinline__ void sg_lsolve(Ctx & K, double * v, int start, int end, bool permuted = true)
+{
+  if(K.A->kind == 2)
+    tri_lsolve(K, v, start);
+  else
+  {
+    arrow_lsolve<NT>(K, v, start, end);
+    if(K.A->kind == 1 && permuted) permute_up<NT>(K, v, true);
+  }
+}
+// StructuredG::solveInPlaceLTranspose (StructuredG.cpp:45-65)
+template<int NT>
+__device__ __forceinline__ void sg_ltsolve(Ctx & K, double * v, bool permuted = true)
+{
+  if(K.A->kind == 2)
+    tri_ltsolve(K, v);
+  else
+  {
+    if(K.A->kind == 1 && permuted) permute_up<NT>(K, v, false);
+    arrow_ltsolve<NT>(K, v);
+  }
+}
+
+// ---- OrthonormalSequence::applyToTheLeft / applyTransposeToTheLeft (OrthonormalSequence.cpp:189-207) -----------------
+// v (LDS, n entries) <- Q v (TR = false: last element first) or Q^T v (TR = true: first element first).
+// Entry: v complete and visible to every thread (a barrier has been passed).  Exit: same.
+template<int NT, int NCH, bool TR>
+__device__ void q_apply(Ctx & K, double * v, int nseq)
+{
+  constexpr int VPT = 1024 / NT;
+  const BgiArgs & A = *K.A;
+  const int n = A.n, t0 = K.tid * VPT;
+  if(nseq == 0) return;
+  double vr[NCH][VPT];
+#pragma unroll
+  for(int c = 0; c < NCH; ++c)
+#pragma unroll
+    for(int i = 0; i < VPT; ++i)
+    {
+      const int e = 1024 * c + t0 + i;
+      vr[c][i] = (e < n) ? v[e] : 0.0;
+    }
+  for(int kk = 0; kk < nseq; ++kk)
+  {
+    const int k = TR ? kk : nseq - 1 - kk;
+    const volatile int * ds = K.desc + 4 * (size_t)k;
+    const int kind = ds[0], st = ds[1], sz = ds[2];
+    const double * row = K.pool + (size_t)k * A.row_len;
+    if(kind == 0)
+    {
+      // one reflector: v -= tau (E.v) E on rows [st, n)  (OrthonormalSequence.cpp:59-63, :98-102)
+      const double tau = *(const volatile double *)(K.tau + k);
+      double er[NCH][VPT], p[VPT];
+#pragma unroll
+      for(int i = 0; i < VPT; ++i) p[i] = 0.0;
+#pragma unroll
+      for(int c = 0; c < NCH; ++c)
+      {
+        const int e0 = 1024 * c + t0;
+#pragma unroll
+        for(int i = 0; i < VPT; ++i)
+        {
+          const int e = e0 + i;
+          const bool in = (e >= st && e < n);
+          er[c][i] = in ? row[e] : 0.0;
+          if(in) p[i] = FMA(er[c][i], vr[c][i], p[i]);
+        }
+      }
+#pragma unroll
+      for(int s2 = 1; s2 < VPT; s2 <<= 1)
+#pragma unroll
+        for(int i = 0; i < VPT; i += 2 * s2) p[i] = p[i] + p[i + s2];
+      const double dd = block_sum<NT>(K, p[0]);
+      const double sc = tau * dd;
+#pragma unroll
+      for(int c = 0; c < NCH; ++c)
+#pragma unroll
+        for(int i = 0; i < VPT; ++i)
+        {
+          const int e = 1024 * c + t0 + i;
+          if(e >= st && e < n) vr[c][i] = FMA(-sc, er[c][i], vr[c][i]);
+        }
+    }
+    else if(sz > 0)
+    {
+      // a Givens sequence on rows st .. st + sz (OrthonormalSequence.cpp:76-78, :115-117): serial, one wave, v in LDS
+#pragma unroll
+      for(int c = 0; c < NCH; ++c)
+#pragma unroll
+        for(int i = 0; i < VPT; ++i)
+        {
+          const int e = 1024 * c + t0 + i;
+          if(e < n) v[e] = vr[c][i];
+        }
+      __syncthreads();
+      if(K.wave == 0)
+      {
+        const double *cp = row, *sp = row + A.qcap;
+        double * w = v + st;
+        const int lane = K.lane;
+        if(TR)
+        {
+          double xc = w[0];
+          for(int i0 = 0; i0 < sz; i0 += 64)
+          {
+            const int cnt = min(64, sz - i0);
+            const double cl = (lane < cnt) ? cp[i0 + lane] : 0.0, sl = (lane < cnt) ? sp[i0 + lane] : 0.0;
+            const double yl = (lane < cnt) ? w[i0 + 1 + lane] : 0.0;
+            double out = 0.0;
+            for(int j = 0; j < cnt; ++j)
+            {
+              const double c = bcast_lane(cl, j), s = bcast_lane(sl, j), y = bcast_lane(yl, j);
+              const double xn = FMA(c, xc, -(s * y));
+              const double yn = FMA(s, xc, c * y);
+              if(lane == j) out = xn;
+              xc = yn;
+            }
+            if(lane < cnt) w[i0 + lane] = out;
+          }
+          if(lane == 0) w[sz] = xc;
+        }
+        else
+        {
+          double yc = w[sz];
+          for(int i1 = sz; i1 > 0; i1 -= 64)
+          {
+            const int cnt = min(64, i1), i0 = i1 - cnt; // rotations i0 .. i1-1, applied in descending order
+            const double cl = (lane < cnt) ? cp[i0 + lane] : 0.0, sl = (lane < cnt) ? sp[i0 + lane] : 0.0;
+            const double xl = (lane < cnt) ? w[i0 + lane] : 0.0;
+            double out = 0.0;
+            for(int j = cnt - 1; j >= 0; --j)
+            {
+              const double c = bcast_lane(cl, j), s = bcast_lane(sl, j), xv = bcast_lane(xl, j);
+              const double xn = FMA(c, xv, s * yc);
+              const double yn = FMA(-s, xv, c * yc);
+              if(lane == j) out = yn;
+              yc = xn;
+            }
+            if(lane < cnt) w[i0 + 1 + lane] = out;
+          }
+          if(lane == 0) w[0] = yc;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for(int c = 0; c < NCH; ++c)
+#pragma unroll
+        for(int i = 0; i < VPT; ++i)
+        {
+          const int e = 1024 * c + t0 + i;
+          vr[c][i] = (e < n) ? v[e] : 0.0;
+        }
+    }
+  }
+#pragma unroll
+  for(int c = 0; c < NCH; ++c)
+#pragma unroll
+    for(int i = 0; i < VPT; ++i)
+    {
+      const int e = 1024 * c + t0 + i;
+      if(e < n) v[e] = vr[c][i];
+    }
+  __syncthreads();
+}
+
+// ---- StructuredQR::RSolve (StructuredQR.cpp:64-68): r <- R^-1 d1, R packed in HBM, r in LDS --------------------------
+// Per element the order is the column-oriented back substitution's: contributions of columns k in descending order.
+template<int NT>
+__device__ void r_solve(Ctx & K, int q)
+{
+  const double * R = K.Rp;
+  double *r = K.r, *tri = K.tri;
+  for(int k = K.tid; k < q; k += NT) r[k] = K.d[k];
+  __syncthreads();
+  for(int c1 = q; c1 > 0;)
+  {
+    const int c0 = (c1 - 1) & ~63, nc = c1 - c0;
+    // stage the diagonal block (columns c0 .. c1-1, rows c0 .. column) in LDS, packed by columns
+    for(int e = K.tid; e < nc * (nc + 1) / 2; e += NT)
+    {
+      // column jj of the block holds jj + 1 entries starting at jj (jj + 1) / 2
+      int jj = (int)((__builtin_sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while((jj + 1) * (jj + 2) / 2 <= e) ++jj;
+      while(jj * (jj + 1) / 2 > e) --jj;
+      const int ii = e - jj * (jj + 1) / 2;
+      tri[e] = RP(R, c0 + ii, c0 + jj);
+    }
+    __syncthreads();
+    if(K.wave == 0)
+    {
+      const int lane = K.lane;
+      double xi = (lane < nc) ? r[c0 + lane] : 0.0;
+      for(int k = nc - 1; k >= 0; --k)
+      {
+        const double * col = tri + k * (k + 1) / 2;
+        const double v = bcast_lane(xi, k) / col[k];
+        if(lane == k)
+          xi = v;
+        else if(lane < k)
+          xi = FMA(-col[lane], v, xi);
+      }
+      if(lane < nc) r[c0 + lane] = xi;
+    }
+    __syncthreads();
+    // rows above the block: r_i -= sum_k R(i,k) r_k, k descending
+    for(int i = K.tid; i < c0; i += NT)
+    {
+      double acc = r[i];
+      for(int k = c1 - 1; k >= c0; --k) acc = FMA(-RP(R, i, k), r[k], acc);
+      r[i] = acc;
+    }
+    __syncthreads();
+    c1 = c0;
+  }
+}
+
+// ---- lexicographic (value, index) minimum over the workgroup: strict '<' with first index winning ---------------------
+template<int NT>
+__device__ __forceinline__ void block_argmin(Ctx & K, double & val, int & idx, int & tag)
+{
+  constexpr int NW = NT / 64;
+#pragma unroll
+  for(int off = 32; off >= 1; off >>= 1)
+  {
+    const double ov = shfl_xor_d(val, off);
+    const int oi = __shfl_xor(idx, off), ot = __shfl_xor(tag, off);
+    if(ov < val || (ov == val && oi < idx))
+    {
+      val = ov;
+      idx = oi;
+      tag = ot;
+    }
+  }
+  if(NW == 1) return;
+  double * slot = K.red + 16 * K.par;
+  int * islot = K.ired + 32 * K.par;
+  K.par ^= 1;
+  if(K.lane == 0)
+  {
+    slot[K.wave] = val;
+    islot[K.wave] = idx;
+    islot[16 + K.wave] = tag;
+  }
+  __syncthreads();
+  val = slot[0];
+  idx = islot[0];
+  tag = islot[16];
+#pragma unroll
+  for(int w = 1; w < NW; ++w)
+  {
+    const double ov = slot[w];
+    const int oi = islot[w], ot = islot[16 + w];
+    if(ov < val || (ov == val && oi < idx))
+    {
+      val = ov;
+      idx = oi;
+      tag = ot;
+    }
+  }
+}
+
+// n+ . v without the sign: SingleNZSegmentVector::dot (SingleNZSegmentVector.h:52-56) or the bound's row
+__device__ __forceinline__ double cstr_dot(const Ctx & K, int p, const double * v)
+{
+  const BgiArgs & A = *K.A;
+  if(p >= A.m) return v[p - A.m];
+  const int b = A.to_block[p], len = A.cvar[b];
+  const double * c = K.cblk[b] + (size_t)(p - A.cum_cstr[b]) * A.cld[b];
+  const double * w = v + A.cum_var[b];
+  double acc = 0.0;
+  for(int k = 0; k < len; ++k) acc = FMA(c[k], w[k], acc);
+  return acc;
+}
+
+// =========================================================================================================
+// the kernel
+// =========================================================================================================
+template<int NT, int NCH>
+__global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
+{
+  extern __shared__ double sm[];
+  const int pb = blockIdx.x, tid = threadIdx.x;
+  const int n = A.n, m = A.m, nb = A.nb;
+  Ctx K;
+  K.A = &A;
+  K.tid = tid;
+  K.lane = tid & 63;
+  K.wave = tid >> 6;
+  K.diag = A.diag + (size_t)pb * A.nblk;
+  K.side = A.side + (size_t)pb * (A.nblk > 1 ? A.nblk - 1 : 0);
+  K.cblk = A.cblk + (size_t)pb * A.ncb;
+  K.d = sm;
+  K.z = K.d + A.n_pad;
+  K.x = K.z + A.n_pad;
+  K.u = K.x + A.n_pad;
+  K.r = K.u + A.qcap;
+  K.tri = K.r + A.qcap;
+  K.red = K.tri + kTri;
+  K.ired = reinterpret_cast<int *>(K.red + 32);
+  K.par = 0;
+  K.pool = A.pool + (size_t)pb * A.max_iter * A.row_len;
+  K.Rp = A.Rp + (size_t)pb * A.rlen;
+  K.tau = A.tau + (size_t)pb * A.max_iter;
+  K.desc = A.desc + (size_t)pb * A.max_iter * 4;
+  K.active = A.active + (size_t)pb * A.qcap;
+  K.status = A.status + (size_t)pb * (m + nb);
+  double *d = K.d, *z = K.z, *x = K.x, *u = K.u, *r = K.r;
+  double * sh = K.red + 32 + 32; // a few doubles of broadcast scratch (after ired: 64 ints = 32 doubles)
+  const double * a = A.a + (size_t)pb * n;
+  const double *bl = A.bl + (size_t)pb * m, *bu = A.bu + (size_t)pb * m;
+  const double *xl = nb ? A.xl + (size_t)pb * nb : nullptr, *xu = nb ? A.xu + (size_t)pb * nb : nullptr;
+  jrlqp_trace_rec * trace = A.trace ? A.trace + (size_t)pb * A.trace_cap : nullptr;
+
+  int q = 0, nseq = 0, it = 0, rc = JRLQP_UNKNOWN;
+  double f = 0.0;
+
+  for(int i = tid; i < m + nb; i += NT) K.status[i] = JRLQP_INACTIVE;
+  for(int i = tid; i < n; i += NT) x[i] = 0.0;
+  for(int i = tid; i < A.qcap; i += NT) u[i] = r[i] = 0.0;
+  __syncthreads();
+
+  // ---- init_ (BlockGISolver.cpp:62-107) ----
+  // processInitialActiveSet: data equalities / fixed variables are not functional in the reference (assert, :475)
+  {
+    int bad = 0;
+    for(int i = tid; i < m; i += NT) bad |= (bl[i] == bu[i]);
+    for(int i = tid; i < nb; i += NT) bad |= (xl[i] == xu[i]);
+    if(__syncthreads_or(bad))
+    {
+      rc = JRLQP_INCONSISTENT_INPUT;
+      goto done;
+    }
+  }
+  if(A.fail[pb]) // lltInPlace (:71-73), factorised by the kernels of structured.hip
+  {
+    rc = JRLQP_NON_POS_HESSIAN;
+    goto done;
+  }
+  // initializePrimalDualPoints (:476-481): x = -G^-1 a, f = a.x / 2
+  for(int i = tid; i < n; i += NT) x[i] = a[i];
+  __syncthreads();
+  sg_lsolve<NT>(K, x, 0, n, false);
+  sg_ltsolve<NT>(K, x, false);
+  for(int i = tid; i < n; i += NT) x[i] = -x[i];
+  __syncthreads();
+  f = 0.5 * dot_tree<NT>(K, 0, n, [&](int e) { return a[e]; }, [&](int e) { return x[e]; });
+
+  // ---- DualSolver::solve loop (DualSolver.cpp:96-167) ----
+  {
+    bool skip_step1 = false;
+    int p = -1, pst = JRLQP_INACTIVE;
+    rc = JRLQP_MAX_ITER_REACHED;
+    for(; it < A.max_iter; ++it)
+    {
+      if(!skip_step1)
+      {
+        // selectViolatedConstraint_ (BlockGISolver.cpp:109-162): thread j owns constraints j, j + NT, ... in order
+        double bval = 0.0;
+        int bidx = 0x7fffffff, btag = JRLQP_INACTIVE;
+        for(int j = tid; j < m; j += NT)
+        {
+          if(K.status[j] != JRLQP_INACTIVE) continue;
+          const int b = A.to_block[j], len = A.cvar[b];
+          const double * c = K.cblk[b] + (size_t)(j - A.cum_cstr[b]) * A.cld[b];
+          const double * w = x + A.cum_var[b];
+          double cx = 0.0;
+          for(int k = 0; k < len; ++k) cx = FMA(c[k], w[k], cx); // C^T x (StructuredC.cpp:66-77)
+          const double sl = cx - bl[j];
+          if(sl < bval)
+          {
+            bval = sl;
+            bidx = j;
+            btag = JRLQP_LOWER;
+          }
+          else
+          {
+            const double su = bu[j] - cx;
+            if(su < bval)
+            {
+              bval = su;
+              bidx = j;
+              btag = JRLQP_UPPER;
+            }
+          }
+        }
+        for(int i = tid; i < nb; i += NT)
+        {
+          if(K.status[m + i] != JRLQP_INACTIVE) continue;
+          const double sl = x[i] - xl[i];
+          if(sl < bval)
+          {
+            bval = sl;
+            bidx = m + i;
+            btag = JRLQP_LOWER_BOUND;
+          }
+          else
+          {
+            const double su = xu[i] - x[i];
+            if(su < bval)
+            {
+              bval = su;
+              bidx = m + i;
+              btag = JRLQP_UPPER_BOUND;
+            }
+          }
+        }
+        block_argmin<NT>(K, bval, bidx, btag);
+        p = bidx;
+        pst = btag;
+        if(pst == JRLQP_INACTIVE)
+        {
+          rc = JRLQP_SUCCESS;
+          break;
+        }
+        if(tid == 0) u[q] = 0.0;
+      }
+
+      // ---- computeStep_ (BlockGISolver.cpp:164-172) ----
+      // d = Q^T L^-1 n+  (StructuredJ.cpp:43-57)
+      int wst, wen;
+      for(int i = tid; i < n; i += NT) d[i] = 0.0;
+      __syncthreads();
+      if(p < m)
+      {
+        const int b = A.to_block[p], len = A.cvar[b];
+        const double * c = K.cblk[b] + (size_t)(p - A.cum_cstr[b]) * A.cld[b];
+        wst = A.cum_var[b];
+        wen = wst + len;
+        for(int i = tid; i < len; i += NT) d[wst + i] = c[i];
+      }
+      else
+      {
+        wst = p - m;
+        wen = wst + 1;
+        if(tid == 0) d[wst] = (pst == JRLQP_UPPER_BOUND) ? -1.0 : 1.0;
+      }
+      __syncthreads();
+      sg_lsolve<NT>(K, d, wst, wen);
+      if(pst == JRLQP_UPPER)
+      {
+        for(int i = tid; i < n; i += NT) d[i] = -d[i];
+        __syncthreads();
+      }
+      q_apply<NT, NCH, true>(K, d, nseq);
+      // z = L^-T Q [0; d2]  (StructuredJ.cpp:32-41)
+      for(int i = tid; i < n; i += NT) z[i] = (i < q) ? 0.0 : d[i];
+      __syncthreads();
+      q_apply<NT, NCH, false>(K, z, nseq);
+      sg_ltsolve<NT>(K, z);
+      r_solve<NT>(K, q);
+
+      // ---- computeStepLength_ (BlockGISolver.cpp:174-242) ----
+      double t1 = A.big_bnd, t2 = A.big_bnd;
+      int l = 0;
+      {
+        // (the position-indexed EQUALITY/FIXED exemption of :186 never fires: equalities are rejected above)
+        double tv = A.big_bnd;
+        int ti = 0x7fffffff, tt = 0;
+        for(int k = tid; k < q; k += NT)
+        {
+          if(r[k] > 0.0)
+          {
+            const double tk = u[k] / r[k];
+            if(tk < tv)
+            {
+              tv = tk;
+              ti = k;
+            }
+          }
+        }
+        block_argmin<NT>(K, tv, ti, tt);
+        if(ti != 0x7fffffff)
+        {
+          t1 = tv;
+          l = ti;
+        }
+      }
+      const double zz = dot_tree<NT>(K, 0, n, [&](int e) { return z[e]; }, [&](int e) { return z[e]; });
+      double cz = 0.0;
+      if(__builtin_sqrt(zz) > 1e-14)
+      {
+        if(tid == 0) sh[0] = cstr_dot(K, p, z);
+        if(tid == 64 % NT) sh[1] = cstr_dot(K, p, x);
+        __syncthreads();
+        cz = sh[0];
+        const double cxp = sh[1];
+        const double b = (pst == JRLQP_LOWER) ? bl[p] : (pst == JRLQP_UPPER) ? bu[p] : (pst == JRLQP_LOWER_BOUND) ? xl[p - m] : xu[p - m];
+        t2 = (b - cxp) / cz;
+        __syncthreads(); // sh is reused
+      }
+      const double t = (t2 < t1) ? t2 : t1;
+
+      if(trace && it < A.trace_cap && tid == 0)
+      {
+        trace[it].p = p;
+        trace[it].status = pst;
+        trace[it].l = l;
+        trace[it].t1 = t1;
+        trace[it].t2 = t2;
+        trace[it].kind = (t2 >= A.big_bnd) ? 2 : ((t == t2) ? 0 : 1);
+      }
+
+      if(t >= A.big_bnd)
+      {
+        rc = JRLQP_INFEASIBLE;
+        break;
+      }
+
+      bool drop;
+      if(t2 >= A.big_bnd)
+      {
+        for(int k = tid; k < q; k += NT) u[k] = FMA(-t, r[k], u[k]);
+        if(tid == 0) u[q] += t;
+        drop = true;
+      }
+      else
+      {
+        for(int i = tid; i < n; i += NT) x[i] = FMA(t, z[i], x[i]);
+        const double nz = (pst == JRLQP_UPPER || pst == JRLQP_UPPER_BOUND) ? -cz : cz; // dot_ (:255-273)
+        const double uq = u[q];
+        f = FMA(t * nz, 0.5 * t + uq, f);
+        __syncthreads(); // every thread has read u[q]
+        for(int k = tid; k < q; k += NT) u[k] = FMA(-t, r[k], u[k]);
+        if(tid == 0) u[q] += t;
+        drop = !(t == t2);
+      }
+      __syncthreads();
+
+      if(!drop)
+      {
+        // ---- addConstraint: A_.activate + StructuredQR::add (StructuredQR.cpp:70-84), makeHouseholder of d.tail(n - q)
+        const double tail = dot_tree<NT>(K, q + 1, n, [&](int e) { return d[e]; }, [&](int e) { return d[e]; });
+        const double c0 = d[q];
+        double tau, beta;
+        double * row = K.pool + (size_t)nseq * A.row_len;
+        if(tail <= 2.2250738585072014e-308)
+        {
+          tau = 0.0;
+          beta = c0;
+          for(int e = q + 1 + tid; e < n; e += NT) row[e] = 0.0;
+        }
+        else
+        {
+          beta = __builtin_sqrt(FMA(c0, c0, tail));
+          if(c0 >= 0.0) beta = -beta;
+          const double den = c0 - beta;
+          for(int e = q + 1 + tid; e < n; e += NT) row[e] = d[e] / den;
+          tau = (beta - c0) / beta;
+        }
+        for(int k = tid; k < q; k += NT) RP(K.Rp, k, q) = d[k];
+        if(tid == 0)
+        {
+          row[q] = 1.0;
+          RP(K.Rp, q, q) = beta;
+          K.tau[nseq] = tau;
+          int * ds = K.desc + 4 * (size_t)nseq;
+          ds[0] = 0;
+          ds[1] = q;
+          ds[2] = 1;
+          ds[3] = 0;
+          K.status[p] = pst;
+          K.active[q] = p;
+        }
+        ++q;
+        ++nseq;
+        skip_step1 = false;
+        __syncthreads();
+      }
+      else
+      {
+        // ---- removeConstraint (DualSolver.cpp:237-244) + StructuredQR::remove (StructuredQR.cpp:86-102) ----
+        // u.segment(l, q - l) = u.tail(q - l) (u has q + 1 entries); ActiveSet::deactivate(l) erases position l
+        const int removed = K.active[l];
+        for(int base = l; base < q; base += NT)
+        {
+          const int k = base + tid;
+          const double tu = (k < q) ? u[k + 1] : 0.0;
+          const int ta = (k + 1 < q) ? K.active[k + 1] : 0;
+          __syncthreads();
+          if(k < q) u[k] = tu;
+          if(k + 1 < q) K.active[k] = ta;
+          __syncthreads();
+        }
+        if(tid == 0) K.status[removed] = JRLQP_INACTIVE;
+        const int q1 = q - 1, sz = q1 - l;
+        double * R = K.Rp;
+        double * row = K.pool + (size_t)nseq * A.row_len;
+        double *cp = row, *sp = row + A.qcap;
+        // rows above l: new column k-1 <- old column k; thread j owns row j (no cross-thread hazard)
+        for(int j = tid; j < l; j += NT)
+          for(int k = l + 1; k < q; ++k) RP(R, j, k - 1) = RP(R, j, k);
+        // rows >= l: one lane per old column k = l+1 .. q-1, a carried value per lane, chunks of 64 columns
+        if(K.wave == 0)
+        {
+          const int lane = K.lane;
+          for(int cb = 0; cb < sz; cb += 64)
+          {
+            const int k = l + 1 + cb + lane;
+            const bool valid = k < q;
+            double xc = valid ? RP(R, l, k) : 0.0;
+            const double dg = valid ? RP(R, k, k) : 0.0;
+            // rotations generated by earlier chunks
+            for(int i0 = l; i0 < l + cb; i0 += 64)
+            {
+              const double cl = cp[i0 - l + lane], sl = sp[i0 - l + lane]; // (i0 - l + lane < cb <= sz)
+              for(int j = 0; j < 64; ++j)
+              {
+                const int i = i0 + j;
+                const double c = bcast_lane(cl, j), s = bcast_lane(sl, j);
+                if(valid)
+                {
+                  const double y = RP(R, i + 1, k);
+                  const double xn = FMA(c, xc, -(s * y));
+                  xc = FMA(s, xc, c * y);
+                  RP(R, i, k - 1) = xn;
+                }
+              }
+            }
+            // this chunk's own rotations: lane jj generates G_i, i = l + cb + jj
+            const int cnt = min(64, sz - cb);
+            double cmine = 0.0, smine = 0.0;
+            for(int jj = 0; jj < cnt; ++jj)
+            {
+              const int i = l + cb + jj;
+              double c, s, rr;
+              make_givens(bcast_lane(xc, jj), bcast_lane(dg, jj), c, s, rr);
+              if(lane == jj)
+              {
+                RP(R, i, i) = rr;
+                cmine = c;
+                smine = s;
+              }
+              else if(valid && lane > jj)
+              {
+                const double y = RP(R, i + 1, k);
+                const double xn = FMA(c, xc, -(s * y));
+                xc = FMA(s, xc, c * y);
+                RP(R, i, k - 1) = xn;
+              }
+            }
+            if(lane < cnt)
+            {
+              cp[cb + lane] = cmine;
+              sp[cb + lane] = smine;
+            }
+            __threadfence_block();
+            wave_sync();
+          }
+        }
+        if(tid == 0)
+        {
+          int * ds = K.desc + 4 * (size_t)nseq;
+          ds[0] = 1;
+          ds[1] = sz ? l : 0;
+          ds[2] = sz;
+          ds[3] = 0;
+          K.tau[nseq] = 0.0;
+        }
+        q = q1;
+        ++nseq;
+        skip_step1 = true;
+        __syncthreads();
+      }
+    }
+  }
+
+done:
+  __syncthreads();
+  {
+    double * xo = A.x + (size_t)pb * n;
+    for(int i = tid; i < n; i += NT) xo[i] = x[i];
+    // DualSolver::multipliers (DualSolver.cpp:38-69)
+    double * uo = A.u + (size_t)pb * (m + nb);
+    for(int i = tid; i < m + nb; i += NT) uo[i] = 0.0;
+    __syncthreads();
+    for(int k = tid; k < q; k += NT)
+    {
+      const int i = K.active[k];
+      const int st = K.status[i];
+      uo[i] = (st == JRLQP_UPPER || st == JRLQP_UPPER_BOUND) ? u[k] : -u[k];
+    }
+    if(tid == 0)
+    {
+      A.term[pb] = rc;
+      A.iters[pb] = it;
+      A.f[pb] = f;
+    }
+  }
+}
+
+template<int NT, int NCH>
+hipError_t launch_one(const BgiArgs & a, int nprob, size_t lds, hipStream_t st)
+{
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blockgi_kernel<NT, NCH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL((blockgi_kernel<NT, NCH>), dim3(nprob), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
+} // namespace
+
+long blockgi_lds_bytes(int n, int m, int nb)
+{
+  const int n_pad = (n + 3) & ~3;
+  int qcap = (n < m + nb ? n : m + nb) + 1;
+  qcap = (qcap + 3) & ~3;
+  return (long)sizeof(double) * (3L * n_pad + 2L * qcap + kTri + 32 + 32 + 8);
+}
+
+hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t st)
+{
+  const size_t lds = (size_t)blockgi_lds_bytes(a.n, a.m, a.nb);
+  if(a.n <= 1024) return launch_one<256, 1>(a, nprob, lds, st);
+  if(a.n <= 2048) return launch_one<256, 2>(a, nprob, lds, st);
+  return launch_one<256, 3>(a, nprob, lds, st);
+}
+} // namespace jrlqp

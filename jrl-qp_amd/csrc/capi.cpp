@@ -4,6 +4,7 @@
 #include <atomic>
 
 #include "../../include/jrlqp_hip.h"
+#include "blockgi.h"
 #include "gi_batch.h"
 #include "selftest.h"
 #include "structured.h"
@@ -33,6 +34,24 @@ struct jrlqp_blocks
   int *d_bs = nullptr, *d_ldd = nullptr, *d_lds = nullptr, *d_fail = nullptr;
   double **d_diag = nullptr, **d_side = nullptr;
   double * d_tmp = nullptr;
+  bool bound = false;
+};
+
+// plan object of the structured GI solver: a jrlqp_blocks plan (factorisation of G) + the block-diagonal C description
+// + the per-problem HBM workspace of the device-resident loop
+struct jrlqp_blockgi
+{
+  jrlqp_blocks * blocks = nullptr;
+  int kind = 0, nblk = 0, n = 0, m = 0, nb = 0, ncb = 0, nprob = 0, max_iter = 0;
+  int n_pad = 0, qcap = 0, row_len = 0;
+  long rlen = 0;
+  std::vector<int> h_cld;
+  std::vector<const double *> h_cblk;
+  int *d_boff = nullptr, *d_cvar = nullptr, *d_ccstr = nullptr, *d_cumv = nullptr, *d_cumc = nullptr, *d_toblk = nullptr, *d_cld = nullptr;
+  const double ** d_cblk = nullptr;
+  double *d_pool = nullptr, *d_Rp = nullptr, *d_tau = nullptr;
+  int *d_desc = nullptr, *d_active = nullptr;
+  size_t ws_bytes = 0;
   bool bound = false;
 };
 
@@ -312,6 +331,155 @@ int jrlqp_selftest_mfma_f64(const double * dA, const double * dB, const double *
 {
   if(!dA || !dB || !dC || !dD) return JRLQP_ERR_INVALID_ARGUMENT;
   hipError_t e = jrlqp::launch_selftest_mfma_f64(dA, dB, dC, dD, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? JRLQP_OK : hip_fail(e);
+}
+
+// ---- structured GI solver (experimental::BlockGISolver) ---------------------------------------------------------
+int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, const int * cvar, const int * ccstr, int use_bounds,
+                         int nprob, int max_iter, jrlqp_blockgi ** out)
+{
+  if(!out || !block_sizes || kind < 0 || kind > 2 || nblk < 1 || ncb < 0 || nprob < 1 || max_iter < 1) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(ncb > 0 && (!cvar || !ccstr)) return JRLQP_ERR_INVALID_ARGUMENT;
+  int n = 0, nv = 0, m = 0;
+  for(int i = 0; i < nblk; ++i) n += block_sizes[i];
+  for(int i = 0; i < ncb; ++i)
+  {
+    if(cvar[i] < 0 || ccstr[i] < 0) return JRLQP_ERR_INVALID_ARGUMENT;
+    nv += cvar[i];
+    m += ccstr[i];
+  }
+  if(ncb > 0 && nv != n) return JRLQP_ERR_INVALID_ARGUMENT; // StructuredC::nbVar() == G.nbVar() (BlockGISolver.cpp:35)
+  if(n > jrlqp::kBgiMaxN) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  const int nb = use_bounds ? n : 0;
+  if(jrlqp::blockgi_lds_bytes(n, m, nb) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  jrlqp_blockgi * h = new(std::nothrow) jrlqp_blockgi;
+  if(!h) return JRLQP_ERR_WORKSPACE;
+  int rc = jrlqp_blocks_create(kind, nblk, block_sizes, nprob, 1, &h->blocks);
+  if(rc != JRLQP_OK)
+  {
+    delete h;
+    return rc;
+  }
+  h->kind = kind; h->nblk = nblk; h->n = n; h->m = m; h->nb = nb; h->ncb = ncb; h->nprob = nprob; h->max_iter = max_iter;
+  h->n_pad = (n + 3) & ~3;
+  h->qcap = (((n < m + nb) ? n : (m + nb)) + 1 + 3) & ~3;
+  h->row_len = h->n_pad > 2 * h->qcap ? h->n_pad : 2 * h->qcap;
+  h->rlen = ((long)h->qcap * (h->qcap + 1) / 2 + 3) & ~3L;
+  std::vector<int> boff(nblk), cumv(ncb + 1), cumc(ncb + 1), toblk(m + 1);
+  for(int i = 0, o = 0; i < nblk; ++i)
+  {
+    boff[i] = o;
+    o += block_sizes[i];
+  }
+  {
+    int cv = 0, cc = 0;
+    for(int i = 0; i < ncb; ++i)
+    {
+      cumv[i] = cv;
+      cumc[i] = cc;
+      for(int k = 0; k < ccstr[i]; ++k) toblk[cc + k] = i;
+      cv += cvar[i];
+      cc += ccstr[i];
+    }
+    cumv[ncb] = cv;
+    cumc[ncb] = cc;
+  }
+  const size_t nc = ncb > 0 ? ncb : 1;
+  const size_t pool_b = sizeof(double) * (size_t)nprob * max_iter * h->row_len;
+  const size_t r_b = sizeof(double) * (size_t)nprob * h->rlen;
+  hipError_t e = hipMalloc(&h->d_boff, sizeof(int) * nblk);
+  if(e == hipSuccess) e = hipMalloc(&h->d_cvar, sizeof(int) * nc);
+  if(e == hipSuccess) e = hipMalloc(&h->d_ccstr, sizeof(int) * nc);
+  if(e == hipSuccess) e = hipMalloc(&h->d_cumv, sizeof(int) * (nc + 1));
+  if(e == hipSuccess) e = hipMalloc(&h->d_cumc, sizeof(int) * (nc + 1));
+  if(e == hipSuccess) e = hipMalloc(&h->d_toblk, sizeof(int) * (m + 1));
+  if(e == hipSuccess) e = hipMalloc(&h->d_cld, sizeof(int) * nc);
+  if(e == hipSuccess) e = hipMalloc(&h->d_cblk, sizeof(double *) * (size_t)nprob * nc);
+  if(e == hipSuccess) e = hipMalloc(&h->d_pool, pool_b);
+  if(e == hipSuccess) e = hipMalloc(&h->d_Rp, r_b);
+  if(e == hipSuccess) e = hipMalloc(&h->d_tau, sizeof(double) * (size_t)nprob * max_iter);
+  if(e == hipSuccess) e = hipMalloc(&h->d_desc, sizeof(int) * 4 * (size_t)nprob * max_iter);
+  if(e == hipSuccess) e = hipMalloc(&h->d_active, sizeof(int) * (size_t)nprob * h->qcap);
+  if(e == hipSuccess) e = hipMemcpy(h->d_boff, boff.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
+  if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_cvar, cvar, sizeof(int) * ncb, hipMemcpyHostToDevice);
+  if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_ccstr, ccstr, sizeof(int) * ncb, hipMemcpyHostToDevice);
+  if(e == hipSuccess) e = hipMemcpy(h->d_cumv, cumv.data(), sizeof(int) * (ncb + 1), hipMemcpyHostToDevice);
+  if(e == hipSuccess) e = hipMemcpy(h->d_cumc, cumc.data(), sizeof(int) * (ncb + 1), hipMemcpyHostToDevice);
+  if(e == hipSuccess) e = hipMemcpy(h->d_toblk, toblk.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice);
+  if(e != hipSuccess)
+  {
+    jrlqp_blockgi_destroy(h);
+    return hip_fail(e);
+  }
+  h->ws_bytes = pool_b + r_b + (sizeof(double) + 4 * sizeof(int)) * (size_t)nprob * max_iter + sizeof(int) * (size_t)nprob * h->qcap;
+  *out = h;
+  return JRLQP_OK;
+}
+
+void jrlqp_blockgi_destroy(jrlqp_blockgi * h)
+{
+  if(!h) return;
+  jrlqp_blocks_destroy(h->blocks);
+  (void)hipFree(h->d_boff); (void)hipFree(h->d_cvar); (void)hipFree(h->d_ccstr); (void)hipFree(h->d_cumv); (void)hipFree(h->d_cumc);
+  (void)hipFree(h->d_toblk); (void)hipFree(h->d_cld); (void)hipFree(h->d_cblk); (void)hipFree(h->d_pool); (void)hipFree(h->d_Rp);
+  (void)hipFree(h->d_tau); (void)hipFree(h->d_desc); (void)hipFree(h->d_active);
+  delete h;
+}
+
+long long jrlqp_blockgi_workspace_bytes(const jrlqp_blockgi * h)
+{
+  return h ? (long long)h->ws_bytes : -1;
+}
+
+int jrlqp_blockgi_bind(jrlqp_blockgi * h, double * const * ddiag, const int * ldd, double * const * doff, const int * ldo,
+                       const double * const * dcblk, const int * ldc, void * stream)
+{
+  if(!h || (h->ncb > 0 && (!dcblk || !ldc))) return JRLQP_ERR_INVALID_ARGUMENT;
+  int rc = jrlqp_blocks_bind(h->blocks, ddiag, ldd, doff, ldo, stream);
+  if(rc != JRLQP_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if(h->ncb > 0)
+  {
+    h->h_cld.assign(ldc, ldc + h->ncb);
+    h->h_cblk.assign(dcblk, dcblk + (size_t)h->nprob * h->ncb);
+    HIP_TRY(hipMemcpyAsync(h->d_cld, h->h_cld.data(), sizeof(int) * h->ncb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_cblk, h->h_cblk.data(), sizeof(double *) * h->h_cblk.size(), hipMemcpyHostToDevice, st));
+  }
+  h->bound = true;
+  return JRLQP_OK;
+}
+
+int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl, const double * dbu, const double * dxl,
+                        const double * dxu, const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm,
+                        int * diters, double * df, jrlqp_trace_rec * dtrace, int trace_cap, void * stream)
+{
+  if(!h || !h->bound || !da || !dx || !dterm || !diters || !df) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(h->m + h->nb > 0 && (!du || !dstatus)) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(h->m > 0 && (!dbl || !dbu)) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(h->nb > 0 && (!dxl || !dxu)) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
+  jrlqp_options o;
+  jrlqp_default_options(&o);
+  if(opts) o = *opts;
+  if(o.max_iter > h->max_iter) return JRLQP_ERR_WORKSPACE; // the orthonormal sequence grows by one element per iteration
+  // lltInPlace (BlockGISolver.cpp:71): the block factorisation kernels of structured.hip, same stream
+  int rc = jrlqp_blocks_llt(h->blocks, stream);
+  if(rc != JRLQP_OK) return rc;
+  const jrlqp_blocks * p = h->blocks;
+  jrlqp::BgiArgs a;
+  a.kind = h->kind; a.nblk = h->nblk; a.n = h->n;
+  a.bs = p->d_bs; a.boff = h->d_boff; a.ldd = p->d_ldd; a.lds = p->d_lds;
+  a.diag = p->d_diag; a.side = p->d_side; a.fail = p->d_fail;
+  a.m = h->m; a.nb = h->nb; a.ncb = h->ncb;
+  a.cvar = h->d_cvar; a.ccstr = h->d_ccstr; a.cum_var = h->d_cumv; a.cum_cstr = h->d_cumc; a.to_block = h->d_toblk; a.cld = h->d_cld;
+  a.cblk = h->d_cblk;
+  a.a = da; a.bl = dbl; a.bu = dbu; a.xl = dxl; a.xu = dxu;
+  a.max_iter = o.max_iter; a.big_bnd = o.big_bnd;
+  a.n_pad = h->n_pad; a.qcap = h->qcap; a.row_len = h->row_len;
+  a.pool = h->d_pool; a.Rp = h->d_Rp; a.rlen = h->rlen; a.tau = h->d_tau; a.desc = h->d_desc; a.active = h->d_active;
+  a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
+  a.trace = dtrace; a.trace_cap = dtrace ? trace_cap : 0;
+  hipError_t e = jrlqp::launch_blockgi(a, h->nprob, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }
 

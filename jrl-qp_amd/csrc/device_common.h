@@ -8,6 +8,7 @@
 namespace jrlqp
 {
 #define FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define AT(P, ld, i, j) (P)[(i) + (size_t)(j) * (ld)]
 
 // single-wave producer/consumer through LDS (or through memory the wave itself wrote): the hardware executes one
 // wave's accesses in order, so only the compiler has to be told not to move accesses across this point
@@ -39,6 +40,29 @@ __device__ __forceinline__ double opaque_v(double v)
 {
   asm volatile("" : "+v"(v));
   return v;
+}
+
+// ---- DPP lane exchanges (no LDS round trip) and the in-wave part of the C4 reduction tree ---------------------------
+template<int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v)
+{
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes as an ADJACENT-FIRST pairwise tree (lane 2i with 2i+1, then pairs of pairs, ...): rule C4 of
+// the oracle (oracle/blockgi_oracle.c orc_dot_tree).  Every lane returns the same bits: each level adds the totals of
+// two sibling groups, and a + b == b + a.  quad_perm / row_half_mirror / row_mirror inside a row of 16, then the four
+// row totals through v_readlane.
+__device__ __forceinline__ double wave_sum_tree(double s)
+{
+  s = s + dpp_mov_d<0xB1>(s);  // lane ^ 1   (quad_perm [1,0,3,2])
+  s = s + dpp_mov_d<0x4E>(s);  // lane ^ 2   (quad_perm [2,3,0,1])
+  s = s + dpp_mov_d<0x141>(s); // the other quad of each group of 8 (row_half_mirror)
+  s = s + dpp_mov_d<0x140>(s); // the other half of each row of 16 (row_mirror)
+  const double r0 = bcast_lane(s, 0), r1 = bcast_lane(s, 16), r2 = bcast_lane(s, 32), r3 = bcast_lane(s, 48);
+  return (r0 + r1) + (r2 + r3);
 }
 
 // Eigen JacobiRotation<double>::makeGivens(p, q, &r), real case (reference call sites GoldfarbIdnaniSolver.cpp:229,249;
@@ -106,4 +130,39 @@ __device__ __forceinline__ double givens_r_only(double p, double q)
   const double r = hi * sqrt_1to2(FMA(t, t, 1.0));
   return (hi == 0.0) ? 0.0 : r;
 }
+
+// ---- wave-level substitutions on one block (shared by the structured Cholesky family and the structured GI loop) ----
+// x (n) <- L^-1 x for one right-hand side held one element per lane (forward substitution, column oriented)
+__device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, double xi, int lane)
+{
+  for(int k = 0; k < n; ++k)
+  {
+    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
+    if(lane == k)
+      xi = v;
+    else if(lane > k && lane < n)
+      xi = FMA(-AT(L, ldl, lane, k), v, xi);
+  }
+  return xi;
+}
+// x <- L^-T x (backward substitution)
+__device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, double xi, int lane)
+{
+  for(int k = n - 1; k >= 0; --k)
+  {
+    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
+    if(lane == k)
+      xi = v;
+    else if(lane < k)
+      xi = FMA(-AT(L, ldl, k, lane), v, xi);
+  }
+  return xi;
+}
+
+// logical diagonal block i of get<Up> (blockArrowLLT.cpp:22-46)
+__device__ __forceinline__ int dsel(int nblk, int up, int i)
+{
+  return up ? (i + 1) % nblk : i;
+}
+
 } // namespace jrlqp

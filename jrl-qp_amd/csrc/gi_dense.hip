@@ -23,6 +23,7 @@ namespace jrlqp
 {
 namespace
 {
+#undef AT
 #define AT(P, ld, i, j) (P)[(size_t)(i) + (size_t)(j) * (size_t)(ld)]
 constexpr int NONE = 0x7fffffff;
 enum : int { INACTIVE = 0, LOWER = 1, UPPER = 2, EQUALITY = 3, LOWER_BOUND = 4, UPPER_BOUND = 5, FIXED = 6 };

@@ -25,7 +25,6 @@ namespace jrlqp
 {
 namespace
 {
-#define AT(P, ld, i, j) (P)[(i) + (size_t)(j) * (ld)]
 
 // ---- wave-level primitives on a block held in LDS (ld odd => conflict-free row-per-lane access) -----------
 // in-place lower Cholesky, lane = row; returns -1 or the failing column (Eigen llt_inplace semantics)
@@ -63,33 +62,6 @@ __device__ void wave_trsm_right_lt(const double * L, int ldl, int n, double * X,
     }
 }
 
-// x (n) <- L^-1 x for one right-hand side held one element per lane (forward substitution, column oriented)
-__device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, double xi, int lane)
-{
-  for(int k = 0; k < n; ++k)
-  {
-    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
-    if(lane == k)
-      xi = v;
-    else if(lane > k && lane < n)
-      xi = FMA(-AT(L, ldl, lane, k), v, xi);
-  }
-  return xi;
-}
-// x <- L^-T x (backward substitution)
-__device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, double xi, int lane)
-{
-  for(int k = n - 1; k >= 0; --k)
-  {
-    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
-    if(lane == k)
-      xi = v;
-    else if(lane < k)
-      xi = FMA(-AT(L, ldl, k, lane), v, xi);
-  }
-  return xi;
-}
-
 __device__ __forceinline__ void load_block(double * dst, int ldd, const double * src, int lds_, int rows, int cols, int tid, int nthr)
 {
   for(int e = tid; e < rows * cols; e += nthr)
@@ -97,12 +69,6 @@ __device__ __forceinline__ void load_block(double * dst, int ldd, const double *
     int i = e % rows, j = e / rows;
     AT(dst, ldd, i, j) = AT(src, lds_, i, j);
   }
-}
-
-// logical diagonal block i of get<Up> (blockArrowLLT.cpp:22-46)
-__device__ __forceinline__ int dsel(int nblk, int up, int i)
-{
-  return up ? (i + 1) % nblk : i;
 }
 
 // =========================================================================================================
