@@ -6,6 +6,14 @@
 
 namespace jrlqp
 {
+// One element of the orthonormal sequence (OrthonormalSequence.h:88-93 EmbeddedSeq): a Householder reflector
+// (kind 0, size 1, rows [start, n)) or a Givens sequence (kind 1, `size` rotations on rows start .. start + size)
+struct SeqRec
+{
+  int kind, start, size, pad;
+  double tau, pad2;
+};
+
 // One batch of identically shaped structured QPs.  Every pointer is a DEVICE pointer.
 struct BgiArgs
 {
@@ -37,8 +45,7 @@ struct BgiArgs
   double * pool;  // [nprob * max_iter * row_len]   Householder vectors (absolute row index) / Givens (c | s)
   double * Rp;    // [nprob * rlen]   R packed by columns: R(i,j) at i + j(j+1)/2
   long rlen;
-  double * tau;   // [nprob * max_iter]
-  int * desc;     // [nprob * max_iter * 4]  {kind, start, size, 0}
+  SeqRec * desc;  // [nprob * max_iter]  one record per element of the orthonormal sequence
   int * active;   // [nprob * qcap]
   // outputs
   double *x, *u;
@@ -46,10 +53,11 @@ struct BgiArgs
   double * f;
   jrlqp_trace_rec * trace;
   int trace_cap;
+  long long * prof; // diagnostic only (jrlqp_debug_set_profile): 16 int64 per problem, 100 MHz ticks per phase; or nullptr
 };
 
 constexpr int kBgiMaxN = 3072; // unknowns per structured QP (vectors live in LDS)
 
-long blockgi_lds_bytes(int n, int m, int nb);
+long blockgi_lds_bytes(int n, int m, int nb, int nblk);
 hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t stream);
 } // namespace jrlqp

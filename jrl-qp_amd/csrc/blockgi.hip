@@ -38,9 +38,19 @@ namespace
 
 constexpr int kTri = 64 * 65 / 2; // doubles of LDS scratch for one packed 64 x 64 upper triangle
 
+// per-block description of L, staged in LDS once per solve: every block solve starts from these (a pointer fetched
+// from HBM first would put one more memory latency in front of each of the ~100 block solves of an L^-T pass)
+struct BlkMeta
+{
+  double * diag; // diagonal block b
+  double * side; // side / sub-diagonal block b (b < nblk - 1)
+  int bs, boff, ldd, lds;
+};
+
 struct Ctx
 {
   const BgiArgs * A;
+  const BlkMeta * bm;
   int tid, lane, wave;
   double * const * diag;
   double * const * side;
@@ -48,8 +58,9 @@ struct Ctx
   double *d, *z, *x, *u, *r, *tri, *red;
   int * ired;
   int par; // parity of the reduction scratch slot (two slots: one barrier per reduction)
-  double *pool, *Rp, *tau;
-  int *desc, *active, *status;
+  double *pool, *Rp;
+  SeqRec * desc;
+  int *active, *status;
 };
 
 // ---- C4 reduction over the workgroup -------------------------------------------------------------------------------
@@ -62,7 +73,7 @@ __device__ __forceinline__ double block_sum(Ctx & K, double s)
   double * slot = K.red + 16 * K.par;
   K.par ^= 1;
   if(K.lane == 0) slot[K.wave] = s;
-  __syncthreads();
+  lds_barrier();
   double w[NW];
 #pragma unroll
   for(int i = 0; i < NW; ++i) w[i] = slot[i];
@@ -102,13 +113,13 @@ __device__ __forceinline__ double dot_tree(Ctx & K, int lo, int hi, FA fa, FB fb
 // Block arrow, L v <- v with the non-zero window [start, end) of v (blockArrowLLT.cpp:92-176).  The up variant's row
 // permutation (:163-170) is a change of offsets only: logical block i sits at physical rows boff[dsel(i)].
 template<int NT>
-__device__ void arrow_lsolve(Ctx & K, double * v, int start, int end)
+__device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int end)
 {
   const BgiArgs & A = *K.A;
   constexpr int NW = NT / 64;
   const int up = A.kind == 1, nblk = A.nblk, lane = K.lane;
-  const int ib = dsel(nblk, up, nblk - 1), nbk = A.bs[ib];
-  const int shift = up ? A.bs[0] : 0; // permuted row = physical row - shift for the off-head blocks
+  const int ib = dsel(nblk, up, nblk - 1), nbk = K.bm[ib].bs;
+  const int shift = up ? K.bm[0].bs : 0; // permuted row = physical row - shift for the off-head blocks
   if(up)
   {
     start = max(0, start - shift);
@@ -116,12 +127,12 @@ __device__ void arrow_lsolve(Ctx & K, double * v, int start, int end)
   }
   for(int i = K.wave; i < nblk - 1; i += NW)
   {
-    const int id = dsel(nblk, up, i), ni = A.bs[id], n0 = A.boff[id] - shift;
+    const int id = dsel(nblk, up, i), ni = K.bm[id].bs, n0 = K.bm[id].boff - shift;
     const int s = max(start - n0, 0);
     if(ni < s || end <= n0) continue; // (:121-127)
-    const double * Dg = K.diag[id];
-    const int ldd = A.ldd[id];
-    double * vi = v + A.boff[id] + s;
+    const double * Dg = K.bm[id].diag;
+    const int ldd = K.bm[id].ldd;
+    double * vi = v + K.bm[id].boff + s;
     double xi = (lane < ni - s) ? vi[lane] : 0.0;
     xi = wave_fwd(Dg + s + (size_t)s * ldd, ldd, ni - s, xi, lane);
     if(lane < ni - s) vi[lane] = xi;
@@ -129,26 +140,23 @@ __device__ void arrow_lsolve(Ctx & K, double * v, int start, int end)
   __syncthreads();
   if(K.wave == 0)
   {
-    double * vb = v + A.boff[ib];
+    double * vb = v + K.bm[ib].boff;
     double acc = (lane < nbk) ? vb[lane] : 0.0;
     for(int i = 0; i < nblk - 1; ++i)
     {
-      const int id = dsel(nblk, up, i), ni = A.bs[id], n0 = A.boff[id] - shift;
+      const int id = dsel(nblk, up, i), ni = K.bm[id].bs, n0 = K.bm[id].boff - shift;
       const int s = max(start - n0, 0);
       if(ni < s || end <= n0) continue;
       if(lane < nbk)
       {
-        const double * Sg = K.side[i];
-        const int ldsg = A.lds[i];
-        const double * Xi = v + A.boff[id];
-        for(int k = s; k < ni; ++k)
-        {
-          const double bv = up ? AT(Sg, ldsg, k, lane) : AT(Sg, ldsg, lane, k);
-          acc = FMA(-bv, Xi[k], acc);
-        }
+        const double * Sg = K.bm[i].side;
+        const int ldsg = K.bm[i].lds;
+        const double * Xi = v + K.bm[id].boff;
+        acc = chain_neg8(s, 1, ni - s, acc, [&](int k) { return up ? AT(Sg, ldsg, k, lane) : AT(Sg, ldsg, lane, k); },
+                         [&](int k) { return Xi[k]; });
       }
     }
-    acc = wave_fwd(K.diag[ib], A.ldd[ib], nbk, acc, lane);
+    acc = wave_fwd(K.bm[ib].diag, K.bm[ib].ldd, nbk, acc, lane);
     if(lane < nbk) vb[lane] = acc;
   }
   __syncthreads();
@@ -156,41 +164,40 @@ __device__ void arrow_lsolve(Ctx & K, double * v, int start, int end)
 
 // L^T v <- v, full vector (blockArrowLLT.cpp:179-277 with start = 0, end = n)
 template<int NT>
-__device__ void arrow_ltsolve(Ctx & K, double * v)
+__device__ __forceinline__ void arrow_ltsolve(Ctx & K, double * v)
 {
   const BgiArgs & A = *K.A;
   constexpr int NW = NT / 64;
   const int up = A.kind == 1, nblk = A.nblk, lane = K.lane;
-  const int ib = dsel(nblk, up, nblk - 1), nbk = A.bs[ib];
-  double * vb = v + A.boff[ib];
+  const int ib = dsel(nblk, up, nblk - 1), nbk = K.bm[ib].bs;
+  double * vb = v + K.bm[ib].boff;
   if(K.wave == 0)
   {
     double xi = (lane < nbk) ? vb[lane] : 0.0;
-    xi = wave_bwd(K.diag[ib], A.ldd[ib], nbk, xi, lane);
+    xi = wave_bwd(K.bm[ib].diag, K.bm[ib].ldd, nbk, xi, lane);
     if(lane < nbk) vb[lane] = xi;
   }
   __syncthreads();
   for(int i = K.wave; i < nblk - 1; i += NW)
   {
-    const int id = dsel(nblk, up, i), ni = A.bs[id];
-    const double * Sg = K.side[i];
-    const int ldsg = A.lds[i];
-    double * vi = v + A.boff[id];
+    const int id = dsel(nblk, up, i), ni = K.bm[id].bs;
+    const double * Sg = K.bm[i].side;
+    const int ldsg = K.bm[i].lds;
+    double * vi = v + K.bm[id].boff;
     double acc = (lane < ni) ? vi[lane] : 0.0;
-    if(lane < ni)
-      for(int k = nbk - 1; k >= 0; --k)
-      {
-        const double bv = up ? AT(Sg, ldsg, lane, k) : AT(Sg, ldsg, k, lane);
-        acc = FMA(-bv, vb[k], acc);
-      }
-    const double solved = wave_bwd(K.diag[id], A.ldd[id], ni, acc, lane);
+    {
+      const int rl = (lane < ni) ? lane : 0; // idle lanes run the same (discarded) chain: no divergent loads
+      acc = chain_neg8(nbk - 1, -1, nbk, acc, [&](int k) { return up ? AT(Sg, ldsg, rl, k) : AT(Sg, ldsg, k, rl); },
+                       [&](int k) { return vb[k]; });
+    }
+    const double solved = wave_bwd(K.bm[id].diag, K.bm[id].ldd, ni, acc, lane);
     if(lane < ni) vi[lane] = solved;
   }
   __syncthreads();
 }
 
 // Block tridiagonal (triBlockDiagLLT.cpp:37-96): serial over the blocks, one wave
-__device__ void tri_lsolve(Ctx & K, double * v, int start)
+__device__ __forceinline__ void tri_lsolve(Ctx & K, double * v, int start)
 {
   const BgiArgs & A = *K.A;
   const int lane = K.lane;
@@ -200,9 +207,9 @@ __device__ void tri_lsolve(Ctx & K, double * v, int start)
     bool zero = true;
     for(int i = 0; i < A.nblk; ++i)
     {
-      const int ni = A.bs[i];
-      const double * Li = K.diag[i];
-      const int ldd = A.ldd[i];
+      const int ni = K.bm[i].bs;
+      const double * Li = K.bm[i].diag;
+      const int ldd = K.bm[i].ldd;
       if(n + ni >= start)
       {
         if(zero)
@@ -215,11 +222,13 @@ __device__ void tri_lsolve(Ctx & K, double * v, int start)
         }
         else
         {
-          const double * Sg = K.side[i - 1];
-          const int ldsg = A.lds[i - 1];
+          const double * Sg = K.bm[i - 1].side;
+          const int ldsg = K.bm[i - 1].lds;
           double acc = (lane < ni) ? v[n + lane] : 0.0;
-          if(lane < ni)
-            for(int k = 0; k < li; ++k) acc = FMA(-AT(Sg, ldsg, lane, k), v[l + k], acc);
+          {
+            const int rl = (lane < ni) ? lane : 0;
+            acc = chain_neg8(0, 1, li, acc, [&](int k) { return AT(Sg, ldsg, rl, k); }, [&](int k) { return v[l + k]; });
+          }
           acc = wave_fwd(Li, ldd, ni, acc, lane);
           if(lane < ni) v[n + lane] = acc;
         }
@@ -234,7 +243,7 @@ __device__ void tri_lsolve(Ctx & K, double * v, int start)
 }
 
 // triBlockDiagLTransposeSolve (triBlockDiagLLT.cpp:98-158), full vector
-__device__ void tri_ltsolve(Ctx & K, double * v)
+__device__ __forceinline__ void tri_ltsolve(Ctx & K, double * v)
 {
   const BgiArgs & A = *K.A;
   const int lane = K.lane;
@@ -244,9 +253,9 @@ __device__ void tri_ltsolve(Ctx & K, double * v)
     bool zero = true;
     for(int i = A.nblk - 1; i >= 0; --i)
     {
-      const int ni = A.bs[i];
-      const double * Li = K.diag[i];
-      const int ldd = A.ldd[i];
+      const int ni = K.bm[i].bs;
+      const double * Li = K.bm[i].diag;
+      const int ldd = K.bm[i].ldd;
       if(zero)
       {
         double xi = (lane < ni) ? v[n - ni + lane] : 0.0;
@@ -256,11 +265,13 @@ __device__ void tri_ltsolve(Ctx & K, double * v)
       }
       else
       {
-        const double * Sg = K.side[i];
-        const int ldsg = A.lds[i];
+        const double * Sg = K.bm[i].side;
+        const int ldsg = K.bm[i].lds;
         double acc = (lane < ni) ? v[n - ni + lane] : 0.0;
-        if(lane < ni)
-          for(int k = li - 1; k >= 0; --k) acc = FMA(-AT(Sg, ldsg, k, lane), v[(l - li) + k], acc);
+        {
+          const int rl = (lane < ni) ? lane : 0;
+          acc = chain_neg8(li - 1, -1, li, acc, [&](int k) { return AT(Sg, ldsg, k, rl); }, [&](int k) { return v[(l - li) + k]; });
+        }
         acc = wave_bwd(Li, ldd, ni, acc, lane);
         if(lane < ni) v[n - ni + lane] = acc;
       }
@@ -277,10 +288,10 @@ __device__ void tri_ltsolve(Ctx & K, double * v)
 // PERMUTED order (first block moved last) and blockArrowLTransposeSolve expects its argument in that order -- d, and
 // with it the orthonormal sequence, live in permuted coordinates.  forward: v <- [v(n0:), v(:n0)]; backward: the inverse.
 template<int NT>
-__device__ void permute_up(Ctx & K, double * v, bool forward)
+__device__ __forceinline__ void permute_up(Ctx & K, double * v, bool forward)
 {
   constexpr int PER = kBgiMaxN / NT;
-  const int n = K.A->n, n0 = K.A->bs[0], s = n - n0;
+  const int n = K.A->n, n0 = K.bm[0].bs, s = n - n0;
   double tmp[PER];
 #pragma unroll
   for(int j = 0; j < PER; ++j)
@@ -333,7 +344,7 @@ __device__ __forceinline__ void sg_ltsolve(Ctx & K, double * v, bool permuted = 
 // v (LDS, n entries) <- Q v (TR = false: last element first) or Q^T v (TR = true: first element first).
 // Entry: v complete and visible to every thread (a barrier has been passed).  Exit: same.
 template<int NT, int NCH, bool TR>
-__device__ void q_apply(Ctx & K, double * v, int nseq)
+__device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long * qprof)
 {
   constexpr int VPT = 1024 / NT;
   const BgiArgs & A = *K.A;
@@ -348,17 +359,86 @@ __device__ void q_apply(Ctx & K, double * v, int nseq)
       const int e = 1024 * c + t0 + i;
       vr[c][i] = (e < n) ? v[e] : 0.0;
     }
-  for(int kk = 0; kk < nseq; ++kk)
-  {
+  // Reflector rows stream from HBM / the Infinity Cache (one row per iteration ever made: far more than L2 holds), and
+  // one reflector costs far less than one memory latency: the rows and descriptors of the next DEPTH elements are kept
+  // in flight in a register ring.  Row addresses depend on the element index only, and whole 4-packs inside the row are
+  // loaded unconditionally (entries above `st` are unused garbage, masked below).
+  constexpr int DEPTH = (24 / (NCH * VPT)) > 6 ? 6 : (24 / (NCH * VPT)) < 2 ? 2 : (24 / (NCH * VPT)); // two rings of <= 24 doubles per thread
+  double ring[DEPTH][NCH][VPT];
+  int rkind[DEPTH], rst[DEPTH], rsz[DEPTH];
+  double rtau[DEPTH];
+  auto fetch = [&](int kk, double(&en)[NCH][VPT], int & nkind, int & nst, int & nsz, double & ntau) {
     const int k = TR ? kk : nseq - 1 - kk;
-    const volatile int * ds = K.desc + 4 * (size_t)k;
-    const int kind = ds[0], st = ds[1], sz = ds[2];
+    // (records are written by thread 0 behind a barrier and only ever read with vector loads)
+    const int4 rec = *reinterpret_cast<const int4 *>(K.desc + k);
+    nkind = rec.x;
+    nst = rec.y;
+    nsz = rec.z;
+    ntau = K.desc[k].tau;
     const double * row = K.pool + (size_t)k * A.row_len;
+#pragma unroll
+    for(int c = 0; c < NCH; ++c)
+    {
+      const int e0 = 1024 * c + t0;
+      if(e0 < A.n_pad)
+      {
+        if constexpr(VPT == 4)
+        {
+          const double2 lo = *reinterpret_cast<const double2 *>(row + e0), hi = *reinterpret_cast<const double2 *>(row + e0 + 2);
+          en[c][0] = lo.x;
+          en[c][1] = lo.y;
+          en[c][2] = hi.x;
+          en[c][3] = hi.y;
+        }
+        else if constexpr(VPT == 2)
+        {
+          const double2 lo = *reinterpret_cast<const double2 *>(row + e0);
+          en[c][0] = lo.x;
+          en[c][1] = lo.y;
+        }
+        else
+        {
+#pragma unroll
+          for(int i = 0; i < VPT; ++i) en[c][i] = (e0 + i < A.n_pad) ? row[e0 + i] : 0.0;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for(int i = 0; i < VPT; ++i) en[c][i] = 0.0;
+      }
+    }
+  };
+  // group g + 1 is requested (clamped indices: no branch around a load) before group g is processed
+  double nxt[DEPTH][NCH][VPT];
+  int nkind[DEPTH], nst[DEPTH], nsz[DEPTH];
+  double ntau[DEPTH];
+#pragma unroll
+  for(int j = 0; j < DEPTH; ++j) fetch(min(j, nseq - 1), ring[j], rkind[j], rst[j], rsz[j], rtau[j]);
+  for(int kk0 = 0; kk0 < nseq; kk0 += DEPTH)
+  {
+#pragma unroll
+  for(int j = 0; j < DEPTH; ++j) fetch(min(kk0 + DEPTH + j, nseq - 1), nxt[j], nkind[j], nst[j], nsz[j], ntau[j]);
+#pragma unroll
+  for(int j = 0; j < DEPTH; ++j)
+  {
+    const int kk = kk0 + j;
+    if(kk < nseq)
+    {
+    const int k = TR ? kk : nseq - 1 - kk;
+    const int kind = rkind[j], st = rst[j], sz = rsz[j];
+    const double tau = rtau[j];
+    const double * row = K.pool + (size_t)k * A.row_len;
+    double er[NCH][VPT];
+#pragma unroll
+    for(int c = 0; c < NCH; ++c)
+#pragma unroll
+      for(int i = 0; i < VPT; ++i) er[c][i] = ring[j][c][i];
+    const long long tq0 = qprof ? wall_clock64() : 0;
     if(kind == 0)
     {
       // one reflector: v -= tau (E.v) E on rows [st, n)  (OrthonormalSequence.cpp:59-63, :98-102)
-      const double tau = *(const volatile double *)(K.tau + k);
-      double er[NCH][VPT], p[VPT];
+      double p[VPT];
 #pragma unroll
       for(int i = 0; i < VPT; ++i) p[i] = 0.0;
 #pragma unroll
@@ -370,8 +450,9 @@ __device__ void q_apply(Ctx & K, double * v, int nseq)
         {
           const int e = e0 + i;
           const bool in = (e >= st && e < n);
-          er[c][i] = in ? row[e] : 0.0;
-          if(in) p[i] = FMA(er[c][i], vr[c][i], p[i]);
+          er[c][i] = in ? er[c][i] : 0.0;
+          const double pn = FMA(er[c][i], vr[c][i], p[i]);
+          p[i] = in ? pn : p[i];
         }
       }
 #pragma unroll
@@ -386,7 +467,8 @@ __device__ void q_apply(Ctx & K, double * v, int nseq)
         for(int i = 0; i < VPT; ++i)
         {
           const int e = 1024 * c + t0 + i;
-          if(e >= st && e < n) vr[c][i] = FMA(-sc, er[c][i], vr[c][i]);
+          const double vn = FMA(-sc, er[c][i], vr[c][i]);
+          vr[c][i] = (e >= st && e < n) ? vn : vr[c][i];
         }
     }
     else if(sz > 0)
@@ -406,45 +488,75 @@ __device__ void q_apply(Ctx & K, double * v, int nseq)
         const double *cp = row, *sp = row + A.qcap;
         double * w = v + st;
         const int lane = K.lane;
+        // The rotations form one serial chain through the carried element.  Systolic form: lane j owns rotation j of
+        // a chunk of 64 and the carried value travels lane to lane with one DPP wave shift per step -- every lane
+        // recomputes its step each time, and lane j's result is final from step j on (its input is).  Per step the
+        // chain costs one shift + one fma (ascending) or one shift + mul + fma (descending); the second output of each
+        // rotation is formed once, after the chain.
         if(TR)
         {
+          // ascending i: (w_i, w_i+1) <- (c w_i - s w_i+1, s w_i + c w_i+1); carried: the new w_i+1
           double xc = w[0];
+          // (the next chunk's coefficients are requested before the current chunk's chain runs)
+          double cn = (lane < sz) ? cp[lane] : 0.0, snn = (lane < sz) ? sp[lane] : 0.0;
           for(int i0 = 0; i0 < sz; i0 += 64)
           {
             const int cnt = min(64, sz - i0);
-            const double cl = (lane < cnt) ? cp[i0 + lane] : 0.0, sl = (lane < cnt) ? sp[i0 + lane] : 0.0;
-            const double yl = (lane < cnt) ? w[i0 + 1 + lane] : 0.0;
-            double out = 0.0;
-            for(int j = 0; j < cnt; ++j)
+            const bool on = lane < cnt;
+            const double c = cn, sn = snn;
+            if(i0 + 64 < sz)
             {
-              const double c = bcast_lane(cl, j), s = bcast_lane(sl, j), y = bcast_lane(yl, j);
-              const double xn = FMA(c, xc, -(s * y));
-              const double yn = FMA(s, xc, c * y);
-              if(lane == j) out = xn;
-              xc = yn;
+              const int ix = min(i0 + 64 + lane, sz - 1);
+              cn = cp[ix];
+              snn = sp[ix];
+              if(i0 + 64 + lane >= sz) cn = snn = 0.0;
             }
-            if(lane < cnt) w[i0 + lane] = out;
+            const double y = on ? w[i0 + 1 + lane] : 0.0;
+            const double b = c * y, sy = sn * y;
+            double out = 0.0, t = xc;
+            for(int step = 0; step < cnt; ++step)
+            {
+              t = dpp_shift_d<0x138>(out, xc); // wave_shr:1 -- lane j takes lane j-1's carry, lane 0 the chunk's input
+              out = FMA(sn, t, b);
+            }
+            if(on) w[i0 + lane] = FMA(c, t, -sy);
+            xc = bcast_lane(out, cnt - 1);
           }
           if(lane == 0) w[sz] = xc;
         }
         else
         {
+          // descending i: (w_i, w_i+1) <- (c w_i + s w_i+1, -s w_i + c w_i+1); carried: the new w_i.  The chunk is
+          // aligned to the TOP lanes (rotation i1-1 on lane 63) so that the input enters at the end of the shift.
           double yc = w[sz];
+          double cn, snn;
+          {
+            const int cnt = min(64, sz), j = lane - (64 - cnt);
+            cn = (j >= 0) ? cp[sz - cnt + j] : 0.0;
+            snn = (j >= 0) ? sp[sz - cnt + j] : 0.0;
+          }
           for(int i1 = sz; i1 > 0; i1 -= 64)
           {
-            const int cnt = min(64, i1), i0 = i1 - cnt; // rotations i0 .. i1-1, applied in descending order
-            const double cl = (lane < cnt) ? cp[i0 + lane] : 0.0, sl = (lane < cnt) ? sp[i0 + lane] : 0.0;
-            const double xl = (lane < cnt) ? w[i0 + lane] : 0.0;
-            double out = 0.0;
-            for(int j = cnt - 1; j >= 0; --j)
+            const int cnt = min(64, i1), i0 = i1 - cnt;
+            const int j = lane - (64 - cnt); // rotation i0 + j
+            const bool on = j >= 0;
+            const double c = cn, sn = snn;
+            if(i0 > 0)
             {
-              const double c = bcast_lane(cl, j), s = bcast_lane(sl, j), xv = bcast_lane(xl, j);
-              const double xn = FMA(c, xv, s * yc);
-              const double yn = FMA(-s, xv, c * yc);
-              if(lane == j) out = yn;
-              yc = xn;
+              const int cnt2 = min(64, i0), j2 = lane - (64 - cnt2), ix = max(i0 - cnt2 + j2, 0);
+              cn = cp[ix];
+              snn = sp[ix];
+              if(j2 < 0) cn = snn = 0.0;
             }
-            if(lane < cnt) w[i0 + 1 + lane] = out;
+            const double xv = on ? w[i0 + j] : 0.0;
+            double out = 0.0, t = yc;
+            for(int step = 0; step < cnt; ++step)
+            {
+              t = dpp_shift_d<0x130>(out, yc); // wave_shl:1 -- lane j takes lane j+1's carry, lane 63 the chunk's input
+              out = FMA(c, xv, sn * t);
+            }
+            if(on) w[i0 + j + 1] = FMA(-sn, xv, c * t);
+            yc = bcast_lane(out, 64 - cnt);
           }
           if(lane == 0) w[0] = yc;
         }
@@ -459,6 +571,21 @@ __device__ void q_apply(Ctx & K, double * v, int nseq)
           vr[c][i] = (e < n) ? v[e] : 0.0;
         }
     }
+    if(qprof) qprof[kind] += wall_clock64() - tq0;
+    } // kk < nseq
+  }
+#pragma unroll
+  for(int j = 0; j < DEPTH; ++j)
+  {
+    rkind[j] = nkind[j];
+    rst[j] = nst[j];
+    rsz[j] = nsz[j];
+    rtau[j] = ntau[j];
+#pragma unroll
+    for(int c = 0; c < NCH; ++c)
+#pragma unroll
+      for(int i = 0; i < VPT; ++i) ring[j][c][i] = nxt[j][c][i];
+  }
   }
 #pragma unroll
   for(int c = 0; c < NCH; ++c)
@@ -474,7 +601,7 @@ __device__ void q_apply(Ctx & K, double * v, int nseq)
 // ---- StructuredQR::RSolve (StructuredQR.cpp:64-68): r <- R^-1 d1, R packed in HBM, r in LDS --------------------------
 // Per element the order is the column-oriented back substitution's: contributions of columns k in descending order.
 template<int NT>
-__device__ void r_solve(Ctx & K, int q)
+__device__ __forceinline__ void r_solve(Ctx & K, int q)
 {
   const double * R = K.Rp;
   double *r = K.r, *tri = K.tri;
@@ -513,9 +640,7 @@ __device__ void r_solve(Ctx & K, int q)
     // rows above the block: r_i -= sum_k R(i,k) r_k, k descending
     for(int i = K.tid; i < c0; i += NT)
     {
-      double acc = r[i];
-      for(int k = c1 - 1; k >= c0; --k) acc = FMA(-RP(R, i, k), r[k], acc);
-      r[i] = acc;
+      r[i] = chain_neg8(c1 - 1, -1, nc, r[i], [&](int k) { return RP(R, i, k); }, [&](int k) { return r[k]; });
     }
     __syncthreads();
     c1 = c0;
@@ -549,7 +674,7 @@ __device__ __forceinline__ void block_argmin(Ctx & K, double & val, int & idx, i
     islot[K.wave] = idx;
     islot[16 + K.wave] = tag;
   }
-  __syncthreads();
+  lds_barrier();
   val = slot[0];
   idx = islot[0];
   tag = islot[16];
@@ -575,9 +700,7 @@ __device__ __forceinline__ double cstr_dot(const Ctx & K, int p, const double * 
   const int b = A.to_block[p], len = A.cvar[b];
   const double * c = K.cblk[b] + (size_t)(p - A.cum_cstr[b]) * A.cld[b];
   const double * w = v + A.cum_var[b];
-  double acc = 0.0;
-  for(int k = 0; k < len; ++k) acc = FMA(c[k], w[k], acc);
-  return acc;
+  return chain_neg8(0, 1, len, 0.0, [&](int k) { return -c[k]; }, [&](int k) { return w[k]; });
 }
 
 // =========================================================================================================
@@ -606,10 +729,22 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
   K.red = K.tri + kTri;
   K.ired = reinterpret_cast<int *>(K.red + 32);
   K.par = 0;
+  {
+    BlkMeta * bm = reinterpret_cast<BlkMeta *>(K.red + 32 + 32 + 8);
+    for(int b = tid; b < A.nblk; b += NT)
+    {
+      bm[b].diag = K.diag[b];
+      bm[b].side = (b < A.nblk - 1) ? K.side[b] : nullptr;
+      bm[b].bs = A.bs[b];
+      bm[b].boff = A.boff[b];
+      bm[b].ldd = A.ldd[b];
+      bm[b].lds = (b < A.nblk - 1) ? A.lds[b] : 0;
+    }
+    K.bm = bm;
+  }
   K.pool = A.pool + (size_t)pb * A.max_iter * A.row_len;
   K.Rp = A.Rp + (size_t)pb * A.rlen;
-  K.tau = A.tau + (size_t)pb * A.max_iter;
-  K.desc = A.desc + (size_t)pb * A.max_iter * 4;
+  K.desc = A.desc + (size_t)pb * A.max_iter;
   K.active = A.active + (size_t)pb * A.qcap;
   K.status = A.status + (size_t)pb * (m + nb);
   double *d = K.d, *z = K.z, *x = K.x, *u = K.u, *r = K.r;
@@ -621,6 +756,19 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
 
   int q = 0, nseq = 0, it = 0, rc = JRLQP_UNKNOWN;
   double f = 0.0;
+  // diagnostic phase timer (thread 0, 100 MHz wall clock): 0 init, 1 scan, 2 L^-1 n+, 3 Q^T d, 4 Q z, 5 L^-T z, 6 R solve,
+  // 7 step length, 8 update, 9 add, 10 drop
+  long long pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // 11, 12: reflectors / Givens sequences inside Q applications
+  long long tp = (A.prof && tid == 0) ? wall_clock64() : 0;
+  const long long cyc0 = clock64(), wall0 = tp;
+  auto stamp = [&](int slot) {
+    if(A.prof && tid == 0)
+    {
+      const long long t = wall_clock64();
+      pacc[slot] += t - tp;
+      tp = t;
+    }
+  };
 
   for(int i = tid; i < m + nb; i += NT) K.status[i] = JRLQP_INACTIVE;
   for(int i = tid; i < n; i += NT) x[i] = 0.0;
@@ -652,6 +800,7 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
   for(int i = tid; i < n; i += NT) x[i] = -x[i];
   __syncthreads();
   f = 0.5 * dot_tree<NT>(K, 0, n, [&](int e) { return a[e]; }, [&](int e) { return x[e]; });
+  stamp(0);
 
   // ---- DualSolver::solve loop (DualSolver.cpp:96-167) ----
   {
@@ -671,8 +820,8 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
           const int b = A.to_block[j], len = A.cvar[b];
           const double * c = K.cblk[b] + (size_t)(j - A.cum_cstr[b]) * A.cld[b];
           const double * w = x + A.cum_var[b];
-          double cx = 0.0;
-          for(int k = 0; k < len; ++k) cx = FMA(c[k], w[k], cx); // C^T x (StructuredC.cpp:66-77)
+          // C^T x (StructuredC.cpp:66-77); -(-a) is exact, so the shared eight-ahead chain helper is used on -c
+          const double cx = chain_neg8(0, 1, len, 0.0, [&](int k) { return -c[k]; }, [&](int k) { return w[k]; });
           const double sl = cx - bl[j];
           if(sl < bval)
           {
@@ -722,6 +871,7 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
         }
         if(tid == 0) u[q] = 0.0;
       }
+      stamp(1);
 
       // ---- computeStep_ (BlockGISolver.cpp:164-172) ----
       // d = Q^T L^-1 n+  (StructuredJ.cpp:43-57)
@@ -749,13 +899,18 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
         for(int i = tid; i < n; i += NT) d[i] = -d[i];
         __syncthreads();
       }
-      q_apply<NT, NCH, true>(K, d, nseq);
+      stamp(2);
+      q_apply<NT, NCH, true>(K, d, nseq, (A.prof && tid == 0) ? pacc + 11 : nullptr);
+      stamp(3);
       // z = L^-T Q [0; d2]  (StructuredJ.cpp:32-41)
       for(int i = tid; i < n; i += NT) z[i] = (i < q) ? 0.0 : d[i];
       __syncthreads();
-      q_apply<NT, NCH, false>(K, z, nseq);
+      q_apply<NT, NCH, false>(K, z, nseq, (A.prof && tid == 0) ? pacc + 11 : nullptr);
+      stamp(4);
       sg_ltsolve<NT>(K, z);
+      stamp(5);
       r_solve<NT>(K, q);
+      stamp(6);
 
       // ---- computeStepLength_ (BlockGISolver.cpp:174-242) ----
       double t1 = A.big_bnd, t2 = A.big_bnd;
@@ -797,6 +952,7 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
         __syncthreads(); // sh is reused
       }
       const double t = (t2 < t1) ? t2 : t1;
+      stamp(7);
 
       if(trace && it < A.trace_cap && tid == 0)
       {
@@ -833,6 +989,7 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
         drop = !(t == t2);
       }
       __syncthreads();
+      stamp(8);
 
       if(!drop)
       {
@@ -860,12 +1017,7 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
         {
           row[q] = 1.0;
           RP(K.Rp, q, q) = beta;
-          K.tau[nseq] = tau;
-          int * ds = K.desc + 4 * (size_t)nseq;
-          ds[0] = 0;
-          ds[1] = q;
-          ds[2] = 1;
-          ds[3] = 0;
+          K.desc[nseq] = SeqRec{0, q, 1, 0, tau, 0.0};
           K.status[p] = pst;
           K.active[q] = p;
         }
@@ -873,6 +1025,7 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
         ++nseq;
         skip_step1 = false;
         __syncthreads();
+        stamp(9);
       }
       else
       {
@@ -957,17 +1110,13 @@ __global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
         }
         if(tid == 0)
         {
-          int * ds = K.desc + 4 * (size_t)nseq;
-          ds[0] = 1;
-          ds[1] = sz ? l : 0;
-          ds[2] = sz;
-          ds[3] = 0;
-          K.tau[nseq] = 0.0;
+          K.desc[nseq] = SeqRec{1, sz ? l : 0, sz, 0, 0.0, 0.0};
         }
         q = q1;
         ++nseq;
         skip_step1 = true;
         __syncthreads();
+        stamp(10);
       }
     }
   }
@@ -992,6 +1141,12 @@ done:
       A.term[pb] = rc;
       A.iters[pb] = it;
       A.f[pb] = f;
+      if(A.prof)
+        {
+          for(int i = 0; i < 13; ++i) A.prof[(size_t)pb * 16 + i] = pacc[i];
+          A.prof[(size_t)pb * 16 + 13] = clock64() - cyc0;       // core clock cycles
+          A.prof[(size_t)pb * 16 + 14] = wall_clock64() - wall0; // 100 MHz ticks
+        }
     }
   }
 }
@@ -1007,19 +1162,21 @@ hipError_t launch_one(const BgiArgs & a, int nprob, size_t lds, hipStream_t st)
 }
 } // namespace
 
-long blockgi_lds_bytes(int n, int m, int nb)
+long blockgi_lds_bytes(int n, int m, int nb, int nblk)
 {
   const int n_pad = (n + 3) & ~3;
   int qcap = (n < m + nb ? n : m + nb) + 1;
   qcap = (qcap + 3) & ~3;
-  return (long)sizeof(double) * (3L * n_pad + 2L * qcap + kTri + 32 + 32 + 8);
+  return (long)sizeof(double) * (3L * n_pad + 2L * qcap + kTri + 32 + 32 + 8) + (long)sizeof(BlkMeta) * nblk;
 }
 
 hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t st)
 {
-  const size_t lds = (size_t)blockgi_lds_bytes(a.n, a.m, a.nb);
+  const size_t lds = (size_t)blockgi_lds_bytes(a.n, a.m, a.nb, a.nblk);
+  // four waves per problem up to 1024 unknowns; eight beyond (the block-parallel phases -- L^-T over ~100 blocks,
+  // the constraint scan -- and the per-reflector work scale with the wave count; rule C4 does not depend on it)
   if(a.n <= 1024) return launch_one<256, 1>(a, nprob, lds, st);
-  if(a.n <= 2048) return launch_one<256, 2>(a, nprob, lds, st);
-  return launch_one<256, 3>(a, nprob, lds, st);
+  if(a.n <= 2048) return launch_one<512, 2>(a, nprob, lds, st);
+  return launch_one<512, 3>(a, nprob, lds, st);
 }
 } // namespace jrlqp

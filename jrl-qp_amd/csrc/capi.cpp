@@ -49,8 +49,9 @@ struct jrlqp_blockgi
   std::vector<const double *> h_cblk;
   int *d_boff = nullptr, *d_cvar = nullptr, *d_ccstr = nullptr, *d_cumv = nullptr, *d_cumc = nullptr, *d_toblk = nullptr, *d_cld = nullptr;
   const double ** d_cblk = nullptr;
-  double *d_pool = nullptr, *d_Rp = nullptr, *d_tau = nullptr;
-  int *d_desc = nullptr, *d_active = nullptr;
+  double *d_pool = nullptr, *d_Rp = nullptr;
+  jrlqp::SeqRec * d_desc = nullptr;
+  int * d_active = nullptr;
   size_t ws_bytes = 0;
   bool bound = false;
 };
@@ -351,7 +352,7 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   if(ncb > 0 && nv != n) return JRLQP_ERR_INVALID_ARGUMENT; // StructuredC::nbVar() == G.nbVar() (BlockGISolver.cpp:35)
   if(n > jrlqp::kBgiMaxN) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const int nb = use_bounds ? n : 0;
-  if(jrlqp::blockgi_lds_bytes(n, m, nb) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  if(jrlqp::blockgi_lds_bytes(n, m, nb, nblk) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
   jrlqp_blockgi * h = new(std::nothrow) jrlqp_blockgi;
   if(!h) return JRLQP_ERR_WORKSPACE;
   int rc = jrlqp_blocks_create(kind, nblk, block_sizes, nprob, 1, &h->blocks);
@@ -397,8 +398,7 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   if(e == hipSuccess) e = hipMalloc(&h->d_cblk, sizeof(double *) * (size_t)nprob * nc);
   if(e == hipSuccess) e = hipMalloc(&h->d_pool, pool_b);
   if(e == hipSuccess) e = hipMalloc(&h->d_Rp, r_b);
-  if(e == hipSuccess) e = hipMalloc(&h->d_tau, sizeof(double) * (size_t)nprob * max_iter);
-  if(e == hipSuccess) e = hipMalloc(&h->d_desc, sizeof(int) * 4 * (size_t)nprob * max_iter);
+  if(e == hipSuccess) e = hipMalloc(&h->d_desc, sizeof(jrlqp::SeqRec) * (size_t)nprob * max_iter);
   if(e == hipSuccess) e = hipMalloc(&h->d_active, sizeof(int) * (size_t)nprob * h->qcap);
   if(e == hipSuccess) e = hipMemcpy(h->d_boff, boff.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
   if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_cvar, cvar, sizeof(int) * ncb, hipMemcpyHostToDevice);
@@ -411,7 +411,7 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
     jrlqp_blockgi_destroy(h);
     return hip_fail(e);
   }
-  h->ws_bytes = pool_b + r_b + (sizeof(double) + 4 * sizeof(int)) * (size_t)nprob * max_iter + sizeof(int) * (size_t)nprob * h->qcap;
+  h->ws_bytes = pool_b + r_b + sizeof(jrlqp::SeqRec) * (size_t)nprob * max_iter + sizeof(int) * (size_t)nprob * h->qcap;
   *out = h;
   return JRLQP_OK;
 }
@@ -422,7 +422,7 @@ void jrlqp_blockgi_destroy(jrlqp_blockgi * h)
   jrlqp_blocks_destroy(h->blocks);
   (void)hipFree(h->d_boff); (void)hipFree(h->d_cvar); (void)hipFree(h->d_ccstr); (void)hipFree(h->d_cumv); (void)hipFree(h->d_cumc);
   (void)hipFree(h->d_toblk); (void)hipFree(h->d_cld); (void)hipFree(h->d_cblk); (void)hipFree(h->d_pool); (void)hipFree(h->d_Rp);
-  (void)hipFree(h->d_tau); (void)hipFree(h->d_desc); (void)hipFree(h->d_active);
+  (void)hipFree(h->d_desc); (void)hipFree(h->d_active);
   delete h;
 }
 
@@ -476,9 +476,10 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.a = da; a.bl = dbl; a.bu = dbu; a.xl = dxl; a.xu = dxu;
   a.max_iter = o.max_iter; a.big_bnd = o.big_bnd;
   a.n_pad = h->n_pad; a.qcap = h->qcap; a.row_len = h->row_len;
-  a.pool = h->d_pool; a.Rp = h->d_Rp; a.rlen = h->rlen; a.tau = h->d_tau; a.desc = h->d_desc; a.active = h->d_active;
+  a.pool = h->d_pool; a.Rp = h->d_Rp; a.rlen = h->rlen; a.desc = h->d_desc; a.active = h->d_active;
   a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
   a.trace = dtrace; a.trace_cap = dtrace ? trace_cap : 0;
+  a.prof = g_prof.load();
   hipError_t e = jrlqp::launch_blockgi(a, h->nprob, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }

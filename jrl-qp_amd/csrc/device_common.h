@@ -19,6 +19,14 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for exchanges that go through LDS only: waits for this wave's LDS traffic, NOT for its outstanding
+// global loads (__syncthreads() carries a release fence, i.e. s_waitcnt vmcnt(0): every prefetch in flight would be
+// drained at each reduction).  Global data produced for other waves still needs __syncthreads().
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // value of v in lane `src` (src wave-uniform): two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double bcast_lane(double v, int src)
 {
@@ -48,6 +56,15 @@ __device__ __forceinline__ double dpp_mov_d(double v)
 {
   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// DPP move with a fallback value: lanes whose source lane does not exist (wave shifts: the first / last lane) get `old`
+template<int CTRL>
+__device__ __forceinline__ double dpp_shift_d(double v, double old)
+{
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -131,32 +148,148 @@ __device__ __forceinline__ double givens_r_only(double p, double q)
   return (hi == 0.0) ? 0.0 : r;
 }
 
+// Division with the denominator-only part hoisted.  hipcc expands a/b (f64) into
+//   s0 = div_scale(b,b,a); r = rcp(s0); two Newton steps on r; s1 = div_scale(a,b,a); q0 = s1*r; e = fma(-s0,q0,s1);
+//   q = div_fmas(e, r, q0); div_fixup(q, b, a)
+// and div_scale / div_fmas / div_fixup are identities unless an operand is zero/denormal/huge (exponent beyond
+// +-768 or so).  Inside the safe range below the quotient is therefore exactly fma(e, r, q0) with r depending on the
+// DENOMINATOR ONLY: a substitution chain can precompute r for all its pivots at once (one lane per pivot) and keep
+// three dependent ops per step instead of thirteen.  Outside the safe range the caller falls back to a/b, so the
+// result is bit-identical to the plain division in every case.
+__device__ __forceinline__ double recip_refined(double den)
+{
+  double r = __builtin_amdgcn_rcp(den);
+  double e = FMA(-den, r, 1.0);
+  r = FMA(r, e, r);
+  e = FMA(-den, r, 1.0);
+  r = FMA(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_pre(double num, double den, double rinv)
+{
+  const double q0 = num * rinv;
+  const double e = FMA(-den, q0, num);
+  return FMA(e, rinv, q0);
+}
+__device__ __forceinline__ bool div_safe_den(double d)
+{
+  const double a = fabs(d);
+  return a > 0x1p-400 && a < 0x1p400;
+}
+__device__ __forceinline__ bool div_safe_num(double v)
+{
+  const double a = fabs(v);
+  return (a > 0x1p-400 && a < 0x1p400) || v == 0.0;
+}
+
+
 // ---- wave-level substitutions on one block (shared by the structured Cholesky family and the structured GI loop) ----
-// x (n) <- L^-1 x for one right-hand side held one element per lane (forward substitution, column oriented)
+constexpr int kAhead = 16; // operands of a dependent chain are requested this many steps ahead (one HBM/L2 latency per group)
+
+// x (n <= 64) <- L^-1 x, one element per lane (forward substitution, column oriented; Eigen triangularView<Lower>::
+// solveInPlace call sites blockArrowLLT.cpp:139,151, triBlockDiagLLT.cpp:77,87).  L is read from HBM/L2: the column
+// entries are fetched kAhead steps ahead with unconditional (in-footprint) loads so that one memory latency is paid
+// per group, and the pivots' reciprocals are hoisted (div_pre): ~4 dependent fp64 ops per step instead of ~14.
+// A post-hoc range check licenses the hoisted reciprocals; outside it the chain is redone with plain a/b.
 __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, double xi, int lane)
 {
-  for(int k = 0; k < n; ++k)
+  const bool act = lane < n;
+  const int rl = act ? lane : 0;
+  const double dg = (n > 0) ? AT(L, ldl, rl, rl) : 1.0;
+  const double rinv = recip_refined(dg);
+  const double x0 = xi;
+  double pre = 0.0;
+  for(int k0 = 0; k0 < n; k0 += kAhead)
   {
-    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
-    if(lane == k)
-      xi = v;
-    else if(lane > k && lane < n)
-      xi = FMA(-AT(L, ldl, lane, k), v, xi);
+    double lv[kAhead];
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j) lv[j] = AT(L, ldl, rl, min(k0 + j, n - 1));
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j)
+    {
+      const int k = k0 + j;
+      if(k < n)
+      {
+        const double v = div_pre(bcast_lane(xi, k), bcast_lane(dg, k), bcast_lane(rinv, k));
+        const double upd = FMA(-lv[j], v, xi);
+        pre = (lane == k) ? xi : pre;
+        xi = (act && lane > k) ? upd : xi;
+        xi = (lane == k) ? v : xi;
+      }
+    }
+  }
+  if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
+  {
+    xi = x0;
+    for(int k = 0; k < n; ++k)
+    {
+      const double v = bcast_lane(xi, k) / bcast_lane(dg, k);
+      if(lane == k)
+        xi = v;
+      else if(lane > k && act)
+        xi = FMA(-AT(L, ldl, rl, k), v, xi);
+    }
   }
   return xi;
 }
-// x <- L^-T x (backward substitution)
+// x <- L^-T x (backward substitution; call sites blockArrowLLT.cpp:211,241,248, triBlockDiagLLT.cpp:139,149)
 __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, double xi, int lane)
 {
-  for(int k = n - 1; k >= 0; --k)
+  const bool act = lane < n;
+  const int rl = act ? lane : 0;
+  const double dg = (n > 0) ? AT(L, ldl, rl, rl) : 1.0;
+  const double rinv = recip_refined(dg);
+  const double x0 = xi;
+  double pre = 0.0;
+  for(int k0 = n - 1; k0 >= 0; k0 -= kAhead)
   {
-    double v = bcast_lane(xi, k) / AT(L, ldl, k, k);
-    if(lane == k)
-      xi = v;
-    else if(lane < k)
-      xi = FMA(-AT(L, ldl, k, lane), v, xi);
+    double lv[kAhead];
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j) lv[j] = AT(L, ldl, max(k0 - j, 0), rl);
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j)
+    {
+      const int k = k0 - j;
+      if(k >= 0)
+      {
+        const double v = div_pre(bcast_lane(xi, k), bcast_lane(dg, k), bcast_lane(rinv, k));
+        const double upd = FMA(-lv[j], v, xi);
+        pre = (lane == k) ? xi : pre;
+        xi = (lane < k) ? upd : xi;
+        xi = (lane == k) ? v : xi;
+      }
+    }
+  }
+  if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
+  {
+    xi = x0;
+    for(int k = n - 1; k >= 0; --k)
+    {
+      const double v = bcast_lane(xi, k) / bcast_lane(dg, k);
+      if(lane == k)
+        xi = v;
+      else if(lane < k)
+        xi = FMA(-AT(L, ldl, k, rl), v, xi);
+    }
   }
   return xi;
+}
+
+// acc <- fma(-a(k), b(k), acc) for k = k0, k0 + step, ... (cnt terms, in that order): the a() operands (HBM/L2) are
+// fetched kAhead terms ahead with unconditional loads (the index is clamped into the valid range)
+template<class FA, class FB>
+__device__ __forceinline__ double chain_neg8(int k0, int step, int cnt, double acc, FA fa, FB fb)
+{
+  for(int c0 = 0; c0 < cnt; c0 += kAhead)
+  {
+    double av[kAhead];
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j) av[j] = fa(k0 + step * min(c0 + j, cnt - 1));
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j)
+      if(c0 + j < cnt) acc = FMA(-av[j], fb(k0 + step * (c0 + j)), acc);
+  }
+  return acc;
 }
 
 // logical diagonal block i of get<Up> (blockArrowLLT.cpp:22-46)

@@ -180,40 +180,6 @@ __device__ __forceinline__ void givens_cs(const GivensHalf & h, double & c, doub
   }
 }
 
-// Division with the denominator-only part hoisted.  hipcc expands a/b (f64) into
-//   s0 = div_scale(b,b,a); r = rcp(s0); two Newton steps on r; s1 = div_scale(a,b,a); q0 = s1*r; e = fma(-s0,q0,s1);
-//   q = div_fmas(e, r, q0); div_fixup(q, b, a)
-// and div_scale / div_fmas / div_fixup are identities unless an operand is zero/denormal/huge (exponent beyond
-// +-768 or so).  Inside the safe range below the quotient is therefore exactly fma(e, r, q0) with r depending on the
-// DENOMINATOR ONLY: a substitution chain can precompute r for all its pivots at once (one lane per pivot) and keep
-// three dependent ops per step instead of thirteen.  Outside the safe range the caller falls back to a/b, so the
-// result is bit-identical to the plain division in every case.
-__device__ __forceinline__ double recip_refined(double den)
-{
-  double r = __builtin_amdgcn_rcp(den);
-  double e = FMA(-den, r, 1.0);
-  r = FMA(r, e, r);
-  e = FMA(-den, r, 1.0);
-  r = FMA(r, e, r);
-  return r;
-}
-__device__ __forceinline__ double div_pre(double num, double den, double rinv)
-{
-  const double q0 = num * rinv;
-  const double e = FMA(-den, q0, num);
-  return FMA(e, rinv, q0);
-}
-__device__ __forceinline__ bool div_safe_den(double d)
-{
-  const double a = fabs(d);
-  return a > 0x1p-400 && a < 0x1p400;
-}
-__device__ __forceinline__ bool div_safe_num(double v)
-{
-  const double a = fabs(v);
-  return (a > 0x1p-400 && a < 0x1p400) || v == 0.0;
-}
-
 // minimum over the 64 lanes, every lane gets it: four DPP exchanges inside each row of 16, then the four row
 // minima through readlane -- no LDS crossbar (ds_bpermute) round trips
 template<int CTRL>
