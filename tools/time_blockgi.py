@@ -77,12 +77,12 @@ if what in ("all", "ik"):
             ms, iters, term, ws = gpu_time([qp] * B, 64)
             print(f"{name}: batch {B:4d}: GPU {ms:8.3f} ms ({ms / B * 1e3:8.1f} us/problem, {B / ms * 1e3:9.0f} solves/s) iters {iters[0]} term {term[0]};  "
                   f"CPU oracle structured {cs:.3f} ms, dense {cd:.3f} ms (1 core)", flush=True)
-if what in ("all", "c5"):
+if what in ("all", "c5", "c5b64"):
     for sa in (1.0,):
         base = [SP.mpc_arrow_qp(100, 30, 10, seed=s, scale_a=sa) for s in range(2)]
         cs, it = cpu_time(base[0], 1000)
         print(f"c5 (n=3030, m=1000, scale_a={sa}): CPU oracle structured {cs:.1f} ms, {it} iterations (dense oracle: ~50 s)", flush=True)
-        for B in (1, 16, 64):
+        for B in ((64,) if what == "c5b64" else (1, 16, 64)):
             qps = (base * B)[:B]
             ms, iters, term, ws = gpu_time(qps, 1000, reps=3)
             print(f"   batch {B:3d}: GPU {ms:9.2f} ms  ({ms / B:8.2f} ms/problem, {B / ms * 1e3:7.1f} solves/s)  iters {iters[:2]} term {term[:2]}  "
