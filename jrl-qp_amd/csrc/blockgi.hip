@@ -363,7 +363,9 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
   // one reflector costs far less than one memory latency: the rows and descriptors of the next DEPTH elements are kept
   // in flight in a register ring.  Row addresses depend on the element index only, and whole 4-packs inside the row are
   // loaded unconditionally (entries above `st` are unused garbage, masked below).
-  constexpr int DEPTH = (24 / (NCH * VPT)) > 6 ? 6 : (24 / (NCH * VPT)) < 2 ? 2 : (24 / (NCH * VPT)); // two rings of <= 24 doubles per thread
+  // two rings of DEPTH rows: <= 24 doubles per thread each for the large shapes; 12 for n <= 1024, where registers decide
+  // how many problems share a CU
+  constexpr int DEPTH = (NCH == 1) ? 3 : ((24 / (NCH * VPT)) > 6 ? 6 : (24 / (NCH * VPT)) < 2 ? 2 : (24 / (NCH * VPT)));
   double ring[DEPTH][NCH][VPT];
   int rkind[DEPTH], rst[DEPTH], rsz[DEPTH];
   double rtau[DEPTH];
@@ -707,7 +709,7 @@ __device__ __forceinline__ double cstr_dot(const Ctx & K, int p, const double * 
 // the kernel
 // =========================================================================================================
 template<int NT, int NCH>
-__global__ __launch_bounds__(NT) void blockgi_kernel(const BgiArgs A)
+__global__ __launch_bounds__(NT, (NT == 256) ? 3 : 0) void blockgi_kernel(const BgiArgs A)
 {
   extern __shared__ double sm[];
   const int pb = blockIdx.x, tid = threadIdx.x;

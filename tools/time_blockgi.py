@@ -73,7 +73,7 @@ if what in ("all", "ik"):
     tri, arr = fixtures()
     for name, qp in (("MultiIK tri-block 9x43 m=1621", tri), ("MultiIK arrow-up 5x42 m=25+box", arr)):
         cs, it = cpu_time(qp, 500); cd, _ = cpu_time(qp, 500, dense=True)
-        for B in (1, 256):
+        for B in (1, 256, 1024):
             ms, iters, term, ws = gpu_time([qp] * B, 64)
             print(f"{name}: batch {B:4d}: GPU {ms:8.3f} ms ({ms / B * 1e3:8.1f} us/problem, {B / ms * 1e3:9.0f} solves/s) iters {iters[0]} term {term[0]};  "
                   f"CPU oracle structured {cs:.3f} ms, dense {cd:.3f} ms (1 core)", flush=True)
