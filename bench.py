@@ -83,6 +83,90 @@ def cpu_baseline(pb, budget_s=12.0):
     }
 
 
+def bench_structured(args, rank, world, device, jdist):
+    """Secondary workload (BASELINE config c5): a batch of structured QPs -- block-arrow Hessian (100 stage blocks of 30 +
+    head), block-diagonal C with 10 one-sided constraints per stage -- through jrlqp_blockgi_solve (factorisation + the
+    device-resident structured GI loop).  A step = one batch; each rank owns its own shard (weak scaling).  The metric of
+    this line is structured-GI solves/s; roofline: HBM, algorithmic bytes = the reflector rows both Q applications of
+    every iteration read + inputs + outputs."""
+    import numpy as np
+    import torch
+
+    import jrl_qp_amd.capi as capi
+    import jrl_qp_amd.structured_problems as SP
+
+    B = args.batch if args.batch != BATCH else 256  # one problem per CU
+    lo, hi = jdist.shard_range(B * world, rank, world)
+    base = [SP.mpc_arrow_qp(100, 30, 10, seed=s, scale_a=1.0) for s in range(2)]
+    q0 = base[0]
+    n, m = q0.n, q0.m
+    idx = torch.tensor([(lo + i) % 2 for i in range(hi - lo)], device=device)  # two distinct problems, tiled on the device
+    dev2 = lambda f: torch.tensor(np.stack([f(q) for q in base]), device=device)[idx].contiguous()
+    H0 = dev2(lambda q: np.ascontiguousarray(q.G.T))
+    Cb = dev2(lambda q: np.concatenate([c.ravel(order="F") for c in q.Cblocks]))
+    a, bl, bu = dev2(lambda q: q.a), dev2(lambda q: q.bl), dev2(lambda q: q.bu)
+    solver = capi.BlockGISolver("arrow_down", q0.bs, [c.shape for c in q0.Cblocks], False, hi - lo, max_iter=1000, device=device)
+    H = H0.clone()
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        H.copy_(H0)  # the solver factorises G in place (like the reference): restored outside the kernel timing events
+        solver._bind(H, Cb)
+        return solver.solve(H, a, Cb, bl, bu)
+
+    for _ in range(max(args.warmup, 1)):
+        r = step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    steps = min(args.steps, 5)
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        H.copy_(H0)
+        solver._bind(H, Cb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r = solver.solve(H, a, Cb, bl, bu)
+        e1.record(stream)
+        torch.cuda.synchronize(device)
+        kern_ms.append(e0.elapsed_time(e1))
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    iters = r.iters.cpu().numpy()
+    term = r.term.cpu().numpy()
+    n_ok, sum_it, elapsed = jdist.reduce_stats(int((term == 0).sum()), int(iters.sum()), elapsed, device=device)
+    if rank == 0:
+        total = B * world
+        # algorithmic bytes: iteration k (k elements in the orthonormal sequence) reads ~k reflector rows of n doubles twice
+        rows = float(sum(int(i) * (int(i) - 1) for i in iters))  # 2 * sum_{k<iters} k
+        alg = rows * n * 8 + (hi - lo) * (8.0 * (q0.G.size * 0 + 201 * 900 + n + 1000 * 30 + 2 * m) + 8 * (n + m) + 4 * m + 16)
+        avg_s = float(np.mean(kern_ms)) * 1e-3
+        traffic = None
+        try:
+            traffic = float(json.load(open(os.path.join(ROOT, "profiles", "r1_blockgi_c5_batch64_traffic.json")))["traffic_bytes_per_launch_fetch_x2_plus_write"]) if hi - lo == 64 else None
+        except Exception:
+            pass
+        out = {
+            "metric": "structured GI QP solves/sec, block arrow 100x30+30 (n=3030, m=1000), batch per GPU",
+            "value": total * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4] (c5) as a batch: {B} structured QPs per GPU, block arrow (down) 100 stage blocks of 30 + head, "
+                                   f"10 one-sided constraints per stage, through jrlqp_blockgi_solve (in-place block LLT + device-resident "
+                                   f"structured GI loop); wall time includes restoring G before each solve",
+                       "batch_per_gpu": B, "mean_iterations": sum_it / total, "solved": n_ok},
+            "roofline": {"bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "blockgi_kernel<512,3>", "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3,
+                         "note": "algorithmic bytes = reflector rows read by the two Q applications of every iteration; a single CU per problem is "
+                                 "instruction-issue/barrier bound (DESIGN.md 7.3)"},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +176,9 @@ def main():
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--m", type=int, default=M_INEQ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+                    help="c3 (default, the BASELINE metric): batch of dense QPs; c5: batch of structured block-arrow QPs "
+                         "(100 stages x 30 + head, 10 constraints per stage) through the structured GI solver")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from separate rocprofv3 --pmc passes (default: profiles/r1_pmc_traffic.json if it matches)")
     args = ap.parse_args()
@@ -112,6 +199,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
+
+    if args.workload == "c5":
+        return bench_structured(args, rank, world, device, jdist)
 
     n, m, B = args.n, args.m, args.batch
     total = B * world

@@ -80,10 +80,12 @@ def _pattern(rng, bs, kind):
     return A
 
 
-def random_structured_qp(kind, bs, mc, seed, double_sided=True, ridge=0.0) -> StructuredQP:
+def random_structured_qp(kind, bs, mc, seed, double_sided=True, ridge=0.0, cbs=None, box=None) -> StructuredQP:
     """G with the requested block structure (tri: A A^T, arrows: A^T A, as the reference's tests), a ~ U[-1,1],
     per-block constraints C_i (n_i x mc[i]) from the planted-solution generator with no objective
-    (ProblemCharacteristics(n_i, 0, 0, m_i).doubleSidedIneq(true), BlockGISolverTest.in.cpp:93-101)."""
+    (ProblemCharacteristics(n_i, 0, 0, m_i).doubleSidedIneq(true), BlockGISolverTest.in.cpp:93-101).
+    cbs: row partition of the block-diagonal C when it is NOT the partition of G (StructuredC only needs the totals to
+    match: constraint windows then straddle blocks of G); box: half-width of box bounds xl = -box, xu = +box, or None."""
     rng = np.random.default_rng(seed)
     A = _pattern(rng, bs, kind)
     G = A @ A.T if kind == "tri" else A.T @ A
@@ -93,7 +95,8 @@ def random_structured_qp(kind, bs, mc, seed, double_sided=True, ridge=0.0) -> St
     G = np.asfortranarray(0.5 * (G + G.T))
     a = rng.uniform(-1, 1, n)
     Cb, bl, bu = [], [], []
-    for ni, mi in zip(bs, mc):
+    assert cbs is None or sum(cbs) == sum(bs)
+    for ni, mi in zip(bs if cbs is None else cbs, mc):
         if mi == 0:
             Cb.append(np.zeros((ni, 0), order="F"))
             continue
@@ -102,7 +105,10 @@ def random_structured_qp(kind, bs, mc, seed, double_sided=True, ridge=0.0) -> St
         Cb.append(np.asfortranarray(pb.C.T))
         bl.append(pb.l)
         bu.append(pb.u)
-    return StructuredQP(kind, list(bs), G, a, Cb, np.concatenate(bl), np.concatenate(bu), meta=dict(seed=seed))
+    xl = xu = None
+    if box is not None:
+        xl, xu = np.full(n, -float(box)), np.full(n, float(box))
+    return StructuredQP(kind, list(bs), G, a, Cb, np.concatenate(bl), np.concatenate(bu), xl, xu, meta=dict(seed=seed))
 
 
 def mpc_arrow_qp(nstage=100, nx=30, mc=10, seed=0, scale_a=4.0) -> StructuredQP:

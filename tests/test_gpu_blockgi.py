@@ -87,6 +87,14 @@ def test_wider_problems_bit_exact(oracle, SP, capi, kind, bs, mc):
     check_batch(oracle, SP, capi, qps, min_iters=100)
 
 
+@pytest.mark.parametrize("kind", ["tri", "arrow_up", "arrow_down"])
+def test_unaligned_c_blocks_and_box_bounds_bit_exact(oracle, SP, capi, kind):
+    """C blocks that do not follow G's partition (windows straddle blocks of G) + bound constraints."""
+    qps = [SP.random_structured_qp(kind, [6, 9, 4, 7, 5], [5, 7, 6], 300 + seed, ridge=0.05, cbs=[10, 8, 13], box=1.0) for seed in range(12)]
+    g = check_batch(oracle, SP, capi, qps, min_iters=60)
+    assert (g["status"][:, qps[0].m :] != 0).any()
+
+
 def test_sequential_ik_fixture(oracle, SP, capi):
     """BlockGISolverTest.in.cpp:172-227 (tri-block 9 x 43, m = 1621)."""
     d = read_tri_block_diag()

@@ -88,6 +88,21 @@ def test_wider_problems_match_dense(oracle, SP, K, kind, bs, mc):
         assert K.test_kkt(rs.x, rs.u, qp.G, qp.a, qp.dense_C(), qp.bl, qp.bu)
 
 
+@pytest.mark.parametrize("kind", ["tri", "arrow_up", "arrow_down"])
+def test_unaligned_c_blocks_and_box_bounds(oracle, SP, K, kind):
+    """StructuredC only has to cover the same unknowns as G (BlockGISolver.cpp:35): constraint windows that straddle
+    blocks of G, and bound constraints (single-entry normals, StructuredJ.cpp:51-55)."""
+    nb_active = 0
+    for seed in range(8):
+        qp = SP.random_structured_qp(kind, [6, 9, 4, 7, 5], [5, 7, 6], 300 + seed, ridge=0.05, cbs=[10, 8, 13], box=1.0)
+        rd, rs, _, _ = solve_both(oracle, SP, qp)
+        assert rs.term == rd.term == 0
+        assert is_approx(rs.x, rd.x) and np.array_equal(rs.status, rd.status) and rs.iters == rd.iters
+        assert K.test_kkt(rs.x, rs.u, qp.G, qp.a, qp.dense_C(), qp.bl, qp.bu, qp.xl, qp.xu)
+        nb_active += int((rs.status[qp.m :] != 0).sum())
+    assert nb_active > 0  # bounds really get activated
+
+
 def test_sequential_ik_fixture(oracle, SP, K):
     """BlockGISolverTest.in.cpp:172-227."""
     d = read_tri_block_diag()
