@@ -82,6 +82,11 @@ def load_library() -> ct.CDLL:
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise JrlqpError(f"{LIB_PATH} not found: the HIP extension is not built (no CPU fallback exists)")
+    # torch first: the process must end up with ONE HIP runtime.  torch ships its own libamdhip64; if this library were
+    # dlopen'ed before torch, it would bind the system runtime and every launch on torch-allocated memory would fail
+    # (hipErrorNoDevice) -- torch is what the callers use for device memory and streams anyway.
+    import torch  # noqa: F401
+
     lib = ct.CDLL(LIB_PATH)
     for name in EXPORTED:
         if not hasattr(lib, name):
