@@ -138,3 +138,27 @@ def test_mpc_arrow_c5_full_size(oracle, SP, capi):
     qp = SP.mpc_arrow_qp(nstage=100, nx=30, mc=10, seed=0, scale_a=1.0)
     g = check_batch(oracle, SP, capi, [qp], max_iter=1000, min_iters=300)
     assert g["term"][0] == 0
+
+
+def test_fuzz_shapes_bit_exact(oracle, SP, capi):
+    """Random structure / block partition / constraint partition / bounds mixes, small batches each: every output bit for bit."""
+    rng = np.random.default_rng(2026)
+    tot_iters = tot_drops = 0
+    for case in range(24):
+        kind = ["tri", "arrow_up", "arrow_down"][case % 3]
+        nblk = int(rng.integers(2, 7))
+        bs = [int(v) for v in rng.integers(1, 12, nblk)]
+        n = sum(bs)
+        if case % 2:  # C follows its own partition of the unknowns
+            cuts = np.sort(rng.choice(np.arange(1, n), size=min(int(rng.integers(1, 4)), n - 1), replace=False)) if n > 1 else np.array([], int)
+            cbs = [int(v) for v in np.diff(np.concatenate([[0], cuts, [n]]))]
+        else:
+            cbs = list(bs)
+        mc = [int(rng.integers(0, 2 * c + 2)) for c in cbs]
+        if sum(mc) == 0:
+            mc[0] = 2
+        box = [None, 1.0, 0.8][case % 3] if case % 4 else None
+        qps = [SP.random_structured_qp(kind, bs, mc, 5000 + 10 * case + k, ridge=0.05, cbs=cbs, box=box, double_sided=bool(case % 5)) for k in range(4)]
+        g = check_batch(oracle, SP, capi, qps)
+        tot_iters += int(g["iters"].sum())
+    assert tot_iters > 200
