@@ -292,6 +292,29 @@ __device__ __forceinline__ double chain_neg8(int k0, int step, int cnt, double a
   return acc;
 }
 
+// same with BOTH operand streams fetched ahead (operands in LDS: a dependent loop that reads, waits and fmas one term at
+// a time pays one LDS round trip per term; eight terms in flight hide it)
+template<class FA, class FB>
+__device__ __forceinline__ double chain2_neg(int k0, int step, int cnt, double acc, FA fa, FB fb)
+{
+  constexpr int W = 8;
+  for(int c0 = 0; c0 < cnt; c0 += W)
+  {
+    double av[W], bv[W];
+#pragma unroll
+    for(int j = 0; j < W; ++j)
+    {
+      const int k = k0 + step * min(c0 + j, cnt - 1);
+      av[j] = fa(k);
+      bv[j] = fb(k);
+    }
+#pragma unroll
+    for(int j = 0; j < W; ++j)
+      if(c0 + j < cnt) acc = FMA(-av[j], bv[j], acc);
+  }
+  return acc;
+}
+
 // logical diagonal block i of get<Up> (blockArrowLLT.cpp:22-46)
 __device__ __forceinline__ int dsel(int nblk, int up, int i)
 {

@@ -33,10 +33,11 @@ __device__ int wave_llt(double * L, int ld, int n, int lane)
   for(int j = 0; j < n; ++j)
   {
     double acc = 0.0;
-    if(lane >= j && lane < n)
     {
-      acc = AT(L, ld, lane, j);
-      for(int k = 0; k < j; ++k) acc = FMA(-AT(L, ld, lane, k), AT(L, ld, j, k), acc);
+      // (every lane runs the chain on a valid row: no divergent LDS traffic; rows outside [j, n) are discarded)
+      const int rl = (lane >= j && lane < n) ? lane : j;
+      acc = chain2_neg(0, 1, j, AT(L, ld, rl, j), [&](int k) { return AT(L, ld, rl, k); }, [&](int k) { return AT(L, ld, j, k); });
+      acc = (lane >= j && lane < n) ? acc : 0.0;
     }
     double piv = bcast_lane(acc, j);
     if(piv <= 0.0) return j;
@@ -56,8 +57,8 @@ __device__ void wave_trsm_right_lt(const double * L, int ldl, int n, double * X,
   if(lane < r)
     for(int j = 0; j < n; ++j)
     {
-      double s = AT(X, ldx, lane, j);
-      for(int k = 0; k < j; ++k) s = FMA(-AT(X, ldx, lane, k), AT(L, ldl, j, k), s);
+      const double s = chain2_neg(0, 1, j, AT(X, ldx, lane, j), [&](int k) { return AT(X, ldx, lane, k); },
+                                  [&](int k) { return AT(L, ldl, j, k); });
       AT(X, ldx, lane, j) = s / AT(L, ldl, j, j);
     }
 }
@@ -188,12 +189,10 @@ __global__ __launch_bounds__(256) void arrow_head_kernel(const BlockDesc D)
       const int r = e % nbk, c = e / nbk;
       if(e < nbk * nbk && r >= c)
       {
-        double a = acc[s];
-        if(!D.up)
-          for(int k = 0; k < ni; ++k) a = FMA(-Bs[r + k * 65], Bs[c + k * 65], a); // B_i(r,k) B_i(c,k)
-        else
-          for(int k = 0; k < ni; ++k) a = FMA(-Bs[k + r * 65], Bs[k + c * 65], a); // side stores B_i^T
-        acc[s] = a;
+        if(!D.up) // B_i(r,k) B_i(c,k)
+          acc[s] = chain2_neg(0, 1, ni, acc[s], [&](int k) { return Bs[r + k * 65]; }, [&](int k) { return Bs[c + k * 65]; });
+        else // side stores B_i^T
+          acc[s] = chain2_neg(0, 1, ni, acc[s], [&](int k) { return Bs[k + r * 65]; }, [&](int k) { return Bs[k + c * 65]; });
       }
     }
   }
@@ -414,9 +413,8 @@ __global__ __launch_bounds__(64) void tri_llt_kernel(const BlockDesc D)
     {
       int r = e % n1, c = e / n1;
       if(r < c) continue;
-      double acc = AT(Dn, ldn, r, c);
-      for(int k = 0; k < ni; ++k) acc = FMA(-AT(Xs, ldl, r, k), AT(Xs, ldl, c, k), acc);
-      AT(Dn, ldn, r, c) = acc;
+      AT(Dn, ldn, r, c) = chain2_neg(0, 1, ni, AT(Dn, ldn, r, c), [&](int k) { return AT(Xs, ldl, r, k); },
+                                      [&](int k) { return AT(Xs, ldl, c, k); });
     }
     __threadfence_block();
     wave_sync();
