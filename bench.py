@@ -83,6 +83,62 @@ def cpu_baseline(pb, budget_s=12.0):
     }
 
 
+def bench_single_large(args, rank, world, device, jdist):
+    """Secondary workload (BASELINE config c2): one dense QP, n = 1024, m = 2048, 307 strongly active, through Mode A
+    (jrlqp_dense_solve: state in HBM, host keeps the active-set state machine, one kernel per hook).  The path does not
+    shard: at N > 1 every rank solves its own replica.  A step = one solve; G is restored before each
+    solve (the solver factorises it in place, like the reference).  Roofline: HBM against the streamed-state model of
+    SURVEY.md 8(d) -- per iteration 8(nm + n^2 + n(n-q) + q^2/2) + 16 n(n-q) bytes, q ~ iterations/2 -- the state
+    (32 MiB) stays in the Infinity Cache, so this is an upper bound on HBM bytes, not a measurement."""
+    import numpy as np
+    import torch
+
+    import jrl_qp_amd.capi as capi
+    import jrl_qp_amd.problems as P
+
+    n, m = 1024, 2048
+    pb = P.generate_batch(1, P.benchmark_characteristics(n, m), first_index=rank)
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(device)
+    G0, a, C, bl, bu = dev(pb.G[0]), dev(pb.a[0]), dev(pb.C[0]), dev(pb.bl[0]), dev(pb.bu[0])
+    s = capi.DenseSolver(n, m, False, max_iter=100000)
+    G = G0.clone()
+    steps = min(args.steps, 5)
+    for _ in range(max(1, min(args.warmup, 2))):
+        G.copy_(G0)
+        r = s.solve(G, a, C, bl, bu)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        G.copy_(G0)
+        r = s.solve(G, a, C, bl, bu)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    n_ok, sum_it, elapsed = jdist.reduce_stats(int(r["term"] == 0), int(r["iters"]), elapsed, device=device)
+    if rank == 0:
+        it = r["iters"]
+        q = it / 2.0
+        per_iter = 8.0 * (n * m + n * n + n * (n - q) + q * q / 2) + 16.0 * n * (n - q)
+        alg = 8.0 * (n * n + n + n * m + 2 * m) + it * per_iter
+        sec = elapsed / steps
+        out = {"metric": "dense GI, one large QP (n=1024, m=2048): solves/sec per GPU (replicas)", "value": world * steps / elapsed, "unit": "solves/s",
+               "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 2)), "ms_per_step": sec * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1] (c2): one dense QP n=1024, m_ineq=2048, 307 strongly active, Mode A (host-driven hooks); "
+                                      "replicas only at N > 1", "iterations": it, "solved": n_ok, "us_per_iteration": sec / max(it, 1) * 1e6},
+               "roofline": {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "kernel": "per-hook kernels (select / jtn / z / step_tail / add_chain / rot_apply)",
+                            "algorithmic_bytes_per_launch": alg,
+                            "note": "streamed-state model (upper bound: J, R, C = 32 MiB stay in the Infinity Cache); the iteration is bound by "
+                                    "the serial Givens coefficient chain and the blocked back substitution, not by bandwidth (DESIGN.md 7.1)"}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def bench_structured(args, rank, world, device, jdist):
     """Secondary workload (BASELINE config c5): a batch of structured QPs -- block-arrow Hessian (100 stage blocks of 30 +
     head), block-diagonal C with 10 one-sided constraints per stage -- through jrlqp_blockgi_solve (factorisation + the
@@ -176,9 +232,10 @@ def main():
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--m", type=int, default=M_INEQ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c2"],
                     help="c3 (default, the BASELINE metric): batch of dense QPs; c5: batch of structured block-arrow QPs "
-                         "(100 stages x 30 + head, 10 constraints per stage) through the structured GI solver")
+                         "(100 stages x 30 + head, 10 constraints per stage) through the structured GI solver; "
+                         "c2: ONE large dense QP (n=1024, m=2048) through the host-driven hooks (replicas only at N > 1)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from separate rocprofv3 --pmc passes (default: profiles/r1_pmc_traffic.json if it matches)")
     args = ap.parse_args()
@@ -202,6 +259,8 @@ def main():
 
     if args.workload == "c5":
         return bench_structured(args, rank, world, device, jdist)
+    if args.workload == "c2":
+        return bench_single_large(args, rank, world, device, jdist)
 
     n, m, B = args.n, args.m, args.batch
     total = B * world
