@@ -55,6 +55,24 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.jrlqp_status_string(-2).decode().startswith("problem size")
 
 
+def test_blockgi_plan_validation_without_gpu(pkg):
+    """jrlqp_blockgi_create rejects inconsistent shapes before touching the device (no GPU needed)."""
+    import jrl_qp_amd.capi as capi
+
+    lib = capi.load_library()
+    h = ct.c_void_p()
+    I = lambda *v: (ct.c_int * len(v))(*v)
+    # StructuredC must cover exactly the unknowns of G (BlockGISolver.cpp:35)
+    assert lib.jrlqp_blockgi_create(2, 2, I(3, 4), 2, I(3, 3), I(2, 2), 0, 1, 100, ct.byref(h)) == -1
+    assert lib.jrlqp_blockgi_create(5, 2, I(3, 4), 2, I(3, 4), I(2, 2), 0, 1, 100, ct.byref(h)) == -1  # kind
+    assert lib.jrlqp_blockgi_create(2, 2, I(3, 4), 2, I(3, 4), I(2, 2), 0, 0, 100, ct.byref(h)) == -1  # nprob
+    assert lib.jrlqp_blockgi_create(2, 2, I(3, 4), 2, I(3, 4), I(2, 2), 0, 1, 0, ct.byref(h)) == -1  # max_iter
+    assert lib.jrlqp_blockgi_create(2, 2, I(3, 70), 2, I(3, 70), I(2, 2), 0, 1, 10, ct.byref(h)) in (-2, -3, -4)  # block > 64 rows
+    assert lib.jrlqp_blockgi_create(2, 64, I(*([60] * 64)), 1, I(3840), I(1), 0, 1, 10, ct.byref(h)) == -2  # n > 3072
+    assert lib.jrlqp_blockgi_workspace_bytes(None) == -1
+    assert lib.jrlqp_blockgi_solve(None, *([None] * 12), None, 0, None) == -1
+
+
 def test_product_does_not_touch_the_oracle():
     """The product path must not import, link or execute anything under oracle/ (only tests/, smoke() and
     bench.py's cpu_baseline may)."""
