@@ -31,6 +31,8 @@ struct DenseViews
 struct DenseState
 {
   double *J, *R, *d, *z, *x, *u, *r, *cc, *ss;
+  double *cc2, *ss2, *rfin; // output of a coefficient chain run ahead of the add/drop decision (its own buffers: a drop
+                            // writes cc/ss on the main stream while a discarded chain may still be running)
   unsigned char * st; // activation status per constraint / bound
   double * pval;      // select partials
   int *pidx, *pstat;
@@ -42,8 +44,12 @@ hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st);
 hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st);
 hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st);
 hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st);
-hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st);
+// spec != nullptr: the Givens coefficient chain of an ADDITION is launched on `spec` as soon as d exists (ev_d), beside
+// z / r / the ratio test on `st`; ev_chain marks its end.  dense_add(..., chain_ready = true) then only commits.
+hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st,
+                      hipStream_t spec = nullptr, hipEvent_t ev_d = nullptr, hipEvent_t ev_chain = nullptr);
 hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st);
-hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st);
+hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, bool chain_ready = false,
+                     hipEvent_t ev_chain = nullptr);
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st);
 } // namespace jrlqp

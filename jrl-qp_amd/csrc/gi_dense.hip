@@ -657,9 +657,9 @@ __global__ void advance_kernel(int n, int q, double t, int primal, const double 
   if(i == q) u[q] = u[q] + t;
 }
 
-// K10 part 1 (one wave): the Givens coefficient recurrence on d (i = n-2 .. q), then all (c_i, s_i) in parallel;
-// R(:, q) = d(0:q) with the new diagonal; status byte of the activated constraint.
-__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, double * d, double * cc, double * ss, double * R, int ld, unsigned char * st, int p, int pstat)
+// K10 part 1 (one wave): the Givens coefficient recurrence on d (i = n-2 .. q), then all (c_i, s_i) in parallel.  Reads d
+// only and writes only its own outputs, so it can run ahead of the add/drop decision beside z / r / the ratio test.
+__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const double * d, double * cc, double * ss, double * rfin)
 {
   extern __shared__ double sm[]; // d (n) | rho (n)
   double * dsm = sm;
@@ -693,10 +693,18 @@ __global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, double * d,
     cc[i] = c;
     ss[i] = s;
   }
-  for(int k = lane; k < q; k += 64) AT(R, ld, k, q) = dsm[k];
-  if(lane == 0)
+  if(lane == 0) *rfin = r;
+}
+
+// K10 part 1b: R(:, q) = d(0:q) with the new diagonal; status byte of the activated constraint (GoldfarbIdnaniSolver.cpp:233)
+__global__ __launch_bounds__(256) void add_commit_kernel(int q, const double * d, const double * rfin, double * R, int ld, unsigned char * st, int p,
+                                                         int pstat)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if(k < q) AT(R, ld, k, q) = d[k];
+  if(k == q)
   {
-    AT(R, ld, q, q) = r;
+    AT(R, ld, q, q) = *rfin;
     st[p] = (unsigned char)pstat;
   }
 }
@@ -862,7 +870,8 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
   return hipGetLastError();
 }
 
-hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st)
+hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st, hipStream_t spec,
+                      hipEvent_t ev_d, hipEvent_t ev_chain)
 {
   const int n = v.n;
   const double sign = (pstat == UPPER || pstat == UPPER_BOUND) ? -1.0 : 1.0;
@@ -874,6 +883,16 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   }
   else
     hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d);
+  if(spec && q < n)
+  {
+    // d is all the coefficient recurrence needs: it starts now, beside z, r and the ratio test
+    hipError_t e = hipEventRecord(ev_d, st);
+    if(e == hipSuccess) e = hipStreamWaitEvent(spec, ev_d, 0);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), sizeof(double) * 2 * n, spec, n, q, s.d, s.cc2, s.ss2, s.rfin);
+    e = hipEventRecord(ev_chain, spec);
+    if(e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
   hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (((q + 1) & ~1) + 64 * 65 + 2), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
                      p - v.m, s.mb);
@@ -887,11 +906,18 @@ hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, 
   return hipGetLastError();
 }
 
-hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st)
+hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, bool chain_ready, hipEvent_t ev_chain)
 {
   const int n = v.n;
-  hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), sizeof(double) * 2 * n, st, n, q, s.d, s.cc, s.ss, s.R, n, s.st, p, pstat);
-  if(n - 2 >= q) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, n - 2, 1, s.cc, s.ss);
+  if(chain_ready)
+  {
+    hipError_t e = hipStreamWaitEvent(st, ev_chain, 0);
+    if(e != hipSuccess) return e;
+  }
+  else
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), sizeof(double) * 2 * n, st, n, q, s.d, s.cc2, s.ss2, s.rfin);
+  hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat);
+  if(n - 2 >= q) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2);
   return hipGetLastError();
 }
 

@@ -29,7 +29,9 @@ struct jrlqp_dense
   double f = 0.0;
   int last_hip = 0;
   hipStream_t side = nullptr;          // runs the next pass's constraint scan beside the Givens sweep
-  hipEvent_t ev_x = nullptr, ev_sel = nullptr;
+  hipStream_t spec = nullptr;          // runs the coefficient chain of an addition ahead of the add/drop decision
+  hipEvent_t ev_x = nullptr, ev_sel = nullptr, ev_d = nullptr, ev_chain = nullptr;
+  bool chain_pending = false;          // a chain launched on `spec` has not been waited for by the main stream yet
 };
 
 namespace
@@ -72,6 +74,9 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = dmalloc(s.r, mt + 2);
   if(e == hipSuccess) e = dmalloc(s.cc, n);
   if(e == hipSuccess) e = dmalloc(s.ss, n);
+  if(e == hipSuccess) e = dmalloc(s.cc2, n);
+  if(e == hipSuccess) e = dmalloc(s.ss2, n);
+  if(e == hipSuccess) e = dmalloc(s.rfin, 1);
   if(e == hipSuccess) e = dmalloc(s.st, mt);
   const size_t parts = ((size_t)m + 15) / 16; // select_partial_kernel: one partial per 16 constraints
   if(e == hipSuccess) e = dmalloc(s.pval, parts);
@@ -81,6 +86,9 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h->h_mb), sizeof(Mailbox), hipHostMallocMapped);
   if(e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s.mb), h->h_mb, 0);
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->spec, hipStreamNonBlocking);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_d, hipEventDisableTiming);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming);
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming);
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming);
   if(e != hipSuccess)
@@ -99,11 +107,17 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
 {
   if(!h) return;
   DenseState & s = h->s;
+  if(h->spec) (void)hipStreamSynchronize(h->spec);
+  if(h->side) (void)hipStreamSynchronize(h->side);
   (void)hipFree(s.J); (void)hipFree(s.R); (void)hipFree(s.d); (void)hipFree(s.z); (void)hipFree(s.x);
   (void)hipFree(s.u); (void)hipFree(s.r); (void)hipFree(s.cc); (void)hipFree(s.ss); (void)hipFree(s.st);
+  (void)hipFree(s.cc2); (void)hipFree(s.ss2); (void)hipFree(s.rfin);
   (void)hipFree(s.pval); (void)hipFree(s.pidx); (void)hipFree(s.pstat); (void)hipFree(s.info);
   if(h->h_mb) (void)hipHostFree(h->h_mb);
   if(h->side) (void)hipStreamDestroy(h->side);
+  if(h->spec) (void)hipStreamDestroy(h->spec);
+  if(h->ev_d) (void)hipEventDestroy(h->ev_d);
+  if(h->ev_chain) (void)hipEventDestroy(h->ev_chain);
   if(h->ev_x) (void)hipEventDestroy(h->ev_x);
   if(h->ev_sel) (void)hipEventDestroy(h->ev_sel);
   delete h;
@@ -239,6 +253,11 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
 
   h->it = 0;
   h->term = JRLQP_UNKNOWN;
+  if(h->chain_pending) // a discarded chain of the previous solve may still be reading d
+  {
+    TRY(hipStreamWaitEvent(st, h->ev_chain, 0));
+    h->chain_pending = false;
+  }
   int info = -1;
   rc = jrlqp_dense_init(h, &info, nullptr, stream);
   if(rc != JRLQP_OK) return rc;
@@ -316,8 +335,22 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
     }
     double t1, zz, nz, nx, uq;
     int l;
-    rc = jrlqp_dense_step(h, p, pstat, q, big, &t1, &l, &zz, &nz, &nx, &uq, stream);
-    if(rc != JRLQP_OK) return rc;
+    {
+      // computeStep_ with the coefficient chain of a possible addition started on the side as soon as d exists: most
+      // passes add, and the chain (n - q dependent radius steps) is as long as z, r and the ratio test together.  A
+      // chain that is still reading d must have ended before d is overwritten: the main stream waits for it here.
+      if(h->chain_pending)
+      {
+        TRY(hipStreamWaitEvent(st, h->ev_chain, 0));
+        h->chain_pending = false;
+      }
+      const bool spec = q < n;
+      TRY(dense_step(h->v, h->s, p, pstat, q, big, st, spec ? h->spec : nullptr, h->ev_d, h->ev_chain));
+      h->chain_pending = spec;
+      TRY(hipStreamSynchronize(st));
+      const Mailbox & mb = *h->h_mb;
+      t1 = mb.t1; l = mb.l; zz = mb.zz; nz = mb.cz; nx = mb.cx; uq = mb.uq;
+    }
     double t2 = big;
     if(std::sqrt(zz) > 1e-14) t2 = (bound_value(p, pstat) - nx) / nz;
     const double t = (t2 < t1) ? t2 : t1;
@@ -350,8 +383,8 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
           TRY(dense_select(h->v, h->s, p, h->side));
           prefetched = true;
         }
-        rc = jrlqp_dense_add(h, p, pstat, q, stream);
-        if(rc != JRLQP_OK) return rc;
+        TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending, h->ev_chain)); // commit: the chain ran ahead
+        h->chain_pending = false;
         activate(p, pstat);
         skip = false;
       }
