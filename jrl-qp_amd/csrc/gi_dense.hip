@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64) void rot_apply_kernel(double * J, int ld, int n
 {
   const int row = blockIdx.x * 64 + threadIdx.x;
   if(row >= n || i_hi < i_lo) return;
-  constexpr int U = 8; // columns fetched per group: the loads of a group are in flight together
+  constexpr int U = 16; // columns fetched per group: the loads of a group are in flight together
   if(descending)
   {
     double carry = AT(J, ld, row, i_hi + 1);
