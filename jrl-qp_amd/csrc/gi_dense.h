@@ -37,8 +37,11 @@ struct DenseState
   double * pval;      // select partials
   int *pidx, *pstat;
   int * info;         // LLT info (device)
+  int * psel;         // {p, status} of the last selection (device copy of the mailbox entries)
   Mailbox * mb;       // device view of the mailbox
 };
+
+constexpr int kSelOnDevice = -2; // dense_step: take (p, status) from DenseState::psel instead of the arguments
 
 hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st);
 hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st);

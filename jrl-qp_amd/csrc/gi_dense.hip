@@ -344,9 +344,19 @@ __device__ __forceinline__ double tile_column_dot(const double * __restrict__ M,
   return acc;
 }
 
-__global__ __launch_bounds__(64) void jtn_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign, double * out)
+// psel != nullptr: the vector is the column of `vbase` the last selection picked (psel = {p, status} on the DEVICE): the
+// host launches the step without having seen p, and reads it only once per pass, together with the step's scalars
+__global__ __launch_bounds__(64) void jtn_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign, double * out,
+                                                 const int * psel = nullptr, const double * vbase = nullptr, int ldv = 0, int m = 0)
 {
   extern __shared__ double sh[]; // vector (n) | tile (CT x (KT+1))
+  if(psel)
+  {
+    const int p = psel[0];
+    if(p < 0 || p >= m) return; // none selected, or a bound (jrow_kernel)
+    v = vbase + (size_t)p * ldv;
+    sign = (psel[1] == UPPER) ? -1.0 : 1.0;
+  }
   double * vs = sh;
   double * tile = sh + n;
   const int lane = threadIdx.x;
@@ -358,8 +368,15 @@ __global__ __launch_bounds__(64) void jtn_kernel(const double * __restrict__ M, 
 }
 
 // bound constraint: d = +-row pb of J
-__global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb, double sign, double * out)
+__global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb, double sign, double * out, const int * psel = nullptr, int m = 0)
 {
+  if(psel)
+  {
+    const int p = psel[0];
+    if(p < m) return; // none selected, or a general constraint (jtn_kernel)
+    pb = p - m;
+    sign = (psel[1] == UPPER_BOUND) ? -1.0 : 1.0;
+  }
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if(j < n)
   {
@@ -416,7 +433,8 @@ __global__ __launch_bounds__(64) void select_partial_kernel(const double * __res
 // K4 final: combine the partials (in index order) and scan the bounds; result to the host-visible mailbox
 __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const double * pval, const int * pidx, const int * pstat, int m, int nb,
                                                           const double * __restrict__ x, const double * __restrict__ xl,
-                                                          const double * __restrict__ xu, const unsigned char * __restrict__ st, int excl, Mailbox * mb)
+                                                          const double * __restrict__ xu, const unsigned char * __restrict__ st, int excl, Mailbox * mb,
+                                                          int * psel)
 {
   __shared__ double sv[4];
   __shared__ int si[4], ss[4];
@@ -478,6 +496,8 @@ __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const dou
       }
     mb->p = (ix == NONE) ? -1 : ix;
     mb->pstatus = sx;
+    psel[0] = (ix == NONE) ? -1 : ix; // device copy: the step kernels of this pass read it without a host round trip
+    psel[1] = sx;
   }
 }
 
@@ -543,10 +563,18 @@ __global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ 
 __global__ __launch_bounds__(256) void step_tail_kernel(const double * __restrict__ R, int ld, int n, int q, const double * __restrict__ d, double * r,
                                                         const double * __restrict__ u, const unsigned char * __restrict__ st, double big,
                                                         const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
-                                                        int pb, Mailbox * mb)
+                                                        int pb, Mailbox * mb, const int * psel = nullptr, const double * cbase = nullptr, int ldc = 0,
+                                                        int m = 0)
 {
   extern __shared__ double rs[]; // q doubles (the running right-hand side) | 64 x 65 staging block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if(psel)
+  {
+    const int p = psel[0];
+    if(p < 0) return; // nothing violated: the host terminates on the p it reads with this pass's scalars
+    cp = (p < m) ? cbase + (size_t)p * ldc : nullptr;
+    pb = p - m;
+  }
   if(wave == 0)
   {
     double * Rb = rs + ((q + 1) & ~1);
@@ -866,7 +894,7 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
   if(parts > 0)
     hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * (v.n + CT * (KT + 1)), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
                        excl, s.pval, s.pidx, s.pstat);
-  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb);
+  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb, s.psel);
   return hipGetLastError();
 }
 
@@ -874,15 +902,23 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
                       hipEvent_t ev_d, hipEvent_t ev_chain)
 {
   const int n = v.n;
+  const bool dev_p = (p == kSelOnDevice); // (p, status) are read from s.psel by the kernels
   const double sign = (pstat == UPPER || pstat == UPPER_BOUND) ? -1.0 : 1.0;
   const double * cp = nullptr;
-  if(p < v.m)
+  if(dev_p)
+  {
+    if(v.m > 0)
+      hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C,
+                         v.ldc, v.m);
+    if(v.nb > 0) hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, 0, 1.0, s.d, s.psel, v.m);
+  }
+  else if(p < v.m)
   {
     cp = v.C + (size_t)p * v.ldc;
-    hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, cp, sign, s.d);
+    hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0);
   }
   else
-    hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d);
+    hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d, nullptr, 0);
   if(spec && q < n)
   {
     // d is all the coefficient recurrence needs: it starts now, beside z, r and the ratio test
@@ -894,8 +930,12 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     if(e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
-  hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (((q + 1) & ~1) + 64 * 65 + 2), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
-                     p - v.m, s.mb);
+  if(dev_p)
+    hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (((q + 1) & ~1) + 64 * 65 + 2), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
+                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m);
+  else
+    hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (((q + 1) & ~1) + 64 * 65 + 2), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
+                       p - v.m, s.mb, nullptr, nullptr, 0, 0);
   return hipGetLastError();
 }
 

@@ -83,6 +83,7 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = dmalloc(s.pidx, parts);
   if(e == hipSuccess) e = dmalloc(s.pstat, parts);
   if(e == hipSuccess) e = dmalloc(s.info, 1);
+  if(e == hipSuccess) e = dmalloc(s.psel, 2);
   if(e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h->h_mb), sizeof(Mailbox), hipHostMallocMapped);
   if(e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s.mb), h->h_mb, 0);
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
@@ -112,7 +113,7 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   (void)hipFree(s.J); (void)hipFree(s.R); (void)hipFree(s.d); (void)hipFree(s.z); (void)hipFree(s.x);
   (void)hipFree(s.u); (void)hipFree(s.r); (void)hipFree(s.cc); (void)hipFree(s.ss); (void)hipFree(s.st);
   (void)hipFree(s.cc2); (void)hipFree(s.ss2); (void)hipFree(s.rfin);
-  (void)hipFree(s.pval); (void)hipFree(s.pidx); (void)hipFree(s.pstat); (void)hipFree(s.info);
+  (void)hipFree(s.pval); (void)hipFree(s.pidx); (void)hipFree(s.pstat); (void)hipFree(s.info); (void)hipFree(s.psel);
   if(h->h_mb) (void)hipHostFree(h->h_mb);
   if(h->side) (void)hipStreamDestroy(h->side);
   if(h->spec) (void)hipStreamDestroy(h->spec);
@@ -316,21 +317,17 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
   for(; h->it < o.max_iter; ++h->it)
   {
     const int q = (int)h->active.size();
+    // ONE host round trip per pass: the selection (on the side stream beside the previous sweep, or here) leaves
+    // (p, status) on the device, the step kernels read it there, and the host sees p together with the step's scalars
     if(!skip)
     {
       if(prefetched)
       {
-        TRY(hipStreamSynchronize(h->side));
-        p = h->h_mb->p;
-        pstat = h->h_mb->pstatus;
+        TRY(hipStreamWaitEvent(st, h->ev_sel, 0));
         prefetched = false;
       }
       else
-      {
-        rc = jrlqp_dense_select(h, &p, &pstat, stream);
-        if(rc != JRLQP_OK) return rc;
-      }
-      if(p < 0 || pstat == INACTIVE) return finish(JRLQP_SUCCESS);
+        TRY(dense_select(h->v, h->s, -1, st));
       TRY(hipMemsetAsync(h->s.u + q, 0, sizeof(double), st)); // u[q] = 0 (DualSolver.cpp:121)
     }
     double t1, zz, nz, nx, uq;
@@ -345,10 +342,16 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
         h->chain_pending = false;
       }
       const bool spec = q < n;
-      TRY(dense_step(h->v, h->s, p, pstat, q, big, st, spec ? h->spec : nullptr, h->ev_d, h->ev_chain));
+      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, h->ev_d, h->ev_chain));
       h->chain_pending = spec;
       TRY(hipStreamSynchronize(st));
       const Mailbox & mb = *h->h_mb;
+      if(!skip)
+      {
+        p = mb.p;
+        pstat = mb.pstatus;
+        if(p < 0 || pstat == INACTIVE) return finish(JRLQP_SUCCESS);
+      }
       t1 = mb.t1; l = mb.l; zz = mb.zz; nz = mb.cz; nx = mb.cx; uq = mb.uq;
     }
     double t2 = big;
@@ -381,6 +384,7 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
           TRY(hipEventRecord(h->ev_x, st));
           TRY(hipStreamWaitEvent(h->side, h->ev_x, 0));
           TRY(dense_select(h->v, h->s, p, h->side));
+          TRY(hipEventRecord(h->ev_sel, h->side));
           prefetched = true;
         }
         TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending, h->ev_chain)); // commit: the chain ran ahead
