@@ -151,7 +151,7 @@ def bench_structured(args, rank, world, device, jdist):
     import jrl_qp_amd.capi as capi
     import jrl_qp_amd.structured_problems as SP
 
-    B = args.batch if args.batch != BATCH else 256  # one problem per CU
+    B = args.batch if args.batch != BATCH else 512  # two problems per CU (throughput layout of jrlqp_blockgi_*)
     lo, hi = jdist.shard_range(B * world, rank, world)
     base = [SP.mpc_arrow_qp(100, 30, 10, seed=s, scale_a=1.0) for s in range(2)]
     q0 = base[0]

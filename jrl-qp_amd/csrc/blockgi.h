@@ -47,6 +47,8 @@ struct BgiArgs
   long rlen;
   SeqRec * desc;  // [nprob * max_iter]  one record per element of the orthonormal sequence
   int * active;   // [nprob * qcap]
+  double * xu_ws; // [nprob * (n_pad + qcap)]  x and u of the throughput layout (see blockgi_lds_bytes)
+  int xu_global;  // 1: x and u live in xu_ws (HBM/L2) instead of LDS, so that two large problems share a CU
   // outputs
   double *x, *u;
   int *status, *term, *iters;
@@ -58,6 +60,8 @@ struct BgiArgs
 
 constexpr int kBgiMaxN = 3072; // unknowns per structured QP (vectors live in LDS)
 
-long blockgi_lds_bytes(int n, int m, int nb, int nblk);
+// xu_global = 1 (throughput layout for large problems in large batches): x and u are kept in the HBM workspace, which
+// brings a 3000-unknown problem under half a CU's LDS
+long blockgi_lds_bytes(int n, int m, int nb, int nblk, int xu_global = 0);
 hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t stream);
 } // namespace jrlqp

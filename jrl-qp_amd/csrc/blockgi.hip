@@ -709,7 +709,7 @@ __device__ __forceinline__ double cstr_dot(const Ctx & K, int p, const double * 
 // the kernel
 // =========================================================================================================
 template<int NT, int NCH>
-__global__ __launch_bounds__(NT, (NT == 256) ? 3 : 0) void blockgi_kernel(const BgiArgs A)
+__global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 : 0) void blockgi_kernel(const BgiArgs A)
 {
   extern __shared__ double sm[];
   const int pb = blockIdx.x, tid = threadIdx.x;
@@ -724,9 +724,18 @@ __global__ __launch_bounds__(NT, (NT == 256) ? 3 : 0) void blockgi_kernel(const 
   K.cblk = A.cblk + (size_t)pb * A.ncb;
   K.d = sm;
   K.z = K.d + A.n_pad;
-  K.x = K.z + A.n_pad;
-  K.u = K.x + A.n_pad;
-  K.r = K.u + A.qcap;
+  if(A.xu_global)
+  {
+    K.x = A.xu_ws + (size_t)pb * (A.n_pad + A.qcap);
+    K.u = K.x + A.n_pad;
+    K.r = K.z + A.n_pad;
+  }
+  else
+  {
+    K.x = K.z + A.n_pad;
+    K.u = K.x + A.n_pad;
+    K.r = K.u + A.qcap;
+  }
   K.tri = K.r + A.qcap;
   K.red = K.tri + kTri;
   K.ired = reinterpret_cast<int *>(K.red + 32);
@@ -1164,20 +1173,24 @@ hipError_t launch_one(const BgiArgs & a, int nprob, size_t lds, hipStream_t st)
 }
 } // namespace
 
-long blockgi_lds_bytes(int n, int m, int nb, int nblk)
+long blockgi_lds_bytes(int n, int m, int nb, int nblk, int xu_global)
 {
   const int n_pad = (n + 3) & ~3;
   int qcap = (n < m + nb ? n : m + nb) + 1;
   qcap = (qcap + 3) & ~3;
-  return (long)sizeof(double) * (3L * n_pad + 2L * qcap + kTri + 32 + 32 + 8) + (long)sizeof(BlkMeta) * nblk;
+  const long vecs = xu_global ? (2L * n_pad + qcap) : (3L * n_pad + 2L * qcap);
+  return (long)sizeof(double) * (vecs + kTri + 32 + 32 + 8) + (long)sizeof(BlkMeta) * nblk;
 }
 
 hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t st)
 {
-  const size_t lds = (size_t)blockgi_lds_bytes(a.n, a.m, a.nb, a.nblk);
+  const size_t lds = (size_t)blockgi_lds_bytes(a.n, a.m, a.nb, a.nblk, a.xu_global);
   // four waves per problem up to 1024 unknowns; eight beyond (the block-parallel phases -- L^-T over ~100 blocks,
-  // the constraint scan -- and the per-reflector work scale with the wave count; rule C4 does not depend on it)
+  // the constraint scan -- and the per-reflector work scale with the wave count; rule C4 does not depend on it).
+  // Throughput layout (xu_global, chosen by the caller for large batches of large problems): four waves and half the
+  // LDS, so that two problems share a CU and twice as many reflector rows are in flight per CU.
   if(a.n <= 1024) return launch_one<256, 1>(a, nprob, lds, st);
+  if(a.xu_global) return (a.n <= 2048) ? launch_one<256, 2>(a, nprob, lds, st) : launch_one<256, 3>(a, nprob, lds, st);
   if(a.n <= 2048) return launch_one<512, 2>(a, nprob, lds, st);
   return launch_one<512, 3>(a, nprob, lds, st);
 }

@@ -49,7 +49,8 @@ struct jrlqp_blockgi
   std::vector<const double *> h_cblk;
   int *d_boff = nullptr, *d_cvar = nullptr, *d_ccstr = nullptr, *d_cumv = nullptr, *d_cumc = nullptr, *d_toblk = nullptr, *d_cld = nullptr;
   const double ** d_cblk = nullptr;
-  double *d_pool = nullptr, *d_Rp = nullptr;
+  double *d_pool = nullptr, *d_Rp = nullptr, *d_xu = nullptr;
+  int xu_global = 0;
   jrlqp::SeqRec * d_desc = nullptr;
   int * d_active = nullptr;
   size_t ws_bytes = 0;
@@ -400,6 +401,10 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   if(e == hipSuccess) e = hipMalloc(&h->d_Rp, r_b);
   if(e == hipSuccess) e = hipMalloc(&h->d_desc, sizeof(jrlqp::SeqRec) * (size_t)nprob * max_iter);
   if(e == hipSuccess) e = hipMalloc(&h->d_active, sizeof(int) * (size_t)nprob * h->qcap);
+  // throughput layout: large problems (n > 1024) in batches of at least half the CUs keep x and u in HBM so that two
+  // problems share a CU (same results: the layout does not enter the arithmetic)
+  h->xu_global = (n > 1024 && nprob >= 128 && 2 * jrlqp::blockgi_lds_bytes(n, m, nb, nblk, 1) <= jrlqp::kLdsPerCU) ? 1 : 0;
+  if(e == hipSuccess) e = hipMalloc(&h->d_xu, sizeof(double) * (size_t)nprob * (h->n_pad + h->qcap));
   if(e == hipSuccess) e = hipMemcpy(h->d_boff, boff.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
   if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_cvar, cvar, sizeof(int) * ncb, hipMemcpyHostToDevice);
   if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_ccstr, ccstr, sizeof(int) * ncb, hipMemcpyHostToDevice);
@@ -422,7 +427,7 @@ void jrlqp_blockgi_destroy(jrlqp_blockgi * h)
   jrlqp_blocks_destroy(h->blocks);
   (void)hipFree(h->d_boff); (void)hipFree(h->d_cvar); (void)hipFree(h->d_ccstr); (void)hipFree(h->d_cumv); (void)hipFree(h->d_cumc);
   (void)hipFree(h->d_toblk); (void)hipFree(h->d_cld); (void)hipFree(h->d_cblk); (void)hipFree(h->d_pool); (void)hipFree(h->d_Rp);
-  (void)hipFree(h->d_desc); (void)hipFree(h->d_active);
+  (void)hipFree(h->d_desc); (void)hipFree(h->d_active); (void)hipFree(h->d_xu);
   delete h;
 }
 
@@ -477,6 +482,7 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.max_iter = o.max_iter; a.big_bnd = o.big_bnd;
   a.n_pad = h->n_pad; a.qcap = h->qcap; a.row_len = h->row_len;
   a.pool = h->d_pool; a.Rp = h->d_Rp; a.rlen = h->rlen; a.desc = h->d_desc; a.active = h->d_active;
+  a.xu_ws = h->d_xu; a.xu_global = h->xu_global;
   a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
   a.trace = dtrace; a.trace_cap = dtrace ? trace_cap : 0;
   a.prof = g_prof.load();

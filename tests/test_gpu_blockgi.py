@@ -133,6 +133,22 @@ def test_mpc_arrow_medium(oracle, SP, capi):
     check_batch(oracle, SP, capi, qps, min_iters=40)
 
 
+def test_throughput_layout_large_batch(oracle, SP, capi):
+    """n > 1024 in a batch of >= 128 problems selects the throughput layout (x and u in HBM, four waves, two problems per
+    CU): same bits as the latency layout and as the oracle, for every problem of the batch."""
+    base = [SP.mpc_arrow_qp(nstage=36, nx=30, mc=4, seed=s, scale_a=1.0) for s in range(2)]
+    assert base[0].n > 1024
+    refs = [oracle_solve(oracle, SP, q, max_iter=600)[0] for q in base]
+    qps = [base[i % 2] for i in range(128)]
+    g = gpu_solve(capi, qps, max_iter=600)
+    for b in range(128):
+        r = refs[b % 2]
+        assert g["term"][b] == r.term == 0 and g["iters"][b] == r.iters and r.iters > 40
+        assert np.array_equal(g["status"][b], r.status) and np.array_equal(g["x"][b], r.x) and np.array_equal(g["u"][b], r.u) and g["f"][b] == r.f
+    g1 = gpu_solve(capi, [base[0]], max_iter=600)  # latency layout (batch of one)
+    assert np.array_equal(g1["x"][0], refs[0].x) and g1["iters"][0] == refs[0].iters
+
+
 def test_mpc_arrow_c5_full_size(oracle, SP, capi):
     """BASELINE config c5: 100 stages x 30 (+ head), 10 constraints per stage: n = 3030, m = 1000, ~590 iterations."""
     qp = SP.mpc_arrow_qp(nstage=100, nx=30, mc=10, seed=0, scale_a=1.0)
