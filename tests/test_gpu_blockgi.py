@@ -133,6 +133,18 @@ def test_mpc_arrow_medium(oracle, SP, capi):
     check_batch(oracle, SP, capi, qps, min_iters=40)
 
 
+@pytest.mark.parametrize("kind", ["tri", "arrow_up", "arrow_down"])
+def test_vertex_solutions_bit_exact(oracle, SP, capi, kind):
+    """Many binding constraints: the active set fills up to q == n (reflectors of length one, empty J2, dual-only steps)."""
+    qps = []
+    for seed in range(40):
+        qp = SP.random_structured_qp(kind, [2, 1, 2], [4, 3, 4], 900 + seed, ridge=0.05, box=0.3)
+        qp.a *= 30  # the unconstrained optimum is far outside the box
+        qps.append(qp)
+    g = check_batch(oracle, SP, capi, qps)
+    assert ((g["status"] != 0).sum(axis=1) == qps[0].n).sum() >= 3  # some solutions are vertices
+
+
 def test_throughput_layout_large_batch(oracle, SP, capi):
     """n > 1024 in a batch of >= 128 problems selects the throughput layout (x and u in HBM, four waves, two problems per
     CU): same bits as the latency layout and as the oracle, for every problem of the batch."""
