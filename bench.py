@@ -201,7 +201,8 @@ def bench_structured(args, rank, world, device, jdist):
         avg_s = float(np.mean(kern_ms)) * 1e-3
         traffic = None
         try:
-            traffic = float(json.load(open(os.path.join(ROOT, "profiles", "r1_blockgi_c5_batch64_traffic.json")))["traffic_bytes_per_launch_fetch_x2_plus_write"]) if hi - lo == 64 else None
+            if hi - lo in (64, 512):  # measured once per round with separate --pmc passes (tools/profile_round.sh)
+                traffic = float(json.load(open(os.path.join(ROOT, "profiles", f"r1_blockgi_c5_batch{hi - lo}_traffic.json")))["traffic_bytes_per_launch_fetch_x2_plus_write"])
         except Exception:
             pass
         out = {
@@ -214,7 +215,7 @@ def bench_structured(args, rank, world, device, jdist):
                                    f"structured GI loop); wall time includes restoring G before each solve",
                        "batch_per_gpu": B, "mean_iterations": sum_it / total, "solved": n_ok},
             "roofline": {"bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "blockgi_kernel<512,3>", "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3,
+                         "traffic": traffic, "kernel": "blockgi_kernel", "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3,
                          "note": "algorithmic bytes = reflector rows read by the two Q applications of every iteration; a single CU per problem is "
                                  "instruction-issue/barrier bound (DESIGN.md 7.3)"},
         }

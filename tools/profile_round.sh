@@ -1,13 +1,20 @@
+# Round profile: bench line, rocprofv3 kernel stats, PMC traffic (FETCH_SIZE / WRITE_SIZE in SEPARATE passes, no other trace
+# domain with --pmc), for the headline batched kernel (c3) and for the structured GI kernel (c5), plus the timing logs of
+# the secondary workloads.  Run on the GPU box:  gpurun -- bash tools/profile_round.sh ; then copy summaries to profiles/.
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/s5; mkdir -p $O
+O=gpurun_out/prof_round; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o bench -- python3 bench.py --no-cpu-baseline > $O/bench_prof.json 2> $O/p_stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -o fetch -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > /dev/null 2> $O/p_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_write -o write -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > /dev/null 2> $O/p_write.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bgi -o bgi -- python3 tools/time_blockgi.py c5b64 > $O/bgi_c5b64.log 2> $O/p_bgi.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_bgi_fetch -o fetch -- python3 tools/time_blockgi.py c5b64 > /dev/null 2> $O/p_bgi_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_bgi_write -o write -- python3 tools/time_blockgi.py c5b64 > /dev/null 2> $O/p_bgi_write.err
+python bench.py --workload c5 --steps 2 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bgi -o bgi -- python3 bench.py --workload c5 --steps 2 --warmup 1 > /dev/null 2> $O/p_bgi.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_bgi_fetch -o fetch -- python3 bench.py --workload c5 --steps 1 --warmup 1 > /dev/null 2> $O/p_bgi_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_bgi_write -o write -- python3 bench.py --workload c5 --steps 1 --warmup 1 > /dev/null 2> $O/p_bgi_write.err
+python bench.py --workload c2 --steps 3 > $O/bench_c2.json 2> $O/bench_c2.err
 python tools/time_dense.py 1024 2048 > $O/c2.log 2>&1
-find $O -name "*.csv" | head -30
-cat $O/bench.json
+python tools/time_blockgi.py > $O/time_blockgi.log 2>&1
+python tools/time_structured.py > $O/time_structured.log 2>&1
+python tools/quick_time.py > $O/quick.log 2>&1
+cut -c1-250 $O/bench.json; cut -c1-250 $O/bench_c5.json
