@@ -18,6 +18,15 @@ def _sets():
     return mod.SETS
 
 
+def _mod():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(GOLD), "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _inputs(P, spec):
     ch = P.Characteristics(**spec["ch"])
     pb = P.generate_batch(spec["count"], ch, first_index=spec["first"])
@@ -60,3 +69,35 @@ def test_hip_reproduces_golden(pkg, name):
     got = dict(x=r.x, u=r.u, status=r.status, term=r.term, iters=r.iters, f=r.f)
     for k, t in got.items():
         assert np.array_equal(t.cpu().numpy(), gold[f"{name}_{k}"]), k
+
+
+SG = ["sg_tri", "sg_arrow_up", "sg_arrow_down_box"]
+
+
+@pytest.mark.parametrize("name", SG)
+def test_structured_oracle_reproduces_golden(pkg, oracle, name):
+    mod = _mod()
+    gold = np.load(GOLD)
+    qps = mod.structured_problems(mod.STRUCTURED[name])
+    if not np.array_equal(mod.structured_digest(qps), gold[f"{name}_inputs_sha256"]):
+        pytest.skip("generator inputs differ on this numpy/scipy build; golden outputs do not apply")
+    exp = mod.structured_expected(oracle, qps)
+    for k, v in exp.items():
+        assert np.array_equal(v, gold[f"{name}_{k}"]), k
+    assert (gold[f"{name}_term"] == 0).all() and gold[f"{name}_iters"].sum() > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SG)
+def test_structured_hip_reproduces_golden(pkg, name):
+    from test_gpu_blockgi import gpu_solve
+    import jrl_qp_amd.capi as capi
+
+    mod = _mod()
+    gold = np.load(GOLD)
+    qps = mod.structured_problems(mod.STRUCTURED[name])
+    if not np.array_equal(mod.structured_digest(qps), gold[f"{name}_inputs_sha256"]):
+        pytest.skip("generator inputs differ on this numpy/scipy build; golden outputs do not apply")
+    g = gpu_solve(capi, qps)
+    for k in ("x", "u", "status", "term", "iters", "f"):
+        assert np.array_equal(g[k], gold[f"{name}_{k}"]), k
