@@ -108,7 +108,8 @@ def random_structured_qp(kind, bs, mc, seed, double_sided=True, ridge=0.0, cbs=N
     xl = xu = None
     if box is not None:
         xl, xu = np.full(n, -float(box)), np.full(n, float(box))
-    return StructuredQP(kind, list(bs), G, a, Cb, np.concatenate(bl), np.concatenate(bu), xl, xu, meta=dict(seed=seed))
+    cat = lambda v: np.concatenate(v) if v else np.zeros(0)
+    return StructuredQP(kind, list(bs), G, a, Cb, cat(bl), cat(bu), xl, xu, meta=dict(seed=seed))
 
 
 def mpc_arrow_qp(nstage=100, nx=30, mc=10, seed=0, scale_a=4.0) -> StructuredQP:

@@ -145,6 +145,21 @@ def test_vertex_solutions_bit_exact(oracle, SP, capi, kind):
     assert ((g["status"] != 0).sum(axis=1) == qps[0].n).sum() >= 3  # some solutions are vertices
 
 
+def test_degenerate_shapes_bit_exact(oracle, SP, capi):
+    """One diagonal block only (the block list degenerates: arrow = head only, tridiagonal = one block), bounds without
+    general constraints, and no constraint at all (x = -G^-1 a, zero iterations)."""
+    for kind in ("tri", "arrow_up", "arrow_down"):
+        qps = [SP.random_structured_qp(kind, [7], [9], 40 + s, ridge=0.05, box=0.5) for s in range(4)]
+        check_batch(oracle, SP, capi, qps, min_iters=4)
+        # bounds only
+        qps = [SP.random_structured_qp(kind, [4, 6, 3], [0, 0, 0], 60 + s, ridge=0.05, box=0.05) for s in range(4)]
+        g = check_batch(oracle, SP, capi, qps, min_iters=4)
+        # unconstrained
+        qps = [SP.random_structured_qp(kind, [4, 6, 3], [0, 0, 0], 80 + s, ridge=0.05) for s in range(2)]
+        g = check_batch(oracle, SP, capi, qps)
+        assert (g["iters"] == 0).all() and (g["term"] == 0).all()
+
+
 def test_throughput_layout_large_batch(oracle, SP, capi):
     """n > 1024 in a batch of >= 128 problems selects the throughput layout (x and u in HBM, four waves, two problems per
     CU): same bits as the latency layout and as the oracle, for every problem of the batch."""
