@@ -439,24 +439,17 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
     const long long tq0 = qprof ? wall_clock64() : 0;
     if(kind == 0)
     {
-      // one reflector: v -= tau (E.v) E on rows [st, n)  (OrthonormalSequence.cpp:59-63, :98-102)
+      // one reflector: v -= tau (E.v) E on rows [st, n)  (OrthonormalSequence.cpp:59-63, :98-102).  The stored row is
+      // ZERO outside [st, n) (written so when the reflector is made) and so is the working vector beyond n: the
+      // products of those positions are exact zeros, a chain that receives fma(0, v, p) keeps p (p is never -0), and
+      // fma(-s, 0, v) = v except that a NEGATIVE zero entry of v may come back as +0 -- no mask instruction anywhere.
       double p[VPT];
 #pragma unroll
       for(int i = 0; i < VPT; ++i) p[i] = 0.0;
 #pragma unroll
       for(int c = 0; c < NCH; ++c)
-      {
-        const int e0 = 1024 * c + t0;
 #pragma unroll
-        for(int i = 0; i < VPT; ++i)
-        {
-          const int e = e0 + i;
-          const bool in = (e >= st && e < n);
-          er[c][i] = in ? er[c][i] : 0.0;
-          const double pn = FMA(er[c][i], vr[c][i], p[i]);
-          p[i] = in ? pn : p[i];
-        }
-      }
+        for(int i = 0; i < VPT; ++i) p[i] = FMA(er[c][i], vr[c][i], p[i]);
 #pragma unroll
       for(int s2 = 1; s2 < VPT; s2 <<= 1)
 #pragma unroll
@@ -466,12 +459,7 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
 #pragma unroll
       for(int c = 0; c < NCH; ++c)
 #pragma unroll
-        for(int i = 0; i < VPT; ++i)
-        {
-          const int e = 1024 * c + t0 + i;
-          const double vn = FMA(-sc, er[c][i], vr[c][i]);
-          vr[c][i] = (e >= st && e < n) ? vn : vr[c][i];
-        }
+        for(int i = 0; i < VPT; ++i) vr[c][i] = FMA(-sc, er[c][i], vr[c][i]);
     }
     else if(sz > 0)
     {
@@ -1013,14 +1001,16 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
         {
           tau = 0.0;
           beta = c0;
-          for(int e = q + 1 + tid; e < n; e += NT) row[e] = 0.0;
+          for(int e = tid; e < A.n_pad; e += NT)
+            if(e != q) row[e] = 0.0;
         }
         else
         {
           beta = __builtin_sqrt(FMA(c0, c0, tail));
           if(c0 >= 0.0) beta = -beta;
           const double den = c0 - beta;
-          for(int e = q + 1 + tid; e < n; e += NT) row[e] = d[e] / den;
+          for(int e = tid; e < A.n_pad; e += NT)
+            if(e != q) row[e] = (e > q && e < n) ? d[e] / den : 0.0; // zero outside (q, n): see q_apply
           tau = (beta - c0) / beta;
         }
         for(int k = tid; k < q; k += NT) RP(K.Rp, k, q) = d[k];
