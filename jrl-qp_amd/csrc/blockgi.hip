@@ -365,7 +365,7 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
   // loaded unconditionally (entries above `st` are unused garbage, masked below).
   // two rings of DEPTH rows: <= 24 doubles per thread each for the large shapes; 12 for n <= 1024, where registers decide
   // how many problems share a CU
-  constexpr int DEPTH = (NCH == 1) ? 3 : ((24 / (NCH * VPT)) > 6 ? 6 : (24 / (NCH * VPT)) < 2 ? 2 : (24 / (NCH * VPT)));
+  constexpr int DEPTH = (NCH == 1) ? 4 : ((36 / (NCH * VPT)) > 8 ? 8 : (36 / (NCH * VPT)) < 2 ? 2 : (36 / (NCH * VPT)));
   double ring[DEPTH][NCH][VPT];
   int rkind[DEPTH], rst[DEPTH], rsz[DEPTH];
   double rtau[DEPTH];
@@ -411,16 +411,13 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
       }
     }
   };
-  // group g + 1 is requested (clamped indices: no branch around a load) before group g is processed
-  double nxt[DEPTH][NCH][VPT];
-  int nkind[DEPTH], nst[DEPTH], nsz[DEPTH];
-  double ntau[DEPTH];
+  // rolling prefetch: slot j of the ring holds element kk0 + j; as soon as an element has been copied out of its slot
+  // the slot is refilled with the element DEPTH positions further (clamped index: no branch around a load), so DEPTH
+  // rows are in flight at any time.  The loop is unrolled by DEPTH: every slot index is a compile-time constant.
 #pragma unroll
   for(int j = 0; j < DEPTH; ++j) fetch(min(j, nseq - 1), ring[j], rkind[j], rst[j], rsz[j], rtau[j]);
   for(int kk0 = 0; kk0 < nseq; kk0 += DEPTH)
   {
-#pragma unroll
-  for(int j = 0; j < DEPTH; ++j) fetch(min(kk0 + DEPTH + j, nseq - 1), nxt[j], nkind[j], nst[j], nsz[j], ntau[j]);
 #pragma unroll
   for(int j = 0; j < DEPTH; ++j)
   {
@@ -436,6 +433,8 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
     for(int c = 0; c < NCH; ++c)
 #pragma unroll
       for(int i = 0; i < VPT; ++i) er[c][i] = ring[j][c][i];
+    fetch(min(kk + DEPTH, nseq - 1), ring[j], rkind[j], rst[j], rsz[j], rtau[j]);
+    __builtin_amdgcn_sched_barrier(0); // the refill is issued HERE, ahead of this element's arithmetic
     const long long tq0 = qprof ? wall_clock64() : 0;
     if(kind == 0)
     {
@@ -563,18 +562,6 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
     }
     if(qprof) qprof[kind] += wall_clock64() - tq0;
     } // kk < nseq
-  }
-#pragma unroll
-  for(int j = 0; j < DEPTH; ++j)
-  {
-    rkind[j] = nkind[j];
-    rst[j] = nst[j];
-    rsz[j] = nsz[j];
-    rtau[j] = ntau[j];
-#pragma unroll
-    for(int c = 0; c < NCH; ++c)
-#pragma unroll
-      for(int i = 0; i < VPT; ++i) ring[j][c][i] = nxt[j][c][i];
   }
   }
 #pragma unroll
