@@ -477,46 +477,63 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
         const double *cp = row, *sp = row + A.qcap;
         double * w = v + st;
         const int lane = K.lane;
-        // The rotations form one serial chain through the carried element.  Systolic form: lane j owns rotation j of
-        // a chunk of 64 and the carried value travels lane to lane with one DPP wave shift per step -- every lane
-        // recomputes its step each time, and lane j's result is final from step j on (its input is).  Per step the
-        // chain costs one shift + one fma (ascending) or one shift + mul + fma (descending); the second output of each
-        // rotation is formed once, after the chain.
+        // The rotations form one serial chain through the carried element.  Ascending order: ONE fma per step (the
+        // product c*y does not depend on the carry).  Chunks of 64 rotations: lane j stages the operands of rotation j
+        // in LDS, then EVERY lane runs the same scalar chain over uniform LDS reads, eight steps' operands requested
+        // ahead of the eight dependent fmas; lane j keeps the carry that entered step j and forms the rotation's second
+        // output afterwards.
+        double *S = K.tri, *B = S + 64;
         if(TR)
         {
           // ascending i: (w_i, w_i+1) <- (c w_i - s w_i+1, s w_i + c w_i+1); carried: the new w_i+1
           double xc = w[0];
-          // (the next chunk's coefficients are requested before the current chunk's chain runs)
           double cn = (lane < sz) ? cp[lane] : 0.0, snn = (lane < sz) ? sp[lane] : 0.0;
           for(int i0 = 0; i0 < sz; i0 += 64)
           {
             const int cnt = min(64, sz - i0);
             const bool on = lane < cnt;
             const double c = cn, sn = snn;
-            if(i0 + 64 < sz)
+            if(i0 + 64 < sz) // the next chunk's coefficients are requested before this chunk's chain runs
             {
               const int ix = min(i0 + 64 + lane, sz - 1);
               cn = cp[ix];
               snn = sp[ix];
-              if(i0 + 64 + lane >= sz) cn = snn = 0.0;
             }
             const double y = on ? w[i0 + 1 + lane] : 0.0;
-            const double b = c * y, sy = sn * y;
-            double out = 0.0, t = xc;
-            for(int step = 0; step < cnt; ++step)
+            const double sy = sn * y;
+            S[lane] = sn;
+            B[lane] = c * y;
+            wave_sync();
+            double tin = 0.0;
+            for(int j0 = 0; j0 < cnt; j0 += 8)
             {
-              t = dpp_shift_d<0x138>(out, xc); // wave_shr:1 -- lane j takes lane j-1's carry, lane 0 the chunk's input
-              out = FMA(sn, t, b);
+              double sv[8], bv[8];
+#pragma unroll
+              for(int u = 0; u < 8; ++u)
+              {
+                sv[u] = S[min(j0 + u, 63)];
+                bv[u] = B[min(j0 + u, 63)];
+              }
+#pragma unroll
+              for(int u = 0; u < 8; ++u)
+              {
+                const double nx = FMA(sv[u], xc, bv[u]);
+                tin = (lane == j0 + u) ? xc : tin;
+                xc = (j0 + u < cnt) ? nx : xc;
+              }
             }
-            if(on) w[i0 + lane] = FMA(c, t, -sy);
-            xc = bcast_lane(out, cnt - 1);
+            if(on) w[i0 + lane] = FMA(c, tin, -sy);
+            wave_sync();
           }
           if(lane == 0) w[sz] = xc;
         }
         else
         {
-          // descending i: (w_i, w_i+1) <- (c w_i + s w_i+1, -s w_i + c w_i+1); carried: the new w_i.  The chunk is
-          // aligned to the TOP lanes (rotation i1-1 on lane 63) so that the input enters at the end of the shift.
+          // descending i: (w_i, w_i+1) <- (c w_i + s w_i+1, -s w_i + c w_i+1); carried: the new w_i.  Here a step is
+          // mul + fma on three operands: the systolic form is the faster one -- lane j owns rotation j, the carry
+          // travels lane to lane with one DPP wave shift per step, every lane recomputes its step each time and lane
+          // j's result is final from step j on.  The chunk is aligned to the TOP lanes (rotation i1-1 on lane 63); the
+          // entry lane's result is known up front and it is given coefficients that reproduce it whatever arrives.
           double yc = w[sz];
           double cn, snn;
           {
@@ -538,12 +555,20 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
               if(j2 < 0) cn = snn = 0.0;
             }
             const double xv = on ? w[i0 + j] : 0.0;
-            double out = 0.0, t = yc;
+            double cl = c, xl = xv, sl = sn;
+            if(lane == 63)
+            {
+              xl = FMA(c, xv, sn * yc);
+              cl = 1.0;
+              sl = 0.0;
+            }
+            double out = 0.0, t = 0.0;
             for(int step = 0; step < cnt; ++step)
             {
-              t = dpp_shift_d<0x130>(out, yc); // wave_shl:1 -- lane j takes lane j+1's carry, lane 63 the chunk's input
-              out = FMA(c, xv, sn * t);
+              t = dpp_shift0_d<0x130>(out); // wave_shl:1 -- lane j takes lane j+1's carry
+              out = FMA(cl, xl, sl * t);
             }
+            t = (lane == 63) ? yc : t;
             if(on) w[i0 + j + 1] = FMA(-sn, xv, c * t);
             yc = bcast_lane(out, 64 - cnt);
           }

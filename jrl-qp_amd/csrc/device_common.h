@@ -68,6 +68,15 @@ __device__ __forceinline__ double dpp_shift_d(double v, double old)
   return __hiloint2double(hi, lo);
 }
 
+// DPP move, lanes without a source lane get zero (bound_ctrl): no preload of the destination, two instructions in all
+template<int CTRL>
+__device__ __forceinline__ double dpp_shift0_d(double v)
+{
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
 // Sum over the 64 lanes as an ADJACENT-FIRST pairwise tree (lane 2i with 2i+1, then pairs of pairs, ...): rule C4 of
 // the oracle (oracle/blockgi_oracle.c orc_dot_tree).  Every lane returns the same bits: each level adds the totals of
 // two sibling groups, and a + b == b + a.  quad_perm / row_half_mirror / row_mirror inside a row of 16, then the four
