@@ -9,6 +9,7 @@
 #include "selftest.h"
 #include "structured.h"
 
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -404,6 +405,8 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   // throughput layout: large problems (n > 1024) in batches of at least half the CUs keep x and u in HBM so that two
   // problems share a CU (same results: the layout does not enter the arithmetic)
   h->xu_global = (n > 1024 && nprob >= 128 && 2 * jrlqp::blockgi_lds_bytes(n, m, nb, nblk, 1) <= jrlqp::kLdsPerCU) ? 1 : 0;
+  if(const char * lay = std::getenv("JRLQP_BLOCKGI_LAYOUT")) // diagnostic override: "throughput" | "latency"
+    if(n > 1024) h->xu_global = (lay[0] == 't') ? 1 : 0;
   if(e == hipSuccess) e = hipMalloc(&h->d_xu, sizeof(double) * (size_t)nprob * (h->n_pad + h->qcap));
   if(e == hipSuccess) e = hipMemcpy(h->d_boff, boff.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
   if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_cvar, cvar, sizeof(int) * ncb, hipMemcpyHostToDevice);
