@@ -368,56 +368,146 @@ __global__ void permute_rows_kernel(double * M, int ldm, int nrhs, int ntot, int
 }
 
 // =========================================================================================================
-// block tridiagonal: serial chain over blocks, one workgroup (one wave) per problem
+// block tridiagonal: serial chain over blocks, one workgroup per problem (grid.x = number of problems).
+// Within a block the three steps run RIGHT-LOOKING on 256 threads out of LDS: as soon as column k of L (or of X) is
+// final, every element to its right receives its k-th term -- each element still accumulates its terms in ascending k,
+// which is all the rounding contract fixes, so the result is the bit pattern of the column-by-column reference order,
+// while the critical path is one barrier + one division per COLUMN instead of one LDS round trip per TERM.
 // =========================================================================================================
-__global__ __launch_bounds__(64) void tri_llt_kernel(const BlockDesc D)
+constexpr int kTriThreads = 256;
+
+// in-place lower Cholesky of the n x n block in LDS; diagL receives the diagonal of the factor (the diagonal of L in
+// LDS keeps the running sums).  Returns -1, or the failing column j: columns < j are final, nothing of column j on is
+// meaningful (the caller writes back columns < j only, like Eigen's llt_inplace leaves the rest untouched).
+__device__ int block_llt(double * L, int ld, int n, double * diagL, int tid)
+{
+  for(int c = tid; c < n; c += kTriThreads) diagL[c] = AT(L, ld, c, c);
+  __syncthreads();
+  const double p0 = AT(L, ld, 0, 0);
+  if(p0 <= 0.0) return 0;
+  const double l0 = __builtin_sqrt(p0);
+  for(int r = tid; r < n; r += kTriThreads)
+  {
+    if(r == 0)
+      diagL[0] = l0;
+    else
+      AT(L, ld, r, 0) = AT(L, ld, r, 0) / l0;
+  }
+  __syncthreads();
+  for(int k = 0; k + 1 < n; ++k)
+  {
+    const int c1 = k + 1;
+    const double lck = AT(L, ld, c1, k);
+    const double piv = FMA(-lck, lck, AT(L, ld, c1, c1)); // every thread: the pivot of the column that becomes final now
+    if(piv <= 0.0) return c1;
+    const double lp = __builtin_sqrt(piv);
+    // threads as a 16 x 16 tile over (row, column) of the trailing block: no integer division on the way
+    for(int c = c1 + (tid >> 4); c < n; c += 16)
+      for(int r = c1 + (tid & 15); r < n; r += 16)
+      {
+        if(r < c) continue;
+        if(r == c1) // (c1, c1): its value is `piv`, kept in registers; only the factor's diagonal is recorded
+        {
+          diagL[c1] = lp;
+          continue;
+        }
+        const double acc = FMA(-AT(L, ld, r, k), AT(L, ld, c, k), AT(L, ld, r, c));
+        if(c == c1)
+          AT(L, ld, r, c) = acc / lp;
+        else
+          AT(L, ld, r, c) = acc;
+      }
+    __syncthreads();
+  }
+  return -1;
+}
+
+// X (r x n) <- X L^-T, L lower with its diagonal in diagL
+__device__ void block_trsm_right_lt(const double * L, int ldl, const double * diagL, int n, double * X, int ldx, int rows, int tid)
+{
+  const double d0 = diagL[0];
+  for(int r = tid; r < rows; r += kTriThreads) AT(X, ldx, r, 0) = AT(X, ldx, r, 0) / d0;
+  __syncthreads();
+  for(int k = 0; k + 1 < n; ++k)
+  {
+    const int c1 = k + 1;
+    const double d1 = diagL[c1];
+    for(int j = c1 + (tid >> 4); j < n; j += 16)
+      for(int r = (tid & 15); r < rows; r += 16)
+      {
+        const double acc = FMA(-AT(X, ldx, r, k), AT(L, ldl, j, k), AT(X, ldx, r, j));
+        if(j == c1)
+          AT(X, ldx, r, j) = acc / d1;
+        else
+          AT(X, ldx, r, j) = acc;
+      }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
 {
   extern __shared__ double sm[];
-  const int lane = threadIdx.x, pb = blockIdx.x;
+  const int tid = threadIdx.x, pb = blockIdx.x;
   int maxb = 0;
   for(int k = 0; k < D.nblk; ++k) maxb = max(maxb, D.bs[k]);
   const int ldl = maxb | 1;
-  double * Ls = sm;                      // current diagonal block
-  double * Xs = Ls + (size_t)maxb * ldl; // current sub-diagonal block (n_{i+1} x n_i)
+  // three block buffers: the diagonal block being factorised, the sub-diagonal block, and the NEXT diagonal block,
+  // which is fetched while this one is factorised and receives its rank update in LDS (no store -> load round trip
+  // through HBM between consecutive blocks of the chain)
+  double * Ls = sm;
+  double * Xs = Ls + (size_t)maxb * ldl;
+  double * Ns = Xs + (size_t)maxb * ldl;
+  double * diagL = Ns + (size_t)maxb * ldl;
+  load_block(Ls, ldl, D.diag[(size_t)pb * D.nblk], D.ldd[0], D.bs[0], D.bs[0], tid, kTriThreads);
   for(int i = 0; i < D.nblk; ++i)
   {
     const int ni = D.bs[i];
     double * Dg = D.diag[(size_t)pb * D.nblk + i];
     const int ldd = D.ldd[i];
-    load_block(Ls, ldl, Dg, ldd, ni, ni, lane, 64);
-    wave_sync();
-    int ret = wave_llt(Ls, ldl, ni, lane);
-    for(int e = lane; e < ni * ni; e += 64)
+    const bool last = (i == D.nblk - 1);
+    const int n1 = last ? 0 : D.bs[i + 1];
+    double * Sg = last ? nullptr : D.side[(size_t)pb * (D.nblk - 1) + i];
+    const int ldsg = last ? 1 : D.lds[i];
+    if(!last)
     {
-      int r = e % ni, c = e / ni;
-      if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+      load_block(Xs, ldl, Sg, ldsg, n1, ni, tid, kTriThreads);
+      load_block(Ns, ldl, D.diag[(size_t)pb * D.nblk + i + 1], D.ldd[i + 1], n1, n1, tid, kTriThreads);
     }
-    if(ret > 0) // triBlockDiagLLT.cpp:19,32
+    __syncthreads();
+    const int ret = block_llt(Ls, ldl, ni, diagL, tid);
+    __syncthreads();
+    // write the factor back: all of the lower triangle on success, the finished columns only on failure
+    const int cols = (ret < 0) ? ni : ret;
+    for(int e = tid; e < ni * cols; e += kTriThreads)
     {
-      if(lane == 0) D.fail[pb] = 1;
+      const int r = e % ni, c = e / ni;
+      if(r > c)
+        AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+      else if(r == c)
+        AT(Dg, ldd, r, c) = diagL[c];
+    }
+    if(ret > 0) // triBlockDiagLLT.cpp:19,32 (a failure at column 0 goes undetected there, and here)
+    {
+      if(tid == 0) D.fail[pb] = 1;
       return;
     }
-    if(i == D.nblk - 1) break;
-    const int n1 = D.bs[i + 1];
-    double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
-    const int ldsg = D.lds[i];
-    load_block(Xs, ldl, Sg, ldsg, n1, ni, lane, 64);
-    wave_sync();
-    wave_trsm_right_lt(Ls, ldl, ni, Xs, ldl, n1, lane); // S_i <- S_i L_i^-T
-    wave_sync();
-    for(int e = lane; e < n1 * ni; e += 64) AT(Sg, ldsg, e % n1, e / n1) = AT(Xs, ldl, e % n1, e / n1);
-    // D_{i+1} -= S_i S_i^T (lower)
-    double * Dn = D.diag[(size_t)pb * D.nblk + i + 1];
-    const int ldn = D.ldd[i + 1];
-    for(int e = lane; e < n1 * n1; e += 64)
+    if(last) break;
+    block_trsm_right_lt(Ls, ldl, diagL, ni, Xs, ldl, n1, tid); // S_i <- S_i L_i^-T
+    for(int e = tid; e < n1 * ni; e += kTriThreads) AT(Sg, ldsg, e % n1, e / n1) = AT(Xs, ldl, e % n1, e / n1);
+    // D_{i+1} -= S_i S_i^T (lower), in LDS: one element per thread, terms in ascending k
+    for(int c = (tid >> 4); c < n1; c += 16)
+    for(int r = (tid & 15); r < n1; r += 16)
     {
-      int r = e % n1, c = e / n1;
       if(r < c) continue;
-      AT(Dn, ldn, r, c) = chain2_neg(0, 1, ni, AT(Dn, ldn, r, c), [&](int k) { return AT(Xs, ldl, r, k); },
-                                      [&](int k) { return AT(Xs, ldl, c, k); });
+      const double v = chain2_neg(0, 1, ni, AT(Ns, ldl, r, c), [&](int k) { return AT(Xs, ldl, r, k); }, [&](int k) { return AT(Xs, ldl, c, k); });
+      AT(Ns, ldl, r, c) = v;
+      AT(D.diag[(size_t)pb * D.nblk + i + 1], D.ldd[i + 1], r, c) = v; // (what a failing factorisation of block i+1 leaves behind)
     }
-    __threadfence_block();
-    wave_sync();
+    __syncthreads();
+    double * t = Ls; // the updated next block becomes the current one
+    Ls = Ns;
+    Ns = t;
   }
 }
 
@@ -560,7 +650,10 @@ hipError_t launch_tri_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t 
 {
   hipError_t e = hipMemsetAsync(d.fail, 0, sizeof(int) * nprob, st);
   if(e != hipSuccess) return e;
-  hipLaunchKernelGGL(tri_llt_kernel, dim3(nprob), dim3(64), lds_arrow_block(maxb), st, d);
+  const size_t lds = lds_arrow_block(maxb) / 2 * 3 + sizeof(double) * 64;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_llt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL(tri_llt_kernel, dim3(nprob), dim3(kTriThreads), lds, st, d);
   return hipGetLastError();
 }
 
