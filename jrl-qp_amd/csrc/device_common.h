@@ -208,11 +208,19 @@ __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, dou
   const double rinv = recip_refined(dg);
   const double x0 = xi;
   double pre = 0.0;
+  // the operands of group g + 1 are requested before group g is consumed: one exposed memory latency per CALL
+  double lv[kAhead], ln[kAhead];
+#pragma unroll
+  for(int j = 0; j < kAhead; ++j) ln[j] = (n > 0) ? AT(L, ldl, rl, min(j, n - 1)) : 0.0;
   for(int k0 = 0; k0 < n; k0 += kAhead)
   {
-    double lv[kAhead];
 #pragma unroll
-    for(int j = 0; j < kAhead; ++j) lv[j] = AT(L, ldl, rl, min(k0 + j, n - 1));
+    for(int j = 0; j < kAhead; ++j) lv[j] = ln[j];
+    if(k0 + kAhead < n)
+    {
+#pragma unroll
+      for(int j = 0; j < kAhead; ++j) ln[j] = AT(L, ldl, rl, min(k0 + kAhead + j, n - 1));
+    }
 #pragma unroll
     for(int j = 0; j < kAhead; ++j)
     {
@@ -250,11 +258,18 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
   const double rinv = recip_refined(dg);
   const double x0 = xi;
   double pre = 0.0;
+  double lv[kAhead], ln[kAhead];
+#pragma unroll
+  for(int j = 0; j < kAhead; ++j) ln[j] = (n > 0) ? AT(L, ldl, max(n - 1 - j, 0), rl) : 0.0;
   for(int k0 = n - 1; k0 >= 0; k0 -= kAhead)
   {
-    double lv[kAhead];
 #pragma unroll
-    for(int j = 0; j < kAhead; ++j) lv[j] = AT(L, ldl, max(k0 - j, 0), rl);
+    for(int j = 0; j < kAhead; ++j) lv[j] = ln[j];
+    if(k0 - kAhead >= 0)
+    {
+#pragma unroll
+      for(int j = 0; j < kAhead; ++j) ln[j] = AT(L, ldl, max(k0 - kAhead - j, 0), rl);
+    }
 #pragma unroll
     for(int j = 0; j < kAhead; ++j)
     {
@@ -289,11 +304,19 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
 template<class FA, class FB>
 __device__ __forceinline__ double chain_neg8(int k0, int step, int cnt, double acc, FA fa, FB fb)
 {
+  if(cnt <= 0) return acc;
+  double av[kAhead], an[kAhead];
+#pragma unroll
+  for(int j = 0; j < kAhead; ++j) an[j] = fa(k0 + step * min(j, cnt - 1));
   for(int c0 = 0; c0 < cnt; c0 += kAhead)
   {
-    double av[kAhead];
 #pragma unroll
-    for(int j = 0; j < kAhead; ++j) av[j] = fa(k0 + step * min(c0 + j, cnt - 1));
+    for(int j = 0; j < kAhead; ++j) av[j] = an[j];
+    if(c0 + kAhead < cnt)
+    {
+#pragma unroll
+      for(int j = 0; j < kAhead; ++j) an[j] = fa(k0 + step * min(c0 + kAhead + j, cnt - 1));
+    }
 #pragma unroll
     for(int j = 0; j < kAhead; ++j)
       if(c0 + j < cnt) acc = FMA(-av[j], fb(k0 + step * (c0 + j)), acc);
