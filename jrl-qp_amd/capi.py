@@ -491,6 +491,30 @@ class BlockGISolver:
             pass
 
 
+
+class BoxAndSingleConstraintSolver:
+    """Mirror of experimental::BoxAndSingleConstraintSolver (include/jrl-qp/experimental/BoxAndSingleConstraintSolver.h:9-33)
+    over a batch:  min 1/2 ||x - x0||^2  s.t.  c^T x >= bl,  xl <= x <= xu.   It is the dense GI solver on G = I,
+    a = -x0 and one general constraint (the reference's class derives from GoldfarbIdnaniSolver and only replaces init_
+    by a closed form, BoxAndSingleConstraintSolver.cpp:46-94); objectiveValue() includes the constant 1/2 ||x0||^2 like
+    the reference's (tests/BoxAndSingleConstraintSolverTest.cpp:30,42)."""
+
+    def __init__(self, n, B, device="cuda"):
+        import torch
+
+        self.n, self.B = n, B
+        self.solver = BatchSolver(n, 1, True, B, device=device)
+        self.G = torch.eye(n, dtype=torch.float64, device=device).expand(B, n, n).contiguous()
+        self.bu = torch.full((B, 1), float("inf"), dtype=torch.float64, device=device)
+
+    def solve(self, x0, c, bl, xl, xu):
+        """x0, c, xl, xu: (B, n) float64 CUDA tensors; bl: (B,) or (B, 1)."""
+        r = self.solver.solve(self.G, (-x0).contiguous(), c.reshape(self.B, 1, self.n).contiguous(), bl.reshape(self.B, 1).contiguous(), self.bu,
+                              xl.contiguous(), xu.contiguous())
+        f = r.f + 0.5 * (x0 * x0).sum(dim=1)
+        return BatchResult(r.x, r.u, r.status, r.term, r.iters, f, None)
+
+
 def selftest_arith(a, b, c):
     """Device a/b, sqrt|a|, fma(a,b,c) and makeGivens(a,b) for float64 CUDA tensors a, b, c."""
     import torch

@@ -192,3 +192,37 @@ def test_randomised_shape_sweep(capi, P, oracle):
         assert_bit_identical(gpu, ref, f"trial {trial}: {ch}")
         seen_terms |= set(ref["term"].tolist())
     assert 0 in seen_terms
+
+
+def test_box_and_single_constraint_solver(pkg, oracle):
+    """experimental::BoxAndSingleConstraintSolver == GoldfarbIdnaniSolver on the same problem
+    (tests/BoxAndSingleConstraintSolverTest.cpp:16-47), constraint inactive and active; here both sides bit for bit."""
+    import torch
+
+    import jrl_qp_amd.capi as capi
+
+    rng = np.random.default_rng(99)
+    n, B = 10, 22
+    x0 = rng.uniform(-2, 2, (B, n))
+    c = rng.standard_normal((B, n))
+    xl = rng.uniform(-1.5, -0.5, (B, n))
+    xu = rng.uniform(0.5, 1.5, (B, n))
+    xb = np.clip(x0, xl, xu)  # solution without the general constraint
+    cxb = (c * xb).sum(axis=1)
+    smax = (np.where(c > 0, c * xu, c * xl)).sum(axis=1)  # max of c.x over the box
+    bl = np.where(np.arange(B) % 2 == 0, cxb - 1.0, cxb + 0.5 * (smax - cxb))  # even: inactive, odd: active
+    dev = lambda v: torch.tensor(v, device="cuda")
+    s = capi.BoxAndSingleConstraintSolver(n, B)
+    r = s.solve(dev(x0), dev(c), dev(bl), dev(xl), dev(xu))
+    torch.cuda.synchronize()
+    x, f, term, status = r.x.cpu().numpy(), r.f.cpu().numpy(), r.term.cpu().numpy(), r.status.cpu().numpy()
+    nact = 0
+    for b in range(B):
+        ref = oracle.solve(np.eye(n), -x0[b], c[b].reshape(n, 1), [bl[b]], [np.inf], xl[b], xu[b])
+        assert term[b] == ref.term == 0
+        assert np.array_equal(x[b], ref.x)
+        assert abs(f[b] - (ref.f + 0.5 * x0[b] @ x0[b])) <= 1e-12 * (1 + abs(f[b]))
+        assert abs(f[b] - 0.5 * np.sum((x[b] - x0[b]) ** 2)) <= 1e-10 * (1 + abs(f[b]))
+        nact += int(status[b, 0] != 0)
+        assert (c[b] @ x[b]) >= bl[b] - 1e-9
+    assert 8 <= nact <= 14
