@@ -51,18 +51,6 @@ __device__ int wave_llt(double * L, int ld, int n, int lane)
   return -1;
 }
 
-// X (r x n, r <= 64) <- X L^-T : lane = row of X; column j becomes available in increasing j
-__device__ void wave_trsm_right_lt(const double * L, int ldl, int n, double * X, int ldx, int r, int lane)
-{
-  if(lane < r)
-    for(int j = 0; j < n; ++j)
-    {
-      const double s = chain2_neg(0, 1, j, AT(X, ldx, lane, j), [&](int k) { return AT(X, ldx, lane, k); },
-                                  [&](int k) { return AT(L, ldl, j, k); });
-      AT(X, ldx, lane, j) = s / AT(L, ldl, j, j);
-    }
-}
-
 __device__ __forceinline__ void load_block(double * dst, int ldd, const double * src, int lds_, int rows, int cols, int tid, int nthr)
 {
   for(int e = tid; e < rows * cols; e += nthr)
@@ -72,13 +60,109 @@ __device__ __forceinline__ void load_block(double * dst, int ldd, const double *
   }
 }
 
+constexpr int kTriThreads = 256;
+
+// in-place lower Cholesky of the n x n block in LDS; diagL receives the diagonal of the factor (the diagonal of L in
+// LDS keeps the running sums).  Returns -1, or the failing column j: columns < j are final, nothing of column j on is
+// meaningful (the caller writes back columns < j only, like Eigen's llt_inplace leaves the rest untouched).
+__device__ int block_llt(double * L, int ld, int n, double * diagL, int tid)
+{
+  for(int c = tid; c < n; c += kTriThreads) diagL[c] = AT(L, ld, c, c);
+  __syncthreads();
+  const double p0 = AT(L, ld, 0, 0);
+  if(p0 <= 0.0) return 0;
+  const double l0 = __builtin_sqrt(p0);
+  for(int r = tid; r < n; r += kTriThreads)
+  {
+    if(r == 0)
+      diagL[0] = l0;
+    else
+      AT(L, ld, r, 0) = AT(L, ld, r, 0) / l0;
+  }
+  __syncthreads();
+  for(int k = 0; k + 1 < n; ++k)
+  {
+    const int c1 = k + 1;
+    const double lck = AT(L, ld, c1, k);
+    const double piv = FMA(-lck, lck, AT(L, ld, c1, c1)); // every thread: the pivot of the column that becomes final now
+    if(piv <= 0.0) return c1;
+    const double lp = __builtin_sqrt(piv);
+    // threads as a 16 x 16 tile over (row, column) of the trailing block: no integer division on the way
+    for(int c = c1 + (tid >> 4); c < n; c += 16)
+      for(int r = c1 + (tid & 15); r < n; r += 16)
+      {
+        if(r < c) continue;
+        if(r == c1) // (c1, c1): its value is `piv`, kept in registers; only the factor's diagonal is recorded
+        {
+          diagL[c1] = lp;
+          continue;
+        }
+        const double acc = FMA(-AT(L, ld, r, k), AT(L, ld, c, k), AT(L, ld, r, c));
+        if(c == c1)
+          AT(L, ld, r, c) = acc / lp;
+        else
+          AT(L, ld, r, c) = acc;
+      }
+    __syncthreads();
+  }
+  return -1;
+}
+
+// X (r x n) <- X L^-T, L lower with its diagonal in diagL
+__device__ void block_trsm_right_lt(const double * L, int ldl, const double * diagL, int n, double * X, int ldx, int rows, int tid)
+{
+  const double d0 = diagL[0];
+  for(int r = tid; r < rows; r += kTriThreads) AT(X, ldx, r, 0) = AT(X, ldx, r, 0) / d0;
+  __syncthreads();
+  for(int k = 0; k + 1 < n; ++k)
+  {
+    const int c1 = k + 1;
+    const double d1 = diagL[c1];
+    for(int j = c1 + (tid >> 4); j < n; j += 16)
+      for(int r = (tid & 15); r < rows; r += 16)
+      {
+        const double acc = FMA(-AT(X, ldx, r, k), AT(L, ldl, j, k), AT(X, ldx, r, j));
+        if(j == c1)
+          AT(X, ldx, r, j) = acc / d1;
+        else
+          AT(X, ldx, r, j) = acc;
+      }
+    __syncthreads();
+  }
+}
+
+// X (n x ncols) <- L^-1 X, L lower with its diagonal in diagL (Eigen triangularView<Lower>::solveInPlace on the left,
+// blockArrowLLT.cpp:70): row k is final after its division; every row below then receives its k-th term
+__device__ void block_trsm_left(const double * L, int ldl, const double * diagL, int n, double * X, int ldx, int ncols, int tid)
+{
+  const double d0 = diagL[0];
+  for(int c = tid; c < ncols; c += kTriThreads) AT(X, ldx, 0, c) = AT(X, ldx, 0, c) / d0;
+  __syncthreads();
+  for(int k = 0; k + 1 < n; ++k)
+  {
+    const int r1 = k + 1;
+    const double d1 = diagL[r1];
+    for(int c = (tid >> 4); c < ncols; c += 16)
+      for(int r = r1 + (tid & 15); r < n; r += 16)
+      {
+        const double acc = FMA(-AT(L, ldl, r, k), AT(X, ldx, k, c), AT(X, ldx, r, c));
+        if(r == r1)
+          AT(X, ldx, r, c) = acc / d1;
+        else
+          AT(X, ldx, r, c) = acc;
+      }
+    __syncthreads();
+  }
+}
+
 // =========================================================================================================
-// block arrow LLT, phase 1: one workgroup (one wave) per off-head block
+// block arrow LLT, phase 1: one 256-thread workgroup per off-head block, right-looking out of LDS (see the comment on
+// the block-tridiagonal kernel: same bits as the column-by-column order, one barrier + one division per column)
 // =========================================================================================================
-__global__ __launch_bounds__(64) void arrow_block_kernel(const BlockDesc D)
+__global__ __launch_bounds__(kTriThreads) void arrow_block_kernel(const BlockDesc D)
 {
   extern __shared__ double sm[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const int i = blockIdx.x; // logical block index < nblk - 1
   const int pb = blockIdx.y; // problem in the batch
   const int id = dsel(D.nblk, D.up, i), ib = dsel(D.nblk, D.up, D.nblk - 1);
@@ -88,40 +172,37 @@ __global__ __launch_bounds__(64) void arrow_block_kernel(const BlockDesc D)
   const int ldd = D.ldd[id], ldsg = D.lds[i];
   const int ldl = ni | 1;
   double * Ls = sm;
-  load_block(Ls, ldl, Dg, ldd, ni, ni, lane, 64);
-  wave_sync();
-  int ret = wave_llt(Ls, ldl, ni, lane);
-  if(ret > 0) // reference quirk: a failure at column 0 goes undetected (blockArrowLLT.cpp:65)
+  double * Xs = Ls + (size_t)ni * ldl;
+  const int ldx = D.up ? (ni | 1) : (nbk | 1);
+  double * diagL = Xs + (size_t)(D.up ? nbk : ni) * ldx;
+  load_block(Ls, ldl, Dg, ldd, ni, ni, tid, kTriThreads);
+  if(!D.up)
+    load_block(Xs, ldx, Sg, ldsg, nbk, ni, tid, kTriThreads); // side[i]: nbk x ni
+  else
+    load_block(Xs, ldx, Sg, ldsg, ni, nbk, tid, kTriThreads); // side[i]: ni x nbk
+  __syncthreads();
+  const int ret = block_llt(Ls, ldl, ni, diagL, tid);
+  __syncthreads();
+  if(ret > 0 && tid == 0) atomicExch(&D.fail[pb], 1); // reference quirk: a failure at column 0 goes undetected (blockArrowLLT.cpp:65)
+  const int cols = (ret < 0) ? ni : ret; // write the factor back: the finished columns only on failure
+  for(int e = tid; e < ni * cols; e += kTriThreads)
   {
-    if(lane == 0) atomicExch(&D.fail[pb], 1);
-  }
-  // write the factor back (lower triangle only)
-  for(int e = lane; e < ni * ni; e += 64)
-  {
-    int r = e % ni, c = e / ni;
-    if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+    const int r = e % ni, c = e / ni;
+    if(r > c)
+      AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+    else if(r == c)
+      AT(Dg, ldd, r, c) = diagL[c];
   }
   if(ret > 0) return;
   if(!D.up)
   {
-    // side[i] (nbk x ni) <- side[i] L_i^-T   (:71-72)
-    const int ldx = nbk | 1;
-    double * Xs = Ls + (size_t)ni * ldl;
-    load_block(Xs, ldx, Sg, ldsg, nbk, ni, lane, 64);
-    wave_sync();
-    wave_trsm_right_lt(Ls, ldl, ni, Xs, ldx, nbk, lane);
-    wave_sync();
-    for(int e = lane; e < nbk * ni; e += 64) AT(Sg, ldsg, e % nbk, e / nbk) = AT(Xs, ldx, e % nbk, e / nbk);
+    block_trsm_right_lt(Ls, ldl, diagL, ni, Xs, ldx, nbk, tid); // side[i] <- side[i] L_i^-T   (:71-72)
+    for(int e = tid; e < nbk * ni; e += kTriThreads) AT(Sg, ldsg, e % nbk, e / nbk) = AT(Xs, ldx, e % nbk, e / nbk);
   }
   else
   {
-    // side[i] (ni x nbk) <- L_i^-1 side[i]; it then stores B_i^T   (:68-70)
-    for(int c = 0; c < nbk; ++c)
-    {
-      double xi = (lane < ni) ? AT(Sg, ldsg, lane, c) : 0.0;
-      xi = wave_fwd(Ls, ldl, ni, xi, lane);
-      if(lane < ni) AT(Sg, ldsg, lane, c) = xi;
-    }
+    block_trsm_left(Ls, ldl, diagL, ni, Xs, ldx, nbk, tid); // side[i] <- L_i^-1 side[i]; it then stores B_i^T   (:68-70)
+    for(int e = tid; e < ni * nbk; e += kTriThreads) AT(Sg, ldsg, e % ni, e / ni) = AT(Xs, ldx, e % ni, e / ni);
   }
 }
 
@@ -374,77 +455,6 @@ __global__ void permute_rows_kernel(double * M, int ldm, int nrhs, int ntot, int
 // which is all the rounding contract fixes, so the result is the bit pattern of the column-by-column reference order,
 // while the critical path is one barrier + one division per COLUMN instead of one LDS round trip per TERM.
 // =========================================================================================================
-constexpr int kTriThreads = 256;
-
-// in-place lower Cholesky of the n x n block in LDS; diagL receives the diagonal of the factor (the diagonal of L in
-// LDS keeps the running sums).  Returns -1, or the failing column j: columns < j are final, nothing of column j on is
-// meaningful (the caller writes back columns < j only, like Eigen's llt_inplace leaves the rest untouched).
-__device__ int block_llt(double * L, int ld, int n, double * diagL, int tid)
-{
-  for(int c = tid; c < n; c += kTriThreads) diagL[c] = AT(L, ld, c, c);
-  __syncthreads();
-  const double p0 = AT(L, ld, 0, 0);
-  if(p0 <= 0.0) return 0;
-  const double l0 = __builtin_sqrt(p0);
-  for(int r = tid; r < n; r += kTriThreads)
-  {
-    if(r == 0)
-      diagL[0] = l0;
-    else
-      AT(L, ld, r, 0) = AT(L, ld, r, 0) / l0;
-  }
-  __syncthreads();
-  for(int k = 0; k + 1 < n; ++k)
-  {
-    const int c1 = k + 1;
-    const double lck = AT(L, ld, c1, k);
-    const double piv = FMA(-lck, lck, AT(L, ld, c1, c1)); // every thread: the pivot of the column that becomes final now
-    if(piv <= 0.0) return c1;
-    const double lp = __builtin_sqrt(piv);
-    // threads as a 16 x 16 tile over (row, column) of the trailing block: no integer division on the way
-    for(int c = c1 + (tid >> 4); c < n; c += 16)
-      for(int r = c1 + (tid & 15); r < n; r += 16)
-      {
-        if(r < c) continue;
-        if(r == c1) // (c1, c1): its value is `piv`, kept in registers; only the factor's diagonal is recorded
-        {
-          diagL[c1] = lp;
-          continue;
-        }
-        const double acc = FMA(-AT(L, ld, r, k), AT(L, ld, c, k), AT(L, ld, r, c));
-        if(c == c1)
-          AT(L, ld, r, c) = acc / lp;
-        else
-          AT(L, ld, r, c) = acc;
-      }
-    __syncthreads();
-  }
-  return -1;
-}
-
-// X (r x n) <- X L^-T, L lower with its diagonal in diagL
-__device__ void block_trsm_right_lt(const double * L, int ldl, const double * diagL, int n, double * X, int ldx, int rows, int tid)
-{
-  const double d0 = diagL[0];
-  for(int r = tid; r < rows; r += kTriThreads) AT(X, ldx, r, 0) = AT(X, ldx, r, 0) / d0;
-  __syncthreads();
-  for(int k = 0; k + 1 < n; ++k)
-  {
-    const int c1 = k + 1;
-    const double d1 = diagL[c1];
-    for(int j = c1 + (tid >> 4); j < n; j += 16)
-      for(int r = (tid & 15); r < rows; r += 16)
-      {
-        const double acc = FMA(-AT(X, ldx, r, k), AT(L, ldl, j, k), AT(X, ldx, r, j));
-        if(j == c1)
-          AT(X, ldx, r, j) = acc / d1;
-        else
-          AT(X, ldx, r, j) = acc;
-      }
-    __syncthreads();
-  }
-}
-
 __global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
 {
   extern __shared__ double sm[];
@@ -614,8 +624,13 @@ hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipS
 {
   hipError_t e = hipMemsetAsync(d.fail, 0, sizeof(int) * nprob, st);
   if(e != hipSuccess) return e;
-  if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(64), lds_arrow_block(maxb), st, d);
-  hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), sizeof(double) * ((size_t)maxb * (maxb | 1) + 64 * 65), st, d);
+  const size_t lds_blk = lds_arrow_block(maxb) + sizeof(double) * 64;
+  const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + 64 * 65);
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk);
+  if(e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
+  if(e != hipSuccess) return e;
+  if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(kTriThreads), lds_blk, st, d);
+  hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), lds_head, st, d);
   return hipGetLastError();
 }
 
