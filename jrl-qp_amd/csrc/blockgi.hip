@@ -612,29 +612,44 @@ __device__ __forceinline__ void r_solve(Ctx & K, int q)
   for(int c1 = q; c1 > 0;)
   {
     const int c0 = (c1 - 1) & ~63, nc = c1 - c0;
-    // stage the diagonal block (columns c0 .. c1-1, rows c0 .. column) in LDS, packed by columns
-    for(int e = K.tid; e < nc * (nc + 1) / 2; e += NT)
+    // stage the diagonal block (columns c0 .. c1-1, rows c0 .. column) in LDS, packed by columns: column jj of the block
+    // holds jj + 1 entries starting at jj (jj + 1) / 2; thread = (row ii, column jj0 + multiples of NT / 64)
+    for(int jj = K.tid >> 6; jj < nc; jj += NT / 64)
     {
-      // column jj of the block holds jj + 1 entries starting at jj (jj + 1) / 2
-      int jj = (int)((__builtin_sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while((jj + 1) * (jj + 2) / 2 <= e) ++jj;
-      while(jj * (jj + 1) / 2 > e) --jj;
-      const int ii = e - jj * (jj + 1) / 2;
-      tri[e] = RP(R, c0 + ii, c0 + jj);
+      const int ii = K.tid & 63;
+      if(ii <= jj) tri[jj * (jj + 1) / 2 + ii] = RP(R, c0 + ii, c0 + jj);
     }
     __syncthreads();
     if(K.wave == 0)
     {
+      // back substitution inside the block: pivots by v_readlane, reciprocals of the diagonal hoisted out of the chain
+      // (div_pre; redone with plain divisions if an operand leaves the range in which that is the compiler's quotient)
       const int lane = K.lane;
-      double xi = (lane < nc) ? r[c0 + lane] : 0.0;
+      const double x0 = (lane < nc) ? r[c0 + lane] : 0.0;
+      const double dg = (lane < nc) ? tri[lane * (lane + 1) / 2 + lane] : 1.0;
+      const double rinv = recip_refined(dg);
+      double xi = x0, pre = 0.0;
       for(int k = nc - 1; k >= 0; --k)
       {
         const double * col = tri + k * (k + 1) / 2;
-        const double v = bcast_lane(xi, k) / col[k];
-        if(lane == k)
-          xi = v;
-        else if(lane < k)
-          xi = FMA(-col[lane], v, xi);
+        const double v = div_pre(bcast_lane(xi, k), bcast_lane(dg, k), bcast_lane(rinv, k));
+        const double upd = FMA(-col[min(lane, k)], v, xi);
+        pre = (lane == k) ? xi : pre;
+        xi = (lane < k) ? upd : xi;
+        xi = (lane == k) ? v : xi;
+      }
+      if(!__all(lane >= nc || (div_safe_den(dg) && div_safe_num(pre))))
+      {
+        xi = x0;
+        for(int k = nc - 1; k >= 0; --k)
+        {
+          const double * col = tri + k * (k + 1) / 2;
+          const double v = bcast_lane(xi, k) / col[k];
+          if(lane == k)
+            xi = v;
+          else if(lane < k)
+            xi = FMA(-col[lane], v, xi);
+        }
       }
       if(lane < nc) r[c0 + lane] = xi;
     }
