@@ -361,32 +361,37 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
     }
   // Reflector rows stream from HBM / the Infinity Cache (one row per iteration ever made: far more than L2 holds), and
   // one reflector costs far less than one memory latency: the rows and descriptors of the next DEPTH elements are kept
-  // in flight in a register ring.  Row addresses depend on the element index only, and whole 4-packs inside the row are
-  // loaded unconditionally (entries above `st` are unused garbage, masked below).
-  // two rings of DEPTH rows: <= 24 doubles per thread each for the large shapes; 12 for n <= 1024, where registers decide
-  // how many problems share a CU
+  // in flight in a register ring (<= 36 doubles per thread for the large shapes; 16 for n <= 1024, where registers
+  // decide how many problems share a CU).  Row addresses depend on the element index only -- the fetch pointers simply
+  // step by one row / one record per element -- and whole VPT-packs inside the row are loaded unconditionally (a row
+  // is zero outside its reflector's support).
   constexpr int DEPTH = (NCH == 1) ? 4 : ((36 / (NCH * VPT)) > 8 ? 8 : (36 / (NCH * VPT)) < 2 ? 2 : (36 / (NCH * VPT)));
   double ring[DEPTH][NCH][VPT];
   int rkind[DEPTH], rst[DEPTH], rsz[DEPTH];
   double rtau[DEPTH];
-  auto fetch = [&](int kk, double(&en)[NCH][VPT], int & nkind, int & nst, int & nsz, double & ntau) {
-    const int k = TR ? kk : nseq - 1 - kk;
+  // element fetched next (in application order kf = 0, 1, ...; clamped at the last one) and its row / record
+  int kf = 0;
+  const ptrdiff_t rstep = TR ? (ptrdiff_t)A.row_len : -(ptrdiff_t)A.row_len;
+  const double * frow = K.pool + (size_t)(TR ? 0 : nseq - 1) * A.row_len + t0;
+  const SeqRec * frec = K.desc + (TR ? 0 : nseq - 1);
+  bool act[NCH];
+#pragma unroll
+  for(int c = 0; c < NCH; ++c) act[c] = (1024 * c + t0 < A.n_pad);
+  auto fetch = [&](double(&en)[NCH][VPT], int & nkind, int & nst, int & nsz, double & ntau) {
     // (records are written by thread 0 behind a barrier and only ever read with vector loads)
-    const int4 rec = *reinterpret_cast<const int4 *>(K.desc + k);
+    const int4 rec = *reinterpret_cast<const int4 *>(frec);
     nkind = rec.x;
     nst = rec.y;
     nsz = rec.z;
-    ntau = K.desc[k].tau;
-    const double * row = K.pool + (size_t)k * A.row_len;
+    ntau = frec->tau;
 #pragma unroll
     for(int c = 0; c < NCH; ++c)
     {
-      const int e0 = 1024 * c + t0;
-      if(e0 < A.n_pad)
+      if(act[c])
       {
         if constexpr(VPT == 4)
         {
-          const double2 lo = *reinterpret_cast<const double2 *>(row + e0), hi = *reinterpret_cast<const double2 *>(row + e0 + 2);
+          const double2 lo = *reinterpret_cast<const double2 *>(frow + 1024 * c), hi = *reinterpret_cast<const double2 *>(frow + 1024 * c + 2);
           en[c][0] = lo.x;
           en[c][1] = lo.y;
           en[c][2] = hi.x;
@@ -394,28 +399,35 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
         }
         else if constexpr(VPT == 2)
         {
-          const double2 lo = *reinterpret_cast<const double2 *>(row + e0);
+          const double2 lo = *reinterpret_cast<const double2 *>(frow + 1024 * c);
           en[c][0] = lo.x;
           en[c][1] = lo.y;
         }
         else
         {
 #pragma unroll
-          for(int i = 0; i < VPT; ++i) en[c][i] = (e0 + i < A.n_pad) ? row[e0 + i] : 0.0;
+          for(int i = 0; i < VPT; ++i) en[c][i] = (1024 * c + t0 + i < A.n_pad) ? frow[1024 * c + i] : 0.0;
         }
       }
-      else
-      {
-#pragma unroll
-        for(int i = 0; i < VPT; ++i) en[c][i] = 0.0;
-      }
+    }
+    if(kf + 1 < nseq) // (uniform) the last element is simply fetched again by the slots that run past the end
+    {
+      ++kf;
+      frow += rstep;
+      frec += TR ? 1 : -1;
     }
   };
+#pragma unroll
+  for(int j = 0; j < DEPTH; ++j)
+#pragma unroll
+    for(int c = 0; c < NCH; ++c)
+#pragma unroll
+      for(int i = 0; i < VPT; ++i) ring[j][c][i] = 0.0;
   // rolling prefetch: slot j of the ring holds element kk0 + j; as soon as an element has been copied out of its slot
   // the slot is refilled with the element DEPTH positions further (clamped index: no branch around a load), so DEPTH
   // rows are in flight at any time.  The loop is unrolled by DEPTH: every slot index is a compile-time constant.
 #pragma unroll
-  for(int j = 0; j < DEPTH; ++j) fetch(min(j, nseq - 1), ring[j], rkind[j], rst[j], rsz[j], rtau[j]);
+  for(int j = 0; j < DEPTH; ++j) fetch(ring[j], rkind[j], rst[j], rsz[j], rtau[j]);
   for(int kk0 = 0; kk0 < nseq; kk0 += DEPTH)
   {
 #pragma unroll
@@ -433,7 +445,7 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
     for(int c = 0; c < NCH; ++c)
 #pragma unroll
       for(int i = 0; i < VPT; ++i) er[c][i] = ring[j][c][i];
-    fetch(min(kk + DEPTH, nseq - 1), ring[j], rkind[j], rst[j], rsz[j], rtau[j]);
+    fetch(ring[j], rkind[j], rst[j], rsz[j], rtau[j]);
     __builtin_amdgcn_sched_barrier(0); // the refill is issued HERE, ahead of this element's arithmetic
     const long long tq0 = qprof ? wall_clock64() : 0;
     if(kind == 0)
