@@ -83,6 +83,87 @@ def cpu_baseline(pb, budget_s=12.0):
     }
 
 
+def bench_ik(args, rank, world, device, jdist):
+    """Secondary workload: a batch of copies of one of the reference's MultiIK fixtures (tests/MultiIK.zip of the reference,
+    committed as tests/golden/MultiIK.zip: the tri-block "Sequential IK" problem, n = 387, m = 1621, or the arrow
+    "Simultaneous IK" problem, n = 210, 25 inequalities + box) through jrlqp_blockgi_solve.  The reference prints
+    "Vanilla vs Structured" milliseconds for exactly these two problems (tests/BlockGISolverTest.in.cpp:252-268, :332-348)."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ikdata  # reader of the fixture files (data, not reference code)
+
+    import jrl_qp_amd.capi as capi
+
+    tri = args.workload == "ik-tri"
+    B = args.batch if args.batch != BATCH else 1024
+    lo, hi = jdist.shard_range(B * world, rank, world)
+    nloc = hi - lo
+    if tri:
+        d = ikdata.read_tri_block_diag()
+        nd, C = d["block"], d["C"]
+        first = np.array([int(np.flatnonzero(C[:, i])[0]) for i in range(C.shape[1])])
+        blk = first // nd
+        Cb = [np.asfortranarray(C[i * nd:(i + 1) * nd, blk == i]) for i in range(d["nblk"])]
+        kind, xl, xu = "tridiag", None, None
+    else:
+        d = ikdata.read_arrow()
+        nd = d["block"]
+        Cb = [np.asfortranarray(d["C"][i * nd:(i + 1) * nd, 5 * i:5 * (i + 1)]) for i in range(d["nblk"])]
+        kind, xl, xu = "arrow_up", d["xl"], d["xu"]
+    n, m = d["G"].shape[0], sum(c.shape[1] for c in Cb)
+    rep = lambda v: torch.tensor(np.ascontiguousarray(v), device=device).unsqueeze(0).expand(nloc, *np.shape(v)).contiguous()
+    H0 = rep(d["G"].T)
+    Cbt = rep(np.concatenate([c.ravel(order="F") for c in Cb]))
+    a, bl, bu = rep(d["a"]), rep(d["bl"]), rep(d["bu"])
+    xlt, xut = (rep(xl), rep(xu)) if xl is not None else (None, None)
+    solver = capi.BlockGISolver(kind, [nd] * d["nblk"], [c.shape for c in Cb], xl is not None, nloc, max_iter=64, device=device)
+    H = H0.clone()
+    stream = torch.cuda.current_stream(device)
+    for _ in range(max(args.warmup, 1)):
+        H.copy_(H0)
+        solver._bind(H, Cbt)
+        r = solver.solve(H, a, Cbt, bl, bu, xlt, xut)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        H.copy_(H0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        r = solver.solve(H, a, Cbt, bl, bu, xlt, xut)
+        e1.record(stream)
+        torch.cuda.synchronize(device)
+        kern_ms.append(e0.elapsed_time(e1))
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    n_ok, sum_it, elapsed = jdist.reduce_stats(int((r.term == 0).sum().item()), int(r.iters.sum().item()), elapsed, device=device)
+    if rank == 0:
+        total = B * world
+        gbytes = 8.0 * (sum(c.size for c in Cb) + (2 * d["nblk"] - 1) * nd * nd + n + 2 * m + (2 * n if xl is not None else 0))
+        alg = nloc * (gbytes + 8.0 * (n + m) + 4.0 * m + 16)
+        avg_s = float(np.mean(kern_ms)) * 1e-3
+        out = {"metric": f"structured GI QP solves/sec, MultiIK {'tri-block 9x43 (m=1621)' if tri else 'arrow 5x42 (25 ineq + box)'} fixture, batch per GPU",
+               "value": total * args.steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "reference fixture (tests/golden/MultiIK.zip), replicated",
+               "config": {"workload": f"{B} copies per GPU of the reference's MultiIK fixture through jrlqp_blockgi_solve (in-place block LLT + structured GI "
+                                      f"loop); wall time includes restoring G before each solve", "batch_per_gpu": B,
+                          "mean_iterations": sum_it / total, "solved": n_ok},
+               "roofline": {"bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "kernel": "tri_llt / arrow_* + blockgi_kernel<256,1>", "algorithmic_bytes_per_launch": alg,
+                            "avg_launch_ms": avg_s * 1e3,
+                            "note": "compulsory bytes only (G blocks, C, vectors, results once); these few-iteration solves are bound by the serial "
+                                    "substitution chains of the block solves (DESIGN.md 7.3)"}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def bench_single_large(args, rank, world, device, jdist):
     """Secondary workload (BASELINE config c2): one dense QP, n = 1024, m = 2048, 307 strongly active, through Mode A
     (jrlqp_dense_solve: state in HBM, host keeps the active-set state machine, one kernel per hook).  The path does not
@@ -233,10 +314,12 @@ def main():
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--m", type=int, default=M_INEQ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c2"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c2", "ik-tri", "ik-arrow"],
                     help="c3 (default, the BASELINE metric): batch of dense QPs; c5: batch of structured block-arrow QPs "
                          "(100 stages x 30 + head, 10 constraints per stage) through the structured GI solver; "
-                         "c2: ONE large dense QP (n=1024, m=2048) through the host-driven hooks (replicas only at N > 1)")
+                         "c2: ONE large dense QP (n=1024, m=2048) through the host-driven hooks (replicas only at N > 1); "
+                         "ik-tri / ik-arrow: batches of the reference's MultiIK fixtures (tests/golden/MultiIK.zip) through the "
+                         "structured GI solver")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from separate rocprofv3 --pmc passes (default: profiles/r1_pmc_traffic.json if it matches)")
     args = ap.parse_args()
@@ -262,6 +345,8 @@ def main():
         return bench_structured(args, rank, world, device, jdist)
     if args.workload == "c2":
         return bench_single_large(args, rank, world, device, jdist)
+    if args.workload.startswith("ik-"):
+        return bench_ik(args, rank, world, device, jdist)
 
     n, m, B = args.n, args.m, args.batch
     total = B * world
