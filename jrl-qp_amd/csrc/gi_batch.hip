@@ -356,7 +356,7 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 // WARM  : warm-started solve (src/experimental/GoldfarbIdnaniSolver.cpp): the initial active set comes from the data
 //         equalities plus a guess, J and R from a Householder QR of L^-1 N; then the same loop
 template<int NT, int CMODE, bool PROF, bool WARM>
-__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? (WARM ? 2 : 3) : 1) void gi_batch_kernel(const BatchArgs A)
+__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : 3) : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0, last3_ = 0;
   if(PROF)
@@ -1819,7 +1819,7 @@ long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
 int batch_pick_cmode(int n, int m, int nb, int warm)
 {
   // registers: the specialised instantiations below; LDS when C fits beside the factors; else stream
-  if(n == 50 && m <= 256) return 2;
+  if((n == 50 || n == 64) && m <= 256) return 2;
   if(batch_lds_bytes(n, m, nb, 1, warm) <= kLdsPerCU) return 1;
   if(batch_lds_bytes(n, m, nb, 0, warm) <= kLdsPerCU) return 0;
   return -1;
@@ -1829,6 +1829,7 @@ hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)
 {
   const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode, a.warm);
   if(cmode == 2 && a.n == 50) return launch_prof<50, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 64) return launch_prof<64, 2>(a, lds, stream);
   if(cmode == 1) return launch_prof<0, 1>(a, lds, stream);
   return launch_prof<0, 0>(a, lds, stream);
 }

@@ -98,6 +98,10 @@ CASES = [
     dict(nVar=50, nObj=50, nIneq=150, nStrongActIneq=12),
     dict(nVar=50, nObj=50, nIneq=256, nStrongActIneq=20),
     dict(nVar=50, nObj=50, nEq=4, nIneq=196, nStrongActIneq=10, bounds=True, nStrongActBounds=5, doubleSidedIneq=True),
+    # the n = 64 register-resident specialisation (two workgroups per CU): extras in LDS (m = 256), bounds + equalities
+    dict(nVar=64, nObj=64, nIneq=128, nStrongActIneq=19),
+    dict(nVar=64, nObj=64, nIneq=256, nStrongActIneq=25),
+    dict(nVar=64, nObj=64, nEq=5, nIneq=190, nStrongActIneq=12, bounds=True, nStrongActBounds=6, doubleSidedIneq=True),
 ]
 
 
