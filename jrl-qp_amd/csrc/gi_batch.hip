@@ -392,6 +392,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   // thread during the (overlapped) scan, so that nothing has to be published once the winner among the waves is known
   double * npw = tail;
   if(CMODE == 2) tail = npw + 3 * n;
+  // CMODE 2: the state of the (sliced) speculative coefficient chain of wave 3 between its slices: seeds + radius, one
+  // value per lane.  In registers it would be live across every other phase of the pass (all waves share one register
+  // allocation) and push column entries of the scanning waves into scratch.
+  double * gsc = tail;
+  if(CMODE == 2) tail = gsc + 6 * 64;
   // WARM: N -> B = L^-1 N -> its QR factors (n x q), b_act, Householder coefficients
   double * Bw = tail;
   double * bact = Bw + (WARM ? n * ld : 0);
@@ -429,8 +434,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   double creg[NR];
   double my_bl = 0.0, my_bu = 0.0;
   const int myc = (CMODE == 2 && tid < CREG_MAX) ? tid : -1; // constraint held in this thread's registers (waves 0-2)
-  if(CMODE == 2)
-  {
+  // At three workgroups per CU (168 VGPRs) the columns are fetched AFTER the initial factorisation: live across it they
+  // push hipcc into spilling column entries for the whole kernel (reloaded one by one inside every scan).  The exposed
+  // load latency is paid once per solve.
+  constexpr bool LATE_C = (CMODE == 2 && NT == 50 && !WARM);
+  auto load_columns = [&]() __attribute__((always_inline)) {
     const bool own = myc >= 0 && myc < m;
     const double * ci = Cg + (size_t)(own ? myc : 0) * n;
     if((NR % 2 == 0) && ((reinterpret_cast<size_t>(Cg) & 15) == 0)) // a column is NR*8 bytes: 16-byte loads when aligned
@@ -440,17 +448,21 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       for(int k = 0; k < NR / 2; ++k)
       {
         const double2 v = c2[k];
-        creg[2 * k] = own ? v.x : 0.0;
-        creg[2 * k + 1] = own ? v.y : 0.0;
+        creg[2 * k] = v.x; // (a thread that owns no constraint never reads creg)
+        creg[2 * k + 1] = v.y;
       }
     }
     else
     {
 #pragma unroll
-      for(int k = 0; k < NR; ++k) creg[k] = own ? ci[k] : 0.0;
+      for(int k = 0; k < NR; ++k) creg[k] = ci[k];
     }
     my_bl = own ? blg[myc] : 0.0;
     my_bu = own ? bug[myc] : 0.0;
+  };
+  if(CMODE == 2)
+  {
+    if(!LATE_C) load_columns();
     for(int e = tid; e < ne * n; e += WG)
     {
       int k = e % n, i = e / n;
@@ -820,10 +832,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     }
     __syncthreads();
     STAMP(2)
+    if(CMODE == 2 && LATE_C) load_columns();
 
     const double big = A.big_bnd;
     constexpr bool SPEC = (CMODE == 2); // speculative Givens coefficient chain on wave 3 (which holds no constraint)
-    constexpr int SPEC_A0 = 10, SPEC_B = 8; // steps run beside trsv/ratio (plus q/2) and beside the primal/dual update
+    constexpr int SPEC_A0 = 24, SPEC_B = 20; // steps run beside trsv/ratio (plus q/2) and beside the primal/dual update
     int p = -1, pstat = INACTIVE;
     int addno = 0; // number of constraints added so far: the hand-off token of add_chain / add_apply
 
@@ -1193,33 +1206,95 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     // next rotation index
     double gc_d = 0.0, gc_rho = 0.0, gc_kq = 0.0;
     int gc_i = -1;
+    // The recurrence runs SEEDED and systolically (device_common.h givens_seed / givens_seeded_step): lane i owns step i,
+    // gc_rc is its radius r_i, one loop-invariant sweep per step.  chain_finish checks every step against the plain
+    // formula and falls back to the plain recurrence (chain_exact) if any radius differs.
+    GivensSeed gc_seed;
+    double gc_rc = 0.0;
+    constexpr bool GC_LDS = (CMODE == 2); // chain state parked in LDS between the slices (see gsc above)
+    auto chain_park = [&]() {
+      if(!GC_LDS) return;
+      gsc[lane] = gc_seed.Pn;
+      gsc[64 + lane] = gc_seed.Pu;
+      gsc[128 + lane] = gc_seed.W;
+      gsc[192 + lane] = gc_seed.G;
+      gsc[256 + lane] = gc_seed.h;
+      gsc[320 + lane] = gc_rc;
+    };
+    auto chain_unpark = [&](bool seeds) {
+      const int rl = (lane < n) ? lane : (n - 1);
+      const double dv = ds[rl];
+      gc_d = (lane < n) ? dv : 0.0;
+      if(!GC_LDS) return;
+      gc_seed.a = fabs(gc_d);
+      if(seeds)
+      {
+        gc_seed.Pn = gsc[lane];
+        gc_seed.Pu = gsc[64 + lane];
+        gc_seed.W = gsc[128 + lane];
+        gc_seed.G = gsc[192 + lane];
+        gc_seed.h = gsc[256 + lane];
+      }
+      gc_rc = gsc[320 + lane];
+    };
     auto chain_begin = [&]() {
       const int rl = (lane < n) ? lane : (n - 1);
-      gc_d = ds[rl];
-      gc_rho = opaque_v(bcast_lane(gc_d, n - 1));
-      gc_kq = 0.0;
+      const double dv = ds[rl];
+      gc_d = (lane < n) ? dv : 0.0; // (lanes >= n: zero -- they sit above the chain and must stay at radius 0)
+      const double sincl = wave_suffix_sum_approx(gc_d * gc_d, lane);
+      gc_seed = givens_seed(gc_d, dpp_shift0_d<0x130>(sincl)); // lane i: sum over k > i
+      gc_rc = gc_d;
       gc_i = n - 2;
     };
     // up to `count` more steps of the coefficient recurrence (rotation indices n-2 .. q)
-    auto chain_steps = [&](int count) {
+    auto chain_run = [&](int count) {
       const int stop = (gc_i - count + 1 > q) ? (gc_i - count + 1) : q;
-      for(int i = gc_i; i >= stop; --i)
+      for(int i = gc_i; i >= stop; --i) gc_rc = givens_seeded_step(dpp_shift0_d<0x130>(gc_rc), gc_seed);
+      gc_i = (gc_i >= stop) ? (stop - 1) : gc_i;
+    };
+    // one slice of the chain: state from / to LDS when the chain is interleaved with the other waves' phases
+    auto chain_steps = [&](int count, bool first = false) {
+      if(first)
+        chain_begin();
+      else
+        chain_unpark(true);
+      chain_run(count);
+      chain_park();
+    };
+    // the plain recurrence: every lane runs it (uniform values); lane i keeps r_{i+1}
+    auto chain_exact = [&]() {
+      gc_rho = opaque_v(bcast_lane(gc_d, n - 1));
+      gc_kq = 0.0;
+      for(int i = n - 2; i >= q; --i)
       {
         const double p_i = opaque_v(bcast_lane(gc_d, i));
         gc_kq = (lane == i) ? gc_rho : gc_kq;
         gc_rho = givens_r_only(p_i, gc_rho);
       }
-      gc_i = (gc_i >= stop) ? (stop - 1) : gc_i;
     };
     auto chain_finish = [&](int pp, int ps, int token) {
       STAMP(13)
+      chain_unpark(false);
+      gc_rho = bcast_lane(gc_d, n - 1);
       if(n - 2 >= q)
       {
+        // lane i: r_{i+1} is its upper neighbour's radius (the SIGNED d_{n-1} for the first rotation)
+        gc_kq = dpp_shift0_d<0x130>(gc_rc);
+        gc_kq = (lane == n - 2) ? gc_rho : gc_kq;
         GivensHalf h;
-        (void)givens_r(gc_d, gc_kq, h);
+        double rex = givens_r(gc_d, gc_kq, h);
+        const bool mine = lane >= q && lane <= n - 2;
+        if(__any(mine && !(rex == gc_rc)))
+        {
+          chain_exact();
+          (void)givens_r(gc_d, gc_kq, h);
+          if(PROF && CMODE == 2 && lane == 0) atomicAdd(&prof_lds[13], 1ULL); // (slot 13 is idle when wave 3 runs the chain)
+        }
+        else
+          gc_rho = bcast_lane(gc_rc, q);
         double cl, sl;
         givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
-        if(lane >= q && lane <= n - 2)
+        if(mine)
         {
           zs[lane] = cl;
           rs[lane] = sl;
@@ -1240,8 +1315,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       }
     };
     auto add_chain = [&](int pp, int ps, int token) {
-      chain_begin();
-      chain_steps(n);
+      chain_steps(n, true);
       chain_finish(pp, ps, token);
     };
 
@@ -1639,8 +1713,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           if(SPEC && wave == 3)
           {
             STAMP3(24)
-            chain_begin();
-            chain_steps(SPEC_A0 + (q >> 1));
+            chain_steps(SPEC_A0 + (q >> 1), true);
             STAMP3(25)
           }
           else if(wave == 0)
@@ -1810,7 +1883,7 @@ long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
   long dbl = 2L * n * ld + 4L * n + 2L * (n + 2);
   if(warm) dbl += (long)n * ld + 2L * n;
   if(cmode == 1) dbl += (long)m * ld + 2L * m;
-  if(cmode == 2) dbl += 3L * n;                                    // per-wave n+ slots
+  if(cmode == 2) dbl += 3L * n + 6L * 64;                          // per-wave n+ slots, parked chain state
   if(cmode == 2 && m > WG - 64) dbl += (long)(m - (WG - 64)) * ld; // extra columns beyond the 192 register-resident ones
   long bytes = dbl * 8 + (long)sizeof(Ctl) + 4L * (n + 2) + (long)(m + nb);
   return (bytes + 15) & ~15L;

@@ -33,7 +33,7 @@ capi.load_library().jrlqp_debug_set_profile(prof.data_ptr())
 s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"]); torch.cuda.synchronize()
 capi.load_library().jrlqp_debug_set_profile(None)
 pr = prof.cpu().numpy().astype(np.float64)
-names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)", "add:chain", "add:cs+apply", "add:wave0 scan", "trsv loop", "ratio", "llt chain", "llt pivot", "combine+np+barrier", "compute_d", "combine", "publish np", "w3: other", "w3: chain A", "w3: wait S2+step", "w3: chain B", "w3: wait S3", "w3: chain rest", "w3: cs+flag", "w3: apply"]
+names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)", "add:chain | seeded-chain fallbacks (C in registers)", "add:cs+apply", "add:wave0 scan", "trsv loop", "ratio", "llt chain", "llt pivot", "combine+np+barrier", "compute_d", "combine", "publish np", "w3: other", "w3: chain A", "w3: wait S2+step", "w3: chain B", "w3: wait S3", "w3: chain rest", "w3: cs+flag", "w3: apply"]
 tot = pr[:, :10].sum(axis=1) + pr[:, 13:24].sum(axis=1)  # slots 24-31: wave 3's own time line
 print("mean cycles per solve", tot.mean(), " mean realtime us", pr[:, 12].mean() / 100.0, " => clock GHz", tot.mean() / (pr[:, 12].mean() / 100.0) / 1e3)
 for i, nm in enumerate(names):
