@@ -558,15 +558,26 @@ __global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ 
   if(lane < 16 && r0 + lane < n) z[r0 + lane] = acc;
 }
 
-// K7 + K8: one workgroup of 4 waves.  wave 0: r = R^-1 d1 (blocked back substitution, 64-column blocks) and the
-// ratio test; waves 1-3: z.z, n.z, n.x as three in-order chains.  Results to the mailbox.
-__global__ __launch_bounds__(256) void step_tail_kernel(const double * __restrict__ R, int ld, int n, int q, const double * __restrict__ d, double * r,
+// K7 + K8, two workgroups of 8 waves.
+//
+// block 0: r = R^-1 d1 and the ratio test.  The back substitution is blocked by 64 columns; row i's chain
+// (acc = d_i; acc = fma(-R(i,k), r_k, acc) for k = q-1 .. i+1; r_i = acc / R(i,i)) is untouched, only WHO advances it
+// changes: wave 0 solves the diagonal block of column block cb out of registers (lane = row, the block's row in 64
+// statically indexed registers, hoisted reciprocals: ~5 dependent ops per step), then waves 1-7 each take a row block
+// above it and advance those 64 chains through the block's 64 columns -- their tile of R was fetched into registers
+// while wave 0 was solving, and wave 0 fetches the next diagonal block while they update.  Two LDS-only barriers per
+// column block; the running right-hand side lives in LDS.
+//
+// block 1: z.z, n.z, n.x -- three in-order chains in three lanes of one wave, their operands staged in LDS by the
+// whole workgroup first (a single lane chasing them through global memory pays one L2 latency per eight entries:
+// that, not the arithmetic, was most of this kernel's time).
+__global__ __launch_bounds__(512) void step_tail_kernel(const double * __restrict__ R, int ld, int n, int q, const double * __restrict__ d, double * r,
                                                         const double * __restrict__ u, const unsigned char * __restrict__ st, double big,
                                                         const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
                                                         int pb, Mailbox * mb, const int * psel = nullptr, const double * cbase = nullptr, int ldc = 0,
                                                         int m = 0)
 {
-  extern __shared__ double rs[]; // q doubles (the running right-hand side) | 64 x 65 staging block
+  extern __shared__ double rs[]; // block 0: the running right-hand side (q) ; block 1: z | x | n+ (3 n)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if(psel)
   {
@@ -575,104 +586,165 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const double * __restric
     cp = (p < m) ? cbase + (size_t)p * ldc : nullptr;
     pb = p - m;
   }
-  if(wave == 0)
+  if(blockIdx.x == 1)
   {
-    double * Rb = rs + ((q + 1) & ~1);
-    for(int i = lane; i < q; i += 64) rs[i] = d[i];
-    wave_sync();
-    for(int kb = ((q - 1) / 64) * 64; kb >= 0 && q > 0; kb -= 64)
+    double * zl = rs;
+    double * xl = rs + n;
+    double * cl = rs + 2 * n;
+    for(int i = tid; i < n; i += 512)
     {
-      const int cnt = min(64, q - kb);
-      // stage the diagonal block (coalesced column reads) so that the substitution chain runs out of LDS
-      for(int k = 0; k < cnt; ++k) Rb[lane + k * 65] = (lane < cnt) ? AT(R, ld, kb + lane, kb + k) : 0.0;
-      wave_sync();
-      double rk = (lane < cnt) ? rs[kb + lane] : 0.0;
-      const double dg = (lane < cnt) ? Rb[lane + lane * 65] : 1.0;
-      for(int k = cnt - 1; k >= 0; --k)
+      zl[i] = z[i];
+      xl[i] = x[i];
+      cl[i] = cp ? cp[i] : 0.0;
+    }
+    __syncthreads();
+    if(wave != 0) return;
+    // lane 0: z.z   lane 1: n.z   lane 2: n.x   (n = C[:,p] for a general constraint, e_pb for a bound)
+    const int which = (lane < 3) ? lane : 0;
+    const double * pa = (which == 0) ? zl : cl;
+    const double * pv = (which == 2) ? xl : zl;
+    double acc = 0.0;
+    int k = 0;
+    for(; k + 16 <= n; k += 16)
+    {
+      double av[16], bv[16];
+#pragma unroll
+      for(int t = 0; t < 16; ++t)
       {
-        const double v = bcast_lane(rk, k) / bcast_lane(dg, k);
-        const double upd = FMA(-Rb[lane + k * 65], v, rk);
-        rk = (lane < k) ? upd : rk;
-        rk = (lane == k) ? v : rk;
+        av[t] = pa[k + t];
+        bv[t] = pv[k + t];
+      }
+#pragma unroll
+      for(int t = 0; t < 16; ++t) acc = FMA(av[t], bv[t], acc);
+    }
+    for(; k < n; ++k) acc = FMA(pa[k], pv[k], acc);
+    if(!cp && which != 0) acc = pv[pb];
+    if(lane == 0) mb->zz = acc;
+    if(lane == 1) mb->cz = acc;
+    if(lane == 2) mb->cx = acc;
+    return;
+  }
+
+  for(int i = tid; i < q; i += 512) rs[i] = d[i];
+  const int nblk = (q + 63) >> 6;
+  // One block of R per wave in 64 statically indexed registers, lane = row.  wave 0: the diagonal block it solves next,
+  // blk[k] = R(kb + lane, kb + k), and dg = its pivot; waves 1-7: the tile they advance their row block through
+  double blk[64];
+  double dg = 1.0;
+  auto fetch_diag = [&](int cb) {
+    const int kb = cb << 6, cnt = min(64, q - kb);
+    const int row = kb + ((lane < cnt) ? lane : 0);
+#pragma unroll
+    for(int k = 0; k < 64; ++k) blk[k] = AT(R, ld, row, kb + ((k < cnt) ? k : 0));
+    dg = (lane < cnt) ? AT(R, ld, row, row) : 1.0;
+  };
+  if(wave == 0 && nblk > 0) fetch_diag(nblk - 1);
+  lds_barrier();
+  for(int cb = nblk - 1; cb >= 0; --cb)
+  {
+    const int kb = cb << 6, cnt = min(64, q - kb);
+    // waves 1-7: the tile of the first row block they advance through this column block, requested before r exists
+    const int rb0 = wave - 1;
+    if(wave > 0 && rb0 < cb)
+    {
+      const int row = (rb0 << 6) + lane;
+#pragma unroll
+      for(int k = 0; k < 64; ++k) blk[k] = AT(R, ld, row, kb + ((k < cnt) ? k : 0));
+    }
+    if(wave == 0)
+    {
+      const double rk0 = (lane < cnt) ? rs[kb + lane] : 0.0;
+      const double rinv = recip_refined(dg);
+      double rk = rk0, pre = 0.0;
+#pragma unroll
+      for(int k = 63; k >= 0; --k)
+      {
+        if(k < cnt)
+        {
+          const double v = div_pre(bcast_lane(rk, k), bcast_lane(dg, k), bcast_lane(rinv, k));
+          const double upd = FMA(-blk[k], v, rk);
+          pre = (lane == k) ? rk : pre;
+          rk = (lane < k) ? upd : rk;
+          rk = (lane == k) ? v : rk;
+        }
+      }
+      if(!__all(div_safe_den(dg) && div_safe_num(pre)))
+      {
+        // an operand left the range in which the hoisted reciprocal is provably the compiler's own: redo with a / b
+        rk = rk0;
+#pragma unroll
+        for(int k = 63; k >= 0; --k)
+        {
+          if(k < cnt)
+          {
+            const double v = bcast_lane(rk, k) / bcast_lane(dg, k);
+            const double upd = FMA(-blk[k], v, rk);
+            rk = (lane < k) ? upd : rk;
+            rk = (lane == k) ? v : rk;
+          }
+        }
       }
       if(lane < cnt) rs[kb + lane] = rk;
-      wave_sync();
-      // rows above the block: their chains take this block's columns in descending k (8 loads in flight)
-      for(int i0 = 0; i0 < kb; i0 += 64)
-      {
-        const int i = i0 + lane;
-        if(i < kb)
-        {
-          double acc = rs[i];
-          int k = cnt - 1;
-          for(; k - 7 >= 0; k -= 8)
-          {
-            double rv[8];
-#pragma unroll
-            for(int u = 0; u < 8; ++u) rv[u] = AT(R, ld, i, kb + k - u);
-#pragma unroll
-            for(int u = 0; u < 8; ++u) acc = FMA(-rv[u], rs[kb + k - u], acc);
-          }
-          for(; k >= 0; --k) acc = FMA(-AT(R, ld, i, kb + k), rs[kb + k], acc);
-          rs[i] = acc;
-        }
-      }
-      wave_sync();
     }
-    // ratio test: t1 = min u_k / r_k over r_k > 0 (status by POSITION k: GoldfarbIdnaniSolver.cpp:162)
-    double tk = big;
-    int kk = NONE, dummy = 0;
-    for(int k = lane; k < q; k += 64)
+    lds_barrier();
+    if(wave == 0)
     {
-      double rv = rs[k];
-      r[k] = rv;
-      int sk = st[k];
-      if(sk != EQUALITY && sk != FIXED && rv > 0.0)
-      {
-        double tt = u[k] / rv;
-        if(tt < tk)
-        {
-          tk = tt;
-          kk = k;
-        }
-      }
-    }
-    wave_argmin(tk, kk, dummy);
-    if(lane == 0)
-    {
-      mb->t1 = (kk == NONE) ? big : tk;
-      mb->l = (kk == NONE) ? 0 : kk;
-      mb->uq = u[q];
-    }
-  }
-  else if(lane == 0)
-  {
-    // wave 1: z.z   wave 2: n.z   wave 3: n.x   (n = C[:,p] for a general constraint, e_pb for a bound)
-    double acc = 0.0;
-    if(wave == 1 || cp)
-    {
-      const double * pa = (wave == 1) ? z : cp;
-      const double * pv = (wave == 3) ? x : z;
-      int k = 0;
-      for(; k + 8 <= n; k += 8)
-      {
-        double av[8], bv[8];
-#pragma unroll
-        for(int u = 0; u < 8; ++u)
-        {
-          av[u] = pa[k + u];
-          bv[u] = pv[k + u];
-        }
-#pragma unroll
-        for(int u = 0; u < 8; ++u) acc = FMA(av[u], bv[u], acc);
-      }
-      for(; k < n; ++k) acc = FMA(pa[k], pv[k], acc);
+      if(cb > 0) fetch_diag(cb - 1);
     }
     else
-      acc = (wave == 2) ? z[pb] : x[pb];
-    if(wave == 1) mb->zz = acc;
-    if(wave == 2) mb->cz = acc;
-    if(wave == 3) mb->cx = acc;
+    {
+      for(int rb = rb0; rb < cb; rb += 7)
+      {
+        const int row = (rb << 6) + lane;
+        if(rb != rb0)
+        {
+#pragma unroll
+          for(int k = 0; k < 64; ++k) blk[k] = AT(R, ld, row, kb + ((k < cnt) ? k : 0));
+        }
+        double acc = rs[row];
+#pragma unroll
+        for(int k0 = 56; k0 >= 0; k0 -= 8)
+        {
+          double rv[8];
+#pragma unroll
+          for(int t = 0; t < 8; ++t) rv[t] = rs[kb + min(k0 + t, cnt - 1)];
+#pragma unroll
+          for(int t = 7; t >= 0; --t)
+          {
+            const double nx = FMA(-blk[k0 + t], rv[t], acc);
+            acc = (k0 + t < cnt) ? nx : acc;
+          }
+        }
+        rs[row] = acc;
+      }
+    }
+    lds_barrier();
+  }
+  if(wave != 0) return;
+  // ratio test: t1 = min u_k / r_k over r_k > 0 (status by POSITION k: GoldfarbIdnaniSolver.cpp:162)
+  double tk = big;
+  int kk = NONE, dummy = 0;
+  for(int k = lane; k < q; k += 64)
+  {
+    double rv = rs[k];
+    r[k] = rv;
+    int sk = st[k];
+    if(sk != EQUALITY && sk != FIXED && rv > 0.0)
+    {
+      double tt = u[k] / rv;
+      if(tt < tk)
+      {
+        tk = tt;
+        kk = k;
+      }
+    }
+  }
+  wave_argmin(tk, kk, dummy);
+  if(lane == 0)
+  {
+    mb->t1 = (kk == NONE) ? big : tk;
+    mb->l = (kk == NONE) ? 0 : kk;
+    mb->uq = u[q];
   }
 }
 
@@ -687,39 +759,87 @@ __global__ void advance_kernel(int n, int q, double t, int primal, const double 
 
 // K10 part 1 (one wave): the Givens coefficient recurrence on d (i = n-2 .. q), then all (c_i, s_i) in parallel.  Reads d
 // only and writes only its own outputs, so it can run ahead of the add/drop decision beside z / r / the ratio test.
-__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const double * d, double * cc, double * ss, double * rfin)
+//
+// seeded != 0: the recurrence runs from seeds (device_common.h givens_seed / givens_seeded_step: 8 dependent ops per
+// step instead of 26), systolically in blocks of 64 steps -- lane j owns step hi - j, its radius moves one lane up per
+// sweep (DPP), lane 0 is fed the radius the previous block ended on.  The second pass, which recomputes every rotation
+// from (d_i, r_{i+1}) with the plain formula anyway, compares the radii; any difference reruns the plain recurrence.
+__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const double * d, double * cc, double * ss, double * rfin, int seeded)
 {
-  extern __shared__ double sm[]; // d (n) | rho (n)
+  extern __shared__ double sm[]; // d (n) | rho (n + 1) | suffix sums of d^2 (n + 1, seeded only)
   double * dsm = sm;
   double * rho = sm + n;
+  double * ssq = rho + (n + 1);
   const int lane = threadIdx.x;
   for(int i = lane; i < n; i += 64) dsm[i] = d[i];
   wave_sync();
-  double r = opaque_v(dsm[n - 1]);
-  // The loop body must stay free of stores and exec-mask regions (they stall the in-order wave: measured +40 % on the
-  // batched kernel's chain).  The d values of the next 64 steps sit in a register (lane = step inside the block, read
-  // with v_readlane); lane (i mod 64) keeps r_{i+1}; both are exchanged with LDS once per 64 steps.
-  double kq = 0.0;
-  for(int hi = n - 2; hi >= q; hi -= 64)
+  double r = 0.0;
+  for(int pass = seeded ? 0 : 1; pass < 2; ++pass)
   {
-    const int lo = (hi - 63 > q) ? (hi - 63) : q; // this block: i = hi .. lo
-    const int mine = hi - lane;                   // lane j handles step i = hi - j
-    const double dblk = (mine >= lo) ? dsm[mine] : 0.0;
-    for(int i = hi; i >= lo; --i)
+    if(pass == 0)
     {
-      const double di = opaque_v(bcast_lane(dblk, hi - i));
-      kq = (lane == hi - i) ? r : kq; // r_{i+1}
-      r = givens_r_only(di, r);
+      // ssq[i] ~ sum of d_k^2 over k >= i (lane = chunk of consecutive entries, then a suffix sum over the chunk totals)
+      const int K = (n + 63) / 64;
+      const int c0 = min(lane * K, n), c1 = min(c0 + K, n);
+      double acc = 0.0;
+      for(int i = c1 - 1; i >= c0; --i)
+      {
+        acc = FMA(dsm[i], dsm[i], acc);
+        ssq[i] = acc;
+      }
+      const double above = dpp_shift0_d<0x130>(wave_suffix_sum_approx(acc, lane)); // chunks of the lanes above this one
+      for(int i = c0; i < c1; ++i) ssq[i] += above;
+      if(lane == 0) ssq[n] = 0.0;
+      wave_sync();
+      double rprev = dsm[n - 1]; // r_{hi+1} of the current block (signed for the very first rotation, as in the plain loop)
+      for(int hi = n - 2; hi >= q; hi -= 64)
+      {
+        const int lo = (hi - 63 > q) ? (hi - 63) : q;
+        const int cnt = hi - lo + 1;
+        const int mine = hi - lane; // lane j owns step i = hi - j
+        const int mi = (mine > 0) ? mine : 0;
+        const GivensSeed g = givens_seed(dsm[mi], ssq[mi + 1]);
+        double rc = 0.0;
+        for(int k = 0; k < cnt; ++k) rc = givens_seeded_step(dpp_shift_d<0x138>(rc, rprev), g);
+        const double rin = dpp_shift_d<0x138>(rc, rprev); // r_{i+1} of this lane's step
+        if(mine >= lo) rho[mine + 1] = rin;
+        rprev = bcast_lane(rc, cnt - 1);
+      }
+      r = rprev;
     }
-    if(mine >= lo) rho[mine + 1] = kq;
-  }
-  wave_sync();
-  for(int i = q + lane; i <= n - 2; i += 64)
-  {
-    double c, s, rn;
-    make_givens(dsm[i], rho[i + 1], c, s, rn);
-    cc[i] = c;
-    ss[i] = s;
+    else
+    {
+      r = opaque_v(dsm[n - 1]);
+      // The loop body must stay free of stores and exec-mask regions (they stall the in-order wave: measured +40 % on
+      // the batched kernel's chain).  The d values of the next 64 steps sit in a register (lane = step inside the
+      // block, read with v_readlane); lane (i mod 64) keeps r_{i+1}; both are exchanged with LDS once per 64 steps.
+      double kq = 0.0;
+      for(int hi = n - 2; hi >= q; hi -= 64)
+      {
+        const int lo = (hi - 63 > q) ? (hi - 63) : q; // this block: i = hi .. lo
+        const int mine = hi - lane;                   // lane j handles step i = hi - j
+        const double dblk = (mine >= lo) ? dsm[mine] : 0.0;
+        for(int i = hi; i >= lo; --i)
+        {
+          const double di = opaque_v(bcast_lane(dblk, hi - i));
+          kq = (lane == hi - i) ? r : kq; // r_{i+1}
+          r = givens_r_only(di, r);
+        }
+        if(mine >= lo) rho[mine + 1] = kq;
+      }
+    }
+    wave_sync();
+    bool bad = false;
+    for(int i = q + lane; i <= n - 2; i += 64)
+    {
+      double c, s, rn;
+      make_givens(dsm[i], rho[i + 1], c, s, rn);
+      cc[i] = c;
+      ss[i] = s;
+      if(pass == 0) bad = bad || !(rn == ((i == q) ? r : rho[i])); // the radius this step handed to the next one
+    }
+    if(!__any(bad)) break;
+    wave_sync();
   }
   if(lane == 0) *rfin = r;
 }
@@ -851,6 +971,30 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
 // ============================================================================================================
 // host-side launchers
 // ============================================================================================================
+static size_t tail_lds(int n, int q)
+{
+  return sizeof(double) * (size_t)((3 * n > q + 2) ? 3 * n : q + 2);
+}
+// step_tail_kernel stages three n-vectors in LDS: beyond 64 KiB (n > 2730) the launch needs the limit raised (once)
+static hipError_t tail_attr(int n)
+{
+  static bool done = false;
+  if(done || tail_lds(n, 0) <= 65536) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if(e == hipSuccess) done = true;
+  return e;
+}
+
+// add_chain_kernel: the seeded recurrence needs a third LDS vector; beyond the default 64 KiB it falls back to the plain one
+static int chain_seeded(int n)
+{
+  return sizeof(double) * (3 * (size_t)n + 2) <= 65536 ? 1 : 0;
+}
+static size_t chain_lds(int n)
+{
+  return sizeof(double) * ((chain_seeded(n) ? 3 : 2) * (size_t)n + 2);
+}
+
 hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st)
 {
   for(int j0 = 0; j0 < n; j0 += NB)
@@ -925,16 +1069,20 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     hipError_t e = hipEventRecord(ev_d, st);
     if(e == hipSuccess) e = hipStreamWaitEvent(spec, ev_d, 0);
     if(e != hipSuccess) return e;
-    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), sizeof(double) * 2 * n, spec, n, q, s.d, s.cc2, s.ss2, s.rfin);
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
     e = hipEventRecord(ev_chain, spec);
     if(e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
+  {
+    hipError_t e = tail_attr(n);
+    if(e != hipSuccess) return e;
+  }
   if(dev_p)
-    hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (((q + 1) & ~1) + 64 * 65 + 2), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
+    hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
                        nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m);
   else
-    hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(256), sizeof(double) * (((q + 1) & ~1) + 64 * 65 + 2), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
+    hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
                        p - v.m, s.mb, nullptr, nullptr, 0, 0);
   return hipGetLastError();
 }
@@ -955,7 +1103,7 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
     if(e != hipSuccess) return e;
   }
   else
-    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), sizeof(double) * 2 * n, st, n, q, s.d, s.cc2, s.ss2, s.rfin);
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
   hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat);
   if(n - 2 >= q) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2);
   return hipGetLastError();
