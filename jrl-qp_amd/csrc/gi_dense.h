@@ -46,7 +46,8 @@ constexpr int kSelOnDevice = -2; // dense_step: take (p, status) from DenseState
 hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st);
 hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st);
 hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st);
-hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st);
+// zero_u >= 0: also clears u[zero_u] (the multiplier slot of the constraint this selection is for; saves a memset launch)
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u = -1);
 // spec != nullptr: the Givens coefficient chain of an ADDITION is launched on `spec` as soon as d exists (ev_d), beside
 // z / r / the ratio test on `st`; ev_chain marks its end.  dense_add(..., chain_ready = true) then only commits.
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st,

@@ -434,8 +434,9 @@ __global__ __launch_bounds__(64) void select_partial_kernel(const double * __res
 __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const double * pval, const int * pidx, const int * pstat, int m, int nb,
                                                           const double * __restrict__ x, const double * __restrict__ xl,
                                                           const double * __restrict__ xu, const unsigned char * __restrict__ st, int excl, Mailbox * mb,
-                                                          int * psel)
+                                                          int * psel, double * uq = nullptr)
 {
+  if(uq && threadIdx.x == 0) *uq = 0.0; // u[q] = 0 for the constraint about to be selected (DualSolver.cpp:121)
   __shared__ double sv[4];
   __shared__ int si[4], ss[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1032,13 +1033,14 @@ hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double *
   return hipGetLastError();
 }
 
-hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st)
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u)
 {
   const int parts = (v.m + CT - 1) / CT;
   if(parts > 0)
     hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * (v.n + CT * (KT + 1)), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
                        excl, s.pval, s.pidx, s.pstat);
-  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb, s.psel);
+  hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb, s.psel,
+                     zero_u >= 0 ? s.u + zero_u : nullptr);
   return hipGetLastError();
 }
 

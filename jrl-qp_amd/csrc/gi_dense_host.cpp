@@ -327,8 +327,7 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
         prefetched = false;
       }
       else
-        TRY(dense_select(h->v, h->s, -1, st));
-      TRY(hipMemsetAsync(h->s.u + q, 0, sizeof(double), st)); // u[q] = 0 (DualSolver.cpp:121)
+        TRY(dense_select(h->v, h->s, -1, st, q)); // (also u[q] = 0, DualSolver.cpp:121)
     }
     double t1, zz, nz, nx, uq;
     int l;
@@ -383,7 +382,7 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
         {
           TRY(hipEventRecord(h->ev_x, st));
           TRY(hipStreamWaitEvent(h->side, h->ev_x, 0));
-          TRY(dense_select(h->v, h->s, p, h->side));
+          TRY(dense_select(h->v, h->s, p, h->side, q + 1)); // (also u[q+1] = 0 for the next pass: a slot this pass does not touch)
           TRY(hipEventRecord(h->ev_sel, h->side));
           prefetched = true;
         }
