@@ -299,6 +299,11 @@ int jrlqp_selftest_arith(int n,
  * accumulates shader-clock cycles per phase into dprof[b*16 + slot] (device int64, zero it first; slots are listed
  * in jrl-qp_amd/csrc/gi_batch.hip).  Pass NULL to return to the production kernel.  Never used for quoted times. */
 int jrlqp_debug_set_profile(long long * dprof);
+/* Diagnostic: how the Givens radius recurrence of an addition (GoldfarbIdnaniSolver.cpp:228-231) is run by the batched
+ * kernel and by jrlqp_dense_step/add.  0 (default): seeded and verified, plain recurrence only on a failed check;
+ * 1: plain recurrence always; 2: seeded with deliberately spoiled seeds, so that every sweep fails its check and takes
+ * the fallback.  All three give bit-identical results (tests/test_gpu_chain_modes.py). */
+int jrlqp_debug_set_chain_mode(int mode);
 /* D(16x16) = A(16x4) * B(4x16) + C(16x16), row-major, one MFMA instruction on one wave */
 int jrlqp_selftest_mfma_f64(const double * dA, const double * dB, const double * dC, double * dD, void * stream);
 

@@ -51,6 +51,7 @@ EXPORTED = [
     "jrlqp_blockgi_bind",
     "jrlqp_blockgi_solve",
     "jrlqp_debug_set_profile",
+    "jrlqp_debug_set_chain_mode",
     "jrlqp_selftest_arith",
     "jrlqp_selftest_mfma_f64",
 ]
@@ -142,6 +143,8 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_blockgi_solve.restype = ct.c_int
     lib.jrlqp_blockgi_solve.argtypes = [ct.c_void_p] + [c_dp] * 5 + [ct.POINTER(Options)] + [c_dp] * 6 + [c_dp, ct.c_int, c_dp]
     lib.jrlqp_debug_set_profile.restype = ct.c_int
+    lib.jrlqp_debug_set_chain_mode.restype = ct.c_int
+    lib.jrlqp_debug_set_chain_mode.argtypes = [ct.c_int]
     lib.jrlqp_debug_set_profile.argtypes = [c_dp]
     lib.jrlqp_selftest_arith.restype = ct.c_int
     lib.jrlqp_selftest_arith.argtypes = [ct.c_int] + [c_dp] * 9 + [c_dp]

@@ -17,6 +17,7 @@ namespace
 {
 std::atomic<int> g_last_hip_error{0};
 std::atomic<long long *> g_prof{nullptr};
+std::atomic<int> g_chain_mode{0};
 
 int hip_fail(hipError_t e)
 {
@@ -57,6 +58,14 @@ struct jrlqp_blockgi
   size_t ws_bytes = 0;
   bool bound = false;
 };
+
+namespace jrlqp
+{
+int chain_debug_mode()
+{
+  return g_chain_mode.load();
+}
+} // namespace jrlqp
 
 extern "C" {
 
@@ -160,6 +169,7 @@ static int gi_batch_common(int warm,
   a.prof = g_prof.load();
   a.warm = warm;
   a.as_in = das;
+  a.chain_mode = g_chain_mode.load();
   hipError_t e = jrlqp::launch_gi_batch(a, cmode, static_cast<hipStream_t>(stream));
   if(e != hipSuccess) return hip_fail(e);
   return JRLQP_OK;
@@ -305,6 +315,13 @@ int jrlqp_blocks_solve(jrlqp_blocks * p, int transpose, double * dM, int ldm, lo
   else
     e = jrlqp::launch_block_arrow_solve(d, p->nprob, transpose != 0, dM, ldm, nrhs, start, end, p->d_tmp, st);
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
+}
+
+int jrlqp_debug_set_chain_mode(int mode)
+{
+  if(mode < 0 || mode > 2) return JRLQP_ERR_INVALID_ARGUMENT;
+  g_chain_mode.store(mode);
+  return JRLQP_OK;
 }
 
 int jrlqp_debug_set_profile(long long * dprof)

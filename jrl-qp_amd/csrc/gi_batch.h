@@ -22,7 +22,12 @@ struct BatchArgs
   long long * prof; // diagnostic only: 16 int64 per QP, or nullptr
   int warm;           // 1: warm-started solve (experimental::GoldfarbIdnaniSolver), as_in = activation-status guess
   const int * as_in;  // B x (m+nb) guesses, or nullptr ("no guess"); may alias `status`
+  int chain_mode;     // chain_debug_mode() at launch
 };
+
+// debug knob of the seeded Givens chain (jrlqp_debug_set_chain_mode): 0 = seeded (production), 1 = plain recurrence only,
+// 2 = seeded with deliberately spoiled seeds -- every sweep fails its verification and is redone by the fallback
+int chain_debug_mode();
 
 constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
 

@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       gc_d = (lane < n) ? dv : 0.0; // (lanes >= n: zero -- they sit above the chain and must stay at radius 0)
       const double sincl = wave_suffix_sum_approx(gc_d * gc_d, lane);
       gc_seed = givens_seed(gc_d, dpp_shift0_d<0x130>(sincl)); // lane i: sum over k > i
+      if(A.chain_mode == 2) gc_seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
       gc_rc = gc_d;
       gc_i = n - 2;
     };
@@ -1284,7 +1285,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         GivensHalf h;
         double rex = givens_r(gc_d, gc_kq, h);
         const bool mine = lane >= q && lane <= n - 2;
-        if(__any(mine && !(rex == gc_rc)))
+        if(A.chain_mode == 1 || __any(mine && !(rex == gc_rc)))
         {
           chain_exact();
           (void)givens_r(gc_d, gc_kq, h);

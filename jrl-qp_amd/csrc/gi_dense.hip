@@ -18,6 +18,7 @@
 
 #include "device_common.h"
 #include "gi_dense.h"
+#include "gi_batch.h"
 
 namespace jrlqp
 {
@@ -799,7 +800,8 @@ __global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const doubl
         const int cnt = hi - lo + 1;
         const int mine = hi - lane; // lane j owns step i = hi - j
         const int mi = (mine > 0) ? mine : 0;
-        const GivensSeed g = givens_seed(dsm[mi], ssq[mi + 1]);
+        GivensSeed g = givens_seed(dsm[mi], ssq[mi + 1]);
+        if(seeded == 2) g.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
         double rc = 0.0;
         for(int k = 0; k < cnt; ++k) rc = givens_seeded_step(dpp_shift_d<0x138>(rc, rprev), g);
         const double rin = dpp_shift_d<0x138>(rc, rprev); // r_{i+1} of this lane's step
@@ -989,7 +991,9 @@ static hipError_t tail_attr(int n)
 // add_chain_kernel: the seeded recurrence needs a third LDS vector; beyond the default 64 KiB it falls back to the plain one
 static int chain_seeded(int n)
 {
-  return sizeof(double) * (3 * (size_t)n + 2) <= 65536 ? 1 : 0;
+  const int mode = chain_debug_mode();
+  if(mode == 1 || sizeof(double) * (3 * (size_t)n + 2) > 65536) return 0;
+  return mode == 2 ? 2 : 1;
 }
 static size_t chain_lds(int n)
 {
