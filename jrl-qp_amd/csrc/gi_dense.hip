@@ -303,45 +303,84 @@ __global__ __launch_bounds__(1024) void x0_kernel(const double * __restrict__ L,
 // lane per column streaming its own column, the matrix is spread over 4x as many CUs and every load is coalesced.
 constexpr int CT = 16, KT = 64;
 
+// acc <- in-order chain of up to 64 fmas, a[k * SA] * b[k], k = 0 .. cnt-1, out of LDS: the operands are fetched in four
+// batches of 16, batch g+1 requested before the fmas of batch g, so that the chain pays one LDS latency per 64 steps
+// instead of one per 8.  FULL: cnt == 64, no predication (a select per step would put one more dependent op on the chain).
+template<int SA, bool FULL>
+__device__ __forceinline__ double chain64(double acc, const double * a, const double * b, int cnt)
+{
+  double av[2][16], bv[2][16];
+#pragma unroll
+  for(int u = 0; u < 16; ++u)
+  {
+    const int k = FULL ? u : min(u, cnt - 1);
+    av[0][u] = a[k * SA];
+    bv[0][u] = b[k];
+  }
+#pragma unroll
+  for(int g = 0; g < 4; ++g)
+  {
+    if(g < 3)
+    {
+#pragma unroll
+      for(int u = 0; u < 16; ++u)
+      {
+        const int k = FULL ? ((g + 1) * 16 + u) : min((g + 1) * 16 + u, cnt - 1);
+        av[(g + 1) & 1][u] = a[k * SA];
+        bv[(g + 1) & 1][u] = b[k];
+      }
+    }
+#pragma unroll
+    for(int u = 0; u < 16; ++u)
+    {
+      const double nx = FMA(av[g & 1][u], bv[g & 1][u], acc);
+      acc = (FULL || g * 16 + u < cnt) ? nx : acc;
+    }
+  }
+  return acc;
+}
+
+constexpr int NPRE = 3; // tiles requested ahead of the one being consumed (one tile's chains last ~0.45 us, an L2 round trip ~1 us)
+
 __device__ __forceinline__ double tile_column_dot(const double * __restrict__ M, int ld, int n, int col0, int ncols, const double * vs, double * tile,
                                                   int lane)
 {
   double acc = 0.0;
   const int kk = lane; // row inside the tile this lane loads
-  // software pipeline: the global loads of tile t+1 are in flight while the chains consume tile t out of LDS
-  double nxt[CT];
+  // Software pipeline: the global loads of tiles t+1 .. t+NPRE are in flight while the chains consume tile t out of LDS.
+  // Addresses are CLAMPED instead of predicated and the steady-state loop has no branch: a predicated load sits in its
+  // own exec-mask region, and hipcc then waits with vmcnt(0) -- for EVERY tile in flight -- at each use (that, one L2
+  // round trip per tile, was 2/3 of this kernel's time).  Rows past n only feed chain steps that are never taken,
+  // columns past ncols only feed lanes whose result is dropped.
+  double ring[NPRE][CT];
+  const size_t cmax = (size_t)(col0 + ((ncols > 0) ? ncols - 1 : 0));
+  auto gload = [&](double (&dst)[CT], int k0) {
+    const int row = min(k0 + kk, n - 1);
 #pragma unroll
-  for(int c = 0; c < CT; ++c) nxt[c] = (c < ncols && kk < n) ? M[(size_t)(col0 + c) * ld + kk] : 0.0;
-  for(int k0 = 0; k0 < n; k0 += KT)
-  {
+    for(int c = 0; c < CT; ++c) dst[c] = M[min((size_t)(col0 + c), cmax) * ld + row];
+  };
+  auto consume = [&](double (&buf)[CT], int k0) {
     const int cnt = min(KT, n - k0);
     wave_sync();
 #pragma unroll
-    for(int c = 0; c < CT; ++c) tile[c * (KT + 1) + kk] = nxt[c];
+    for(int c = 0; c < CT; ++c) tile[c * (KT + 1) + kk] = buf[c];
     wave_sync();
-    const int k1 = k0 + KT;
+    gload(buf, k0 + NPRE * KT);
+    const double * tc = tile + min(lane, CT - 1) * (KT + 1);
+    const double nx = (cnt == KT) ? chain64<1, true>(acc, tc, vs + k0, cnt) : chain64<1, false>(acc, tc, vs + k0, cnt);
+    acc = (lane < ncols) ? nx : acc;
+  };
 #pragma unroll
-    for(int c = 0; c < CT; ++c) nxt[c] = (c < ncols && k1 + kk < n) ? M[(size_t)(col0 + c) * ld + k1 + kk] : 0.0;
-    if(lane < ncols)
-    {
-      const double * tc = tile + lane * (KT + 1);
-      const double * vv = vs + k0;
-      int k = 0;
-      for(; k + 8 <= cnt; k += 8)
-      {
-        double cv[8], xv[8];
+  for(int s = 0; s < NPRE; ++s) gload(ring[s], s * KT);
+  int kb = 0;
+  for(; kb + NPRE * KT <= n; kb += NPRE * KT)
+  {
 #pragma unroll
-        for(int u = 0; u < 8; ++u)
-        {
-          cv[u] = tc[k + u];
-          xv[u] = vv[k + u];
-        }
-#pragma unroll
-        for(int u = 0; u < 8; ++u) acc = FMA(cv[u], xv[u], acc);
-      }
-      for(; k < cnt; ++k) acc = FMA(tc[k], vv[k], acc);
-    }
+    for(int s = 0; s < NPRE; ++s) consume(ring[s], kb + s * KT);
   }
+#pragma unroll
+  for(int s = 0; s < NPRE; ++s)
+    if(kb + s * KT < n) consume(ring[s], kb + s * KT);
   return acc;
 }
 
@@ -513,50 +552,38 @@ __global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ 
   const int lane = threadIdx.x;
   const int r0 = blockIdx.x * 16;
   const int rr = lane & 15, cg = lane >> 4; // row in tile, column group
-  const bool rin = r0 + rr < n;
   double acc = 0.0;
-  double nxt[16], dn;
+  // (NPRE tiles in flight; clamped, not predicated, loads and a branch-free steady state: see tile_column_dot)
+  double ring[NPRE][16], dring[NPRE];
+  const int row = min(r0 + rr, n - 1);
+  auto gload = [&](double (&dst)[16], double & dd, int j0) {
 #pragma unroll
-  for(int t = 0; t < 16; ++t)
-  {
-    const int jc = q + t * 4 + cg;
-    nxt[t] = (rin && jc < n) ? AT(J, ld, r0 + rr, jc) : 0.0;
-  }
-  dn = (q + lane < n) ? d[q + lane] : 0.0;
-  for(int j0 = q; j0 < n; j0 += 64)
-  {
+    for(int t = 0; t < 16; ++t) dst[t] = AT(J, ld, row, min(j0 + t * 4 + cg, n - 1));
+    dd = d[min(j0 + lane, n - 1)];
+  };
+  auto consume = [&](double (&buf)[16], double & dd, int j0) {
     const int cnt = min(64, n - j0);
     wave_sync();
 #pragma unroll
-    for(int t = 0; t < 16; ++t) tile[(t * 4 + cg) * 17 + rr] = nxt[t];
-    dsm[lane] = dn;
+    for(int t = 0; t < 16; ++t) tile[(t * 4 + cg) * 17 + rr] = buf[t];
+    dsm[lane] = dd;
     wave_sync();
-    const int j1 = j0 + 64;
+    gload(buf, dd, j0 + NPRE * 64);
+    const double * tr = tile + (lane & 15);
+    const double nx = (cnt == 64) ? chain64<17, true>(acc, tr, dsm, cnt) : chain64<17, false>(acc, tr, dsm, cnt);
+    acc = (lane < 16) ? nx : acc;
+  };
 #pragma unroll
-    for(int t = 0; t < 16; ++t)
-    {
-      const int jc = j1 + t * 4 + cg;
-      nxt[t] = (rin && jc < n) ? AT(J, ld, r0 + rr, jc) : 0.0;
-    }
-    dn = (j1 + lane < n) ? d[j1 + lane] : 0.0;
-    if(lane < 16)
-    {
-      int j = 0;
-      for(; j + 8 <= cnt; j += 8)
-      {
-        double jv[8], dv[8];
+  for(int s = 0; s < NPRE; ++s) gload(ring[s], dring[s], q + s * 64);
+  int jb = q;
+  for(; jb + NPRE * 64 <= n; jb += NPRE * 64)
+  {
 #pragma unroll
-        for(int u = 0; u < 8; ++u)
-        {
-          jv[u] = tile[(j + u) * 17 + lane];
-          dv[u] = dsm[j + u];
-        }
-#pragma unroll
-        for(int u = 0; u < 8; ++u) acc = FMA(jv[u], dv[u], acc);
-      }
-      for(; j < cnt; ++j) acc = FMA(tile[j * 17 + lane], dsm[j], acc);
-    }
+    for(int s = 0; s < NPRE; ++s) consume(ring[s], dring[s], jb + s * 64);
   }
+#pragma unroll
+  for(int s = 0; s < NPRE; ++s)
+    if(jb + s * 64 < n) consume(ring[s], dring[s], jb + s * 64);
   if(lane < 16 && r0 + lane < n) z[r0 + lane] = acc;
 }
 
