@@ -887,67 +887,184 @@ __global__ __launch_bounds__(256) void add_commit_kernel(int q, const double * d
   }
 }
 
-// K10 part 2 / K11 part 2: apply the rotation sequence to the columns of J, lane = row.
+// K10 part 2 / K11 part 2: apply the rotation sequence to the columns of J, one workgroup of TWO waves per 64 rows.
 //   descending (add):   i = i_hi .. i_lo, columns (i, i+1), carry = column i+1
 //   ascending (remove): i = i_lo .. i_hi, columns (i, i+1), carry = column i
-__global__ __launch_bounds__(64) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
-                                                       const double * __restrict__ ss)
+// A row's sweep is one carry chain (two dependent ops per rotation); the point of this kernel is that the chain never
+// waits for memory.  gfx9 counts loads AND stores in one in-order counter (vmcnt): a wave that streams a row in and
+// out waits, for every group of loads, for the write acknowledgements of the stores issued before them -- the sweep
+// used to cost a full memory round trip per 16 rotations, however the loads were scheduled (deeper rings and double
+// buffers were measured slower).  So the two directions of the stream get a wave each:
+//   wave 0 loads (three chunks of 32 columns in flight in registers, clamped addresses, no branch in the steady state:
+//          its vmcnt only ever counts loads), rotates, and leaves the rotated columns in an LDS buffer;
+//   wave 1 copies the buffer of the previous chunk to memory while wave 0 rotates the next one (its vmcnt only counts
+//          stores, which nobody waits for).
+// One LDS-only barrier per chunk; (c_i, s_i) of the whole sweep are staged in LDS once.
+constexpr int RC = 32;      // columns per chunk
+constexpr int RLD = 65;     // leading dimension of a chunk buffer (lane = row: conflict-free)
+
+template<bool DESC, bool FULL>
+__device__ __forceinline__ void rot_chunk(double (&x)[RC], double & carry, const double2 * csl, int t0, int T, double * obuf, int lane)
 {
-  const int row = blockIdx.x * 64 + threadIdx.x;
-  if(row >= n || i_hi < i_lo) return;
-  constexpr int U = 16; // columns fetched per group: the loads of a group are in flight together
-  if(descending)
+  // rotation number t = t0 + u; its (c, s) pair sits at index (DESC ? T-1-t : t) of the staged array: for a full chunk
+  // that is one base address and immediate offsets
+  const double2 * cb = csl + (DESC ? (T - 1 - t0) : t0);
+  auto csat = [&](int u) -> double2 {
+    if(FULL) return DESC ? cb[-u] : cb[u];
+    const int t = min(t0 + u, T - 1);
+    return csl[DESC ? (T - 1 - t) : t];
+  };
+  // the pairs are requested 16 at a time, the second half before the first half's rotations (scheduling barriers: left
+  // alone, hipcc requests each pair two rotations ahead and the chain waits for LDS at every step)
+  constexpr int H = RC / 2;
+  double2 cs0[H], cs1[H];
+#pragma unroll
+  for(int u = 0; u < H; ++u) cs0[u] = csat(u);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for(int u = 0; u < H; ++u) cs1[u] = csat(H + u);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for(int u = 0; u < RC; ++u)
   {
-    double carry = AT(J, ld, row, i_hi + 1);
-    int i = i_hi;
-    for(; i - (U - 1) >= i_lo; i -= U)
+    const double c = (u < H) ? cs0[u % H].x : cs1[u % H].x, sn = (u < H) ? cs0[u % H].y : cs1[u % H].y;
+    double out, nc;
+    if(DESC)
     {
-      double xv[U];
-#pragma unroll
-      for(int u = 0; u < U; ++u) xv[u] = AT(J, ld, row, i - u);
-#pragma unroll
-      for(int u = 0; u < U; ++u)
+      out = FMA(sn, x[u], c * carry);
+      nc = FMA(c, x[u], -(sn * carry));
+    }
+    else
+    {
+      out = FMA(c, carry, -(sn * x[u]));
+      nc = FMA(sn, carry, c * x[u]);
+    }
+    obuf[u * RLD + lane] = out;
+    carry = (FULL || t0 + u < T) ? nc : carry;
+  }
+}
+
+template<bool DESC>
+__device__ __forceinline__ void rot_sweep(double * J, int ld, int n, int row0, int i_lo, int i_hi, const double2 * csl, double * lbuf)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = i_hi - i_lo + 1;
+  const int nchunk = (T + RC - 1) / RC, nfull = T / RC;
+  const int row = min(row0 + lane, n - 1);
+  // rotation t consumes column fcol(t) and produces column wcol(t); consecutive rotations are one column apart:
+  // pointers step by +-ld, no per-access address arithmetic
+  auto fcol = [&](int t) { return DESC ? i_hi - t : i_lo + t + 1; };
+  auto wcol = [&](int t) { return DESC ? i_hi - t + 1 : i_lo + t; };
+  const ptrdiff_t cstep = DESC ? -(ptrdiff_t)ld : (ptrdiff_t)ld;
+  if(wave == 0)
+  {
+    double carry = DESC ? AT(J, ld, row, i_hi + 1) : AT(J, ld, row, i_lo);
+    double ring[3][RC];
+    auto gload = [&](double (&dst)[RC], int k) {
+      if(k < nfull) // (uniform) a full chunk: one pointer, stepped
       {
-        const double c = cc[i - u], s = ss[i - u];
-        AT(J, ld, row, i - u + 1) = FMA(s, xv[u], c * carry);
-        carry = FMA(c, xv[u], -(s * carry));
+        const double * p = &AT(J, ld, row, fcol(k * RC));
+#pragma unroll
+        for(int u = 0; u < RC; ++u)
+        {
+          dst[u] = *p;
+          p += cstep;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for(int u = 0; u < RC; ++u) dst[u] = AT(J, ld, row, fcol(min(k * RC + u, T - 1)));
+      }
+    };
+#pragma unroll
+    for(int s3 = 0; s3 < 3; ++s3) gload(ring[s3], s3);
+    int k = 0;
+#pragma unroll 1
+    for(; k + 6 <= nfull; k += 3) // (three more FULL chunks exist beyond the three consumed here: the refill needs no clamp)
+    {
+#pragma unroll
+      for(int s3 = 0; s3 < 3; ++s3)
+      {
+        rot_chunk<DESC, true>(ring[s3], carry, csl, (k + s3) * RC, T, lbuf + ((k + s3) & 1) * (RC * RLD), lane);
+        const double * p = &AT(J, ld, row, fcol((k + s3 + 3) * RC));
+#pragma unroll
+        for(int u = 0; u < RC; ++u)
+        {
+          ring[s3][u] = *p;
+          p += cstep;
+        }
+        lds_barrier();
       }
     }
-    for(; i >= i_lo; --i)
+    // the rest: chunk by chunk, refills through the general (clamping) path
+    for(; k < nchunk; k += 3)
     {
-      const double c = cc[i], s = ss[i];
-      const double xv = AT(J, ld, row, i);
-      AT(J, ld, row, i + 1) = FMA(s, xv, c * carry);
-      carry = FMA(c, xv, -(s * carry));
+#pragma unroll
+      for(int s3 = 0; s3 < 3; ++s3)
+      {
+        if(k + s3 < nchunk)
+        {
+          if(k + s3 < nfull)
+            rot_chunk<DESC, true>(ring[s3], carry, csl, (k + s3) * RC, T, lbuf + ((k + s3) & 1) * (RC * RLD), lane);
+          else
+            rot_chunk<DESC, false>(ring[s3], carry, csl, (k + s3) * RC, T, lbuf + ((k + s3) & 1) * (RC * RLD), lane);
+          if(k + s3 + 3 < nchunk) gload(ring[s3], k + s3 + 3);
+          lds_barrier();
+        }
+      }
     }
-    AT(J, ld, row, i_lo) = carry;
+    if(row0 + lane < n) AT(J, ld, row, DESC ? i_lo : i_hi + 1) = carry;
   }
   else
   {
-    double carry = AT(J, ld, row, i_lo);
-    int i = i_lo;
-    for(; i + (U - 1) <= i_hi; i += U)
+    for(int k = 0; k < nchunk; ++k)
     {
-      double yv[U];
+      lds_barrier(); // chunk k is in its buffer
+      const double * ib = lbuf + (k & 1) * (RC * RLD);
+      double v[RC];
 #pragma unroll
-      for(int u = 0; u < U; ++u) yv[u] = AT(J, ld, row, i + u + 1);
-#pragma unroll
-      for(int u = 0; u < U; ++u)
+      for(int u = 0; u < RC; ++u) v[u] = ib[u * RLD + lane];
+      if(row0 + lane < n)
       {
-        const double c = cc[i + u], s = ss[i + u];
-        AT(J, ld, row, i + u) = FMA(c, carry, -(s * yv[u]));
-        carry = FMA(s, carry, c * yv[u]);
+        double * p = &AT(J, ld, row, wcol(k * RC));
+        if(k < nfull)
+        {
+#pragma unroll
+          for(int u = 0; u < RC; ++u)
+          {
+            *p = v[u];
+            p += cstep;
+          }
+        }
+        else
+        {
+#pragma unroll
+          for(int u = 0; u < RC; ++u)
+          {
+            if(k * RC + u < T) *p = v[u];
+            p += cstep;
+          }
+        }
       }
     }
-    for(; i <= i_hi; ++i)
-    {
-      const double c = cc[i], s = ss[i];
-      const double y = AT(J, ld, row, i + 1);
-      AT(J, ld, row, i) = FMA(c, carry, -(s * y));
-      carry = FMA(s, carry, c * y);
-    }
-    AT(J, ld, row, i_hi + 1) = carry;
   }
+}
+
+__global__ __launch_bounds__(128) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
+                                                        const double * __restrict__ ss)
+{
+  extern __shared__ double rsm[]; // two chunk buffers | (c_i, s_i) pairs (T)
+  if(i_hi < i_lo) return;
+  const int T = i_hi - i_lo + 1;
+  double * lbuf = rsm;
+  double2 * csl = reinterpret_cast<double2 *>(rsm + 2 * RC * RLD);
+  for(int k = threadIdx.x; k < T; k += 128) csl[k] = make_double2(cc[i_lo + k], ss[i_lo + k]);
+  __syncthreads();
+  if(descending)
+    rot_sweep<true>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, lbuf);
+  else
+    rot_sweep<false>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, lbuf);
 }
 
 // K11 part 1 (one workgroup, thread = NEW column index of R): delete column l of R, restore triangularity with
@@ -1001,6 +1118,10 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
 // ============================================================================================================
 // host-side launchers
 // ============================================================================================================
+static size_t rot_lds(int T)
+{
+  return sizeof(double) * (size_t)(2 * RC * RLD + 2 * T);
+}
 static size_t tail_lds(int n, int q)
 {
   return sizeof(double) * (size_t)((3 * n > q + 2) ? 3 * n : q + 2);
@@ -1138,7 +1259,7 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
   else
     hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
   hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat);
-  if(n - 2 >= q) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2);
+  if(n - 2 >= q) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2);
   return hipGetLastError();
 }
 
@@ -1147,7 +1268,7 @@ hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int 
   const int n = v.n;
   hipLaunchKernelGGL(remove_r_kernel, dim3(1), dim3(1024), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
   const int qn = q - 1;
-  if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
+  if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(qn - l), st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
   return hipGetLastError();
 }
 
