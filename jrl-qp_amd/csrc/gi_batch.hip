@@ -439,6 +439,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   // load latency is paid once per solve.
   constexpr bool LATE_C = (CMODE == 2 && NT == 50 && !WARM);
   auto load_columns = [&]() __attribute__((always_inline)) {
+    if(m == 0) return; // no general constraint: C may be a null pointer (the loads below are unconditional)
     const bool own = myc >= 0 && myc < m;
     const double * ci = Cg + (size_t)(own ? myc : 0) * n;
     if((NR % 2 == 0) && ((reinterpret_cast<size_t>(Cg) & 15) == 0)) // a column is NR*8 bytes: 16-byte loads when aligned

@@ -102,6 +102,12 @@ CASES = [
     dict(nVar=64, nObj=64, nIneq=128, nStrongActIneq=19),
     dict(nVar=64, nObj=64, nIneq=256, nStrongActIneq=25),
     dict(nVar=64, nObj=64, nEq=5, nIneq=190, nStrongActIneq=12, bounds=True, nStrongActBounds=6, doubleSidedIneq=True),
+    # the register-resident instantiations WITHOUT general constraints (m = 0: C is an empty array / null pointer; the
+    # reference's benchmark families test4 and test7, benchmarks/Solvers.cpp:625-639)
+    dict(nVar=50, nObj=50),
+    dict(nVar=50, nObj=50, bounds=True, nStrongActBounds=20),
+    dict(nVar=64, nObj=64, bounds=True, nStrongActBounds=10),
+    dict(nVar=50, nObj=50, nEq=20),
 ]
 
 
