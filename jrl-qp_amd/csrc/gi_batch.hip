@@ -1894,7 +1894,7 @@ long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
 int batch_pick_cmode(int n, int m, int nb, int warm)
 {
   // registers: the specialised instantiations below; LDS when C fits beside the factors; else stream
-  if((n == 50 || n == 64) && m <= 256) return 2;
+  if((n == 50 || n == 60 || n == 64) && m <= 256) return 2;
   if(batch_lds_bytes(n, m, nb, 1, warm) <= kLdsPerCU) return 1;
   if(batch_lds_bytes(n, m, nb, 0, warm) <= kLdsPerCU) return 0;
   return -1;
@@ -1904,6 +1904,7 @@ hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)
 {
   const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode, a.warm);
   if(cmode == 2 && a.n == 50) return launch_prof<50, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 60) return launch_prof<60, 2>(a, lds, stream); // (a size of the reference's benchmark families)
   if(cmode == 2 && a.n == 64) return launch_prof<64, 2>(a, lds, stream);
   if(cmode == 1) return launch_prof<0, 1>(a, lds, stream);
   return launch_prof<0, 0>(a, lds, stream);

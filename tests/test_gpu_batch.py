@@ -108,6 +108,10 @@ CASES = [
     dict(nVar=50, nObj=50, bounds=True, nStrongActBounds=20),
     dict(nVar=64, nObj=64, bounds=True, nStrongActBounds=10),
     dict(nVar=50, nObj=50, nEq=20),
+    # n = 60 (a size of the reference's benchmark families test1 / test3): its own register-resident instantiation
+    dict(nVar=60, nObj=60, nIneq=120, nStrongActIneq=18),
+    dict(nVar=60, nObj=60, nEq=12, nIneq=60, nStrongActIneq=18, bounds=True, nStrongActBounds=6, doubleSidedIneq=True),
+    dict(nVar=60, nObj=60, nEq=24),
 ]
 
 

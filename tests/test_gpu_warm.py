@@ -108,6 +108,7 @@ WIDE = [
     dict(nVar=10, nObj=10, nEq=3, nIneq=20, nStrongActIneq=3, bounds=True, nStrongActBounds=2, doubleSidedIneq=True),
     dict(nVar=33, nObj=33, nEq=5, nIneq=70, nStrongActIneq=10, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
     dict(nVar=64, nObj=64, nIneq=100, nStrongActIneq=20),
+    dict(nVar=60, nObj=60, nEq=6, nIneq=90, nStrongActIneq=15, bounds=True, nStrongActBounds=5),  # the n = 60 instantiation, warm
     dict(nVar=1, nObj=1, nIneq=3, nStrongActIneq=1),
     dict(nVar=50, nObj=50, nIneq=900, nStrongActIneq=10),  # C streamed from L2/HBM
     dict(nVar=50, nObj=50, nIneq=256, nStrongActIneq=20),  # 64 LDS-staged extra columns
