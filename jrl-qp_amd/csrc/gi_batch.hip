@@ -356,7 +356,7 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 // WARM  : warm-started solve (src/experimental/GoldfarbIdnaniSolver.cpp): the initial active set comes from the data
 //         equalities plus a guess, J and R from a Householder QR of L^-1 N; then the same loop
 template<int NT, int CMODE, bool PROF, bool WARM>
-__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : 3) : 1) void gi_batch_kernel(const BatchArgs A)
+__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : (NT <= 16 ? 5 : (NT <= 32 ? 4 : 3))) : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0, last3_ = 0;
   if(PROF)
@@ -1894,7 +1894,7 @@ long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
 int batch_pick_cmode(int n, int m, int nb, int warm)
 {
   // registers: the specialised instantiations below; LDS when C fits beside the factors; else stream
-  if((n == 50 || n == 60 || n == 64) && m <= 256) return 2;
+  if((n == 10 || n == 16 || n == 20 || n == 30 || n == 32 || n == 40 || n == 50 || n == 60 || n == 64) && m <= 256) return 2;
   if(batch_lds_bytes(n, m, nb, 1, warm) <= kLdsPerCU) return 1;
   if(batch_lds_bytes(n, m, nb, 0, warm) <= kLdsPerCU) return 0;
   return -1;
@@ -1904,6 +1904,12 @@ hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)
 {
   const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode, a.warm);
   if(cmode == 2 && a.n == 50) return launch_prof<50, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 10) return launch_prof<10, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 16) return launch_prof<16, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 20) return launch_prof<20, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 30) return launch_prof<30, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 32) return launch_prof<32, 2>(a, lds, stream);
+  if(cmode == 2 && a.n == 40) return launch_prof<40, 2>(a, lds, stream);
   if(cmode == 2 && a.n == 60) return launch_prof<60, 2>(a, lds, stream); // (a size of the reference's benchmark families)
   if(cmode == 2 && a.n == 64) return launch_prof<64, 2>(a, lds, stream);
   if(cmode == 1) return launch_prof<0, 1>(a, lds, stream);

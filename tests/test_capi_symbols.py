@@ -36,7 +36,9 @@ def test_defaults_and_lds_budget(pkg):
     lds = lib.jrlqp_gi_batch_lds_bytes(50, 200, 0, ct.byref(c))
     assert 0 < lds <= 163840 // 3 and c.value == 2  # BASELINE config c3: C in registers, three workgroups per CU
     lds = lib.jrlqp_gi_batch_lds_bytes(10, 20, 0, ct.byref(c))
-    assert 0 < lds < 16384 and c.value == 1
+    assert 0 < lds <= 163840 // 5 and c.value == 2  # c1 shape: its own register-resident instantiation, five workgroups per CU
+    lds = lib.jrlqp_gi_batch_lds_bytes(12, 24, 0, ct.byref(c))
+    assert 0 < lds < 16384 and c.value == 1  # a size without an instantiation: the generic kernel, C staged in LDS
     lds = lib.jrlqp_gi_batch_lds_bytes(50, 2000, 50, ct.byref(c))
     assert 0 < lds <= 163840 and c.value == 0  # too many constraints: C is streamed
     assert lib.jrlqp_gi_batch_lds_bytes(65, 10, 0, ct.byref(c)) == -1

@@ -112,6 +112,15 @@ CASES = [
     dict(nVar=60, nObj=60, nIneq=120, nStrongActIneq=18),
     dict(nVar=60, nObj=60, nEq=12, nIneq=60, nStrongActIneq=18, bounds=True, nStrongActBounds=6, doubleSidedIneq=True),
     dict(nVar=60, nObj=60, nEq=24),
+    # the other register-resident instantiations (n = 10, 16, 20, 30, 32, 40; up to five workgroups per CU)
+    dict(nVar=16, nObj=16, nEq=2, nIneq=32, nStrongActIneq=4, bounds=True, nStrongActBounds=2, doubleSidedIneq=True),
+    dict(nVar=20, nObj=20, nIneq=40, nStrongActIneq=6),
+    dict(nVar=20, nObj=20, nEq=4, nIneq=250, nStrongActIneq=5, bounds=True, nStrongActBounds=3),  # extra columns in LDS
+    dict(nVar=30, nObj=30, nEq=3, nIneq=60, nStrongActIneq=9, bounds=True, nStrongActBounds=3, doubleSidedIneq=True),
+    dict(nVar=32, nObj=32, nIneq=64, nStrongActIneq=10),
+    dict(nVar=40, nObj=40, nEq=8, nIneq=40, nStrongActIneq=12, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
+    dict(nVar=40, nObj=40, nIneq=300, nStrongActIneq=12),  # m > 256: back to the generic kernel
+    dict(nVar=10, nObj=10, bounds=True, nStrongActBounds=4),
 ]
 
 

@@ -109,6 +109,8 @@ WIDE = [
     dict(nVar=33, nObj=33, nEq=5, nIneq=70, nStrongActIneq=10, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
     dict(nVar=64, nObj=64, nIneq=100, nStrongActIneq=20),
     dict(nVar=60, nObj=60, nEq=6, nIneq=90, nStrongActIneq=15, bounds=True, nStrongActBounds=5),  # the n = 60 instantiation, warm
+    dict(nVar=20, nObj=20, nEq=2, nIneq=40, nStrongActIneq=6, bounds=True, nStrongActBounds=2),
+    dict(nVar=40, nObj=40, nIneq=80, nStrongActIneq=12, doubleSidedIneq=True),
     dict(nVar=1, nObj=1, nIneq=3, nStrongActIneq=1),
     dict(nVar=50, nObj=50, nIneq=900, nStrongActIneq=10),  # C streamed from L2/HBM
     dict(nVar=50, nObj=50, nIneq=256, nStrongActIneq=20),  # 64 LDS-staged extra columns
