@@ -33,6 +33,7 @@ constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
 
 // cmode: where the constraint matrix lives during the solve: 0 = streamed from global memory, 1 = staged in LDS,
 // 2 = one column per thread in registers (specialised compile-time-n instantiations)
+int batch_pad_size(int n, int warm); // instantiated size a problem of n variables runs in (0: none, generic kernel)
 long batch_lds_bytes(int n, int m, int nb, int cmode, int warm = 0);
 int batch_pick_cmode(int n, int m, int nb, int warm = 0); // -1 if unsupported
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream);

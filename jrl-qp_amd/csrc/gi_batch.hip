@@ -373,6 +373,13 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   const int wave = uniform(tid >> 6);
   const int b = blockIdx.x;
   const int n = NT ? NT : A.n;
+  // A compile-time-n instantiation also takes SMALLER problems (cold start only): nr = the caller's n, the problem is
+  // embedded as [G 0; 0 I], [a; 0], [C; 0] -- the factor is [L 0; 0 I], J starts as [J 0; 0 I], every d ends in nr..n-1
+  // zeros, and the extra rotations of an addition act on (0, 0) pairs (identities) or on (d_{nr-1}, 0), which at most
+  // negates the LAST column of the free part of J together with its d entry -- a sign that cancels in every product it
+  // enters (z, the next rotation) and never reaches R, x, u or f.  So the padded run reproduces the unpadded one bit for
+  // bit (up to the sign of exact zeros), and x, u, status are written back in the caller's sizes.
+  const int nr = (NT && !WARM) ? A.n : n;
   const int ld = NT ? (NT | 1) : A.ld;
   const int m = A.m, nb = A.nb;
   const int mt = m + nb;
@@ -422,9 +429,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   int * act = reinterpret_cast<int *>(ctl + 1);
   unsigned char * st = reinterpret_cast<unsigned char *>(act + (n + 2));
 
-  const double * Gg = A.G + (size_t)b * n * n;
-  const double * ag = A.a + (size_t)b * n;
-  const double * Cg = A.C + (size_t)b * n * m;
+  const double * Gg = A.G + (size_t)b * nr * nr;
+  const double * ag = A.a + (size_t)b * nr;
+  const double * Cg = A.C + (size_t)b * nr * m;
   const double * blg = A.bl + (size_t)b * m;
   const double * bug = A.bu + (size_t)b * m;
   const double * xlg = nb ? A.xl + (size_t)b * nb : nullptr;
@@ -441,8 +448,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   auto load_columns = [&]() __attribute__((always_inline)) {
     if(m == 0) return; // no general constraint: C may be a null pointer (the loads below are unconditional)
     const bool own = myc >= 0 && myc < m;
-    const double * ci = Cg + (size_t)(own ? myc : 0) * n;
-    if((NR % 2 == 0) && ((reinterpret_cast<size_t>(Cg) & 15) == 0)) // a column is NR*8 bytes: 16-byte loads when aligned
+    const double * ci = Cg + (size_t)(own ? myc : 0) * nr;
+    if(nr == NR && (NR % 2 == 0) && ((reinterpret_cast<size_t>(Cg) & 15) == 0)) // a column is NR*8 bytes: 16-byte loads when aligned
     {
       const double2 * c2 = reinterpret_cast<const double2 *>(ci);
 #pragma unroll
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     else
     {
 #pragma unroll
-      for(int k = 0; k < NR; ++k) creg[k] = ci[k];
+      for(int k = 0; k < NR; ++k) creg[k] = (k < nr) ? ci[k] : 0.0; // (zero rows of an embedded smaller problem)
     }
     my_bl = own ? blg[myc] : 0.0;
     my_bu = own ? bug[myc] : 0.0;
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     for(int e = tid; e < ne * n; e += WG)
     {
       int k = e % n, i = e / n;
-      Ce[(size_t)i * ld + k] = Cg[(size_t)(CREG_MAX + i) * n + k];
+      Ce[(size_t)i * ld + k] = (k < nr) ? Cg[(size_t)(CREG_MAX + i) * nr + k] : 0.0;
     }
   }
 
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   for(int e = tid; e < n * n; e += WG)
   {
     int i = e % n, j = e / n;
-    R[i + j * ld] = Gg[e];
+    R[i + j * ld] = (i < nr && j < nr) ? Gg[i + (size_t)j * nr] : ((i == j) ? 1.0 : 0.0);
   }
   for(int i = tid; i < mt; i += WG) st[i] = 0;
   if(tid < n) xs[tid] = 0.0;
@@ -688,10 +695,10 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     // optional: hand the factor back (the reference leaves it in G's lower triangle)
     if(A.Lout)
     {
-      double * Lg = A.Lout + (size_t)b * n * n;
-      for(int e = tid; e < n * n; e += WG)
+      double * Lg = A.Lout + (size_t)b * nr * nr;
+      for(int e = tid; e < nr * nr; e += WG)
       {
-        int i = e % n, j = e / n;
+        int i = e % nr, j = e / nr;
         if(i >= j) Lg[e] = L[i + j * ld];
       }
     }
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     else if(wave == 0)
     {
       const int rl = (lane < n) ? lane : 0;
-      double xi = (lane < n) ? ag[lane] : 0.0;
+      double xi = (lane < nr) ? ag[lane] : 0.0;
       const double ai = xi;
       double dg = L[rl + rl * ld];
       dg = (lane < n) ? dg : 1.0;
@@ -1830,7 +1837,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   __syncthreads();
 
   // ---------------------------------------------------------------- results (K13: sign-expanded multipliers)
-  if(tid < n) A.x[(size_t)b * n + tid] = xs[tid];
+  if(tid < nr) A.x[(size_t)b * nr + tid] = xs[tid];
   double * ug = A.u + (size_t)b * mt;
   int * sg = A.status + (size_t)b * mt;
   for(int i = tid; i < mt; i += WG)
@@ -1879,8 +1886,21 @@ hipError_t launch_prof(const BatchArgs & a, long lds, hipStream_t stream)
 
 } // namespace
 
+// instantiated sizes of the register-resident kernel; a cold solve of a smaller n runs embedded in the next one
+int batch_pad_size(int n, int warm)
+{
+  static const int sizes[] = {10, 16, 20, 30, 32, 40, 50, 60, 64};
+  for(int s : sizes)
+  {
+    if(s == n) return s;
+    if(s > n) return (warm || n < 8) ? 0 : s; // (tiny problems stay with the generic kernel)
+  }
+  return 0;
+}
+
 long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
 {
+  if(cmode == 2) n = batch_pad_size(n, warm);
   const long ld = n | 1;
   long dbl = 2L * n * ld + 4L * n + 2L * (n + 2);
   if(warm) dbl += (long)n * ld + 2L * n;
@@ -1894,7 +1914,7 @@ long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
 int batch_pick_cmode(int n, int m, int nb, int warm)
 {
   // registers: the specialised instantiations below; LDS when C fits beside the factors; else stream
-  if((n == 10 || n == 16 || n == 20 || n == 30 || n == 32 || n == 40 || n == 50 || n == 60 || n == 64) && m <= 256) return 2;
+  if(batch_pad_size(n, warm) > 0 && m <= 256) return 2;
   if(batch_lds_bytes(n, m, nb, 1, warm) <= kLdsPerCU) return 1;
   if(batch_lds_bytes(n, m, nb, 0, warm) <= kLdsPerCU) return 0;
   return -1;
@@ -1903,15 +1923,22 @@ int batch_pick_cmode(int n, int m, int nb, int warm)
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)
 {
   const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode, a.warm);
-  if(cmode == 2 && a.n == 50) return launch_prof<50, 2>(a, lds, stream);
-  if(cmode == 2 && a.n == 10) return launch_prof<10, 2>(a, lds, stream);
-  if(cmode == 2 && a.n == 16) return launch_prof<16, 2>(a, lds, stream);
-  if(cmode == 2 && a.n == 20) return launch_prof<20, 2>(a, lds, stream);
-  if(cmode == 2 && a.n == 30) return launch_prof<30, 2>(a, lds, stream);
-  if(cmode == 2 && a.n == 32) return launch_prof<32, 2>(a, lds, stream);
-  if(cmode == 2 && a.n == 40) return launch_prof<40, 2>(a, lds, stream);
-  if(cmode == 2 && a.n == 60) return launch_prof<60, 2>(a, lds, stream); // (a size of the reference's benchmark families)
-  if(cmode == 2 && a.n == 64) return launch_prof<64, 2>(a, lds, stream);
+  if(cmode == 2)
+  {
+    switch(batch_pad_size(a.n, a.warm))
+    {
+      case 10: return launch_prof<10, 2>(a, lds, stream);
+      case 16: return launch_prof<16, 2>(a, lds, stream);
+      case 20: return launch_prof<20, 2>(a, lds, stream);
+      case 30: return launch_prof<30, 2>(a, lds, stream);
+      case 32: return launch_prof<32, 2>(a, lds, stream);
+      case 40: return launch_prof<40, 2>(a, lds, stream);
+      case 50: return launch_prof<50, 2>(a, lds, stream); // BASELINE configs c3 / c4
+      case 60: return launch_prof<60, 2>(a, lds, stream);
+      case 64: return launch_prof<64, 2>(a, lds, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   if(cmode == 1) return launch_prof<0, 1>(a, lds, stream);
   return launch_prof<0, 0>(a, lds, stream);
 }

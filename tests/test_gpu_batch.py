@@ -121,6 +121,14 @@ CASES = [
     dict(nVar=40, nObj=40, nEq=8, nIneq=40, nStrongActIneq=12, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
     dict(nVar=40, nObj=40, nIneq=300, nStrongActIneq=12),  # m > 256: back to the generic kernel
     dict(nVar=10, nObj=10, bounds=True, nStrongActBounds=4),
+    # sizes WITHOUT an instantiation: a cold solve runs embedded in the next instantiated size ([G 0; 0 I], zero rows in
+    # C); the results must still be the oracle's, bit for bit
+    dict(nVar=12, nObj=12, nEq=2, nIneq=24, nStrongActIneq=3, bounds=True, nStrongActBounds=2),
+    dict(nVar=21, nObj=21, nIneq=42, nStrongActIneq=6, doubleSidedIneq=True),
+    dict(nVar=45, nObj=45, nEq=5, nIneq=90, nStrongActIneq=12, bounds=True, nStrongActBounds=5, doubleSidedIneq=True),
+    dict(nVar=55, nObj=55, nIneq=110, nStrongActIneq=16),
+    dict(nVar=62, nObj=62, nEq=6, nIneq=200, nStrongActIneq=15, bounds=True, nStrongActBounds=6),
+    dict(nVar=9, nObj=9, nIneq=18, nStrongActIneq=3),
 ]
 
 
