@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     }
     else if(ctl->eq_next != NONE)
     {
-      if(ctl->cnt > n)
+      if(ctl->cnt > nr) // (the caller's n: an embedded problem has no more unknowns than that)
       {
         term = T_OVERCONSTRAINED; // UB in the reference; reported (as the oracle does)
       }

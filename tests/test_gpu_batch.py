@@ -172,6 +172,39 @@ def test_termination_codes_and_edge_cases(capi, P, oracle):
     assert 4 in ref["term"]
 
 
+def test_termination_codes_embedded_size(capi, P, oracle):
+    """The same termination codes for a size that runs EMBEDDED in a larger instantiation (n = 12 inside n = 16): the
+    embedding must not change what is reported (OVERCONSTRAINED counts the caller's unknowns, a failing pivot keeps its
+    column index), and the factor handed back has the caller's shape."""
+    n, m = 12, 14
+    B = 6
+    rng = np.random.default_rng(11)
+    G = np.tile(np.eye(n), (B, 1, 1))
+    a = rng.standard_normal((B, n))
+    C = rng.standard_normal((B, m, n))
+    bl = np.full((B, m), -np.inf)
+    bu = np.full((B, m), 10.0)
+    G[0, 7, 7] = -1.0  # not positive definite (column 7)
+    C[1, 0] = 0.0
+    C[1, 1] = 0.0
+    C[1, 0, 3] = 1.0
+    C[1, 1, 3] = -1.0
+    bu[1, 0] = -1.0
+    bu[1, 1] = -1.0  # x3 <= -1 and -x3 <= -1: infeasible
+    bu[2] = -5.0  # many violated constraints; with max_iter = 2 -> MAX_ITER_REACHED
+    bl[3, :13] = bu[3, :13] = 0.5  # thirteen equalities for twelve unknowns: over-constrained (but fewer than 16)
+    G[4, 0, 0] = 0.0  # failure at column 0
+    pb = P.PackedBatch(n=n, m=m, nb=0, G=G, a=a, C=C, bl=bl, bu=bu, xl=np.zeros((B, 0)), xu=np.zeros((B, 0)),
+                       x_star=np.zeros((B, n)), lam_star=np.zeros((B, m)))
+    ref = oracle.solve_batch(G, a, C, bl, bu, max_iter=2)
+    gpu = run_gpu(capi, pb, max_iter=2, want_factor=True)
+    assert_bit_identical(gpu, ref, "edge cases, embedded size")
+    assert ref["term"][0] == 2 and ref["term"][1] == 3 and ref["term"][3] == 6 and ref["term"][4] == 2
+    assert 4 in ref["term"]
+    ok = ref["term"] != 2
+    assert np.array_equal(np.tril(gpu["L"].transpose(0, 2, 1))[ok], np.tril(ref["L"].transpose(0, 2, 1))[ok])
+
+
 def test_c3_full_bench_batch(capi, P, oracle, pkg):
     """The full BASELINE workload (B = 4096, n = 50, m = 200): bit-exact against the oracle on every problem, and the
     size-independent properties -- every solve reaches the planted optimum, the active set is the planted one, the
