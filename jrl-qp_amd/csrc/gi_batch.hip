@@ -378,8 +378,10 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   // zeros, and the extra rotations of an addition act on (0, 0) pairs (identities) or on (d_{nr-1}, 0), which at most
   // negates the LAST column of the free part of J together with its d entry -- a sign that cancels in every product it
   // enters (z, the next rotation) and never reaches R, x, u or f.  So the padded run reproduces the unpadded one bit for
-  // bit (up to the sign of exact zeros), and x, u, status are written back in the caller's sizes.
-  const int nr = (NT && !WARM) ? A.n : n;
+  // bit (up to the sign of exact zeros), and x, u, status are written back in the caller's sizes.  The warm start is
+  // embedded the same way: N gets zero rows, so do B = L^-1 N and every Householder vector of its QR, and Q leaves the
+  // identity block alone.
+  const int nr = NT ? A.n : n;
   const int ld = NT ? (NT | 1) : A.ld;
   const int m = A.m, nb = A.nb;
   const int mt = m + nb;
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     if(wave == 0)
     {
       const int neq = ctl->cnt;
-      const int budget = n - neq;
+      const int budget = nr - neq; // (the caller's n)
       int base = 0, nrank = 0;
       const unsigned long long lt = (1ull << lane) - 1ull;
       for(int part = 0; part < 2; ++part)
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           const bool keep = iseq || (isne && rank < budget);
           const unsigned long long mk = __ballot(keep);
           const int pos = base + __popcll(mk & lt);
-          if(keep && pos < n) act[pos] = i;
+          if(keep && pos < nr) act[pos] = i;
           if(isne && !keep && budget >= 0) st[i] = INACTIVE;
           base += __popcll(mk);
           nrank += __popcll(mne);
@@ -671,8 +673,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       }
       if(lane == 0)
       {
-        ctl->nact = (base < n) ? base : n;
-        ctl->over = (neq > n);
+        ctl->nact = (base < nr) ? base : nr;
+        ctl->over = (neq > nr);
       }
     }
     __syncthreads();
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         double v;
         if(idx < m)
         {
-          const double c = Cg[(size_t)idx * n + i];
+          const double c = (i < nr) ? Cg[(size_t)idx * nr + i] : 0.0;
           v = (sj == UPPER) ? -c : c;
         }
         else
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           bv = (sj == UPPER_BOUND) ? -xug[idx - m] : xlg[idx - m];
         bact[j] = bv;
       }
-      if(t3 < n) nps[t3] = ag[t3];
+      if(t3 < n) nps[t3] = (t3 < nr) ? ag[t3] : 0.0;
     }
     else if(wave == 0)
     {
@@ -1893,7 +1895,7 @@ int batch_pad_size(int n, int warm)
   for(int s : sizes)
   {
     if(s == n) return s;
-    if(s > n) return (warm || n < 8) ? 0 : s; // (tiny problems stay with the generic kernel)
+    if(s > n) return (n < 8) ? 0 : s; // (tiny problems stay with the generic kernel)
   }
   return 0;
 }

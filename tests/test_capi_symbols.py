@@ -42,8 +42,9 @@ def test_defaults_and_lds_budget(pkg):
     assert l12 == l16 and c.value == 2  # a size without an instantiation runs embedded in the next one (cold solves)
     lds = lib.jrlqp_gi_batch_lds_bytes(5, 10, 0, ct.byref(c))
     assert 0 < lds < 16384 and c.value == 1  # tiny problems: the generic kernel, C staged in LDS
-    lds = lib.jrlqp_gi_batch_warm_lds_bytes(12, 24, 0, ct.byref(c))
-    assert 0 < lds < 32768 and c.value == 1  # warm start: exact sizes only
+    w12 = lib.jrlqp_gi_batch_warm_lds_bytes(12, 24, 0, ct.byref(c))
+    w16 = lib.jrlqp_gi_batch_warm_lds_bytes(16, 24, 0, ct.byref(c))
+    assert w12 == w16 and c.value == 2  # warm starts are embedded the same way
     lds = lib.jrlqp_gi_batch_lds_bytes(50, 2000, 50, ct.byref(c))
     assert 0 < lds <= 163840 and c.value == 0  # too many constraints: C is streamed
     assert lib.jrlqp_gi_batch_lds_bytes(65, 10, 0, ct.byref(c)) == -1

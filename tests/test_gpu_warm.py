@@ -110,6 +110,8 @@ WIDE = [
     dict(nVar=64, nObj=64, nIneq=100, nStrongActIneq=20),
     dict(nVar=60, nObj=60, nEq=6, nIneq=90, nStrongActIneq=15, bounds=True, nStrongActBounds=5),  # the n = 60 instantiation, warm
     dict(nVar=20, nObj=20, nEq=2, nIneq=40, nStrongActIneq=6, bounds=True, nStrongActBounds=2),
+    dict(nVar=45, nObj=45, nEq=5, nIneq=90, nStrongActIneq=12, bounds=True, nStrongActBounds=5, doubleSidedIneq=True),  # embedded in n = 50
+    dict(nVar=12, nObj=12, nIneq=24, nStrongActIneq=4),  # embedded in n = 16
     dict(nVar=40, nObj=40, nIneq=80, nStrongActIneq=12, doubleSidedIneq=True),
     dict(nVar=1, nObj=1, nIneq=3, nStrongActIneq=1),
     dict(nVar=50, nObj=50, nIneq=900, nStrongActIneq=10),  # C streamed from L2/HBM
