@@ -975,28 +975,40 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         }
         if(wave == 1)
         {
+          // the LDS-staged columns, 64 at a time (lane = column inside the pass); a lane keeps its first best one
+          // (strict <: a later pass only wins with a smaller slack), then the general arg-min picks the first index
+          // among equal values across lanes
           double ev = 1.0;
           int ei = NONE, es = INACTIVE;
-          const int i = CREG_MAX + lane;
-          if(lane < ne && st[i] == INACTIVE && i != excl)
+          for(int e0 = 0; e0 < ne; e0 += 64)
           {
-            const double cx = chain_up(Ce + (size_t)lane * ld, 1, xs, 1, 0, n, 0.0);
-            const double sl = cx - blg[i];
-            const double su = bug[i] - cx;
-            if(sl < 0.0)
+            const int i = CREG_MAX + e0 + lane;
+            if(e0 + lane < ne && st[i] == INACTIVE && i != excl)
             {
-              ev = sl;
-              ei = i;
-              es = LOWER;
-            }
-            else if(su < 0.0)
-            {
-              ev = su;
-              ei = i;
-              es = UPPER;
+              const double cx = chain_up(Ce + (size_t)(e0 + lane) * ld, 1, xs, 1, 0, n, 0.0);
+              const double sl = cx - blg[i];
+              const double su = bug[i] - cx;
+              if(sl < 0.0)
+              {
+                if(sl < ev)
+                {
+                  ev = sl;
+                  ei = i;
+                  es = LOWER;
+                }
+              }
+              else if(su < 0.0 && su < ev)
+              {
+                ev = su;
+                ei = i;
+                es = UPPER;
+              }
             }
           }
-          if(ne > 0) wave_argmin_monotone(ev, ei, es);
+          if(ne > 64)
+            wave_argmin(ev, ei, es);
+          else if(ne > 0)
+            wave_argmin_monotone(ev, ei, es);
           if(lane == 0)
           {
             ctl->red_val[3] = ev;
@@ -1916,7 +1928,14 @@ long batch_lds_bytes(int n, int m, int nb, int cmode, int warm)
 int batch_pick_cmode(int n, int m, int nb, int warm)
 {
   // registers: the specialised instantiations below; LDS when C fits beside the factors; else stream
-  if(batch_pad_size(n, warm) > 0 && m <= 256) return 2;
+  // registers (192 columns, the rest staged in LDS and scanned by one wave, 64 per pass).  Beyond 64 staged columns only
+  // while two workgroups still share a CU: measured, n = 50 with 108 / 208 staged columns (one workgroup per CU) is 22-27 %
+  // slower than streaming C, n = 30 / m = 300 and n = 20 / m = 500 are 2.6x / 1.8x faster than the generic kernel
+  if(batch_pad_size(n, warm) > 0)
+  {
+    const long l2 = batch_lds_bytes(n, m, nb, 2, warm);
+    if(l2 <= kLdsPerCU && (m <= 256 || 2 * l2 <= kLdsPerCU)) return 2;
+  }
   if(batch_lds_bytes(n, m, nb, 1, warm) <= kLdsPerCU) return 1;
   if(batch_lds_bytes(n, m, nb, 0, warm) <= kLdsPerCU) return 0;
   return -1;

@@ -119,7 +119,9 @@ CASES = [
     dict(nVar=30, nObj=30, nEq=3, nIneq=60, nStrongActIneq=9, bounds=True, nStrongActBounds=3, doubleSidedIneq=True),
     dict(nVar=32, nObj=32, nIneq=64, nStrongActIneq=10),
     dict(nVar=40, nObj=40, nEq=8, nIneq=40, nStrongActIneq=12, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
-    dict(nVar=40, nObj=40, nIneq=300, nStrongActIneq=12),  # m > 256: back to the generic kernel
+    dict(nVar=40, nObj=40, nIneq=300, nStrongActIneq=12),  # 108 LDS-staged columns: two passes of the second scan
+    dict(nVar=30, nObj=30, nEq=3, nIneq=420, nStrongActIneq=9, bounds=True, nStrongActBounds=3, doubleSidedIneq=True),  # 228 staged columns, four passes
+    dict(nVar=50, nObj=50, nEq=3, nIneq=420, nStrongActIneq=14, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),  # too many to stage: C streamed
     dict(nVar=10, nObj=10, bounds=True, nStrongActBounds=4),
     # sizes WITHOUT an instantiation: a cold solve runs embedded in the next instantiated size ([G 0; 0 I], zero rows in
     # C); the results must still be the oracle's, bit for bit
