@@ -355,7 +355,9 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 // CMODE : 0 = C streamed from global memory, 1 = C staged in LDS, 2 = C in registers (needs NT > 0, m <= 256)
 // WARM  : warm-started solve (src/experimental/GoldfarbIdnaniSolver.cpp): the initial active set comes from the data
 //         equalities plus a guess, J and R from a Householder QR of L^-1 N; then the same loop
-template<int NT, int CMODE, bool PROF, bool WARM>
+// EMB   : the problem is SMALLER than NT and runs embedded (see nr below); a separate instantiation, so that the
+//         exact-size kernels -- BASELINE c3 among them -- keep nr a compile-time constant and their register allocation
+template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false>
 __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : (NT <= 16 ? 5 : (NT <= 32 ? 4 : 3))) : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0, last3_ = 0;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   // bit (up to the sign of exact zeros), and x, u, status are written back in the caller's sizes.  The warm start is
   // embedded the same way: N gets zero rows, so do B = L^-1 N and every Householder vector of its QR, and Q leaves the
   // identity block alone.
-  const int nr = NT ? A.n : n;
+  const int nr = EMB ? A.n : n;
   const int ld = NT ? (NT | 1) : A.ld;
   const int m = A.m, nb = A.nb;
   const int mt = m + nb;
@@ -1881,19 +1883,21 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   }
 }
 
-template<int NT, int CMODE, bool PROF, bool WARM>
+template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false>
 hipError_t launch_one(const BatchArgs & a, long lds, hipStream_t stream)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<NT, CMODE, PROF, WARM>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<NT, CMODE, PROF, WARM, EMB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if(e != hipSuccess) return e;
-  hipLaunchKernelGGL((gi_batch_kernel<NT, CMODE, PROF, WARM>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
+  hipLaunchKernelGGL((gi_batch_kernel<NT, CMODE, PROF, WARM, EMB>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
   return hipGetLastError();
 }
 
 template<int NT, int CMODE>
 hipError_t launch_prof(const BatchArgs & a, long lds, hipStream_t stream)
 {
+  if(NT > 0 && a.n != NT) // a smaller problem, embedded (no phase-profile build of these)
+    return a.warm ? launch_one<NT, CMODE, false, true, true>(a, lds, stream) : launch_one<NT, CMODE, false, false, true>(a, lds, stream);
   if(a.warm) return launch_one<NT, CMODE, false, true>(a, lds, stream); // the phase profile covers the cold path only
   return a.prof ? launch_one<NT, CMODE, true, false>(a, lds, stream) : launch_one<NT, CMODE, false, false>(a, lds, stream);
 }
