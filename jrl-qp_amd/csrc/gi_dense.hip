@@ -1051,10 +1051,29 @@ __device__ __forceinline__ void rot_sweep(double * J, int ld, int n, int row0, i
   }
 }
 
+// The sweep of an ADDITION also commits it (K10 part 1b, add_commit_kernel's work): workgroup 0 writes R(:, q) = d(0:q)
+// with the new diagonal and the status byte of the activated constraint -- one dispatch less on the critical path.
+struct CommitArgs
+{
+  const double *d, *rfin;
+  double * R;
+  unsigned char * st;
+  int q, ld, p, pstat;
+};
+
 __global__ __launch_bounds__(128) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
-                                                        const double * __restrict__ ss)
+                                                        const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0})
 {
   extern __shared__ double rsm[]; // two chunk buffers | (c_i, s_i) pairs (T)
+  if(cm.d && blockIdx.x == 0)
+  {
+    for(int k = threadIdx.x; k < cm.q; k += 128) AT(cm.R, cm.ld, k, cm.q) = cm.d[k];
+    if(threadIdx.x == 0)
+    {
+      AT(cm.R, cm.ld, cm.q, cm.q) = *cm.rfin;
+      cm.st[cm.p] = (unsigned char)cm.pstat;
+    }
+  }
   if(i_hi < i_lo) return;
   const int T = i_hi - i_lo + 1;
   double * lbuf = rsm;
@@ -1258,8 +1277,11 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
   }
   else
     hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
-  hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat);
-  if(n - 2 >= q) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2);
+  if(n - 2 >= q)
+    hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
+                       CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat});
+  else // q = n - 1: nothing to rotate
+    hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat);
   return hipGetLastError();
 }
 
