@@ -1106,29 +1106,61 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
   // shifted left one after the other (a row is private to its thread: no barrier needed)
   double carry = mine ? AT(R, ld, l, tid + 1) : 0.0;
   for(int rr = tid; rr < l; rr += blockDim.x)
-    for(int k = l; k < qn; ++k) AT(R, ld, rr, k) = AT(R, ld, rr, k + 1);
-  __syncthreads();
-  for(int i = l; i < qn; ++i)
   {
-    double y = (tid >= i && tid < qn) ? AT(R, ld, i + 1, tid + 1) : 0.0;
-    if(tid == i)
+    // (16 entries of the row requested together, then stored one column to the left: one memory round trip per 16
+    // columns instead of one per column; across threads every access is coalesced)
+    int k = l;
+    for(; k + 16 <= qn; k += 16)
     {
-      double c, s, rho;
-      make_givens(carry, y, c, s, rho);
-      gc = c;
-      gs = s;
-      cc[i] = c;
-      ss[i] = s;
-      AT(R, ld, i, i) = rho;
+      double v[16];
+#pragma unroll
+      for(int u = 0; u < 16; ++u) v[u] = AT(R, ld, rr, k + 1 + u);
+#pragma unroll
+      for(int u = 0; u < 16; ++u) AT(R, ld, rr, k + u) = v[u];
     }
-    __syncthreads();
-    const double c = gc, s = gs;
-    if(tid > i && tid < qn)
+    for(; k < qn; ++k) AT(R, ld, rr, k) = AT(R, ld, rr, k + 1);
+  }
+  __syncthreads();
+  // Rotation i needs row i+1 of the old R (one entry per column thread, a cache line each): the rows of the next PF
+  // rotations are requested ahead -- clamped addresses, no predicate -- and the per-rotation hand-off of (c, s) goes
+  // through LDS behind LDS-only barriers (a __syncthreads() would drain the prefetches at every step).  A thread only
+  // ever rewrites entries of its own column that it has already consumed.
+  constexpr int PF = 4;
+  const int colr = min(tid + 1, q - 1); // old column this thread reads (clamped for the threads without a column)
+  double yq[PF];
+#pragma unroll
+  for(int u = 0; u < PF; ++u) yq[u] = AT(R, ld, min(l + 1 + u, q - 1), colr);
+  for(int i0 = l; i0 < qn; i0 += PF)
+  {
+#pragma unroll
+    for(int u = 0; u < PF; ++u)
     {
-      AT(R, ld, i, tid) = FMA(c, carry, -(s * y));
-      carry = FMA(s, carry, c * y);
+      const int i = i0 + u;
+      if(i < qn) // (uniform)
+      {
+        const double yl = yq[u];
+        yq[u] = AT(R, ld, min(i + 1 + PF, q - 1), colr);
+        const double y = (tid >= i && tid < qn) ? yl : 0.0;
+        if(tid == i)
+        {
+          double c, s, rho;
+          make_givens(carry, y, c, s, rho);
+          gc = c;
+          gs = s;
+          cc[i] = c;
+          ss[i] = s;
+          AT(R, ld, i, i) = rho;
+        }
+        lds_barrier();
+        const double c = gc, s = gs;
+        if(tid > i && tid < qn)
+        {
+          AT(R, ld, i, tid) = FMA(c, carry, -(s * y));
+          carry = FMA(s, carry, c * y);
+        }
+        lds_barrier();
+      }
     }
-    __syncthreads();
   }
 }
 
@@ -1288,7 +1320,8 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st)
 {
   const int n = v.n;
-  hipLaunchKernelGGL(remove_r_kernel, dim3(1), dim3(1024), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
+  const int rthreads = ((q + 63) / 64) * 64; // thread = column (q <= 1024): no more waves at the barriers than columns need
+  hipLaunchKernelGGL(remove_r_kernel, dim3(1), dim3(rthreads), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
   const int qn = q - 1;
   if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(qn - l), st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
   return hipGetLastError();
