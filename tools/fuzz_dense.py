@@ -1,0 +1,42 @@
+"""Extended fuzz of the host-driven dense path (Mode A, jrlqp_dense_solve) against the oracle: random n in 1 .. 260 with
+random mixes of equalities, bounds, double-sided constraints; bit-identical results required.  Not part of the suite.
+   python tools/fuzz_dense.py [trials (default 80)] [seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+from __graft_entry__ import load_package
+
+load_package()
+import jrl_qp_amd.capi as capi
+import jrl_qp_amd.problems as P
+from oracle_lib import get_oracle
+from test_gpu_dense import check, solve_gpu
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+rng = np.random.default_rng(seed)
+oracle = get_oracle()
+terms = {}
+for trial in range(trials):
+    n = int(rng.integers(1, 261))
+    nEq = int(rng.integers(0, max(1, n // 4) + 1)) if rng.random() < 0.4 else 0
+    bounds = bool(rng.random() < 0.4)
+    nIneq = int(rng.integers(0, 3 * n + 8))
+    room = n - nEq
+    nSA = int(rng.integers(0, min(nIneq, room) + 1))
+    nSB = int(rng.integers(0, max(0, min(n, room - nSA)) + 1)) if bounds else 0
+    ch = P.Characteristics(nVar=n, nObj=n, nEq=nEq, nIneq=nIneq, nStrongActIneq=nSA, bounds=bounds, nStrongActBounds=nSB,
+                           doubleSidedIneq=bool(rng.random() < 0.5))
+    pb = P.generate_batch(1, ch, first_index=900000 + 7 * trial)
+    ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], pb.xl[0] if bounds else None, pb.xu[0] if bounds else None, max_iter=4000)
+    gpu = solve_gpu(capi, pb, 0, bounds, max_iter=4000)
+    check(gpu, ref, f"trial {trial}: {ch}")
+    terms[ref.term] = terms.get(ref.term, 0) + 1
+    if trial % 20 == 19:
+        print(f"{trial + 1} problems ok; termination codes {terms}", flush=True)
+print(f"all {trials} problems bit-identical; termination codes {terms}")
