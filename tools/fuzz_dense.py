@@ -1,6 +1,11 @@
 """Extended fuzz of the host-driven dense path (Mode A, jrlqp_dense_solve) against the oracle: random n in 1 .. 260 with
 random mixes of equalities, bounds, double-sided constraints; bit-identical results required.  Not part of the suite.
-   python tools/fuzz_dense.py [trials (default 80)] [seed]"""
+   python tools/fuzz_dense.py [trials (default 80)] [seed] [first trial]
+
+Observed once per ~3000 trials on the GPU box (twice in 6000): the ORACLE's result array carried a NaN multiplier for an
+inactive constraint while the GPU result was the correct 0 and x, f, status, iterations agreed.  It did not reproduce on
+replaying the same trial and its neighbours (6 x), on 4500 repetitions of the same problem, or under ASan/UBSan on the
+oracle alone (400 random problems); the tool prints the details and reruns the problem when it happens.  Open."""
 import os
 import sys
 
@@ -19,6 +24,7 @@ from test_gpu_dense import check, solve_gpu
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # (earlier trials only consume the random stream)
 rng = np.random.default_rng(seed)
 oracle = get_oracle()
 terms = {}
@@ -32,11 +38,25 @@ for trial in range(trials):
     nSB = int(rng.integers(0, max(0, min(n, room - nSA)) + 1)) if bounds else 0
     ch = P.Characteristics(nVar=n, nObj=n, nEq=nEq, nIneq=nIneq, nStrongActIneq=nSA, bounds=bounds, nStrongActBounds=nSB,
                            doubleSidedIneq=bool(rng.random() < 0.5))
+    if trial < first:
+        continue
     pb = P.generate_batch(1, ch, first_index=900000 + 7 * trial)
     ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], pb.xl[0] if bounds else None, pb.xu[0] if bounds else None, max_iter=4000)
     gpu = solve_gpu(capi, pb, 0, bounds, max_iter=4000)
-    check(gpu, ref, f"trial {trial}: {ch}")
+    try:
+        check(gpu, ref, f"trial {trial}: {ch}")
+    except AssertionError:
+        du = np.nonzero(gpu["u"] != ref.u)[0]
+        print(f"MISMATCH trial {trial}: {ch}\n  term {gpu['term']}/{ref.term} iters {gpu['iters']}/{ref.iters} x equal {np.array_equal(gpu['x'], ref.x)} "
+              f"status equal {np.array_equal(gpu['status'], ref.status)} f equal {gpu['f'] == ref.f}\n  u differs at {du[:8]}: gpu {gpu['u'][du[:8]]} ref {ref.u[du[:8]]}"
+              f"\n  active count {int((ref.status != 0).sum())}", flush=True)
+        # rerun the same problem: deterministic or timing-dependent?
+        again = solve_gpu(capi, pb, 0, bounds, max_iter=4000)
+        print("  second run identical to the oracle:", np.array_equal(again["u"], ref.u) and np.array_equal(again["x"], ref.x), flush=True)
+        fails = globals().get("fails", 0) + 1
+        globals()["fails"] = fails
     terms[ref.term] = terms.get(ref.term, 0) + 1
     if trial % 20 == 19:
         print(f"{trial + 1} problems ok; termination codes {terms}", flush=True)
-print(f"all {trials} problems bit-identical; termination codes {terms}")
+print(f"{trials} problems, {globals().get('fails', 0)} mismatches; termination codes {terms}")
+sys.exit(1 if globals().get("fails", 0) else 0)
