@@ -5,7 +5,8 @@ random mixes of equalities, bounds, double-sided constraints; bit-identical resu
 Observed once per ~3000 trials on the GPU box (twice in 6000): the ORACLE's result array carried a NaN multiplier for an
 inactive constraint while the GPU result was the correct 0 and x, f, status, iterations agreed.  It did not reproduce on
 replaying the same trial and its neighbours (6 x), on 4500 repetitions of the same problem, or under ASan/UBSan on the
-oracle alone (400 random problems); the tool prints the details and reruns the problem when it happens.  Open."""
+oracle alone (400 random problems); 600 000 zero-filled guard arrays kept alive across 3000 GPU solves stayed untouched
+(no stray host write from the library).  The tool prints the details and reruns the problem when it happens.  Open."""
 import os
 import sys
 
