@@ -248,51 +248,6 @@ __global__ __launch_bounds__(256) void jinv_block_kernel(const double * __restri
 // ============================================================================================================
 // K3  x0 = -G^-1 a, f0 = a.x0 / 2: one workgroup, thread = row (strided), pivots through LDS
 // ============================================================================================================
-__global__ __launch_bounds__(1024) void x0_kernel(const double * __restrict__ L, int ldl, int n, const double * __restrict__ a, double * x, double * f0)
-{
-  extern __shared__ double xs[]; // n
-  __shared__ double piv;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for(int i = tid; i < n; i += nt) xs[i] = a[i];
-  __syncthreads();
-  for(int k = 0; k < n; ++k)
-  {
-    if(tid == 0)
-    {
-      piv = xs[k] / AT(L, ldl, k, k);
-      xs[k] = piv;
-    }
-    __syncthreads();
-    const double v = piv;
-    for(int i = k + 1 + tid; i < n; i += nt) xs[i] = FMA(-AT(L, ldl, i, k), v, xs[i]);
-    __syncthreads();
-  }
-  for(int k = n - 1; k >= 0; --k)
-  {
-    if(tid == 0)
-    {
-      piv = xs[k] / AT(L, ldl, k, k);
-      xs[k] = piv;
-    }
-    __syncthreads();
-    const double v = piv;
-    for(int i = tid; i < k; i += nt) xs[i] = FMA(-AT(L, ldl, k, i), v, xs[i]);
-    __syncthreads();
-  }
-  for(int i = tid; i < n; i += nt)
-  {
-    xs[i] = -xs[i];
-    x[i] = xs[i];
-  }
-  __syncthreads();
-  if(tid == 0)
-  {
-    double acc = 0.0;
-    for(int k = 0; k < n; ++k) acc = FMA(a[k], xs[k], acc);
-    *f0 = 0.5 * acc;
-  }
-}
-
 // ============================================================================================================
 // column dots: out[j] = sign * sum_k M[k + j*ld] v[k]   (K4 with M = C, v = x; K5 with M = J, v = C[:,p])
 // lane = column; the vector is staged in LDS; per lane the column is a contiguous stream.
@@ -338,6 +293,146 @@ __device__ __forceinline__ double chain64(double acc, const double * a, const do
     }
   }
   return acc;
+}
+
+// K3: x0 = -G^-1 a = -L^-T (L^-1 a), f0 = a.x0 / 2 -- two substitutions of n steps, blocked by 64 exactly as the back
+// substitution of step_tail: wave 0 solves the 64 x 64 diagonal block out of statically indexed registers (lane = row,
+// hoisted reciprocals, plain division on a failed range check), waves 1-7 advance the row blocks below (forward) / above
+// (backward) through the block's 64 columns from tiles requested while wave 0 was solving; the running vector lives in LDS,
+// two LDS-only barriers per block.  Row i's chain takes its terms in the same order as the unblocked loops (forward: k
+// ascending, backward: k descending).  It replaces one workgroup barrier pair per STEP (1.2 ms at n = 1024).
+//   TRANS = false: forward substitution with L (lower triangle of M);  TRANS = true: back substitution with L^T
+template<bool TRANS>
+__device__ __forceinline__ void blocked_subst(const double * __restrict__ M, int ld, int n, double * rs, int lane, int wave)
+{
+  // entry (i, k) of the triangular factor in use: L(i, k) = M(i, k), or L^T(i, k) = M(k, i)
+  auto T = [&](int i, int k) -> double { return TRANS ? AT(M, ld, k, i) : AT(M, ld, i, k); };
+  const int nblk = (n + 63) >> 6;
+  double blk[64];
+  double dg = 1.0;
+  auto fetch_diag = [&](int cb) {
+    const int kb = cb << 6, cnt = min(64, n - kb);
+    const int row = kb + ((lane < cnt) ? lane : 0);
+#pragma unroll
+    for(int k = 0; k < 64; ++k) blk[k] = T(row, kb + ((k < cnt) ? k : 0));
+    dg = (lane < cnt) ? AT(M, ld, row, row) : 1.0;
+  };
+  auto fetch_tile = [&](int rb, int kb, int cnt) {
+    const int row = min((rb << 6) + lane, n - 1);
+#pragma unroll
+    for(int k = 0; k < 64; ++k) blk[k] = T(row, kb + ((k < cnt) ? k : 0));
+  };
+  const int cb0 = TRANS ? nblk - 1 : 0, cstep = TRANS ? -1 : 1;
+  if(wave == 0) fetch_diag(cb0);
+  lds_barrier();
+  for(int it = 0, cb = cb0; it < nblk; ++it, cb += cstep)
+  {
+    const int kb = cb << 6, cnt = min(64, n - kb);
+    // row blocks still to be advanced through this column block: above it (backward) or below it (forward)
+    const int nrb = TRANS ? cb : nblk - 1 - cb;
+    auto rbk = [&](int j) { return TRANS ? j : cb + 1 + j; }; // j-th of them
+    const int j0 = wave - 1;
+    if(wave > 0 && j0 < nrb) fetch_tile(rbk(j0), kb, cnt);
+    if(wave == 0)
+    {
+      const double rk0 = (lane < cnt) ? rs[kb + lane] : 0.0;
+      const double rinv = recip_refined(dg);
+      double rk = rk0, pre = 0.0;
+#pragma unroll
+      for(int kk = 0; kk < 64; ++kk)
+      {
+        const int k = TRANS ? 63 - kk : kk;
+        if(k < cnt)
+        {
+          const double v = div_pre(bcast_lane(rk, k), bcast_lane(dg, k), bcast_lane(rinv, k));
+          const double upd = FMA(-blk[k], v, rk);
+          pre = (lane == k) ? rk : pre;
+          rk = ((TRANS ? lane < k : lane > k) && lane < cnt) ? upd : rk;
+          rk = (lane == k) ? v : rk;
+        }
+      }
+      if(!__all(div_safe_den(dg) && div_safe_num(pre)))
+      {
+        rk = rk0;
+#pragma unroll
+        for(int kk = 0; kk < 64; ++kk)
+        {
+          const int k = TRANS ? 63 - kk : kk;
+          if(k < cnt)
+          {
+            const double v = bcast_lane(rk, k) / bcast_lane(dg, k);
+            const double upd = FMA(-blk[k], v, rk);
+            rk = ((TRANS ? lane < k : lane > k) && lane < cnt) ? upd : rk;
+            rk = (lane == k) ? v : rk;
+          }
+        }
+      }
+      if(lane < cnt) rs[kb + lane] = rk;
+    }
+    lds_barrier();
+    if(wave == 0)
+    {
+      if(it + 1 < nblk) fetch_diag(cb + cstep);
+    }
+    else
+    {
+      for(int j = j0; j < nrb; j += 7)
+      {
+        const int rb = rbk(j);
+        if(j != j0) fetch_tile(rb, kb, cnt);
+        const int row = (rb << 6) + lane;
+        double acc = rs[min(row, n - 1)];
+#pragma unroll
+        for(int g = 0; g < 8; ++g)
+        {
+          const int k0 = TRANS ? 56 - 8 * g : 8 * g;
+          double rv[8];
+#pragma unroll
+          for(int t = 0; t < 8; ++t) rv[t] = rs[kb + min(k0 + t, cnt - 1)];
+#pragma unroll
+          for(int tt = 0; tt < 8; ++tt)
+          {
+            const int t = TRANS ? 7 - tt : tt;
+            const double nx = FMA(-blk[k0 + t], rv[t], acc);
+            acc = (k0 + t < cnt) ? nx : acc;
+          }
+        }
+        if(row < n) rs[row] = acc;
+      }
+    }
+    lds_barrier();
+  }
+}
+
+__global__ __launch_bounds__(512) void x0_kernel(const double * __restrict__ L, int ldl, int n, const double * __restrict__ a, double * x, double * f0)
+{
+  extern __shared__ double xs[]; // n (the running vector) | n (a, for f0)
+  double * as = xs + n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for(int i = tid; i < n; i += 512)
+  {
+    const double ai = a[i];
+    xs[i] = ai;
+    as[i] = ai;
+  }
+  blocked_subst<false>(L, ldl, n, xs, lane, wave); // (starts with a barrier)
+  blocked_subst<true>(L, ldl, n, xs, lane, wave);
+  for(int i = tid; i < n; i += 512)
+  {
+    const double xi = -xs[i];
+    xs[i] = xi;
+    x[i] = xi;
+  }
+  lds_barrier();
+  if(wave == 0)
+  {
+    // f0 = a.x0 / 2: one in-order chain (every lane runs it on the same LDS words)
+    double acc = 0.0;
+    int k = 0;
+    for(; k + 64 <= n; k += 64) acc = chain64<1, true>(acc, as + k, xs + k, 64);
+    if(k < n) acc = chain64<1, false>(acc, as + k, xs + k, n - k);
+    if(lane == 0) *f0 = 0.5 * acc;
+  }
 }
 
 constexpr int NPRE = 3; // tiles requested ahead of the one being consumed (one tile's chains last ~0.45 us, an L2 round trip ~1 us)
@@ -1232,7 +1327,7 @@ hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t 
 
 hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st)
 {
-  hipLaunchKernelGGL(x0_kernel, dim3(1), dim3(1024), sizeof(double) * n, st, L, ldl, n, a, x, f0);
+  hipLaunchKernelGGL(x0_kernel, dim3(1), dim3(512), sizeof(double) * 2 * n, st, L, ldl, n, a, x, f0);
   return hipGetLastError();
 }
 
