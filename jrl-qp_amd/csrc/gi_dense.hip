@@ -199,23 +199,48 @@ __global__ __launch_bounds__(256) void jinv_block_kernel(const double * __restri
     int i = e % nbk, j = e / nbk;
     Ld[i + j * (NB + 1)] = AT(L, ldl, i0 + i, i0 + j);
   }
-  // rows below the block, descending k, staged 64 at a time (J is zero below its diagonal, so rows k > c add nothing)
-  for(int khi = cmax; khi >= i0 + nbk; khi -= 64)
-  {
+  // rows below the block, descending k, staged 64 at a time (J is zero below its diagonal, so rows k > c add nothing).
+  // The next stage's entries of L and J are requested into registers BEFORE the chains of the current stage run (fixed
+  // trip counts, clamped addresses: no predicated load, no branch between the requests and their use), so a stage costs
+  // its 64 x RW fmas instead of a memory round trip plus the fmas.
+  constexpr int NLS = (64 * NB) / 256, NJT = (64 * 64) / 256; // staged words per thread
+  double pls[NLS], pjt[NJT];
+  auto request = [&](int khi) {
     const int cnt = min(64, khi - (i0 + nbk) + 1);
     const int klo = khi - cnt + 1;
-    __syncthreads();
-    for(int e = tid; e < cnt * nbk; e += 256)
+#pragma unroll
+    for(int u = 0; u < NLS; ++u)
     {
-      int kk = e % cnt, r = e / cnt;
-      Ls[kk * (NB + 1) + r] = AT(L, ldl, klo + kk, i0 + r);
+      const int e = tid + 256 * u, kk = e & 63, r = e >> 6;
+      pls[u] = AT(L, ldl, klo + min(kk, cnt - 1), i0 + min(r, nbk - 1));
     }
-    for(int e = tid; e < cnt * ncol; e += 256)
+#pragma unroll
+    for(int u = 0; u < NJT; ++u)
     {
-      int kk = e % cnt, cc = e / cnt;
-      Jt[kk * 65 + cc] = AT(J, ldj, klo + kk, c0 + cc);
+      const int e = tid + 256 * u, kk = e & 63, cc = e >> 6;
+      pjt[u] = AT(J, ldj, klo + min(kk, cnt - 1), c0 + min(cc, ncol - 1));
     }
+  };
+  int khi = cmax;
+  if(khi >= i0 + nbk) request(khi);
+  for(; khi >= i0 + nbk; khi -= 64)
+  {
+    const int cnt = min(64, khi - (i0 + nbk) + 1);
     __syncthreads();
+#pragma unroll
+    for(int u = 0; u < NLS; ++u)
+    {
+      const int e = tid + 256 * u, kk = e & 63, r = e >> 6;
+      Ls[kk * (NB + 1) + r] = pls[u];
+    }
+#pragma unroll
+    for(int u = 0; u < NJT; ++u)
+    {
+      const int e = tid + 256 * u, kk = e & 63, cc = e >> 6;
+      Jt[kk * 65 + cc] = pjt[u];
+    }
+    lds_barrier();
+    if(khi - 64 >= i0 + nbk) request(khi - 64);
     for(int kk = cnt - 1; kk >= 0; --kk)
     {
       const double jk = live ? Jt[kk * 65 + lane] : 0.0;
