@@ -27,6 +27,40 @@ def algorithmic_bytes_per_solve(n, m, nb):
     return 8 * (n * n + n + n * m + 2 * m + 2 * nb) + 8 * (n + m + nb) + 4 * (m + nb) + 16
 
 
+def kernel_source_hash():
+    """sha256[:16] over the kernel sources (jrl-qp_amd/csrc).  tools/collect_profiles.py stores it next to every PMC
+    traffic figure, and a figure is quoted only while the sources it was measured on are the sources of this tree."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "jrl-qp_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "jrl-qp_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "jrl-qp_amd", "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(pattern, key):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes of tools/profile_round.sh (newest profiles/ file
+    matching `pattern`).  Returns (bytes or None, provenance string): None when no file exists or when the file was
+    measured on other kernel sources than this tree's (stale numbers are never quoted beside fresh timings)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, "no PMC pass on record (profiles/" + pattern + ")"
+    path = files[-1]
+    try:
+        d = json.load(open(path))
+        rel = os.path.relpath(path, ROOT)
+        if d.get("kernel_source_sha16") != kernel_source_hash():
+            return None, f"{rel} was measured on other kernel sources (sha16 {d.get('kernel_source_sha16')}); not quoted"
+        return float(d[key]), f"{rel}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, commit {d.get('commit')}"
+    except (OSError, ValueError, KeyError) as e:
+        return None, f"unreadable {path}: {e}"
+
+
 def cpu_baseline(pb, budget_s=12.0):
     """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample of the same
     workload: the first `sample` QPs, solved round after round (G restored from a copy before every solve, as the
@@ -81,6 +115,80 @@ def cpu_baseline(pb, budget_s=12.0):
                   f"every solve; single-thread probe {per * 1e6:.1f} us/solve",
         "single_thread_us_per_solve": per * 1e6,
     }
+
+
+def visible_gpu_count():
+    """Number of GPUs the rank processes will see, WITHOUT initialising the GPU in this process: counted by a short-lived
+    child (torch.cuda.device_count() honours HIP/ROCR/CUDA_VISIBLE_DEVICES)."""
+    import subprocess
+
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def launch_ranks(n, argv):
+    """Parent of `python bench.py --gpus N`: start N fresh rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, exactly what torch.distributed.run would set), wait for them, and fail loudly -- no
+    silent single-GPU run -- when fewer than N devices are visible or any rank fails.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+
+    have = visible_gpu_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) visible on this node; refusing to run on fewer", file=sys.stderr)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    q.terminate()  # exactly the PIDs started above
+        time.sleep(0.05)
+    return rc
+
+
+def rank_report(jdist, torch, device, local_solves, elapsed_local, x_local, total):
+    """Epilogue of an N-rank run: the RCCL world size this rank saw, every rank's own solves/s (all-gather of the local
+    elapsed times) and the all-gather of x -- the optional result assembly of SURVEY 8(e) -- timed on its own, outside
+    the solve timing."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"rccl_world_size": 1, "backend": None, "per_rank_solves_per_s": [local_solves / elapsed_local], "allgather_x_ms": None}
+    world = dist.get_world_size()
+    t = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    ts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(ts, t)
+    jdist.all_gather_results(x_local, total)  # warm the communicator / buffers
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        xa = jdist.all_gather_results(x_local, total)
+    torch.cuda.synchronize(device)
+    ag_ms = (time.perf_counter() - t0) / reps * 1e3
+    assert xa.shape[0] == total
+    return {"rccl_world_size": world, "backend": dist.get_backend(), "per_rank_solves_per_s": [local_solves / float(v.item()) for v in ts],
+            "allgather_x_ms": ag_ms, "allgather_x_bytes": int(xa.numel() * 8)}
 
 
 def bench_ik(args, rank, world, device, jdist):
@@ -300,12 +408,7 @@ def bench_structured(args, rank, world, device, jdist):
         rows = float(sum(int(i) * (int(i) - 1) for i in iters))  # 2 * sum_{k<iters} k
         alg = rows * n * 8 + (hi - lo) * (8.0 * (q0.G.size * 0 + 201 * 900 + n + 1000 * 30 + 2 * m) + 8 * (n + m) + 4 * m + 16)
         avg_s = float(np.mean(kern_ms)) * 1e-3
-        traffic = None
-        try:
-            if hi - lo in (64, 512):  # measured once per round with separate --pmc passes (tools/profile_round.sh)
-                traffic = float(json.load(open(os.path.join(ROOT, "profiles", f"r1_blockgi_c5_batch{hi - lo}_traffic.json")))["traffic_bytes_per_launch_fetch_x2_plus_write"])
-        except Exception:
-            pass
+        traffic, traffic_source = pmc_traffic(f"r*_blockgi_c5_batch{hi - lo}_traffic.json", "traffic_bytes_per_launch_fetch_x2_plus_write")
         out = {
             "metric": "structured GI QP solves/sec, block arrow 100x30+30 (n=3030, m=1000), batch per GPU",
             "value": total * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 1),
@@ -316,7 +419,7 @@ def bench_structured(args, rank, world, device, jdist):
                                    f"structured GI loop); wall time includes restoring G before each solve",
                        "batch_per_gpu": B, "mean_iterations": sum_it / total, "solved": n_ok},
             "roofline": {"bound": "hbm", "achieved": alg / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "blockgi_kernel", "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "blockgi_kernel", "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_s * 1e3,
                          "note": "algorithmic bytes = reflector rows read by the two Q applications of every iteration; a single CU per problem is "
                                  "instruction-issue/barrier bound (DESIGN.md 7.3)"},
         }
@@ -344,6 +447,16 @@ def main():
                     help="HBM bytes per launch from separate rocprofv3 --pmc passes (default: profiles/r1_pmc_traffic.json if it matches)")
     args = ap.parse_args()
 
+    env_world = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else None
+    if args.gpus > 1 and env_world is None:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It never touches the GPU and
+        # never loads the HIP library; it starts N fresh rank processes and exits with their verdict.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and env_world != args.gpus:
+        print(f"bench.py: launched with WORLD_SIZE={env_world} but --gpus {args.gpus}; run either `python bench.py --gpus N` (spawns its own N "
+              f"ranks) or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`", file=sys.stderr)
+        raise SystemExit(2)
+
     import numpy as np
     import torch
 
@@ -354,10 +467,14 @@ def main():
     import jrl_qp_amd.dist as jdist
     import jrl_qp_amd.problems as P
 
-    rank, local_rank, world = jdist.init_process_group()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    if torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
+        raise SystemExit(3)
+    rank, local_rank, world = jdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: process group has {world} rank(s) but --gpus {args.gpus}")
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
@@ -394,26 +511,27 @@ def main():
         r = step()
         e1.record(stream)
     torch.cuda.synchronize(device)
+    elapsed_local = time.perf_counter() - t0  # this rank's own K steps (per-rank solves/s of the N > 1 report)
     if world > 1:
         torch.distributed.barrier()
         torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0  # ... and the wall clock around EXACTLY `steps` steps
+    elapsed = time.perf_counter() - t0  # ... and the wall clock around EXACTLY `steps` steps, barrier to barrier
     kern_ms = [a.elapsed_time(b) for a, b in evs]
 
     term = r.term.cpu().numpy()
     iters = r.iters.cpu().numpy()
     n_ok, sum_it, elapsed = jdist.reduce_stats(int((term == 0).sum()), int(iters.sum()), elapsed, device=device)
+    ranks = rank_report(jdist, torch, device, (hi - lo) * args.steps, elapsed_local, r.x, total)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
         bytes_per_launch = algorithmic_bytes_per_solve(n, m, 0) * (hi - lo)
-        traffic = args.traffic_bytes
-        if traffic is None and (n, m, hi - lo) == (N_VAR, M_INEQ, BATCH):
-            try:  # measured once per round with two separate --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE), see profiles/
-                traffic = float(json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["traffic_bytes_per_launch"])
-            except Exception:
-                traffic = None
+        traffic, traffic_source = args.traffic_bytes, "--traffic-bytes"
+        if traffic is None:
+            traffic, traffic_source = None, "not measured for this shape"
+            if (n, m, hi - lo) == (N_VAR, M_INEQ, BATCH):
+                traffic, traffic_source = pmc_traffic("r*_pmc_traffic.json", "traffic_bytes_per_launch")
         avg_kernel_s = float(np.mean(kern_ms)) * 1e-3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
         out = {
@@ -421,6 +539,7 @@ def main():
             "value": value,
             "unit": "solves/s",
             "n_gpus": world,
+            "requested_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -439,6 +558,7 @@ def main():
                 "solved": n_ok,
                 "parallelism": f"batch-sharded x{world}, no data-path collective",
             },
+            "ranks": ranks,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -446,6 +566,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": "gi_batch_kernel",
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_kernel_s * 1e3,

@@ -295,10 +295,17 @@ int jrlqp_selftest_arith(int n,
                          double * dgs,
                          double * dgr,
                          void * stream);
-/* Diagnostic: when dprof != NULL, following jrlqp_gi_solve_batch calls run an instrumented build of the kernel that
- * accumulates shader-clock cycles per phase into dprof[b*16 + slot] (device int64, zero it first; slots are listed
- * in jrl-qp_amd/csrc/gi_batch.hip).  Pass NULL to return to the production kernel.  Never used for quoted times. */
-int jrlqp_debug_set_profile(long long * dprof);
+/* Diagnostic: phase profile.  kernel: JRLQP_PROFILE_GI_BATCH (jrlqp_gi_solve_batch[_warm]) or JRLQP_PROFILE_BLOCKGI
+ * (jrlqp_blockgi_solve); each keeps a buffer of its own.  When dprof != NULL the following solves of that family run an
+ * instrumented build of the kernel that accumulates clock ticks per phase into dprof[b*slots_per_problem + slot], slot <
+ * JRLQP_PROFILE_SLOTS (device int64, zero it first; the slots are listed in jrl-qp_amd/csrc/gi_batch.hip / blockgi.hip).
+ * slots_per_problem must be >= JRLQP_PROFILE_SLOTS, and a solve of more than nprob problems while a buffer is set returns
+ * JRLQP_ERR_INVALID_ARGUMENT instead of writing past it.  dprof == NULL returns to the production kernel.  Never used for
+ * quoted times. */
+#define JRLQP_PROFILE_SLOTS 32
+#define JRLQP_PROFILE_GI_BATCH 0
+#define JRLQP_PROFILE_BLOCKGI 1
+int jrlqp_debug_set_profile(int kernel, long long * dprof, int slots_per_problem, int nprob);
 /* Diagnostic: how the Givens radius recurrence of an addition (GoldfarbIdnaniSolver.cpp:228-231) is run by the batched
  * kernel and by jrlqp_dense_step/add.  0 (default): seeded and verified, plain recurrence only on a failed check;
  * 1: plain recurrence always; 2: seeded with deliberately spoiled seeds, so that every sweep fails its check and takes

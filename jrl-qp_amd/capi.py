@@ -145,7 +145,7 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_debug_set_profile.restype = ct.c_int
     lib.jrlqp_debug_set_chain_mode.restype = ct.c_int
     lib.jrlqp_debug_set_chain_mode.argtypes = [ct.c_int]
-    lib.jrlqp_debug_set_profile.argtypes = [c_dp]
+    lib.jrlqp_debug_set_profile.argtypes = [ct.c_int, c_dp, ct.c_int, ct.c_int]
     lib.jrlqp_selftest_arith.restype = ct.c_int
     lib.jrlqp_selftest_arith.argtypes = [ct.c_int] + [c_dp] * 9 + [c_dp]
     lib.jrlqp_selftest_mfma_f64.restype = ct.c_int
@@ -516,6 +516,19 @@ class BoxAndSingleConstraintSolver:
                               xl.contiguous(), xu.contiguous())
         f = r.f + 0.5 * (x0 * x0).sum(dim=1)
         return BatchResult(r.x, r.u, r.status, r.term, r.iters, f, None)
+
+
+PROFILE_SLOTS, PROFILE_GI_BATCH, PROFILE_BLOCKGI = 32, 0, 1
+
+
+def set_profile(kernel: int, prof=None):
+    """Diagnostic phase profile (jrlqp_debug_set_profile): prof = int64 CUDA tensor (nprob, >= 32) or None to switch off."""
+    lib = load_library()
+    if prof is None:
+        check(lib.jrlqp_debug_set_profile(kernel, None, 0, 0))
+    else:
+        assert prof.is_cuda and prof.is_contiguous() and prof.dim() == 2 and prof.element_size() == 8
+        check(lib.jrlqp_debug_set_profile(kernel, _ptr(prof), prof.shape[1], prof.shape[0]))
 
 
 def selftest_arith(a, b, c):

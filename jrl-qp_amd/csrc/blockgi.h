@@ -55,7 +55,8 @@ struct BgiArgs
   double * f;
   jrlqp_trace_rec * trace;
   int trace_cap;
-  long long * prof; // diagnostic only (jrlqp_debug_set_profile): 16 int64 per problem, 100 MHz ticks per phase; or nullptr
+  long long * prof; // diagnostic only (jrlqp_debug_set_profile): prof_stride >= 32 int64 per problem (16 used), 100 MHz ticks per phase; or nullptr
+  int prof_stride;
 };
 
 constexpr int kBgiMaxN = 3072; // unknowns per structured QP (vectors live in LDS)

@@ -1183,9 +1183,9 @@ done:
       A.f[pb] = f;
       if(A.prof)
         {
-          for(int i = 0; i < 13; ++i) A.prof[(size_t)pb * 16 + i] = pacc[i];
-          A.prof[(size_t)pb * 16 + 13] = clock64() - cyc0;       // core clock cycles
-          A.prof[(size_t)pb * 16 + 14] = wall_clock64() - wall0; // 100 MHz ticks
+          for(int i = 0; i < 13; ++i) A.prof[(size_t)pb * A.prof_stride + i] = pacc[i];
+          A.prof[(size_t)pb * A.prof_stride + 13] = clock64() - cyc0;       // core clock cycles
+          A.prof[(size_t)pb * A.prof_stride + 14] = wall_clock64() - wall0; // 100 MHz ticks
         }
     }
   }

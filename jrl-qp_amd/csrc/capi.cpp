@@ -16,7 +16,13 @@
 namespace
 {
 std::atomic<int> g_last_hip_error{0};
-std::atomic<long long *> g_prof{nullptr};
+// diagnostic phase-profile buffers, one per kernel family (jrlqp_debug_set_profile)
+struct ProfBuf
+{
+  long long * p = nullptr;
+  int stride = 0, nprob = 0;
+};
+ProfBuf g_prof[2];
 std::atomic<int> g_chain_mode{0};
 
 int hip_fail(hipError_t e)
@@ -26,13 +32,48 @@ int hip_fail(hipError_t e)
 }
 } // namespace
 
+// Pinned staging area for descriptor uploads: a bind fills it and enqueues asynchronous H2D copies; the event recorded
+// behind them is waited for before the NEXT bind overwrites the area (binds are set-up calls, solves never wait).
+struct PinnedStage
+{
+  char * p = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+  hipError_t init(size_t bytes)
+  {
+    cap = bytes ? bytes : 8;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), cap, hipHostMallocDefault);
+    if(e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    return e;
+  }
+  hipError_t reuse()
+  {
+    if(!pending) return hipSuccess;
+    pending = false;
+    return hipEventSynchronize(ev);
+  }
+  hipError_t submitted(hipStream_t st)
+  {
+    pending = true;
+    return hipEventRecord(ev, st);
+  }
+  void release()
+  {
+    if(ev) (void)hipEventDestroy(ev);
+    if(p) (void)hipHostFree(p);
+    ev = nullptr;
+    p = nullptr;
+  }
+};
+
 // plan object of the structured family: owns the device-side block descriptors, the failure flags and the scratch
 // used by the up-arrow row permutation, so that factorisations and solves allocate nothing
 struct jrlqp_blocks
 {
   int kind = 0, nblk = 0, nprob = 0, max_nrhs = 0, maxb = 0, ntot = 0;
-  std::vector<int> h_bs, h_ldd, h_lds;
-  std::vector<double *> h_diag, h_side;
+  std::vector<int> h_bs;
+  PinnedStage stage; // [ldd: nblk int][lds: ns int][diag: nprob*nblk ptr][side: nprob*ns ptr]
   int *d_bs = nullptr, *d_ldd = nullptr, *d_lds = nullptr, *d_fail = nullptr;
   double **d_diag = nullptr, **d_side = nullptr;
   double * d_tmp = nullptr;
@@ -47,8 +88,8 @@ struct jrlqp_blockgi
   int kind = 0, nblk = 0, n = 0, m = 0, nb = 0, ncb = 0, nprob = 0, max_iter = 0;
   int n_pad = 0, qcap = 0, row_len = 0;
   long rlen = 0;
-  std::vector<int> h_cld;
-  std::vector<const double *> h_cblk;
+  std::vector<int> h_cvar;
+  PinnedStage stage; // [cld: ncb int][cblk: nprob*ncb ptr]
   int *d_boff = nullptr, *d_cvar = nullptr, *d_ccstr = nullptr, *d_cumv = nullptr, *d_cumc = nullptr, *d_toblk = nullptr, *d_cld = nullptr;
   const double ** d_cblk = nullptr;
   double *d_pool = nullptr, *d_Rp = nullptr, *d_xu = nullptr;
@@ -166,7 +207,9 @@ static int gi_batch_common(int warm,
   a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
   a.Lout = dL;
   a.trace = dtrace;
-  a.prof = g_prof.load();
+  a.prof = g_prof[JRLQP_PROFILE_GI_BATCH].p;
+  a.prof_stride = g_prof[JRLQP_PROFILE_GI_BATCH].stride;
+  if(a.prof && B > g_prof[JRLQP_PROFILE_GI_BATCH].nprob) return JRLQP_ERR_INVALID_ARGUMENT;
   a.warm = warm;
   a.as_in = das;
   a.chain_mode = g_chain_mode.load();
@@ -234,6 +277,7 @@ int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, 
   if(e == hipSuccess) e = hipMalloc(&p->d_side, sizeof(double *) * (size_t)nprob * ns);
   if(e == hipSuccess) e = hipMalloc(&p->d_tmp, sizeof(double) * (size_t)nprob * ntot * max_nrhs);
   if(e == hipSuccess) e = hipMemcpy(p->d_bs, block_sizes, sizeof(int) * nblk, hipMemcpyHostToDevice);
+  if(e == hipSuccess) e = p->stage.init(sizeof(int) * 2 * (size_t)(nblk + ns + 2) + sizeof(double *) * (size_t)nprob * (nblk + ns));
   if(e != hipSuccess)
   {
     jrlqp_blocks_destroy(p);
@@ -248,6 +292,7 @@ void jrlqp_blocks_destroy(jrlqp_blocks * p)
   if(!p) return;
   (void)hipFree(p->d_bs); (void)hipFree(p->d_ldd); (void)hipFree(p->d_lds); (void)hipFree(p->d_fail);
   (void)hipFree(p->d_diag); (void)hipFree(p->d_side); (void)hipFree(p->d_tmp);
+  p->stage.release();
   delete p;
 }
 
@@ -258,17 +303,29 @@ int jrlqp_blocks_bind(jrlqp_blocks * p, double * const * ddiag, const int * ldd,
   const int ns = p->nblk - 1;
   for(int i = 0; i < p->nblk; ++i)
     if(ldd[i] < p->h_bs[i]) return JRLQP_ERR_INVALID_ARGUMENT;
-  p->h_ldd.assign(ldd, ldd + p->nblk);
-  p->h_lds.assign(lds ? lds : ldd, (lds ? lds : ldd) + (ns > 0 ? ns : 0));
-  p->h_diag.assign(ddiag, ddiag + (size_t)p->nprob * p->nblk);
-  if(ns > 0) p->h_side.assign(dside, dside + (size_t)p->nprob * ns);
-  HIP_TRY(hipMemcpyAsync(p->d_ldd, p->h_ldd.data(), sizeof(int) * p->nblk, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(p->d_diag, p->h_diag.data(), sizeof(double *) * p->h_diag.size(), hipMemcpyHostToDevice, st));
+  for(int i = 0; i < ns; ++i)
+  { // rows of side block i: kind 0 n_last, kind 1 / kind 2 n_{i+1}
+    const int rows = (p->kind == 0) ? p->h_bs[p->nblk - 1] : p->h_bs[i + 1];
+    if(lds[i] < rows) return JRLQP_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(p->stage.reuse()); // the previous bind's copies have left the staging area
+  const size_t ia = ((sizeof(int) * (size_t)(p->nblk + (ns > 0 ? ns : 0)) + 15) / 16) * 16;
+  int * s_ldd = reinterpret_cast<int *>(p->stage.p);
+  int * s_lds = s_ldd + p->nblk;
+  double ** s_diag = reinterpret_cast<double **>(p->stage.p + ia);
+  double ** s_side = s_diag + (size_t)p->nprob * p->nblk;
+  for(int i = 0; i < p->nblk; ++i) s_ldd[i] = ldd[i];
+  for(int i = 0; i < ns; ++i) s_lds[i] = lds[i];
+  for(size_t i = 0; i < (size_t)p->nprob * p->nblk; ++i) s_diag[i] = ddiag[i];
+  for(size_t i = 0; ns > 0 && i < (size_t)p->nprob * ns; ++i) s_side[i] = dside[i];
+  HIP_TRY(hipMemcpyAsync(p->d_ldd, s_ldd, sizeof(int) * p->nblk, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->d_diag, s_diag, sizeof(double *) * (size_t)p->nprob * p->nblk, hipMemcpyHostToDevice, st));
   if(ns > 0)
   {
-    HIP_TRY(hipMemcpyAsync(p->d_lds, p->h_lds.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(p->d_side, p->h_side.data(), sizeof(double *) * p->h_side.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_lds, s_lds, sizeof(int) * ns, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->d_side, s_side, sizeof(double *) * (size_t)p->nprob * ns, hipMemcpyHostToDevice, st));
   }
+  HIP_TRY(p->stage.submitted(st));
   p->bound = true;
   return JRLQP_OK;
 }
@@ -324,9 +381,13 @@ int jrlqp_debug_set_chain_mode(int mode)
   return JRLQP_OK;
 }
 
-int jrlqp_debug_set_profile(long long * dprof)
+int jrlqp_debug_set_profile(int kernel, long long * dprof, int slots_per_problem, int nprob)
 {
-  g_prof.store(dprof);
+  if(kernel != JRLQP_PROFILE_GI_BATCH && kernel != JRLQP_PROFILE_BLOCKGI) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(dprof && (slots_per_problem < JRLQP_PROFILE_SLOTS || nprob < 1)) return JRLQP_ERR_INVALID_ARGUMENT;
+  g_prof[kernel].p = dprof;
+  g_prof[kernel].stride = dprof ? slots_per_problem : 0;
+  g_prof[kernel].nprob = dprof ? nprob : 0;
   return JRLQP_OK;
 }
 
@@ -361,7 +422,11 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   if(!out || !block_sizes || kind < 0 || kind > 2 || nblk < 1 || ncb < 0 || nprob < 1 || max_iter < 1) return JRLQP_ERR_INVALID_ARGUMENT;
   if(ncb > 0 && (!cvar || !ccstr)) return JRLQP_ERR_INVALID_ARGUMENT;
   int n = 0, nv = 0, m = 0;
-  for(int i = 0; i < nblk; ++i) n += block_sizes[i];
+  for(int i = 0; i < nblk; ++i)
+  {
+    if(block_sizes[i] < 1) return JRLQP_ERR_INVALID_ARGUMENT;
+    n += block_sizes[i];
+  }
   for(int i = 0; i < ncb; ++i)
   {
     if(cvar[i] < 0 || ccstr[i] < 0) return JRLQP_ERR_INVALID_ARGUMENT;
@@ -381,6 +446,7 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
     return rc;
   }
   h->kind = kind; h->nblk = nblk; h->n = n; h->m = m; h->nb = nb; h->ncb = ncb; h->nprob = nprob; h->max_iter = max_iter;
+  if(ncb > 0) h->h_cvar.assign(cvar, cvar + ncb);
   h->n_pad = (n + 3) & ~3;
   h->qcap = (((n < m + nb) ? n : (m + nb)) + 1 + 3) & ~3;
   h->row_len = h->n_pad > 2 * h->qcap ? h->n_pad : 2 * h->qcap;
@@ -425,6 +491,7 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   if(const char * lay = std::getenv("JRLQP_BLOCKGI_LAYOUT")) // diagnostic override: "throughput" | "latency"
     if(n > 1024) h->xu_global = (lay[0] == 't') ? 1 : 0;
   if(e == hipSuccess) e = hipMalloc(&h->d_xu, sizeof(double) * (size_t)nprob * (h->n_pad + h->qcap));
+  if(e == hipSuccess) e = h->stage.init(sizeof(int) * (nc + 4) + sizeof(double *) * (size_t)nprob * nc);
   if(e == hipSuccess) e = hipMemcpy(h->d_boff, boff.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
   if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_cvar, cvar, sizeof(int) * ncb, hipMemcpyHostToDevice);
   if(e == hipSuccess && ncb > 0) e = hipMemcpy(h->d_ccstr, ccstr, sizeof(int) * ncb, hipMemcpyHostToDevice);
@@ -448,6 +515,7 @@ void jrlqp_blockgi_destroy(jrlqp_blockgi * h)
   (void)hipFree(h->d_boff); (void)hipFree(h->d_cvar); (void)hipFree(h->d_ccstr); (void)hipFree(h->d_cumv); (void)hipFree(h->d_cumc);
   (void)hipFree(h->d_toblk); (void)hipFree(h->d_cld); (void)hipFree(h->d_cblk); (void)hipFree(h->d_pool); (void)hipFree(h->d_Rp);
   (void)hipFree(h->d_desc); (void)hipFree(h->d_active); (void)hipFree(h->d_xu);
+  h->stage.release();
   delete h;
 }
 
@@ -460,15 +528,22 @@ int jrlqp_blockgi_bind(jrlqp_blockgi * h, double * const * ddiag, const int * ld
                        const double * const * dcblk, const int * ldc, void * stream)
 {
   if(!h || (h->ncb > 0 && (!dcblk || !ldc))) return JRLQP_ERR_INVALID_ARGUMENT;
+  for(int i = 0; i < h->ncb; ++i)
+    if(ldc[i] < (h->h_cvar[i] > 1 ? h->h_cvar[i] : 1)) return JRLQP_ERR_INVALID_ARGUMENT; // block i of C is cvar[i] x ccstr[i]
   int rc = jrlqp_blocks_bind(h->blocks, ddiag, ldd, doff, ldo, stream);
   if(rc != JRLQP_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if(h->ncb > 0)
   {
-    h->h_cld.assign(ldc, ldc + h->ncb);
-    h->h_cblk.assign(dcblk, dcblk + (size_t)h->nprob * h->ncb);
-    HIP_TRY(hipMemcpyAsync(h->d_cld, h->h_cld.data(), sizeof(int) * h->ncb, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_cblk, h->h_cblk.data(), sizeof(double *) * h->h_cblk.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(h->stage.reuse());
+    const size_t ia = ((sizeof(int) * (size_t)h->ncb + 15) / 16) * 16;
+    int * s_cld = reinterpret_cast<int *>(h->stage.p);
+    const double ** s_cblk = reinterpret_cast<const double **>(h->stage.p + ia);
+    for(int i = 0; i < h->ncb; ++i) s_cld[i] = ldc[i];
+    for(size_t i = 0; i < (size_t)h->nprob * h->ncb; ++i) s_cblk[i] = dcblk[i];
+    HIP_TRY(hipMemcpyAsync(h->d_cld, s_cld, sizeof(int) * h->ncb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_cblk, s_cblk, sizeof(double *) * (size_t)h->nprob * h->ncb, hipMemcpyHostToDevice, st));
+    HIP_TRY(h->stage.submitted(st));
   }
   h->bound = true;
   return JRLQP_OK;
@@ -505,7 +580,9 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.xu_ws = h->d_xu; a.xu_global = h->xu_global;
   a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
   a.trace = dtrace; a.trace_cap = dtrace ? trace_cap : 0;
-  a.prof = g_prof.load();
+  a.prof = g_prof[JRLQP_PROFILE_BLOCKGI].p;
+  a.prof_stride = g_prof[JRLQP_PROFILE_BLOCKGI].stride;
+  if(a.prof && h->nprob > g_prof[JRLQP_PROFILE_BLOCKGI].nprob) return JRLQP_ERR_INVALID_ARGUMENT;
   hipError_t e = jrlqp::launch_blockgi(a, h->nprob, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }

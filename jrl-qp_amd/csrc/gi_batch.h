@@ -19,7 +19,8 @@ struct BatchArgs
   double * f;
   double * Lout;
   jrlqp_trace_rec * trace;
-  long long * prof; // diagnostic only: 16 int64 per QP, or nullptr
+  long long * prof; // diagnostic only (jrlqp_debug_set_profile): prof_stride >= 32 int64 per QP, or nullptr
+  int prof_stride;
   int warm;           // 1: warm-started solve (experimental::GoldfarbIdnaniSolver), as_in = activation-status guess
   const int * as_in;  // B x (m+nb) guesses, or nullptr ("no guess"); may alias `status`
   int chain_mode;     // chain_debug_mode() at launch

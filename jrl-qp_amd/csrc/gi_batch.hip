@@ -327,7 +327,7 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
   return acc;
 }
 
-// PROF: diagnostic build only -- thread 0 accumulates shader-clock cycles per phase into A.prof[b*16 + slot]
+// PROF: diagnostic build only -- thread 0 accumulates shader-clock cycles per phase into A.prof[b*A.prof_stride + slot], 32 slots
 // (slots: 0 load, 1 LLT, 2 J/x0, 3 scan (not overlapped), 4 d=J^T n, 5 trsv||z, 6 step+update, 7 add (+overlapped scan),
 //  8 drop, 9 store, 10 #adds, 11 #drops, 12 s_memrealtime ticks (100 MHz) for the whole solve).
 // The accumulators live in LDS (ds_add_u64, fire-and-forget) and are copied out once at the end: accumulating
@@ -1878,8 +1878,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   if(PROF)
   {
     __syncthreads();
-    if(tid < 32) A.prof[(size_t)b * 32 + tid] = (long long)prof_lds[tid];
-    if(tid == 0) A.prof[(size_t)b * 32 + 12] = wall_clock64() - wall0_;
+    if(tid < 32) A.prof[(size_t)b * A.prof_stride + tid] = (long long)prof_lds[tid];
+    if(tid == 0) A.prof[(size_t)b * A.prof_stride + 12] = wall_clock64() - wall0_;
   }
 }
 

@@ -23,12 +23,14 @@ def shard_range(total: int, rank: int, world: int):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def init_process_group(backend: str | None = None):
+def init_process_group(backend: str | None = None, force: bool = False):
+    """Join the process group described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.  A lone process (world 1) needs no
+    group and gets none unless `force` is set (used to exercise RCCL itself on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,0 +1,61 @@
+"""`python bench.py --gpus N` is its own launcher: the parent starts N fresh rank processes and must fail loudly -- never
+fall back to one GPU -- when the node has fewer than N devices, when the launcher's WORLD_SIZE disagrees with --gpus, or
+when any rank fails."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def _run(args, env=None):
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=900, env=env or _clean_env())
+
+
+def test_more_gpus_than_visible_is_refused():
+    import torch
+
+    n = torch.cuda.device_count() + 1  # counting devices does not initialise the GPU
+    r = _run(["--gpus", str(max(n, 2)), "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "refusing to run on fewer" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_dry_gpus2_on_the_one_gpu_box_fails_loudly():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has several GPUs")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "refusing to run on fewer" in r.stderr and not r.stdout.strip()
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = _run(["--gpus", "2"], env)
+    assert r.returncode == 2 and "WORLD_SIZE=4 but --gpus 2" in r.stderr
+
+
+def test_a_failing_rank_fails_the_launch(monkeypatch):
+    """With the device count check bypassed on a GPU-less box every rank stops at "needs a GPU": the launcher must
+    report that as a failure of the whole run."""
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("needs a box without GPUs")
+    sys.path.insert(0, ROOT)
+    import bench
+
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 2)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    rc = bench.launch_ranks(2, ["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert rc != 0

@@ -69,11 +69,11 @@ def test_spoiled_seeds_take_the_fallback(capi, P, chain_mode):
     for mode in (0, 2):
         chain_mode(mode)
         prof = torch.zeros((pb.B, 32), dtype=torch.int64, device="cuda")
-        lib.jrlqp_debug_set_profile(prof.data_ptr())
+        capi.set_profile(capi.PROFILE_GI_BATCH, prof)
         try:
             run_gpu(capi, pb)
         finally:
-            lib.jrlqp_debug_set_profile(None)
+            capi.set_profile(capi.PROFILE_GI_BATCH, None)
         pr = prof.cpu().numpy()
         counts[mode] = (int(pr[:, 13].sum()), int(pr[:, 10].sum()))  # (fallbacks, additions)
     assert counts[0][0] == 0, counts

@@ -84,6 +84,24 @@ def test_dense_n300(capi, P, oracle):
     assert ref.term == 0 and np.linalg.norm(gpu["x"] - pb.x_star[0]) <= 1e-6
 
 
+def test_c2_full_size(capi, P, oracle):
+    """BASELINE configs[1] (c2) at full size: n = 1024, m = 2048, 307 strongly active, through jrlqp_dense_solve --
+    termination status, iteration count, activation statuses, x, u, f and the Cholesky factor left in G, bit for bit
+    against the oracle (32 LLT panels, ~500 iterations, drops included)."""
+    n, m = 1024, 2048
+    ch = P.benchmark_characteristics(n, m)
+    assert ch.nStrongActIneq == 307
+    pb = P.generate_batch(1, ch, first_index=0)  # the problem bench.py --workload c2 times on rank 0
+    ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], max_iter=100000)
+    gpu = solve_gpu(capi, pb, 0, False, max_iter=100000)
+    check(gpu, ref, "c2 full size")
+    assert ref.term == 0 and ref.iters > 300
+    assert np.array_equal(np.tril(gpu["L"]), np.tril(ref.L))
+    assert np.array_equal(np.triu(gpu["L"], 1), np.triu(pb.G[0], 1))
+    assert np.linalg.norm(gpu["x"] - pb.x_star[0]) <= 1e-6 * max(1.0, np.linalg.norm(pb.x_star[0]))
+    assert int((gpu["status"] != 0).sum()) >= 307
+
+
 def test_dense_status_codes(capi, P, oracle):
     n, m = 4, 6
     rng = np.random.default_rng(5)

@@ -1,0 +1,66 @@
+"""RCCL on the one-GPU box: the HIP batched solver under torch.distributed with backend "nccl" (= RCCL) and world size 1
+-- communicator creation, the epilogue all-reduce of counters and the all-gather of the device-resident results of
+jrl-qp_amd/dist.py, on device tensors the kernel has just written.  (The N = 2 partitioning itself is covered on CPU by
+tests/test_dist_gloo.py; N > 1 on GPUs is the driver's scaling run.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_world1(pkg):
+    import torch
+    import torch.distributed as dist
+
+    import jrl_qp_amd.dist as jdist
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    old = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    rank, local_rank, world = jdist.init_process_group("nccl", force=True)
+    assert (rank, local_rank, world) == (0, 0, 1) and dist.is_initialized() and dist.get_backend() == "nccl"
+    yield jdist
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def test_hip_solver_under_rccl_world1(pkg, oracle, nccl_world1):
+    import torch
+    import torch.distributed as dist
+
+    import jrl_qp_amd.capi as capi
+    import jrl_qp_amd.problems as P
+
+    jdist = nccl_world1
+    total = 96
+    lo, hi = jdist.shard_range(total, dist.get_rank(), dist.get_world_size())
+    assert (lo, hi) == (0, total)
+    pb = P.generate_batch(hi - lo, P.benchmark_characteristics(50, 200), first_index=lo)
+    dev = capi.to_device(pb, "cuda:0")
+    solver = capi.BatchSolver(pb.n, pb.m, False, pb.B, device="cuda:0")
+    r = solver.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"])
+    # epilogue collectives on DEVICE tensors (RCCL): counters / max time, then the result assembly
+    n_ok, sum_it, tmax = jdist.reduce_stats(int((r.term == 0).sum().item()), int(r.iters.sum().item()), 0.125, device="cuda:0")
+    x_all = jdist.all_gather_results(r.x, total)
+    it_all = jdist.all_gather_results(r.iters.to(torch.int64)[:, None], total)
+    assert x_all.is_cuda and x_all.shape == (total, pb.n)
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu)
+    assert np.array_equal(x_all.cpu().numpy(), ref["x"])
+    assert np.array_equal(it_all.cpu().numpy()[:, 0], ref["iters"])
+    assert n_ok == total == int((ref["term"] == 0).sum()) and sum_it == int(ref["iters"].sum()) and tmax == 0.125
+    # one more collective the bench epilogue uses: all_gather of per-rank timings
+    t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+    out = [torch.empty_like(t)]
+    dist.all_gather(out, t)
+    assert float(out[0].item()) == 1.5

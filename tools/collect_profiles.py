@@ -10,7 +10,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r1"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r2"
+sys.path.insert(0, ROOT)
+import subprocess
+
+from bench import kernel_source_hash  # noqa: E402
+
+SHA = kernel_source_hash()  # run this script on the tree the profile was taken on
+try:
+    COMMIT = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    COMMIT = None
 
 
 def first_json_line(path):
@@ -57,6 +67,8 @@ def main():
     write, nw = pmc_per_launch(os.path.join(SRC, "p_write", "write_counter_collection.csv"), "WRITE_SIZE", "gi_batch_kernel")
     traffic = {
         "kernel": "gi_batch_kernel<50,2,false,false>",
+        "kernel_source_sha16": SHA,
+        "commit": COMMIT,
         "workload": bench["config"]["workload"] if "config" in bench else "c3",
         "FETCH_SIZE_KB_per_launch": round(fetch, 1),
         "WRITE_SIZE_KB_per_launch": round(write, 1),
@@ -79,7 +91,7 @@ def main():
     f5, _ = pmc_per_launch(os.path.join(SRC, "p_bgi_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE", "blockgi_kernel")
     w5, _ = pmc_per_launch(os.path.join(SRC, "p_bgi_write", "write_counter_collection.csv"), "WRITE_SIZE", "blockgi_kernel")
     json.dump({
-        "kernel": "blockgi_kernel", "batch": nb,
+        "kernel": "blockgi_kernel", "batch": nb, "kernel_source_sha16": SHA, "commit": COMMIT,
         "FETCH_SIZE_KB_per_launch": round(f5, 1), "WRITE_SIZE_KB_per_launch": round(w5, 1),
         "traffic_bytes_per_launch_fetch_x2_plus_write": int(round((2.0 * f5 + w5) * 1024)),
         "algorithmic_bytes_per_launch": b5["roofline"].get("algorithmic_bytes_per_launch"),

@@ -29,9 +29,9 @@ print(f"B={B} n={n} m={m}: {ms:.3f} ms  -> {B / ms * 1e3:.0f} solves/s ; mean it
 print("all times ms", [round(t, 3) for t in sorted(ts)][:8])
 # ---- phase profile (diagnostic build)
 prof = torch.zeros((B, 32), dtype=torch.int64, device="cuda")
-capi.load_library().jrlqp_debug_set_profile(prof.data_ptr())
+capi.set_profile(capi.PROFILE_GI_BATCH, prof)
 s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"]); torch.cuda.synchronize()
-capi.load_library().jrlqp_debug_set_profile(None)
+capi.set_profile(capi.PROFILE_GI_BATCH, None)
 pr = prof.cpu().numpy().astype(np.float64)
 names = ["load", "llt", "Jinv/x0", "scan", "d=JTn", "trsv||z", "step", "add", "drop", "store", "#adds", "#drops", "realtime(100MHz)", "add:chain | seeded-chain fallbacks (C in registers)", "add:cs+apply", "add:wave0 scan", "trsv loop", "ratio", "llt chain", "llt pivot", "combine+np+barrier", "compute_d", "combine", "publish np", "w3: other", "w3: chain A", "w3: wait S2+step", "w3: chain B", "w3: wait S3", "w3: chain rest", "w3: cs+flag", "w3: apply"]
 tot = pr[:, :10].sum(axis=1) + pr[:, 13:24].sum(axis=1)  # slots 24-31: wave 3's own time line

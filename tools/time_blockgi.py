@@ -34,11 +34,10 @@ def gpu_time(qps, max_iter, reps=5):
         e0.record(); r = s.solve(H, a, Cb, bl, bu, xl, xu); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     if os.environ.get("BGI_PROF"):
-        prof = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
-        lib = capi.load_library()
-        lib.jrlqp_debug_set_profile(ct.c_void_p(prof.data_ptr()))
+        prof = torch.zeros((B, capi.PROFILE_SLOTS), dtype=torch.int64, device="cuda")
+        capi.set_profile(capi.PROFILE_BLOCKGI, prof)
         H.copy_(H0); s._bind(H, Cb); s.solve(H, a, Cb, bl, bu, xl, xu); torch.cuda.synchronize()
-        lib.jrlqp_debug_set_profile(None)
+        capi.set_profile(capi.PROFILE_BLOCKGI, None)
         pr = prof.cpu().numpy().astype(np.float64)[0] / 100.0  # us
         names = ["init", "scan", "L^-1 n+", "Q^T d", "Q z", "L^-T z", "R solve", "step length", "update", "add", "drop", "(Q: reflectors", "Q: Givens)"]
         print("      phase profile, problem 0 (us total; us/iteration): " + "; ".join(f"{nm} {pr[i]:.0f}" for i, nm in enumerate(names))
