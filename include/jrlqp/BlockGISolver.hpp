@@ -95,7 +95,9 @@ public:
     const int n = G.nbVar(), m = C.nbCstr(), nb = xl.size > 0 ? n : 0;
     if(a.size != n || C.nbVar() != n || bl.size != m || bu.size != m || (xl.size != 0 && xl.size != n) || xu.size != xl.size)
       return TerminationStatus::INCONSISTENT_INPUT;
+    err_.clear();
     plan(G, C, nb != 0);
+    if(!err_.empty()) return TerminationStatus::UNKNOWN;
     // stage the blocks back to back on the device (column-major, tight leading dimensions)
     std::vector<double> hbuf(gTot_ + cTot_);
     size_t o = 0;
@@ -147,6 +149,7 @@ public:
     };
     for(const auto & D : G.diag()) unpack(D.data, D.rows, D.cols, D.ld);
     for(const auto & S : G.offDiag()) unpack(S.data, S.rows, S.cols, S.ld);
+    if(!err_.empty()) return TerminationStatus::UNKNOWN;
     return static_cast<TerminationStatus>(term);
   }
 
@@ -155,15 +158,21 @@ public:
   double objectiveValue() const { return f_; }
   int iterations() const { return it_; }
   const std::vector<ActivationStatus> & activeSet() const { return as_; }
+  /** Empty unless an ABI / HIP runtime call failed during the last solve(). */
+  const std::string & lastError() const { return err_; }
 
 private:
-  static void check(int rc, const char * what)
+  // No exception leaves the class (the reference's solvers never throw): the FIRST failing ABI / HIP call is recorded, the
+  // calls after it fail harmlessly on their null handles, and solve() reports TerminationStatus::UNKNOWN (see lastError()).
+  void check(int rc, const char * what) noexcept
   {
-    if(rc != JRLQP_OK) throw std::runtime_error(std::string(what) + ": " + jrlqp_status_string(rc));
+    if(rc == JRLQP_OK || !err_.empty()) return;
+    try { err_ = std::string(what) + ": " + jrlqp_status_string(rc); } catch(...) {}
   }
-  static void hip(hipError_t e)
+  void hip(hipError_t e) noexcept
   {
-    if(e != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e));
+    if(e == hipSuccess || !err_.empty()) return;
+    try { err_ = std::string("HIP: ") + hipGetErrorString(e); } catch(...) {}
   }
   // (re)build the plan when the shape changes: block sizes, kinds, constraint partition
   void plan(const StructuredG & G, const StructuredC & C, bool useBounds)
@@ -270,5 +279,6 @@ private:
   std::vector<double> x_, u_;
   std::vector<ActivationStatus> as_;
   std::vector<int> ias_;
+  std::string err_;
 };
 } // namespace jrlqp

@@ -8,15 +8,17 @@
 //   auto st = qp.solve(G, a, C, bl, bu, xl, xu);              // HOST views; G is overwritten by its Cholesky factor
 //   qp.solution(), qp.multipliers(), qp.objectiveValue(), qp.iterations(), qp.activeSet()
 //
-// The numerics run on the GPU (libjrlqp_hip.so, Mode A: state in HBM, host-driven active-set loop).  solve() copies
+// The numerics run on the GPU (libjrlqp_hip.so): n <= 64 through the device-resident batched kernel with a batch of
+// one (one launch per solve), larger problems through Mode A (state in HBM, host-driven active-set loop).  solve() copies
 // the problem to the device and the factor back (the reference's "G is clobbered" contract); solveDevice() takes
-// device pointers and copies nothing.  Header-only; link with -ljrlqp_hip and the HIP runtime.
+// device pointers and copies nothing.  Contract of the reference kept: no exception leaves the class, and once sized
+// the solver allocates nothing -- buffers are grow-only (tests/cpp/test_multiple_uses.cpp counts hipMalloc / hipFree).
+// Header-only; link with -ljrlqp_hip and the HIP runtime.
 #pragma once
 
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
-#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -85,67 +87,109 @@ public:
   GoldfarbIdnaniSolver & operator=(const GoldfarbIdnaniSolver &) = delete;
   ~GoldfarbIdnaniSolver() { release(); }
 
-  /** Pre-allocate for nbVar variables, nbCstr general constraints, and bounds if useBounds (DualSolver.h:33). */
+  /** Pre-allocate for nbVar variables, nbCstr general constraints, and bounds if useBounds (DualSolver.h:33).
+   *  GROW-ONLY like the reference's workspaces (internal/Workspace.h:37-43): a problem that fits what is already
+   *  allocated -- fewer variables, fewer constraints, no bounds -- reuses it; nothing is freed before the destructor
+   *  unless a larger problem arrives.  Never throws: a failed allocation is reported by the next solve() (UNKNOWN) and
+   *  by lastError(). */
   void resize(int nbVar, int nbCstr, bool useBounds)
   {
     const int nb = useBounds ? nbVar : 0;
-    if(h_ && nbVar == n_ && nbCstr == m_ && nb == nb_) return;
-    release();
+    if(nbVar < 1 || nbCstr < 0) { fail("resize: invalid sizes"); return; }
+    if(!h_ || nbVar > capN_ || nbCstr > capM_ || nb > capNb_)
+    {
+      // grow: capacities never shrink (a solver pre-sized for (5, 8, true) keeps serving (5, 2, false) and (5, 8, true))
+      const int cn = nbVar > capN_ ? nbVar : capN_, cm = nbCstr > capM_ ? nbCstr : capM_;
+      const int cb = (nb > 0 || capNb_ > 0) ? cn : 0;
+      release();
+      capN_ = cn; capM_ = cm; capNb_ = cb;
+      if(!ok(jrlqp_dense_create(cn, cm, cb, &h_), "jrlqp_dense_create")) { h_ = nullptr; return; }
+      const size_t n = size_t(cn), m = size_t(cm), mt = m + size_t(cb);
+      bool a = dev(&dG_, n * n) && dev(&da_, n) && dev(&dC_, n * m) && dev(&dbl_, m) && dev(&dbu_, m) && dev(&dxl_, cb) && dev(&dxu_, cb);
+      a = a && dev(&dx_, n) && dev(&du_, mt) && dev(&dfv_, 1) && devi(&dst_, mt) && devi(&dti_, 2);
+      if(!a) return;
+      x_.reserve(n); u_.reserve(mt); as_.reserve(mt); ias_.reserve(mt);
+    }
+    if(!ok(jrlqp_dense_resize(h_, nbVar, nbCstr, nb), "jrlqp_dense_resize")) return;
     n_ = nbVar; m_ = nbCstr; nb_ = nb;
-    check(jrlqp_dense_create(n_, m_, nb_, &h_), "jrlqp_dense_create");
-    const size_t n = size_t(n_), m = size_t(m_);
-    hip(hipMalloc(&dG_, sizeof(double) * n * n));
-    hip(hipMalloc(&da_, sizeof(double) * n));
-    hip(hipMalloc(&dC_, sizeof(double) * (n * m ? n * m : 1)));
-    hip(hipMalloc(&dbl_, sizeof(double) * (m ? m : 1)));
-    hip(hipMalloc(&dbu_, sizeof(double) * (m ? m : 1)));
-    hip(hipMalloc(&dxl_, sizeof(double) * (nb_ ? nb_ : 1)));
-    hip(hipMalloc(&dxu_, sizeof(double) * (nb_ ? nb_ : 1)));
-    x_.assign(n, 0.0);
-    u_.assign(m + nb_, 0.0);
-    as_.assign(m + nb_, ActivationStatus::INACTIVE);
-    ias_.assign(m + nb_, 0);
+    // (within the reserved capacity: no allocation)
+    x_.assign(size_t(n_), 0.0);
+    u_.assign(size_t(m_) + nb_, 0.0);
+    as_.assign(size_t(m_) + nb_, ActivationStatus::INACTIVE);
+    ias_.assign(size_t(m_) + nb_, 0);
+    err_.clear();
   }
 
   void options(const SolverOptions & o) { options_ = o; }
   const SolverOptions & options() const { return options_; }
 
   /** min 1/2 x^T G x + a^T x  s.t.  bl <= C^T x <= bu, xl <= x <= xu  (GoldfarbIdnaniSolver.h:22-33).
-   *  HOST views.  C is n x m, one constraint per column; xl/xu of size n or 0. */
+   *  HOST views.  C is n x m, one constraint per column; xl/xu of size n or 0.  Like the reference it never throws and
+   *  (on a pre-sized solver) never allocates; size mismatches the reference only assert()s on (GoldfarbIdnaniSolver.cpp:33-39)
+   *  return INCONSISTENT_INPUT, a failing runtime call returns UNKNOWN (see lastError()). */
   TerminationStatus solve(MatrixRef G, VectorConstRef a, MatrixConstRef C, VectorConstRef bl, VectorConstRef bu, VectorConstRef xl,
-                          VectorConstRef xu)
+                          VectorConstRef xu) noexcept
   {
-    resize(G.rows, C.cols, xl.size > 0);
-    if(G.cols != n_ || a.size != n_ || (m_ && C.rows != n_) || bl.size != m_ || bu.size != m_ || xu.size != xl.size)
+    if(G.rows < 1 || G.cols != G.rows || a.size != G.rows || (C.cols && C.rows != G.rows) || bl.size != C.cols || bu.size != C.cols
+       || xu.size != xl.size || (xl.size != 0 && xl.size != G.rows) || G.ld < G.rows || (C.cols && C.ld < C.rows))
       return TerminationStatus::INCONSISTENT_INPUT;
+    resize(G.rows, C.cols, xl.size > 0);
+    if(!err_.empty()) return TerminationStatus::UNKNOWN;
     const size_t n = size_t(n_);
-    hip(hipMemcpy2D(dG_, sizeof(double) * n, G.data, sizeof(double) * size_t(G.ld), sizeof(double) * n, n, hipMemcpyHostToDevice));
-    hip(hipMemcpy(da_, a.data, sizeof(double) * n, hipMemcpyHostToDevice));
+    bool c = hipok(hipMemcpy2D(dG_, sizeof(double) * n, G.data, sizeof(double) * size_t(G.ld), sizeof(double) * n, n, hipMemcpyHostToDevice));
+    c = c && hipok(hipMemcpy(da_, a.data, sizeof(double) * n, hipMemcpyHostToDevice));
     if(m_)
     {
-      hip(hipMemcpy2D(dC_, sizeof(double) * n, C.data, sizeof(double) * size_t(C.ld), sizeof(double) * n, size_t(m_), hipMemcpyHostToDevice));
-      hip(hipMemcpy(dbl_, bl.data, sizeof(double) * m_, hipMemcpyHostToDevice));
-      hip(hipMemcpy(dbu_, bu.data, sizeof(double) * m_, hipMemcpyHostToDevice));
+      c = c && hipok(hipMemcpy2D(dC_, sizeof(double) * n, C.data, sizeof(double) * size_t(C.ld), sizeof(double) * n, size_t(m_), hipMemcpyHostToDevice));
+      c = c && hipok(hipMemcpy(dbl_, bl.data, sizeof(double) * m_, hipMemcpyHostToDevice));
+      c = c && hipok(hipMemcpy(dbu_, bu.data, sizeof(double) * m_, hipMemcpyHostToDevice));
     }
     if(nb_)
     {
-      hip(hipMemcpy(dxl_, xl.data, sizeof(double) * nb_, hipMemcpyHostToDevice));
-      hip(hipMemcpy(dxu_, xu.data, sizeof(double) * nb_, hipMemcpyHostToDevice));
+      c = c && hipok(hipMemcpy(dxl_, xl.data, sizeof(double) * nb_, hipMemcpyHostToDevice));
+      c = c && hipok(hipMemcpy(dxu_, xu.data, sizeof(double) * nb_, hipMemcpyHostToDevice));
     }
+    if(!c) return TerminationStatus::UNKNOWN;
     TerminationStatus st = solveDevice(dG_, n_, da_, dC_, n_, dbl_, dbu_, dxl_, dxu_);
     // the reference leaves the Cholesky factor in G's lower triangle (strictly upper part untouched)
-    hip(hipMemcpy2D(G.data, sizeof(double) * size_t(G.ld), dG_, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDeviceToHost));
+    if(!hipok(hipMemcpy2D(G.data, sizeof(double) * size_t(G.ld), dG_, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDeviceToHost)))
+      return TerminationStatus::UNKNOWN;
     return st;
   }
 
-  /** Same with DEVICE pointers: nothing is copied but the results. */
+  /** Same with DEVICE pointers: nothing is copied but the results.  Sizes are those of the last resize().
+   *  Small problems (n <= JRLQP_BATCH_MAX_N, packed G and C) take the device-resident batched kernel with a batch of one
+   *  -- one launch for the whole solve instead of one host round trip per iteration --, larger ones the host-driven
+   *  hooks (Mode A); both leave the factor in G and give bit-identical results. */
   TerminationStatus solveDevice(double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl, const double * dbu,
-                                const double * dxl, const double * dxu, hipStream_t stream = nullptr)
+                                const double * dxl, const double * dxu, hipStream_t stream = nullptr) noexcept
   {
+    if(!h_) { fail("solveDevice: solver not sized"); return TerminationStatus::UNKNOWN; }
     jrlqp_options o{options_.maxIter_, options_.bigBnd_};
     int term = int(TerminationStatus::UNKNOWN);
-    check(jrlqp_dense_solve(h_, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu, &o, &term, stream), "jrlqp_dense_solve");
-    check(jrlqp_dense_results(h_, x_.data(), u_.data(), ias_.data(), &it_, &f_, stream), "jrlqp_dense_results");
+    int cpl = 0;
+    if(n_ <= JRLQP_BATCH_MAX_N && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
+    {
+      // dL == dG: the kernel reads G completely before it writes the factor (jrlqp_hip.h), i.e. the reference's in-place contract
+      if(!ok(jrlqp_gi_solve_batch(n_, m_, nb_, 1, dG, da, dC, dbl, dbu, dxl, dxu, &o, dx_, du_, dst_, dti_, dti_ + 1, dfv_, dG, nullptr, 0, stream),
+             "jrlqp_gi_solve_batch"))
+        return TerminationStatus::UNKNOWN;
+      int ti[2] = {int(TerminationStatus::UNKNOWN), 0};
+      bool c = hipok(hipMemcpyAsync(x_.data(), dx_, sizeof(double) * n_, hipMemcpyDeviceToHost, stream));
+      if(m_ + nb_) c = c && hipok(hipMemcpyAsync(u_.data(), du_, sizeof(double) * (m_ + nb_), hipMemcpyDeviceToHost, stream));
+      if(m_ + nb_) c = c && hipok(hipMemcpyAsync(ias_.data(), dst_, sizeof(int) * (m_ + nb_), hipMemcpyDeviceToHost, stream));
+      c = c && hipok(hipMemcpyAsync(ti, dti_, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+      c = c && hipok(hipMemcpyAsync(&f_, dfv_, sizeof(double), hipMemcpyDeviceToHost, stream));
+      c = c && hipok(hipStreamSynchronize(stream));
+      if(!c) return TerminationStatus::UNKNOWN;
+      term = ti[0];
+      it_ = ti[1];
+    }
+    else
+    {
+      if(!ok(jrlqp_dense_solve(h_, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu, &o, &term, stream), "jrlqp_dense_solve")) return TerminationStatus::UNKNOWN;
+      if(!ok(jrlqp_dense_results(h_, x_.data(), u_.data(), ias_.data(), &it_, &f_, stream), "jrlqp_dense_results")) return TerminationStatus::UNKNOWN;
+    }
     for(size_t i = 0; i < ias_.size(); ++i) as_[i] = static_cast<ActivationStatus>(ias_[i]);
     return static_cast<TerminationStatus>(term);
   }
@@ -156,21 +200,38 @@ public:
   int iterations() const { return it_; }                                       // DualSolver::iterations()
   const std::vector<ActivationStatus> & activeSet() const { return as_; }      // DualSolver::activeSet()
   void resetActiveSet() {}                                                     // the production solver always cold-starts
+  /** Empty unless an ABI / HIP runtime call failed (the reference has no such failure mode; it never throws either). */
+  const std::string & lastError() const { return err_; }
 
 private:
-  static void check(int rc, const char * what)
+  void fail(const char * what) noexcept
   {
-    if(rc != JRLQP_OK) throw std::runtime_error(std::string(what) + ": " + jrlqp_status_string(rc));
+    try { err_ = what; } catch(...) {}
   }
-  static void hip(hipError_t e)
+  bool ok(int rc, const char * what) noexcept
   {
-    if(e != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e));
+    if(rc == JRLQP_OK) return true;
+    try { err_ = std::string(what) + ": " + jrlqp_status_string(rc); } catch(...) {}
+    return false;
   }
-  void release()
+  bool hipok(hipError_t e) noexcept
+  {
+    if(e == hipSuccess) return true;
+    try { err_ = std::string("HIP: ") + hipGetErrorString(e); } catch(...) {}
+    return false;
+  }
+  bool dev(double ** p, size_t count) noexcept { return hipok(hipMalloc(reinterpret_cast<void **>(p), sizeof(double) * (count ? count : 1))); }
+  bool devi(int ** p, size_t count) noexcept { return hipok(hipMalloc(reinterpret_cast<void **>(p), sizeof(int) * (count ? count : 1))); }
+  void release() noexcept
   {
     if(h_) jrlqp_dense_destroy(h_);
     h_ = nullptr;
-    for(double ** p : {&dG_, &da_, &dC_, &dbl_, &dbu_, &dxl_, &dxu_})
+    for(double ** p : {&dG_, &da_, &dC_, &dbl_, &dbu_, &dxl_, &dxu_, &dx_, &du_, &dfv_})
+    {
+      if(*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    for(int ** p : {&dst_, &dti_})
     {
       if(*p) (void)hipFree(*p);
       *p = nullptr;
@@ -180,10 +241,14 @@ private:
   SolverOptions options_;
   jrlqp_dense * h_ = nullptr;
   int n_ = 0, m_ = 0, nb_ = 0, it_ = 0;
+  int capN_ = 0, capM_ = 0, capNb_ = 0; // allocated capacities (grow-only)
   double f_ = 0.0;
   double *dG_ = nullptr, *da_ = nullptr, *dC_ = nullptr, *dbl_ = nullptr, *dbu_ = nullptr, *dxl_ = nullptr, *dxu_ = nullptr;
+  double *dx_ = nullptr, *du_ = nullptr, *dfv_ = nullptr; // outputs of the batched (B = 1) path
+  int *dst_ = nullptr, *dti_ = nullptr;                   // activation status; {termination status, iterations}
   std::vector<double> x_, u_;
   std::vector<ActivationStatus> as_;
   std::vector<int> ias_;
+  std::string err_;
 };
 } // namespace jrlqp

@@ -100,7 +100,9 @@ void jrlqp_default_options(jrlqp_options * opts);
  * Outputs:
  *   dx [B][n]; du [B][m+nb] sign-expanded multipliers (DualSolver.cpp:38-69); dstatus [B][m+nb] int32 activation
  *   status; dterm [B] int32 TerminationStatus; diters [B] int32; df [B] objective value.
- *   dL   optional [B][n*n]: lower triangle receives the Cholesky factor of G (what the reference leaves in G).
+ *   dL   optional [B][n*n]: lower triangle receives the Cholesky factor of G (what the reference leaves in G); the strictly
+ *        upper part is not written.  dL MAY ALIAS dG: every problem's G is read completely before its factor is written, so
+ *        dL == dG reproduces the reference's in-place contract (G's lower triangle <- L, upper part untouched).
  *   dtrace optional [B][trace_cap] records.
  * No allocation, no host synchronisation: the call enqueues one kernel on `stream` (a hipStream_t, may be NULL).
  * Requires 1 <= n <= JRLQP_BATCH_MAX_N.
@@ -164,6 +166,34 @@ int jrlqp_gi_solve_batch_warm(int n,
                               int trace_cap,
                               void * stream);
 
+/* experimental::BoxAndSingleConstraintSolver over a batch.  Replaces B calls of
+ *     BoxAndSingleConstraintSolver::solve(x0, c, bl, xl, xu)      (include/jrl-qp/experimental/BoxAndSingleConstraintSolver.h:9-33,
+ *                                                                  src/experimental/BoxAndSingleConstraintSolver.cpp:11-44)
+ *   min 1/2 ||x - x0||^2   s.t.  c.x >= bl,   xl <= x <= xu
+ * i.e. the dense GI solver on G = I with ONE general constraint (bu = +inf) and mandatory bounds, whose init_ is the closed
+ * form of BoxAndSingleConstraintSolver.cpp:46-94: start at x0 clamped to the box with the clamped variables' bounds active
+ * (multiplier |x0_i - bound_i|, J a permutation, R = diag(+-1)), no factorisation; then the unchanged GI loop.
+ *   dx0, dc, dxl, dxu [B][n]; dbl [B].  Outputs: dx [B][n]; du, dstatus [B][1+n] (the general constraint first, then the
+ *   bounds); dterm, diters, df [B]; df is 1/2 ||x - x0||^2 itself (the reference's objectiveValue(), constant included).
+ * Requires n <= JRLQP_BATCH_MAX_N.  One launch, no allocation, no host synchronisation. */
+int jrlqp_box_solve_batch(int n,
+                          int B,
+                          const double * dx0,
+                          const double * dc,
+                          const double * dbl,
+                          const double * dxl,
+                          const double * dxu,
+                          const jrlqp_options * opts,
+                          double * dx,
+                          double * du,
+                          int * dstatus,
+                          int * dterm,
+                          int * diters,
+                          double * df,
+                          jrlqp_trace_rec * dtrace,
+                          int trace_cap,
+                          void * stream);
+
 /* LDS bytes one workgroup of the batched kernel uses for (n, m, nb), and where the constraint matrix lives during the
  * solve: *c_placement = 2 one column per thread in registers, 1 staged in LDS, 0 streamed from L2/HBM; returns -1 if
  * unsupported.  Lets a caller reason about occupancy (163840 B of LDS per CU). */
@@ -190,6 +220,12 @@ long jrlqp_gi_batch_warm_lds_bytes(int n, int m, int nb, int * c_placement);
 typedef struct jrlqp_dense jrlqp_dense;
 int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out);
 void jrlqp_dense_destroy(jrlqp_dense * h);
+/* DualSolver::resize(nbVar, nbCstr, useBounds) (DualSolver.h:33) on an existing handle: buffers are grow-only like the
+ * reference's workspaces (internal/Workspace.h:37-43) -- a problem with n, m, nb no larger than what the handle was created
+ * for is solved in the existing buffers, with no allocation on the host or on the device; otherwise JRLQP_ERR_WORKSPACE
+ * (create a larger handle).  This is what keeps "solver(5, 8, true); solve(problems of different shapes)" allocation-free
+ * (tests/GoldfarbIdnaniSolverTest.cpp:101-125). */
+int jrlqp_dense_resize(jrlqp_dense * h, int n, int m, int nb);
 int jrlqp_dense_last_hip_error(const jrlqp_dense * h);
 int jrlqp_dense_bind(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
                      const double * dbu, const double * dxl, const double * dxu);

@@ -25,10 +25,12 @@ EXPORTED = [
     "jrlqp_default_options",
     "jrlqp_gi_solve_batch",
     "jrlqp_gi_solve_batch_warm",
+    "jrlqp_box_solve_batch",
     "jrlqp_gi_batch_lds_bytes",
     "jrlqp_gi_batch_warm_lds_bytes",
     "jrlqp_dense_create",
     "jrlqp_dense_destroy",
+    "jrlqp_dense_resize",
     "jrlqp_dense_last_hip_error",
     "jrlqp_dense_bind",
     "jrlqp_dense_init",
@@ -106,12 +108,16 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_gi_solve_batch_warm.restype = ct.c_int
     lib.jrlqp_gi_solve_batch_warm.argtypes = ([ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 8 + [ct.POINTER(Options)] + [c_dp] * 8
                                               + [ct.c_int, c_dp])
+    lib.jrlqp_box_solve_batch.restype = ct.c_int
+    lib.jrlqp_box_solve_batch.argtypes = [ct.c_int, ct.c_int] + [c_dp] * 5 + [ct.POINTER(Options)] + [c_dp] * 6 + [c_dp, ct.c_int, c_dp]
     lib.jrlqp_gi_solve_batch.restype = ct.c_int
     lib.jrlqp_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 7 + [ct.POINTER(Options)] + [c_dp] * 8 + [ct.c_int, c_dp]
     lib.jrlqp_dense_create.restype = ct.c_int
     lib.jrlqp_dense_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p)]
     lib.jrlqp_dense_destroy.restype = None
     lib.jrlqp_dense_destroy.argtypes = [ct.c_void_p]
+    lib.jrlqp_dense_resize.restype = ct.c_int
+    lib.jrlqp_dense_resize.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int]
     lib.jrlqp_dense_last_hip_error.restype = ct.c_int
     lib.jrlqp_dense_last_hip_error.argtypes = [ct.c_void_p]
     lib.jrlqp_dense_solve.restype = ct.c_int
@@ -497,25 +503,39 @@ class BlockGISolver:
 
 class BoxAndSingleConstraintSolver:
     """Mirror of experimental::BoxAndSingleConstraintSolver (include/jrl-qp/experimental/BoxAndSingleConstraintSolver.h:9-33)
-    over a batch:  min 1/2 ||x - x0||^2  s.t.  c^T x >= bl,  xl <= x <= xu.   It is the dense GI solver on G = I,
-    a = -x0 and one general constraint (the reference's class derives from GoldfarbIdnaniSolver and only replaces init_
-    by a closed form, BoxAndSingleConstraintSolver.cpp:46-94); objectiveValue() includes the constant 1/2 ||x0||^2 like
-    the reference's (tests/BoxAndSingleConstraintSolverTest.cpp:30,42)."""
+    over a batch:  min 1/2 ||x - x0||^2  s.t.  c^T x >= bl,  xl <= x <= xu  -- jrlqp_box_solve_batch: the closed-form init_ of
+    BoxAndSingleConstraintSolver.cpp:46-94 as the kernel's prologue (no factorisation, start at the clamped point with the
+    clamped bounds active), then the batched GI loop.  objectiveValue() = 1/2 ||x - x0||^2 like the reference's."""
 
-    def __init__(self, n, B, device="cuda"):
+    def __init__(self, n, B, device="cuda", max_iter=500, big_bnd=1e100):
         import torch
 
+        self.lib = load_library()
         self.n, self.B = n, B
-        self.solver = BatchSolver(n, 1, True, B, device=device)
-        self.G = torch.eye(n, dtype=torch.float64, device=device).expand(B, n, n).contiguous()
-        self.bu = torch.full((B, 1), float("inf"), dtype=torch.float64, device=device)
+        self.device = torch.device(device)
+        self.opts = Options(max_iter, big_bnd)
+        f64, i32 = torch.float64, torch.int32
+        self.x = torch.empty((B, n), dtype=f64, device=self.device)
+        self.u = torch.empty((B, 1 + n), dtype=f64, device=self.device)
+        self.status = torch.empty((B, 1 + n), dtype=i32, device=self.device)
+        self.term = torch.empty((B,), dtype=i32, device=self.device)
+        self.iters = torch.empty((B,), dtype=i32, device=self.device)
+        self.f = torch.empty((B,), dtype=f64, device=self.device)
 
-    def solve(self, x0, c, bl, xl, xu):
+    def solve(self, x0, c, bl, xl, xu, stream=None):
         """x0, c, xl, xu: (B, n) float64 CUDA tensors; bl: (B,) or (B, 1)."""
-        r = self.solver.solve(self.G, (-x0).contiguous(), c.reshape(self.B, 1, self.n).contiguous(), bl.reshape(self.B, 1).contiguous(), self.bu,
-                              xl.contiguous(), xu.contiguous())
-        f = r.f + 0.5 * (x0 * x0).sum(dim=1)
-        return BatchResult(r.x, r.u, r.status, r.term, r.iters, f, None)
+        import torch
+
+        x0, c, xl, xu = (t.contiguous() for t in (x0, c, xl, xu))
+        bl = bl.reshape(self.B).contiguous()
+        for t in (x0, c, xl, xu):
+            assert t.is_cuda and t.dtype == torch.float64 and t.shape == (self.B, self.n)
+        assert bl.is_cuda and bl.dtype == torch.float64
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(self.lib.jrlqp_box_solve_batch(self.n, self.B, _ptr(x0), _ptr(c), _ptr(bl), _ptr(xl), _ptr(xu), ct.byref(self.opts),
+                                             _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term), _ptr(self.iters),
+                                             _ptr(self.f), None, 0, ct.c_void_p(s.cuda_stream)))
+        return BatchResult(self.x, self.u, self.status, self.term, self.iters, self.f, None)
 
 
 PROFILE_SLOTS, PROFILE_GI_BATCH, PROFILE_BLOCKGI = 32, 0, 1

@@ -246,6 +246,36 @@ int jrlqp_gi_solve_batch_warm(int n, int m, int nb, int B, const double * dG, co
                          dtrace, trace_cap, stream);
 }
 
+int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, const double * dbl, const double * dxl,
+                          const double * dxu, const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm,
+                          int * diters, double * df, jrlqp_trace_rec * dtrace, int trace_cap, void * stream)
+{
+  if(n < 1 || B < 0) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(B == 0) return JRLQP_OK;
+  if(!dx0 || !dc || !dbl || !dxl || !dxu || !dx || !du || !dstatus || !dterm || !diters || !df) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(n > JRLQP_BATCH_MAX_N || jrlqp::batch_lds_bytes(n, 1, n, 1, 0) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  jrlqp_options o;
+  jrlqp_default_options(&o);
+  if(opts) o = *opts;
+  jrlqp::BatchArgs a{};
+  a.n = n; a.m = 1; a.nb = n; a.B = B;
+  a.ld = n | 1;
+  a.max_iter = o.max_iter;
+  a.trace_cap = dtrace ? trace_cap : 0;
+  a.big_bnd = o.big_bnd;
+  a.G = nullptr; a.a = dx0; a.C = dc; a.bl = dbl; a.bu = nullptr; // G = I and bu = +inf are implicit
+  a.xl = dxl; a.xu = dxu;
+  a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
+  a.Lout = nullptr;
+  a.trace = dtrace;
+  a.prof = nullptr; a.prof_stride = 0;
+  a.warm = 0; a.as_in = nullptr;
+  a.chain_mode = g_chain_mode.load();
+  hipError_t e = jrlqp::launch_gi_batch_box(a, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? JRLQP_OK : hip_fail(e);
+}
+
 #define HIP_TRY(x)                      \
   do                                    \
   {                                     \

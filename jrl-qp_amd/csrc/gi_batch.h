@@ -37,5 +37,6 @@ constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
 int batch_pad_size(int n, int warm); // instantiated size a problem of n variables runs in (0: none, generic kernel)
 long batch_lds_bytes(int n, int m, int nb, int cmode, int warm = 0);
 int batch_pick_cmode(int n, int m, int nb, int warm = 0); // -1 if unsupported
+hipError_t launch_gi_batch_box(const BatchArgs & a, hipStream_t stream);
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream);
 } // namespace jrlqp

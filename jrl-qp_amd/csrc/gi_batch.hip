@@ -357,7 +357,9 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 //         equalities plus a guess, J and R from a Householder QR of L^-1 N; then the same loop
 // EMB   : the problem is SMALLER than NT and runs embedded (see nr below); a separate instantiation, so that the
 //         exact-size kernels -- BASELINE c3 among them -- keep nr a compile-time constant and their register allocation
-template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false>
+// BOX   : experimental::BoxAndSingleConstraintSolver -- G = I implicit, A.a holds x0, m == 1, nb == n; the closed-form init_
+//         of src/experimental/BoxAndSingleConstraintSolver.cpp:46-94 replaces LLT / J = L^-T / x0 / initActiveSet
+template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false, bool BOX = false>
 __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : (NT <= 16 ? 5 : (NT <= 32 ? 4 : 3))) : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0, last3_ = 0;
@@ -486,7 +488,13 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   for(int e = tid; e < n * n; e += WG)
   {
     int i = e % n, j = e / n;
-    R[i + j * ld] = (i < nr && j < nr) ? Gg[i + (size_t)j * nr] : ((i == j) ? 1.0 : 0.0);
+    if constexpr(BOX)
+    {
+      R[i + j * ld] = 0.0; // (R.col(q).head(q).setZero() for whatever q comes out, BoxAndSingleConstraintSolver.cpp:69,80)
+      J[i + j * ld] = 0.0; // J.setZero() (:61)
+    }
+    else
+      R[i + j * ld] = (i < nr && j < nr) ? Gg[i + (size_t)j * nr] : ((i == j) ? 1.0 : 0.0);
   }
   for(int i = tid; i < mt; i += WG) st[i] = 0;
   if(tid < n) xs[tid] = 0.0;
@@ -503,7 +511,45 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
 
   // ---------------------------------------------------------------- K1: LLT in LDS (wave 0), while waves 1-3 stage C
   double * L = R;
-  if(wave == 0)
+  if(BOX && wave == 0)
+  {
+    // BoxAndSingleConstraintSolver::init_ (:46-94), lane = variable: the start point is x0 clamped to the box, every clamped
+    // variable's bound is active (in index order) with multiplier |x0_i - bound_i|, J is the permutation that puts the
+    // clamped coordinates first (free coordinate number k goes to column n-1-k) and R = diag(+1 lower / -1 upper)
+    const bool in = lane < n;
+    const double x0 = in ? ag[lane] : 0.0, lo = in ? xlg[lane] : 0.0, hi = in ? xug[lane] : 0.0;
+    const bool blo = in && x0 < lo;
+    const bool bup = in && !blo && x0 > hi;
+    const unsigned long long mk = __ballot(blo || bup);
+    const int pos = __popcll(mk & ((1ull << lane) - 1ull));
+    const double xv = blo ? lo : (bup ? hi : x0);
+    const double uv = blo ? (xv - x0) : (x0 - xv);
+    if(in)
+    {
+      xs[lane] = xv;
+      const int col = (blo || bup) ? pos : (n - 1 - (lane - pos));
+      J[lane + col * ld] = 1.0;
+      if(blo || bup)
+      {
+        R[pos + pos * ld] = blo ? 1.0 : -1.0;
+        us[pos] = uv;
+        act[pos] = m + lane; // (:72 "i + 1": one general constraint in front of the bounds)
+        st[m + lane] = (unsigned char)(blo ? LOWER_BOUND : UPPER_BOUND);
+      }
+    }
+    double f = 0.0; // f_ += 0.5 * u[q] * u[q], in activation order: one chain, every lane the same
+    for(unsigned long long rest = mk; rest; rest &= rest - 1)
+    {
+      const double uq = bcast_lane(uv, __builtin_ctzll(rest));
+      f = FMA(0.5 * uq, uq, f);
+    }
+    if(lane == 0)
+    {
+      ctl->f = f;
+      ctl->nact = __popcll(mk);
+    }
+  }
+  else if(wave == 0)
   {
     // Left-looking by blocks of LB columns, lane = row: the LB accumulators of a row stay in registers while the
     // wave walks the columns k < j0 already factored (one lane-varying + LB broadcast LDS reads feed LB independent
@@ -579,7 +625,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       for(int i = tid - 64; i < m; i += WG - 64)
       {
         bls[i] = blg[i];
-        bus[i] = bug[i];
+        bus[i] = BOX ? __builtin_inf() : bug[i]; // (box solver: bu_[0] = +inf, BoxAndSingleConstraintSolver.cpp:33)
       }
     }
     if constexpr(WARM)
@@ -619,7 +665,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       }
       if(neq) atomicAdd(&ctl->cnt, neq);
     }
-    else
+    else if constexpr(!BOX) // (the box solver's init_ replaces initActiveSet as well: no pre-activation of xl == xu)
     {
       // equalities / fixed variables present?  (GoldfarbIdnaniSolver.cpp:268-287)
       int first = NONE, cnt = 0;
@@ -707,7 +753,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       }
     }
     // ---------------------------------------------------------------- K2 (wave 1): J = L^-T ; K3 (wave 0): x0, f0
-    if(wave == 1)
+    if constexpr(BOX)
+    {
+      q = uniform(ctl->nact); // J, R, x, u, f, the active list: all set by the closed form above
+    }
+    else if(wave == 1)
     {
       // J = L^-T by blocks of JB rows from the bottom, lane = column c: J_ic = (delta_ic - sum_{k = c .. i+1,
       // descending} L_ki J_kc) / L_ii.  The JB accumulators of a column stay in registers while the wave walks the
@@ -1883,13 +1933,13 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   }
 }
 
-template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false>
+template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false, bool BOX = false>
 hipError_t launch_one(const BatchArgs & a, long lds, hipStream_t stream)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<NT, CMODE, PROF, WARM, EMB>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_kernel<NT, CMODE, PROF, WARM, EMB, BOX>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if(e != hipSuccess) return e;
-  hipLaunchKernelGGL((gi_batch_kernel<NT, CMODE, PROF, WARM, EMB>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
+  hipLaunchKernelGGL((gi_batch_kernel<NT, CMODE, PROF, WARM, EMB, BOX>), dim3(a.B), dim3(WG), (size_t)lds, stream, a);
   return hipGetLastError();
 }
 
@@ -1943,6 +1993,13 @@ int batch_pick_cmode(int n, int m, int nb, int warm)
   if(batch_lds_bytes(n, m, nb, 1, warm) <= kLdsPerCU) return 1;
   if(batch_lds_bytes(n, m, nb, 0, warm) <= kLdsPerCU) return 0;
   return -1;
+}
+
+// experimental::BoxAndSingleConstraintSolver over a batch: the generic kernel (runtime n <= 64, c staged in LDS) with the
+// closed-form init_; a.G is not read (G = I), a.a holds x0, a.m == 1, a.nb == a.n
+hipError_t launch_gi_batch_box(const BatchArgs & a, hipStream_t stream)
+{
+  return launch_one<0, 1, false, false, false, true>(a, batch_lds_bytes(a.n, a.m, a.nb, 1, 0), stream);
 }
 
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)

@@ -17,7 +17,8 @@ using namespace jrlqp;
 
 struct jrlqp_dense
 {
-  int n = 0, m = 0, nb = 0;
+  int n = 0, m = 0, nb = 0;             // current problem sizes (jrlqp_dense_resize), within the capacities below
+  int cap_n = 0, cap_m = 0, cap_nb = 0; // what the buffers were allocated for (jrlqp_dense_create): grow-only, like Workspace.h:37-43
   DenseViews v{};
   DenseState s{};
   Mailbox * h_mb = nullptr; // pinned host memory, mapped into the device address space
@@ -63,6 +64,7 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   jrlqp_dense * h = new(std::nothrow) jrlqp_dense;
   if(!h) return JRLQP_ERR_WORKSPACE;
   h->n = n; h->m = m; h->nb = nb;
+  h->cap_n = n; h->cap_m = m; h->cap_nb = nb;
   const size_t mt = (size_t)m + nb;
   DenseState & s = h->s;
   hipError_t e = dmalloc(s.J, (size_t)n * n);
@@ -122,6 +124,22 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   if(h->ev_x) (void)hipEventDestroy(h->ev_x);
   if(h->ev_sel) (void)hipEventDestroy(h->ev_sel);
   delete h;
+}
+
+// DualSolver::resize (DualSolver.h:33) on a pre-sized solver: any problem that fits the capacities of jrlqp_dense_create is
+// solved in the buffers already there -- no allocation, host or device (the "Multiple uses" contract of
+// tests/GoldfarbIdnaniSolverTest.cpp:101-125).  J and R keep the reference's ld = n of the CURRENT problem.
+int jrlqp_dense_resize(jrlqp_dense * h, int n, int m, int nb)
+{
+  if(!h || n < 1 || m < 0 || (nb != 0 && nb != n)) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(n > h->cap_n || m > h->cap_m || nb > h->cap_nb) return JRLQP_ERR_WORKSPACE;
+  if(n == h->n && m == h->m && nb == h->nb) return JRLQP_OK;
+  h->n = n; h->m = m; h->nb = nb;
+  h->bound = false;
+  h->status.assign((size_t)m + nb, 0); // (within the capacity reserved at creation: no allocation)
+  h->active.clear();
+  h->h_bl.resize(m); h->h_bu.resize(m); h->h_xl.resize(nb); h->h_xu.resize(nb);
+  return JRLQP_OK;
 }
 
 int jrlqp_dense_last_hip_error(const jrlqp_dense * h)

@@ -347,3 +347,27 @@ def generate_batch(B: int, ch: Characteristics, first_index: int = 0, seed0: int
         ls[k] = pb.multipliers()
     return PackedBatch(n=n, m=m, nb=nb, G=G, a=a, C=C, bl=bl, bu=bu, xl=xl, xu=xu, x_star=xs, lam_star=ls,
                        meta={"first_index": first_index, "seed0": seed0})
+
+
+def box_and_single_constraint_problem(n: int, act: bool, rng, act_level: float = 0.5):
+    """generateBoxAndSingleConstraintProblem (src/experimental/BoxAndSingleConstraintSolver.cpp:99-176):
+    min 1/2 ||x - x0||^2  s.t.  c.x >= b, xl <= x <= xu, with x0, the box corners and c uniform in [-1, 1]^n
+    (Eigen's VectorXd::Random).  act: b lies between c.xb (xb = x0 clamped to the box: where the constraint starts to be
+    active) and c.su (su = the box vertex furthest along c: the last feasible value), at fraction act_level; otherwise
+    b = c.sl (sl = the vertex closest along c), so that the whole box satisfies the constraint.
+    Returns (x0, c, b, xl, xu)."""
+    assert (not act) or (0.0 < act_level < 1.0)
+    x0 = rng.uniform(-1.0, 1.0, n)
+    r1 = rng.uniform(-1.0, 1.0, n)
+    r2 = rng.uniform(-1.0, 1.0, n)
+    xl, xu = np.minimum(r1, r2), np.maximum(r1, r2)
+    xb = np.clip(x0, xl, xu)
+    c = rng.uniform(-1.0, 1.0, n)
+    sl = np.where(c > 0, xl, xu)
+    su = np.where(c > 0, xu, xl)
+    if act:
+        d1, d2 = float(c @ xb), float(c @ su)
+        b = act_level * d1 + (1.0 - act_level) * d2
+    else:
+        b = float(c @ sl)
+    return x0, c, b, xl, xu

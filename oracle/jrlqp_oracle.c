@@ -617,7 +617,7 @@ static int gi_solve_impl(int warm,
   for(int i = 0; i < n; ++i) S.x[i] = 0.0; /* defined output when init_ fails (the reference leaves x untouched) */
   double *x = S.x, *z = S.z, *u = S.u, *r = S.r;
 
-  if(warm)
+  if(warm == 1)
   {
     /* ---- experimental init_ (experimental/GoldfarbIdnaniSolver.cpp:65-112) ---- */
     double * b_act = cxs + m + 1;
@@ -650,6 +650,49 @@ static int gi_solve_impl(int warm,
       initialize_primal_dual(&S, a, b_act, alpha, beta);
     }
     S.u[S.A.nact] = 0.0;
+    goto main_loop;
+  }
+
+  if(warm == 2)
+  {
+    /* ---- BoxAndSingleConstraintSolver::init_ (experimental/BoxAndSingleConstraintSolver.cpp:46-94): G = I is implicit,
+     * `a` holds x0 itself (:38 "a will contain x0, not -x0"); the start point is x0 clamped to the box, every clamped
+     * variable's bound is active with multiplier |x0_i - bound|, J is the permutation that puts the clamped coordinates
+     * first (free coordinate number k, counted from 0, goes to column n-1-k) and R = diag(+1 lower / -1 upper).
+     * f_ += 0.5 * u[q] * u[q] is read as fma(0.5 * u, u, f) (CANON C2). ---- */
+    const double * x0 = a;
+    int q = 0;
+    for(long e = 0; e < (long)n * n; ++e) S.J[e] = 0.0;
+    for(int i = 0; i < n; ++i)
+    {
+      if(x0[i] < xl[i])
+      {
+        x[i] = xl[i];
+        u[q] = x[i] - x0[i];
+        S.f = FMA(0.5 * u[q], u[q], S.f);
+        for(int k = 0; k < q; ++k) S.R[k + (long)q * n] = 0.0;
+        S.R[q + (long)q * n] = 1.0;
+        S.J[i + (long)q * n] = 1.0;
+        orc_as_activate(&S.A, m + i, ORC_LOWER_BOUND); /* (:72 "i+1": m == 1) */
+        ++q;
+      }
+      else if(x0[i] > xu[i])
+      {
+        x[i] = xu[i];
+        u[q] = x0[i] - x[i];
+        S.f = FMA(0.5 * u[q], u[q], S.f);
+        for(int k = 0; k < q; ++k) S.R[k + (long)q * n] = 0.0;
+        S.R[q + (long)q * n] = -1.0;
+        S.J[i + (long)q * n] = 1.0;
+        orc_as_activate(&S.A, m + i, ORC_UPPER_BOUND);
+        ++q;
+      }
+      else
+      {
+        x[i] = x0[i];
+        S.J[i + (long)(n - i + q - 1) * n] = 1.0;
+      }
+    }
     goto main_loop;
   }
 
@@ -839,6 +882,18 @@ int orc_gi_solve_warm(int n, int m, int nb, double * G, int ldg, const double * 
 {
   return gi_solve_impl(1, as_in, n, m, nb, G, ldg, a, C, ldc, bl, bu, xl, xu, max_iter, big_bnd, xout, uout, status_out,
                        active_out, nactive_out, iters_out, f_out, trace, trace_cap, work);
+}
+
+/* experimental::BoxAndSingleConstraintSolver::solve(x0, c, bl, xl, xu) (BoxAndSingleConstraintSolver.cpp:11-44):
+ *   min 1/2 ||x - x0||^2  s.t.  c.x >= bl,  xl <= x <= xu      (one general constraint, bu = +inf, bounds mandatory)
+ * closed-form init_ (:46-94), then the unchanged GoldfarbIdnaniSolver hooks.  u: 1 + n multipliers, status likewise. */
+int orc_box_solve(int n, const double * x0, const double * c, double bl, const double * xl, const double * xu, int max_iter,
+                  double big_bnd, double * xout, double * uout, int * status_out, int * active_out, int * nactive_out,
+                  int * iters_out, double * f_out, orc_trace_rec * trace, int trace_cap)
+{
+  const double blv[1] = {bl}, buv[1] = {INFINITY};
+  return gi_solve_impl(2, NULL, n, 1, n, NULL, n, x0, c, n, blv, buv, xl, xu, max_iter, big_bnd, xout, uout, status_out,
+                       active_out, nactive_out, iters_out, f_out, trace, trace_cap, NULL);
 }
 
 void orc_gi_solve_batch(int B,

@@ -126,6 +126,13 @@ void orc_gi_solve_batch(int B,
                         double * f,
                         int nthreads);
 
+/* experimental::BoxAndSingleConstraintSolver (src/experimental/BoxAndSingleConstraintSolver.cpp:11-94):
+ *   min 1/2 ||x - x0||^2  s.t.  c.x >= bl,  xl <= x <= xu ; closed-form initial point / active set / J / R, then the GI loop.
+ *   u, status: 1 + n entries (the general constraint first, then the bounds).  f is 1/2 ||x - x0||^2 itself. */
+int orc_box_solve(int n, const double * x0, const double * c, double bl, const double * xl, const double * xu, int max_iter,
+                  double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * iters, double * f,
+                  orc_trace_rec * trace, int trace_cap);
+
 /*
  * Warm-started dense GI solve: experimental::GoldfarbIdnaniSolver::solve(..., as) with options.warmStart_ = true
  * (src/experimental/GoldfarbIdnaniSolver.cpp:20-112, 309-487).  Same arguments as orc_gi_solve plus

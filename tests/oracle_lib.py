@@ -67,6 +67,9 @@ class Oracle:
         L.orc_gi_solve_batch_warm.restype = None
         L.orc_gi_solve_batch_warm.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip,
                                               ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_dp, ct.c_int]
+        L.orc_box_solve.restype = ct.c_int
+        L.orc_box_solve.argtypes = [ct.c_int, c_dp, c_dp, ct.c_double, c_dp, c_dp, ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip,
+                                    c_dp, ct.POINTER(TraceRec), ct.c_int]
         L.orc_llt.restype = ct.c_int
         L.orc_llt.argtypes = [ct.c_int, c_dp, ct.c_int]
         L.orc_inv_lt.restype = None
@@ -153,6 +156,21 @@ class Oracle:
                                          ct.byref(f), tr, trace_cap, None)
         trace = [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in tr[: min(trace_cap, iters.value)]]
         return OracleResult(term, x, u, status, active[: nact.value].copy(), iters.value, f.value, trace, Gf)
+
+    def box_solve(self, x0, c, bl, xl, xu, max_iter=500, big_bnd=1e100, trace_cap=0) -> OracleResult:
+        """experimental::BoxAndSingleConstraintSolver::solve(x0, c, bl, xl, xu): closed-form init_, then the GI loop."""
+        x0, c, xl, xu = (np.ascontiguousarray(v, dtype=np.float64) for v in (x0, c, xl, xu))
+        n = len(x0)
+        x = np.zeros(n)
+        u = np.zeros(1 + n)
+        status = np.zeros(1 + n, dtype=np.int32)
+        active = np.zeros(n + 2, dtype=np.int32)
+        nact, iters, f = ct.c_int(0), ct.c_int(0), ct.c_double(0.0)
+        tr = (TraceRec * max(trace_cap, 1))()
+        term = self.lib.orc_box_solve(n, _dp(x0), _dp(c), float(bl), _dp(xl), _dp(xu), max_iter, big_bnd, _dp(x), _dp(u), _ip(status),
+                                      _ip(active), ct.byref(nact), ct.byref(iters), ct.byref(f), tr, trace_cap)
+        trace = [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in tr[: min(trace_cap, iters.value)]]
+        return OracleResult(term, x, u, status, active[: nact.value].copy(), iters.value, f.value, trace, None)
 
     def solve_batch(self, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, nthreads=1, warm=False, guess=None):
         """Packed batch (see jrl-qp_amd/problems.py PackedBatch).  G is copied.  warm/guess: see solve()."""

@@ -261,34 +261,57 @@ def test_randomised_shape_sweep(capi, P, oracle):
 
 
 def test_box_and_single_constraint_solver(pkg, oracle):
-    """experimental::BoxAndSingleConstraintSolver == GoldfarbIdnaniSolver on the same problem
-    (tests/BoxAndSingleConstraintSolverTest.cpp:16-47), constraint inactive and active; here both sides bit for bit."""
+    """jrlqp_box_solve_batch (closed-form init_ of src/experimental/BoxAndSingleConstraintSolver.cpp:46-94 as the kernel
+    prologue) == the oracle's restatement of that solver, bit for bit (status, iterations, active set, x, u, f), on the
+    reference's own test set-up (tests/BoxAndSingleConstraintSolverTest.cpp:16-47: n = 10, 11 problems with the constraint
+    inactive + 11 active, generator of BoxAndSingleConstraintSolver.cpp:99-176) and on other sizes; and, as in that test,
+    == the plain GoldfarbIdnaniSolver on (G = I, a = -x0) up to the constant 1/2 ||x0||^2."""
     import torch
 
     import jrl_qp_amd.capi as capi
+    import jrl_qp_amd.problems as P
 
-    rng = np.random.default_rng(99)
-    n, B = 10, 22
-    x0 = rng.uniform(-2, 2, (B, n))
-    c = rng.standard_normal((B, n))
-    xl = rng.uniform(-1.5, -0.5, (B, n))
-    xu = rng.uniform(0.5, 1.5, (B, n))
-    xb = np.clip(x0, xl, xu)  # solution without the general constraint
-    cxb = (c * xb).sum(axis=1)
-    smax = (np.where(c > 0, c * xu, c * xl)).sum(axis=1)  # max of c.x over the box
-    bl = np.where(np.arange(B) % 2 == 0, cxb - 1.0, cxb + 0.5 * (smax - cxb))  # even: inactive, odd: active
-    dev = lambda v: torch.tensor(v, device="cuda")
-    s = capi.BoxAndSingleConstraintSolver(n, B)
-    r = s.solve(dev(x0), dev(c), dev(bl), dev(xl), dev(xu))
-    torch.cuda.synchronize()
-    x, f, term, status = r.x.cpu().numpy(), r.f.cpu().numpy(), r.term.cpu().numpy(), r.status.cpu().numpy()
-    nact = 0
-    for b in range(B):
-        ref = oracle.solve(np.eye(n), -x0[b], c[b].reshape(n, 1), [bl[b]], [np.inf], xl[b], xu[b])
-        assert term[b] == ref.term == 0
-        assert np.array_equal(x[b], ref.x)
-        assert abs(f[b] - (ref.f + 0.5 * x0[b] @ x0[b])) <= 1e-12 * (1 + abs(f[b]))
-        assert abs(f[b] - 0.5 * np.sum((x[b] - x0[b]) ** 2)) <= 1e-10 * (1 + abs(f[b]))
-        nact += int(status[b, 0] != 0)
-        assert (c[b] @ x[b]) >= bl[b] - 1e-9
-    assert 8 <= nact <= 14
+    dev = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    for n, reps, seed in ((10, 11, 20201), (1, 4, 5), (7, 6, 6), (33, 6, 7), (64, 5, 8)):
+        rng = np.random.default_rng(seed)
+        pbs = [P.box_and_single_constraint_problem(n, act, rng) for act in (False, True) for _ in range(reps)]
+        B = len(pbs)
+        x0, c, bl, xl, xu = (np.stack([np.atleast_1d(p[k]) for p in pbs]) for k in range(5))
+        s = capi.BoxAndSingleConstraintSolver(n, B)
+        r = s.solve(dev(x0), dev(c), dev(bl), dev(xl), dev(xu))
+        torch.cuda.synchronize()
+        x, u, f = r.x.cpu().numpy(), r.u.cpu().numpy(), r.f.cpu().numpy()
+        term, iters, status = r.term.cpu().numpy(), r.iters.cpu().numpy(), r.status.cpu().numpy()
+        nact = 0
+        for b in range(B):
+            ref = oracle.box_solve(x0[b], c[b], bl[b, 0], xl[b], xu[b])
+            what = f"n={n} problem {b}"
+            assert term[b] == ref.term == 0, what
+            assert iters[b] == ref.iters, what
+            assert np.array_equal(status[b], ref.status), what
+            assert np.array_equal(x[b], ref.x) and np.array_equal(u[b], ref.u) and f[b] == ref.f, what
+            gi = oracle.solve(np.eye(n), -x0[b], c[b].reshape(n, 1), bl[b], [np.inf], xl[b], xu[b])
+            assert np.allclose(x[b], gi.x, rtol=1e-12, atol=1e-14)
+            assert abs(f[b] - (gi.f + 0.5 * x0[b] @ x0[b])) <= 1e-9 * (1 + abs(f[b]))
+            nact += int(status[b, 0] != 0)
+        assert nact == reps  # exactly the "active" half ends with the general constraint active
+    # termination statuses other than SUCCESS come out of the same loop: infeasible constraint, iteration limit
+    n = 5
+    x0 = np.array([[0.5, -2.0, 3.0, 0.1, -0.7]] * 2)
+    xl = np.array([[0.0, -1.0, -1.0, -1.0, -0.5]] * 2)
+    xu = np.array([[1.0, 1.0, 1.0, 1.0, 0.5]] * 2)
+    c = np.ones((2, n))
+    bl = np.array([100.0, 3.9])
+    for max_iter in (500, 0):
+        s = capi.BoxAndSingleConstraintSolver(n, 2, max_iter=max_iter)
+        r = s.solve(dev(x0), dev(c), dev(bl), dev(xl), dev(xu))
+        torch.cuda.synchronize()
+        for b in range(2):
+            ref = oracle.box_solve(x0[b], c[b], bl[b], xl[b], xu[b], max_iter=max_iter)
+            assert int(r.term[b]) == ref.term and int(r.iters[b]) == ref.iters
+            assert np.array_equal(r.x[b].cpu().numpy(), ref.x) and np.array_equal(r.u[b].cpu().numpy(), ref.u)
+            assert float(r.f[b]) == ref.f and np.array_equal(r.status[b].cpu().numpy(), ref.status)
+        if max_iter == 500:
+            assert int(r.term[0]) == 3 and int(r.term[1]) == 0
+        else:
+            assert int(r.term[0]) == 4

@@ -11,10 +11,13 @@ SRC_BLOCK = os.path.join(ROOT, "tests", "cpp", "test_block_host_class.cpp")
 LIBDIR = os.path.join(ROOT, "jrl-qp_amd", "csrc")
 
 
-def _build(out, src=SRC):
+SRC_MULTI = os.path.join(ROOT, "tests", "cpp", "test_multiple_uses.cpp")
+
+
+def _build(out, src=SRC, extra=()):
     cmd = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", src,
            "-o", out, "-L", LIBDIR, "-ljrlqp_hip", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"]
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd + list(extra))
 
 
 def test_host_class_compiles_and_links(pkg, tmp_path):
@@ -46,3 +49,66 @@ def test_block_host_class_reference_tests(pkg, tmp_path):
     _build(exe, SRC_BLOCK)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "block host class OK" in out.stdout, out.stdout + out.stderr
+
+
+# the five shapes of the reference's "Multiple uses" test (tests/GoldfarbIdnaniSolverTest.cpp:103-108), all within (5, 8, true)
+MULTI_SHAPES = [
+    dict(nVar=5, nObj=5),
+    dict(nVar=5, nObj=5, nEq=2),
+    dict(nVar=5, nObj=5, nIneq=8, nStrongActIneq=4),
+    dict(nVar=5, nObj=5, nEq=2, nIneq=6, nStrongActIneq=3),
+    dict(nVar=5, nObj=5, nEq=2, nIneq=6, nStrongActIneq=1, bounds=True, nStrongActBounds=2),
+]
+
+
+def test_multiple_uses_compiles_and_links(pkg, tmp_path):
+    import jrl_qp_amd.capi as capi
+
+    capi.load_library()
+    _build(str(tmp_path / "multiple_uses"), SRC_MULTI, ("-rdynamic", "-ldl"))
+
+
+@pytest.mark.gpu
+def test_multiple_uses_no_allocation_and_parity(pkg, oracle, tmp_path):
+    """One solver pre-sized (5, 8, true) over the five shapes: no HIP allocation call inside solve() (counted by
+    interposition in the C++ test), SUCCESS, x / multipliers = the planted ones to 1e-6 (the reference's checks), and every
+    output bit-identical to the oracle, the Cholesky factor left in G included."""
+    import numpy as np
+
+    import jrl_qp_amd.problems as P
+
+    pbs = [P.generate_batch(1, P.Characteristics(**sh), first_index=3100 + i) for i, sh in enumerate(MULTI_SHAPES)]
+    with open(tmp_path / "problems.bin", "wb") as f:
+        np.array([len(pbs)], dtype=np.int32).tofile(f)
+        for pb in pbs:
+            np.array([pb.n, pb.m, pb.nb], dtype=np.int32).tofile(f)
+            for arr in (pb.G[0], pb.a[0], pb.C[0], pb.bl[0], pb.bu[0], pb.xl[0], pb.xu[0]):
+                np.ascontiguousarray(arr, dtype=np.float64).tofile(f)  # G symmetric; C (m, n) C-order == n x m column-major
+    exe = str(tmp_path / "multiple_uses")
+    _build(exe, SRC_MULTI, ("-rdynamic", "-ldl"))
+    out = subprocess.run([exe, str(tmp_path / "problems.bin"), str(tmp_path / "results.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "multiple uses OK" in out.stdout, out.stdout + out.stderr
+    raw = open(tmp_path / "results.bin", "rb").read()
+    off = 0
+    for pb in pbs:
+        n, m, nb = pb.n, pb.m, pb.nb
+        term, iters = np.frombuffer(raw, dtype=np.int32, count=2, offset=off)
+        off += 8
+        f = np.frombuffer(raw, dtype=np.float64, count=1, offset=off)[0]
+        off += 8
+        x = np.frombuffer(raw, dtype=np.float64, count=n, offset=off)
+        off += 8 * n
+        u = np.frombuffer(raw, dtype=np.float64, count=m + nb, offset=off)
+        off += 8 * (m + nb)
+        Gafter = np.frombuffer(raw, dtype=np.float64, count=n * n, offset=off).reshape(n, n).T  # column-major buffer
+        off += 8 * n * n
+        status = np.frombuffer(raw, dtype=np.int32, count=m + nb, offset=off)
+        off += 4 * (m + nb)
+        hb = nb > 0
+        ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], pb.xl[0] if hb else None, pb.xu[0] if hb else None)
+        assert term == ref.term == 0 and iters == ref.iters
+        assert np.array_equal(x, ref.x) and np.array_equal(u, ref.u) and f == ref.f and np.array_equal(status, ref.status)
+        assert np.array_equal(np.tril(Gafter), np.tril(ref.L)) and np.array_equal(np.triu(Gafter, 1), np.triu(pb.G[0], 1))
+        assert np.allclose(x, pb.x_star[0], rtol=1e-6, atol=1e-9)
+        assert np.allclose(u, pb.lam_star[0], rtol=1e-6, atol=1e-9)
+    assert off == len(raw)
