@@ -80,6 +80,17 @@ struct Ctl
   int nact; // WARM: size of the initial active set
   int over; // WARM: more than n equalities / fixed variables activated
   int pad;
+  // WS (role-specialised main loop): hand-off words between the main wave and the helper waves, see ws_* below
+  double rho;       // R(q, q) of the addition whose coefficients are published (chain wave -> main wave)
+  int fd;           // pass number whose d (and p, pstat, q below) is published            main -> helpers
+  int fz, fx;       // pass number whose z, z.z / n.x, n.z are published                   z wave, dot wave -> main
+  int fcs;          // pass number whose rotation coefficients are published (or abandoned) chain wave -> main
+  int fdr;          // pass number whose d the chain wave has taken into registers          chain wave -> main
+  int fstep;        // pass number whose step is taken (x, u final) and whose decision is in dec
+  int dec;          // decision of pass fstep: 1 add, 2 drop, 3 stop
+  int fscan[3];     // scan number whose winner is published, per scanning wave
+  int wp, wps, wq;  // constraint, status and active-set size of the pass in flight
+  int wit, wterm;   // final iteration count and termination status
 };
 
 // ---- wave-level helpers ---------------------------------------------------------------------------------
@@ -349,6 +360,8 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
   }
 #define PROF_COUNT(slot)                                   \
   if(PROF && tid == 0) atomicAdd(&prof_lds[(slot)], 1ull);
+#define PROF_COUNT3(slot)                                  \
+  if(PROF && tid == 192) atomicAdd(&prof_lds[(slot)], 1ull);
 
 // ---- the kernel ------------------------------------------------------------------------------------------
 // NT    : compile-time n (0 = runtime n)
@@ -451,6 +464,15 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   // push hipcc into spilling column entries for the whole kernel (reloaded one by one inside every scan).  The exposed
   // load latency is paid once per solve.
   constexpr bool LATE_C = (CMODE == 2 && NT == 50 && !WARM);
+  // WS: role-specialised main loop (cold start, C in registers).  Wave 3 -- which owns no constraint column -- is the MAIN
+  // wave: it runs every serial phase of a pass (d = J^T n+, the substitution, the ratio test, the step, the sweep of J, a
+  // removal) in code of its own in which the 100 column registers of the other waves are not live, so that its loops can
+  // keep whole columns / rows of J in flight.  Waves 0-2 are HELPERS: they own the columns of C (the scan), and beside it
+  // wave 0 runs the Givens coefficient chain of a possible addition from the moment d exists -- the whole chain and the
+  // (c, s) pairs, speculatively --, wave 1 z and z.z, wave 2 the two products with n+.  No workgroup barrier inside the
+  // loop: the roles meet through sequence-numbered words in LDS (release/acquire), so a wave never waits for work it does
+  // not depend on.
+  constexpr bool WS = (CMODE == 2) && !WARM && !BOX;
   auto load_columns = [&]() __attribute__((always_inline)) {
     if(m == 0) return; // no general constraint: C may be a null pointer (the loads below are unconditional)
     const bool own = myc >= 0 && myc < m;
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   };
   if(CMODE == 2)
   {
-    if(!LATE_C) load_columns();
+    if(!LATE_C && !WS) load_columns();
     for(int e = tid; e < ne * n; e += WG)
     {
       int k = e % n, i = e / n;
@@ -894,7 +916,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     }
     __syncthreads();
     STAMP(2)
-    if(CMODE == 2 && LATE_C) load_columns();
+    if(CMODE == 2 && LATE_C && !WS) load_columns();
 
     const double big = A.big_bnd;
     constexpr bool SPEC = (CMODE == 2); // speculative Givens coefficient chain on wave 3 (which holds no constraint)
@@ -1109,7 +1131,15 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     // value.  (always_inline: a lambda that is not inlined captures creg[] by address and pushes it to scratch.)
     auto publish_np = [&](int pp, int ps, bool scanned) __attribute__((always_inline)) {
       const bool lower = (ps == LOWER || ps == EQUALITY || ps == LOWER_BOUND || ps == FIXED);
-      if(CMODE == 2 && !scanned) // (a scan already left n+ and b in the owner wave's slot: scan_publish)
+      if(WS && !scanned) // (equality pre-activation: the column registers are not loaded yet: from memory, n threads)
+      {
+        if(pp < CREG_MAX && pp < m)
+        {
+          if(tid < n) npw[(pp >> 6) * n + tid] = (tid < nr) ? Cg[(size_t)pp * nr + tid] : 0.0;
+          if(tid == 0) ctl->bndw[pp >> 6] = lower ? blg[pp] : bug[pp];
+        }
+      }
+      else if(CMODE == 2 && !scanned) // (a scan already left n+ and b in the owner wave's slot: scan_publish)
       {
         if(myc == pp && myc < m) // the owner thread (extra columns are used in place: np_ptr)
         {
@@ -1154,6 +1184,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
 
     // K7 + ratio test (wave 0).  The loop body is branch-free on purpose: conditional LDS loads make hipcc wait
     // with lgkmcnt(0) right after issuing the prefetch (measured 267 cycles per step instead of ~130).
+    double tr_t1 = 0.0; // (t1, l) of the last trsv_ratio, in every lane of the wave that ran it
+    int tr_l = 0;
     auto trsv_ratio = [&]() {
       const int rl = (lane < n) ? lane : 0;
       double rk = ds[rl];
@@ -1221,10 +1253,12 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       double tk = cand ? tt : big;
       int kk = cand ? lane : NONE, dummy = 0;
       wave_argmin_monotone(tk, kk, dummy);
-      if(lane == 0)
+      tr_t1 = (kk == NONE) ? big : tk;
+      tr_l = (kk == NONE) ? 0 : kk;
+      if(!WS && lane == 0)
       {
-        ctl->t1 = (kk == NONE) ? big : tk;
-        ctl->l = (kk == NONE) ? 0 : kk;
+        ctl->t1 = tr_t1;
+        ctl->l = tr_l;
       }
       STAMP(17)
     };
@@ -1754,6 +1788,450 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     {
       if(it >= A.max_iter) // it > 0 only after a warm start purged constraints
         term = T_MAX_ITER;
+      else if constexpr(WS)
+      {
+        // ==================================================================================================
+        // WS main loop: wave 3 = MAIN, waves 0-2 = HELPERS (see the comment at WS above).  Hand-off words in ctl:
+        //   fd    = pass   : d, wp, wps, wq published                       MAIN -> helpers
+        //   fz/fx = pass   : z, z.z  /  n.x, n.z published                  wave 1 / wave 2 -> MAIN
+        //   fcs   = pass   : (c, s) pairs + rho published, or chain abandoned (also: d no longer read)  wave 0 -> MAIN
+        //   fstep = pass   : x, u final, decision in dec                    MAIN -> helpers
+        //   fscan[w] = scan number: winner of wave w published              helpers -> MAIN
+        // A word is written after the data it announces (release) and polled by its readers (acquire).  MAIN waits for fz, fx
+        // every pass and for fcs before it overwrites d, so no helper is ever more than one pass behind and `dec` is read
+        // before it is rewritten.
+        // ==================================================================================================
+        constexpr int MAINW = 3;
+        // (c_i, s_i) at csb[2i], csb[2i+1], 16-byte aligned (the dynamic LDS base is): pointer arithmetic only, so that the
+        // compiler keeps the LDS address space (an integer round trip turns every access into a flat load)
+        double * csb = gsc + (((unsigned)reinterpret_cast<size_t>(gsc) >> 3) & 1u);
+        // A waiting wave sleeps in long naps (an instruction it issues is an issue slot the working waves of its SIMD do not
+        // get, and a helper waits most of the time); the wave that posts a word wakes the sleepers of its workgroup
+        // (s_wakeup), so the hand-off does not wait for a nap to end.  A wake-up that arrives just before the s_sleep is
+        // lost: the nap then bounds the delay.
+        constexpr int NAP = 6; // x 64 cycles
+        auto ws_wait = [&](const int * word, int target) __attribute__((always_inline)) {
+          while(__atomic_load_n(word, __ATOMIC_RELAXED) != target) __builtin_amdgcn_s_sleep(NAP);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        auto ws_post = [&](int * word, int value) __attribute__((always_inline)) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if(lane == 0) __atomic_store_n(word, value, __ATOMIC_RELAXED);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+        };
+        if(tid == 0)
+        {
+          ctl->fd = 0; ctl->fz = 0; ctl->fx = 0; ctl->fcs = 0; ctl->fdr = 0; ctl->fstep = 0; ctl->dec = 0;
+          ctl->fscan[0] = 0; ctl->fscan[1] = 0; ctl->fscan[2] = 0;
+          ctl->wit = it; ctl->wterm = T_SUCCESS; ctl->wq = q;
+        }
+        __syncthreads();
+        if(wave == MAINW)
+        {
+          // ------------------------------------------------------------------------------------------ MAIN
+          int sq = 0, sc = 1;
+          int wterm = T_SUCCESS;
+          const int rl = (lane < n) ? lane : (n - 1);
+          // first selection: the helpers scan with x = x0
+          ws_wait(&ctl->fscan[0], sc);
+          ws_wait(&ctl->fscan[1], sc);
+          ws_wait(&ctl->fscan[2], sc);
+          scan_combine(p, pstat);
+          STAMP3(24)
+          bool running = (p >= 0);
+          if(running && lane == 0) us[q] = 0.0; // DualSolver.cpp:121
+          while(running)
+          {
+            ++sq;
+            // ---- K5: d = +-J^T n+ (general: every entry of the column in flight at once; bound: a row of J)
+            {
+              double dj;
+              if(p < m)
+              {
+                const double * np = np_ptr(p);
+                const double * jc = J + rl * ld;
+                if constexpr(NT > 0)
+                {
+                  // A wave issues at most one instruction every four cycles, whatever its kind: the chain is written for the
+                  // fewest instructions -- compile-time offsets (no address arithmetic), both operands by LDS reads (n+ as a
+                  // broadcast read; a v_readlane pair per term would double the count), groups of DG terms, the next group
+                  // requested before the current one is consumed.
+                  constexpr int DG = 8;
+                  constexpr int NG = (NR + DG - 1) / DG;
+                  double ja[DG], na[DG], jb[DG], nb2[DG];
+                  auto dfetch = [&](double (&jq)[DG], double (&nq)[DG], int g) __attribute__((always_inline)) {
+#pragma unroll
+                    for(int u = 0; u < DG; ++u)
+                    {
+                      const int k = (g * DG + u < NR) ? (g * DG + u) : (NR - 1);
+                      jq[u] = jc[k];
+                      nq[u] = np[k];
+                    }
+                  };
+                  auto dchain = [&](const double (&jq)[DG], const double (&nq)[DG], int g) __attribute__((always_inline)) {
+#pragma unroll
+                    for(int u = 0; u < DG; ++u)
+                      if(g * DG + u < NR) dj = FMA(jq[u], nq[u], dj);
+                  };
+                  dj = 0.0;
+                  dfetch(ja, na, 0);
+#pragma unroll
+                  for(int g = 0; g < NG; g += 2)
+                  {
+                    if(g + 1 < NG) dfetch(jb, nb2, g + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    dchain(ja, na, g);
+                    if(g + 2 < NG) dfetch(ja, na, g + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if(g + 1 < NG) dchain(jb, nb2, g + 1);
+                  }
+                }
+                else
+                  dj = chain_up(jc, 1, np, 1, 0, n, 0.0);
+              }
+              else
+                dj = J[(p - m) + rl * ld];
+              if(pstat == UPPER || pstat == UPPER_BOUND) dj = -dj;
+              if(lane < n) ds[lane] = dj;
+              if(lane == 0)
+              {
+                ctl->wp = p;
+                ctl->wps = pstat;
+                ctl->wq = q;
+              }
+            }
+            ws_post(&ctl->fd, sq);
+            STAMP3(25)
+            // ---- K7 + ratio test
+            trsv_ratio();
+            const double t1 = tr_t1;
+            const int l = tr_l;
+            STAMP3(26)
+            ws_wait(&ctl->fz, sq);
+            ws_wait(&ctl->fx, sq);
+            STAMP3(27)
+            // ---- K8: step length
+            const double cz = uniform_d(ctl->cz);
+            const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
+            double t2 = big;
+            if(__builtin_sqrt(uniform_d(ctl->zz)) > 1e-14) t2 = (uniform_d(bound_of(p, pstat)) - uniform_d(ctl->cx)) / cz;
+            const double t = (t2 < t1) ? t2 : t1;
+            if(A.trace && lane == 0 && it < A.trace_cap)
+            {
+              jrlqp_trace_rec * tr = A.trace + (size_t)b * A.trace_cap + it;
+              tr->p = p;
+              tr->status = pstat;
+              tr->l = l;
+              tr->kind = (t2 >= big) ? 2 : ((t == t2) ? 0 : 1);
+              tr->t1 = t1;
+              tr->t2 = t2;
+            }
+            if(t >= big)
+            {
+              wterm = T_INFEASIBLE; // DualSolver.cpp:131
+              break;
+            }
+            const bool dual_only = (t2 >= big);
+            const bool add = !dual_only && (t == t2);
+            apply_step(t, dotsc, dual_only);
+            if(lane == 0) ctl->dec = add ? 1 : 2;
+            ws_post(&ctl->fstep, sq);
+            STAMP3(28)
+            if(add)
+            {
+              // ---- K10: the coefficients come from the chain wave (speculative since d was published)
+              ws_wait(&ctl->fcs, sq);
+              STAMP3(29)
+              const int qa = uniform(q);
+              if(n - 2 >= qa)
+              {
+                // lane = row of J (lanes >= n shadow row n-1: same values, same addresses).  Columns n-2 .. qa, two dependent
+                // operations per column.  With n a compile-time constant the sweep is unrolled over the column index: every LDS
+                // address is a base register plus an immediate, the operands of column i - AD are requested while column i is
+                // rotated, and one scalar compare-and-branch per column ends the sweep at qa -- nine instructions per column
+                // (an instruction of any kind costs its wave four cycles).
+                double carry = J[rl + (n - 1) * ld];
+                if constexpr(NT > 0)
+                {
+                  // blocks of AB columns, straight-line code inside a block; the operands of block b+1 are requested before
+                  // block b is rotated.  A block runs only if ALL its columns are inside the sweep (the `alive` chain: once
+                  // false it stays false), so that no value loaded ahead is ever merged with another definition -- a merge
+                  // would make the compiler wait for the load at once.  The up to AB-1 columns left go one by one.
+                  constexpr int AB = 4;
+                  constexpr int NB = (NR - 1) / AB;
+                  const double * jr = J + rl;
+                  double xa[AB], ca[AB], sa[AB], xb[AB], cb[AB], sb[AB];
+                  auto afetch = [&](double (&xq)[AB], double (&cq)[AB], double (&sq2)[AB], int b) __attribute__((always_inline)) {
+#pragma unroll
+                    for(int u = 0; u < AB; ++u)
+                    {
+                      const int i = (NR - 2 - AB * b - u >= 0) ? (NR - 2 - AB * b - u) : 0;
+                      xq[u] = jr[i * ld];
+                      const double2 cs2 = *reinterpret_cast<const double2 *>(csb + 2 * i);
+                      cq[u] = cs2.x;
+                      sq2[u] = cs2.y;
+                    }
+                  };
+                  auto arot = [&](const double (&xq)[AB], const double (&cq)[AB], const double (&sq2)[AB], int b) __attribute__((always_inline)) {
+#pragma unroll
+                    for(int u = 0; u < AB; ++u)
+                    {
+                      const int i = NR - 2 - AB * b - u;
+                      J[rl + (i + 1) * ld] = FMA(sq2[u], xq[u], cq[u] * carry);
+                      carry = FMA(cq[u], xq[u], -(sq2[u] * carry));
+                    }
+                  };
+                  int inext = NR - 2;
+                  bool alive = true;
+                  afetch(xa, ca, sa, 0);
+#pragma unroll
+                  for(int b = 0; b < NB; ++b)
+                  {
+                    alive = alive && (NR - 2 - AB * b - (AB - 1) >= qa);
+                    if(alive)
+                    {
+                      if(b & 1)
+                      {
+                        if(b + 1 < NB) afetch(xa, ca, sa, b + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        arot(xb, cb, sb, b);
+                      }
+                      else
+                      {
+                        if(b + 1 < NB) afetch(xb, cb, sb, b + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        arot(xa, ca, sa, b);
+                      }
+                      inext = NR - 2 - AB * (b + 1);
+                    }
+                  }
+                  for(int i = inext; i >= qa; --i)
+                  {
+                    const double xv = J[rl + i * ld];
+                    const double2 cs2 = *reinterpret_cast<const double2 *>(csb + 2 * i);
+                    J[rl + (i + 1) * ld] = FMA(cs2.y, xv, cs2.x * carry);
+                    carry = FMA(cs2.x, xv, -(cs2.y * carry));
+                  }
+                }
+                else
+                {
+                  for(int i = n - 2; i >= qa; --i)
+                  {
+                    const double xv = J[rl + i * ld];
+                    const double c2 = csb[2 * i], s2 = csb[2 * i + 1];
+                    J[rl + (i + 1) * ld] = FMA(s2, xv, c2 * carry);
+                    carry = FMA(c2, xv, -(s2 * carry));
+                  }
+                }
+                J[rl + qa * ld] = carry;
+              }
+              STAMP3(22)
+              // R.col(q).head(q+1) = d.head(q) | rho ; the active set
+              {
+                const double dq = ds[rl];
+                if(lane < qa)
+                  R[lane + qa * ld] = dq;
+                else if(lane == qa)
+                  R[qa + qa * ld] = ctl->rho;
+                if(lane == 0)
+                {
+                  act[qa] = p;
+                  st[p] = (unsigned char)pstat;
+                }
+              }
+              q = uniform(q + 1);
+              ++it;
+              PROF_COUNT3(10)
+              STAMP3(30)
+              ++sc;
+              ws_wait(&ctl->fscan[0], sc);
+              ws_wait(&ctl->fscan[1], sc);
+              ws_wait(&ctl->fscan[2], sc);
+              if(it >= A.max_iter)
+              {
+                wterm = T_MAX_ITER; // checked before the next selection (for(; it_ < maxIter_; ...), DualSolver.cpp:103)
+                break;
+              }
+              scan_combine(p, pstat);
+              STAMP3(31)
+              if(p < 0) break; // SUCCESS (DualSolver.cpp:114)
+              if(lane == 0) us[q] = 0.0; // DualSolver.cpp:121
+              wave_sync();
+            }
+            else
+            {
+              ws_wait(&ctl->fdr, sq); // (do_drop hands its rotations on through the vectors d and z)
+              do_drop(l);
+              q = uniform(q - 1);
+              ++it;
+              PROF_COUNT3(11)
+              ws_wait(&ctl->fcs, sq); // the chain wave is through with this pass (its chain was abandoned)
+              STAMP3(23)
+              if(it >= A.max_iter)
+              {
+                wterm = T_MAX_ITER;
+                break;
+              }
+              // skipStep1: same (p, pstat), u[q] keeps the shifted pending multiplier
+            }
+          }
+          // stop: tell the helpers (they wait either for the next d or for this pass's step)
+          if(lane == 0)
+          {
+            ctl->wit = it;
+            ctl->wterm = wterm;
+            ctl->wq = q;
+            ctl->dec = 3;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if(lane == 0)
+          {
+            __atomic_store_n(&ctl->fstep, -1, __ATOMIC_RELAXED);
+            __atomic_store_n(&ctl->fd, -1, __ATOMIC_RELAXED);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+        }
+        else
+        {
+          // ------------------------------------------------------------------------------------------ HELPERS
+          load_columns();
+          int sq = 0, sc = 0;
+          {
+            double bv;
+            int bi, bs;
+            ++sc;
+            scan_local(-1, bv, bi, bs);
+            scan_publish(-1, bv, bi, bs);
+            ws_post(&ctl->fscan[wave], sc);
+          }
+          for(;;)
+          {
+            ++sq;
+            // wait for this pass's d (or for the end)
+            int got;
+            while((got = __atomic_load_n(&ctl->fd, __ATOMIC_RELAXED)) != sq && got != -1) __builtin_amdgcn_s_sleep(NAP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if(got == -1) break;
+            const int wp = uniform(ctl->wp), wq = uniform(ctl->wq);
+            bool aborted = false;
+            if(wave == 0)
+            {
+              // ---- the Givens coefficient chain of an addition (GoldfarbIdnaniSolver.cpp:228-231), speculative: seeded and
+              // systolic (device_common.h), the state in registers; every eight steps it looks whether MAIN has decided to
+              // drop instead, and gives up if so
+              STAMP(3)
+              const int rl = (lane < n) ? lane : (n - 1);
+              const double dv = ds[rl];
+              const double gd = (lane < n) ? dv : 0.0;
+              ws_post(&ctl->fdr, sq); // d is in registers: MAIN may reuse its LDS vector (a removal does)
+              double rho = bcast_lane(gd, n - 1);
+              if(n - 2 >= wq)
+              {
+                const double sincl = wave_suffix_sum_approx(gd * gd, lane);
+                GivensSeed seed = givens_seed(gd, dpp_shift0_d<0x130>(sincl)); // lane i: sum over k > i
+                if(A.chain_mode == 2) seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
+                double rc = gd;
+                int left = n - 1 - wq; // steps n-2 .. wq
+                while(left > 0)
+                {
+                  const int fs = __atomic_load_n(&ctl->fstep, __ATOMIC_RELAXED); // (requested before the slice, looked at after)
+#pragma unroll
+                  for(int u = 0; u < 8; ++u) rc = givens_seeded_step(dpp_shift0_d<0x130>(rc), seed); // (steps past wq: idempotent)
+                  left -= 8;
+                  if(uniform(fs) == sq || uniform(fs) == -1)
+                  {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if(uniform(ctl->dec) != 1)
+                    {
+                      aborted = true;
+                      break;
+                    }
+                  }
+                }
+                STAMP(4)
+                if(!aborted)
+                {
+                  // lane i: r_{i+1} is its upper neighbour's radius (the SIGNED d_{n-1} for the first rotation); recompute the
+                  // rotation with the plain formula and compare radii: all equal <=> the seeded chain IS the plain chain
+                  double kq = dpp_shift0_d<0x130>(rc);
+                  kq = (lane == n - 2) ? rho : kq;
+                  GivensHalf h;
+                  const double rex = givens_r(gd, kq, h);
+                  const bool mine = lane >= wq && lane <= n - 2;
+                  if(A.chain_mode == 1 || __any(mine && !(rex == rc)))
+                  {
+                    double rr = opaque_v(bcast_lane(gd, n - 1));
+                    kq = 0.0;
+                    for(int i = n - 2; i >= wq; --i)
+                    {
+                      const double p_i = opaque_v(bcast_lane(gd, i));
+                      kq = (lane == i) ? rr : kq;
+                      rr = givens_r_only(p_i, rr);
+                    }
+                    rho = rr;
+                    (void)givens_r(gd, kq, h);
+                    PROF_COUNT(13)
+                  }
+                  else
+                    rho = bcast_lane(rc, wq);
+                  double cl, sl;
+                  givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
+                  if(mine) *reinterpret_cast<double2 *>(csb + 2 * lane) = make_double2(cl, sl);
+                }
+              }
+              if(!aborted && lane == 0) ctl->rho = rho;
+              ws_post(&ctl->fcs, sq);
+              STAMP(5)
+            }
+            else if(wave == 1)
+            {
+              // ---- K6: z = J2 d2, then z.z and n+.z in two lanes
+              const bool general = wp < m;
+              if(lane < n) zs[lane] = chain_up(J + lane, ld, ds, 1, wq, n, 0.0);
+              wave_sync();
+              if(lane < 2)
+              {
+                double acc;
+                if(general || lane == 0)
+                  acc = chain_up((lane == 0) ? zs : np_ptr(wp), 1, zs, 1, 0, n, 0.0);
+                else
+                  acc = zs[wp - m];
+                if(lane == 0) ctl->zz = acc;
+                if(lane == 1) ctl->cz = acc;
+              }
+              ws_post(&ctl->fz, sq);
+            }
+            else
+            {
+              // ---- n+.x
+              const bool general = wp < m;
+              if(lane == 0) ctl->cx = general ? chain_up(np_ptr(wp), 1, xs, 1, 0, n, 0.0) : xs[wp - m];
+              ws_post(&ctl->fx, sq);
+            }
+            // ---- the decision
+            int fs;
+            while((fs = __atomic_load_n(&ctl->fstep, __ATOMIC_RELAXED)) != sq && fs != -1) __builtin_amdgcn_s_sleep(NAP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if(fs == -1) break;
+            if(uniform(ctl->dec) == 1)
+            {
+              double bv;
+              int bi, bs;
+              ++sc;
+              STAMP(6)
+              scan_local(wp, bv, bi, bs); // wp is treated as active (MAIN writes its status byte meanwhile)
+              STAMP(8)
+              scan_publish(wp, bv, bi, bs);
+              ws_post(&ctl->fscan[wave], sc);
+              STAMP(7)
+            }
+          }
+        }
+        __syncthreads();
+        q = uniform(ctl->wq);
+        it = uniform(ctl->wit);
+        term = uniform(ctl->wterm);
+      }
       else
       {
         // Step 1 for the first pass: everybody scans
