@@ -91,6 +91,7 @@ struct Ctl
   int fscan[3];     // scan number whose winner is published, per scanning wave
   int wp, wps, wq;  // constraint, status and active-set size of the pass in flight
   int wit, wterm;   // final iteration count and termination status
+  double t2;        // primal step length of the pass in flight (z wave -> main)
 };
 
 // ---- wave-level helpers ---------------------------------------------------------------------------------
@@ -215,6 +216,23 @@ __device__ __forceinline__ double wave_min_d(double v)
   double m01 = (r1 < r0) ? r1 : r0;
   double m23 = (r3 < r2) ? r3 : r2;
   return (m23 < m01) ? m23 : m01;
+}
+
+// the same with v_min_f64 spelled out (three instructions per exchange instead of five); for operands that are numbers
+__device__ __forceinline__ double vmin_d(double a, double b)
+{
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double wave_min_d_fast(double v)
+{
+  v = vmin_d(v, dpp_move<0xB1>(v));
+  v = vmin_d(v, dpp_move<0x4E>(v));
+  v = vmin_d(v, dpp_move<0x141>(v));
+  v = vmin_d(v, dpp_move<0x140>(v));
+  const double r0 = bcast_lane(v, 0), r1 = bcast_lane(v, 16), r2 = bcast_lane(v, 32), r3 = bcast_lane(v, 48);
+  return vmin_d(vmin_d(r0, r1), vmin_d(r2, r3));
 }
 
 // acc <- chain over k = k0 .. k1-1 (ascending) of fma(a[k*sa], b[k*sb], acc); loads are issued a chunk ahead so
@@ -382,7 +400,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     last3_ = last_;
     wall0_ = wall_clock64();
   }
-  extern __shared__ double smem[];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ unsigned long long prof_lds[PROF ? 32 : 1];
   if(PROF && threadIdx.x < 32) prof_lds[threadIdx.x] = 0;
   const int tid = threadIdx.x;
@@ -1819,6 +1837,229 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           if(lane == 0) __atomic_store_n(word, value, __ATOMIC_RELAXED);
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
         };
+        // K4 on a helper wave, WS form: the column chain runs for every lane without a branch around it (a branch would put
+        // the loads in an exec-mask region of their own), x arrives in double-buffered groups of XG as 16-byte broadcast
+        // reads.  Then the wave's arg-min and the hand-off of the winner: (value, index, status) and, by its owner thread, n+
+        // and the bound.  The LDS-staged extra columns (m > 192) are MAIN's (ws_extras): it has the registers and, after its
+        // sweep, the time.
+        auto ws_scan = [&](int excl) __attribute__((always_inline)) {
+          constexpr int XG = 8;
+          static_assert(NR % 2 == 0 || NT == 0, "x is read in pairs");
+          const int sbyte = (myc < m) ? st[myc] : 1;
+          double cx = 0.0;
+          double xa[XG], xb[XG];
+          auto xfetch = [&](double (&xq)[XG], int g) __attribute__((always_inline)) {
+#pragma unroll
+            for(int u = 0; u < XG; u += 2)
+            {
+              const int k = (g * XG + u < NR) ? (g * XG + u) : (NR - 2);
+              const double2 v = *reinterpret_cast<const double2 *>(xs + k);
+              xq[u] = v.x;
+              xq[u + 1] = v.y;
+            }
+          };
+          auto xchain = [&](const double (&xq)[XG], int g) __attribute__((always_inline)) {
+#pragma unroll
+            for(int u = 0; u < XG; ++u)
+              if(g * XG + u < NR) cx = FMA(creg[g * XG + u], xq[u], cx);
+          };
+          constexpr int XNG = (NR + XG - 1) / XG;
+          double ex = 0.0;
+          const bool e_on = (wave == 2) && (ne > 0); // (uniform) wave 2 -- idle inside a pass -- also takes the extra columns
+          if(e_on)
+          {
+            // lane e: extra column 192 + e as a SECOND chain in the same loop (a dependent fp64 chain leaves every other issue
+            // slot free).  One buffer per operand stream, refilled in place right after use: eight terms of look-ahead.
+            const double * ce = Ce + (size_t)((lane < ne) ? lane : 0) * ld;
+            double eq[XG];
+#pragma unroll
+            for(int u = 0; u < XG; ++u) eq[u] = ce[u];
+            xfetch(xa, 0);
+#pragma unroll
+            for(int k = 0; k < NR; ++k)
+            {
+              const int u = k % XG;
+              cx = FMA(creg[k], xa[u], cx);
+              ex = FMA(eq[u], xa[u], ex);
+              if(k + XG < NR) eq[u] = ce[k + XG];
+              if((u & 1) && k + XG < NR + 1)
+              {
+                const int kk = (k - 1 + XG < NR) ? (k - 1 + XG) : (NR - 2);
+                const double2 v = *reinterpret_cast<const double2 *>(xs + kk);
+                xa[u - 1] = v.x;
+                xa[u] = v.y;
+              }
+              if(u == XG - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          else
+          {
+            xfetch(xa, 0);
+#pragma unroll
+            for(int g = 0; g < XNG; g += 2)
+            {
+              if(g + 1 < XNG) xfetch(xb, g + 1);
+              __builtin_amdgcn_sched_barrier(0);
+              xchain(xa, g);
+              if(g + 2 < XNG) xfetch(xa, g + 2);
+              __builtin_amdgcn_sched_barrier(0);
+              if(g + 1 < XNG) xchain(xb, g + 1);
+            }
+          }
+          // candidates: value < 0 only; lower tested before upper (GoldfarbIdnaniSolver.cpp:99-110)
+          double bval = 1.0;
+          int bidx = NONE, bstat = INACTIVE;
+          {
+            const double sl = cx - my_bl, su = my_bu - cx;
+            const bool ok = (myc < m) && sbyte == INACTIVE && myc != excl;
+            const bool lo = ok && sl < 0.0, up = ok && !lo && su < 0.0;
+            bval = lo ? sl : (up ? su : 1.0);
+            bidx = (lo || up) ? myc : NONE;
+            bstat = lo ? LOWER : (up ? UPPER : INACTIVE);
+          }
+          if(nb > 0)
+          {
+            // bounds: thread i < 192 takes variables i, i + 192, ... (general constraints come first: a bound wins a tie only
+            // through the index order of the arg-min below)
+            double v0 = (bidx == NONE) ? 0.0 : bval;
+            for(int i = tid; i < nb; i += CREG_MAX)
+            {
+              if(st[m + i] != INACTIVE || (m + i) == excl) continue;
+              const double xi = xs[i];
+              const double sl = xi - xlg[i];
+              if(sl < v0)
+              {
+                v0 = sl;
+                bidx = m + i;
+                bstat = LOWER_BOUND;
+              }
+              else
+              {
+                const double su = xug[i] - xi;
+                if(su < v0)
+                {
+                  v0 = su;
+                  bidx = m + i;
+                  bstat = UPPER_BOUND;
+                }
+              }
+            }
+            bval = (bidx == NONE) ? 1.0 : v0;
+            wave_argmin(bval, bidx, bstat);
+          }
+          else
+          {
+            // index monotone in the lane: minimum value, then the first lane holding it
+            const double mn = wave_min_d_fast(bval);
+            const unsigned long long msk = __ballot(bidx != NONE && bval == mn);
+            if(msk == 0)
+              bidx = NONE;
+            else
+            {
+              const int src = __builtin_ctzll(msk);
+              bval = mn;
+              bidx = __builtin_amdgcn_readlane(bidx, src);
+              bstat = __builtin_amdgcn_readlane(bstat, src);
+            }
+          }
+          if(lane == 0)
+          {
+            ctl->red_val[wave] = bval;
+            ctl->red_idx[wave] = bidx;
+            ctl->red_stat[wave] = bstat;
+          }
+          if(myc == bidx && myc < m) // this wave's winner: n+ and its bound into the wave's slot
+          {
+            double * slot = npw + wave * n;
+            if constexpr(NR % 2 == 0)
+            {
+#pragma unroll
+              for(int k = 0; k < NR; k += 2) *reinterpret_cast<double2 *>(slot + k) = make_double2(creg[k], creg[k + 1]);
+            }
+            else
+            {
+#pragma unroll
+              for(int k = 0; k < NR; ++k) slot[k] = creg[k];
+            }
+            ctl->bndw[wave] = (bstat == LOWER) ? my_bl : my_bu;
+          }
+          if(wave == 2 && ne <= 64)
+          {
+            double ev = 1.0;
+            int ei = NONE, es = INACTIVE;
+            const int i = CREG_MAX + lane;
+            if(e_on && lane < ne && st[i] == INACTIVE && i != excl)
+            {
+              const double sl = ex - blg[i], su = bug[i] - ex;
+              if(sl < 0.0)
+              {
+                ev = sl;
+                ei = i;
+                es = LOWER;
+              }
+              else if(su < 0.0)
+              {
+                ev = su;
+                ei = i;
+                es = UPPER;
+              }
+            }
+            if(ne > 0) wave_argmin_monotone(ev, ei, es);
+            if(lane == 0)
+            {
+              ctl->red_val[3] = ev;
+              ctl->red_idx[3] = ei;
+              ctl->red_stat[3] = es;
+            }
+          }
+        };
+        // MAIN's share of K4 (only when there are more than 64 extra columns): the LDS-staged extra columns, 64 per round (lane e = column 192 + e0 + e); a lane keeps its
+        // first best one (strict <), then the arg-min; the winner goes to slot 3 of the reduction words
+        auto ws_extras = [&](int excl) __attribute__((always_inline)) {
+          if(ne <= 64) return; // (wave 2 runs them beside its own columns)
+          double ev = 1.0;
+          int ei = NONE, es = INACTIVE;
+          for(int e0 = 0; e0 < ne; e0 += 64)
+          {
+            const int i = CREG_MAX + e0 + lane;
+            const bool on = e0 + lane < ne;
+            const double * ce = Ce + (size_t)(on ? e0 + lane : 0) * ld;
+            // (a plain chunked chain: MAIN waits for the helpers' scans afterwards anyway, and a second fully unrolled
+            // pipeline here makes the register allocator spill the helpers' column registers)
+            const double cxe = chain_up(ce, 1, xs, 1, 0, n, 0.0);
+            if(on && st[i] == INACTIVE && i != excl)
+            {
+              const double sl = cxe - blg[i];
+              const double su = bug[i] - cxe;
+              if(sl < 0.0)
+              {
+                if(sl < ev)
+                {
+                  ev = sl;
+                  ei = i;
+                  es = LOWER;
+                }
+              }
+              else if(su < 0.0 && su < ev)
+              {
+                ev = su;
+                ei = i;
+                es = UPPER;
+              }
+            }
+          }
+          if(ne > 64)
+            wave_argmin(ev, ei, es);
+          else if(ne > 0)
+            wave_argmin_monotone(ev, ei, es);
+          if(lane == 0)
+          {
+            ctl->red_val[3] = ev;
+            ctl->red_idx[3] = ei;
+            ctl->red_stat[3] = es;
+          }
+          wave_sync();
+        };
         if(tid == 0)
         {
           ctl->fd = 0; ctl->fz = 0; ctl->fx = 0; ctl->fcs = 0; ctl->fdr = 0; ctl->fstep = 0; ctl->dec = 0;
@@ -1833,6 +2074,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           int wterm = T_SUCCESS;
           const int rl = (lane < n) ? lane : (n - 1);
           // first selection: the helpers scan with x = x0
+          ws_extras(-1);
           ws_wait(&ctl->fscan[0], sc);
           ws_wait(&ctl->fscan[1], sc);
           ws_wait(&ctl->fscan[2], sc);
@@ -1908,13 +2150,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             const int l = tr_l;
             STAMP3(26)
             ws_wait(&ctl->fz, sq);
-            ws_wait(&ctl->fx, sq);
             STAMP3(27)
-            // ---- K8: step length
+            // ---- K8: step length (t2 comes from the z wave)
             const double cz = uniform_d(ctl->cz);
             const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
-            double t2 = big;
-            if(__builtin_sqrt(uniform_d(ctl->zz)) > 1e-14) t2 = (uniform_d(bound_of(p, pstat)) - uniform_d(ctl->cx)) / cz;
+            const double t2 = uniform_d(ctl->t2);
             const double t = (t2 < t1) ? t2 : t1;
             if(A.trace && lane == 0 && it < A.trace_cap)
             {
@@ -2042,6 +2282,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               q = uniform(q + 1);
               ++it;
               PROF_COUNT3(10)
+              ws_extras(p); // (p's status byte is written above, after the helpers may have read it: excluded explicitly)
               STAMP3(30)
               ++sc;
               ws_wait(&ctl->fscan[0], sc);
@@ -2096,14 +2337,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           // ------------------------------------------------------------------------------------------ HELPERS
           load_columns();
           int sq = 0, sc = 0;
-          {
-            double bv;
-            int bi, bs;
-            ++sc;
-            scan_local(-1, bv, bi, bs);
-            scan_publish(-1, bv, bi, bs);
-            ws_post(&ctl->fscan[wave], sc);
-          }
+          ++sc;
+          ws_scan(-1);
+          ws_post(&ctl->fscan[wave], sc);
           for(;;)
           {
             ++sq;
@@ -2185,28 +2421,33 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             }
             else if(wave == 1)
             {
-              // ---- K6: z = J2 d2, then z.z and n+.z in two lanes
+              // ---- K6: z = J2 d2; then z.z, n+.z, n+.x as three chains in three lanes of ONE instruction stream, and from them
+              // the primal step length t2 (GoldfarbIdnaniSolver.cpp:174-218): MAIN only takes the minimum with t1
               const bool general = wp < m;
+              const int wps = uniform(ctl->wps);
               if(lane < n) zs[lane] = chain_up(J + lane, ld, ds, 1, wq, n, 0.0);
               wave_sync();
-              if(lane < 2)
+              double acc = 0.0;
+              if(lane < 3)
               {
-                double acc;
                 if(general || lane == 0)
-                  acc = chain_up((lane == 0) ? zs : np_ptr(wp), 1, zs, 1, 0, n, 0.0);
+                  acc = chain_up((lane == 0) ? zs : np_ptr(wp), 1, (lane == 2) ? xs : zs, 1, 0, n, 0.0);
                 else
-                  acc = zs[wp - m];
-                if(lane == 0) ctl->zz = acc;
-                if(lane == 1) ctl->cz = acc;
+                  acc = (lane == 1) ? zs[wp - m] : xs[wp - m];
+              }
+              const double zz = bcast_lane(acc, 0), czv = bcast_lane(acc, 1), cxv = bcast_lane(acc, 2);
+              double t2v = big;
+              if(__builtin_sqrt(zz) > 1e-14) t2v = (uniform_d(bound_of(wp, wps)) - cxv) / czv;
+              if(lane == 0)
+              {
+                ctl->cz = czv;
+                ctl->t2 = t2v;
               }
               ws_post(&ctl->fz, sq);
             }
             else
             {
-              // ---- n+.x
-              const bool general = wp < m;
-              if(lane == 0) ctl->cx = general ? chain_up(np_ptr(wp), 1, xs, 1, 0, n, 0.0) : xs[wp - m];
-              ws_post(&ctl->fx, sq);
+              // (wave 2 has nothing to do inside a pass: it only scans)
             }
             // ---- the decision
             int fs;
@@ -2215,13 +2456,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             if(fs == -1) break;
             if(uniform(ctl->dec) == 1)
             {
-              double bv;
-              int bi, bs;
               ++sc;
               STAMP(6)
-              scan_local(wp, bv, bi, bs); // wp is treated as active (MAIN writes its status byte meanwhile)
-              STAMP(8)
-              scan_publish(wp, bv, bi, bs);
+              ws_scan(wp); // wp is treated as active (MAIN writes its status byte meanwhile)
               ws_post(&ctl->fscan[wave], sc);
               STAMP(7)
             }
