@@ -490,7 +490,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   // (c, s) pairs, speculatively --, wave 1 z and z.z, wave 2 the two products with n+.  No workgroup barrier inside the
   // loop: the roles meet through sequence-numbered words in LDS (release/acquire), so a wave never waits for work it does
   // not depend on.
-  constexpr bool WS = (CMODE == 2) && !WARM && !BOX;
+  constexpr bool WS = (CMODE == 2) && !WARM && !BOX && (NT >= 40); // (below 40 unknowns a pass is too short for the hand-offs to pay)
   auto load_columns = [&]() __attribute__((always_inline)) {
     if(m == 0) return; // no general constraint: C may be a null pointer (the loads below are unconditional)
     const bool own = myc >= 0 && myc < m;
