@@ -158,7 +158,7 @@ public:
   }
 
   /** Same with DEVICE pointers: nothing is copied but the results.  Sizes are those of the last resize().
-   *  Small problems (n <= JRLQP_BATCH_MAX_N, packed G and C) take the device-resident batched kernel with a batch of one
+   *  Small problems (n <= JRLQP_BATCH_WAVE_N = 64, packed G and C) take the device-resident batched kernel with a batch of one
    *  -- one launch for the whole solve instead of one host round trip per iteration --, larger ones the host-driven
    *  hooks (Mode A); both leave the factor in G and give bit-identical results. */
   TerminationStatus solveDevice(double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl, const double * dbu,
@@ -168,7 +168,7 @@ public:
     jrlqp_options o{options_.maxIter_, options_.bigBnd_};
     int term = int(TerminationStatus::UNKNOWN);
     int cpl = 0;
-    if(n_ <= JRLQP_BATCH_MAX_N && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
+    if(n_ <= JRLQP_BATCH_WAVE_N && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
     {
       // dL == dG: the kernel reads G completely before it writes the factor (jrlqp_hip.h), i.e. the reference's in-place contract
       if(!ok(jrlqp_gi_solve_batch(n_, m_, nb_, 1, dG, da, dC, dbl, dbu, dxl, dxu, &o, dx_, du_, dst_, dti_, dti_ + 1, dfv_, dG, nullptr, 0, stream),

@@ -58,7 +58,10 @@ enum jrlqp_status
   JRLQP_ERR_WORKSPACE = -5
 };
 
-#define JRLQP_BATCH_MAX_N 64
+#define JRLQP_BATCH_MAX_N 128 /* largest n of the batched entry points */
+#define JRLQP_BATCH_WAVE_N 64 /* up to here a row of the factors is one lane of a wavefront (gi_batch.hip); beyond it (cold
+                                 start only) the solver of gi_batch_big.hip: J in LDS, R in LDS or in a stream-ordered scratch
+                                 buffer, one workgroup per CU looping over the batch */
 
 /* jrl::qp::SolverOptions, include/jrl-qp/SolverOptions.h:16-20 (maxIter_ = 500, bigBnd_ = 1e100).  warmStart_ and
  * the logging fields have no GPU counterpart: the production solver resets the active set anyway
@@ -105,7 +108,8 @@ void jrlqp_default_options(jrlqp_options * opts);
  *        dL == dG reproduces the reference's in-place contract (G's lower triangle <- L, upper part untouched).
  *   dtrace optional [B][trace_cap] records.
  * No allocation, no host synchronisation: the call enqueues one kernel on `stream` (a hipStream_t, may be NULL).
- * Requires 1 <= n <= JRLQP_BATCH_MAX_N.
+ * Requires 1 <= n <= JRLQP_BATCH_MAX_N.  (For 104 < n <= 128 the packed R factor no longer fits in LDS beside J: the call then
+ * brackets its kernel with a stream-ordered hipMallocAsync / hipFreeAsync of 66 KB per CU -- still no host synchronisation.)
  */
 int jrlqp_gi_solve_batch(int n,
                          int m,

@@ -150,7 +150,12 @@ void jrlqp_default_options(jrlqp_options * o)
 
 long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds)
 {
-  if(n < 1 || n > JRLQP_BATCH_MAX_N || m < 0 || (nb != 0 && nb != n)) return -1;
+  if(n > JRLQP_BATCH_WAVE_N && n <= JRLQP_BATCH_MAX_N && m >= 0 && (nb == 0 || nb == n))
+  {
+    if(c_in_lds) *c_in_lds = 0;
+    return jrlqp::batch_big_lds_bytes(n, m, nb, nullptr);
+  }
+  if(n < 1 || n > JRLQP_BATCH_WAVE_N || m < 0 || (nb != 0 && nb != n)) return -1;
   int cmode = jrlqp::batch_pick_cmode(n, m, nb);
   if(cmode < 0) return -1;
   if(c_in_lds) *c_in_lds = cmode;
@@ -190,7 +195,10 @@ static int gi_batch_common(int warm,
   if(nb > 0 && (!dxl || !dxu)) return JRLQP_ERR_INVALID_ARGUMENT;
   if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
   if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
-  const int cmode = jrlqp::batch_pick_cmode(n, m, nb, warm);
+  const bool bign = n > JRLQP_BATCH_WAVE_N; // more rows than one lane-per-row wavefront: gi_batch_big.hip (cold start only)
+  int r_in_lds = 0;
+  if(bign && (warm || jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0)) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  const int cmode = bign ? 0 : jrlqp::batch_pick_cmode(n, m, nb, warm);
   if(cmode < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
 
   jrlqp_options o;
@@ -213,14 +221,38 @@ static int gi_batch_common(int warm,
   a.warm = warm;
   a.as_in = das;
   a.chain_mode = g_chain_mode.load();
-  hipError_t e = jrlqp::launch_gi_batch(a, cmode, static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if(bign)
+  {
+    // persistent grid: one workgroup per CU (J alone takes most of a CU's LDS), each looping over its share of the batch
+    int dev = 0, ncu = 0;
+    if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
+      return JRLQP_ERR_NO_DEVICE;
+    const int nwg = B < ncu ? B : ncu;
+    double * ws = nullptr;
+    if(!r_in_lds)
+    {
+      // R (packed, 66 KB at n = 128) does not fit beside J: a stream-ordered scratch allocation, returned to the pool by the
+      // same stream right behind the kernel -- no host synchronisation, no race between streams
+      hipError_t ea = hipMallocAsync(reinterpret_cast<void **>(&ws), sizeof(double) * (size_t)nwg * jrlqp::batch_big_ws_doubles_per_wg(n), st);
+      if(ea != hipSuccess) return hip_fail(ea);
+    }
+    hipError_t e = jrlqp::launch_gi_batch_big(a, nwg, ws, st);
+    if(ws)
+    {
+      hipError_t ef = hipFreeAsync(ws, st);
+      if(e == hipSuccess) e = ef;
+    }
+    return e == hipSuccess ? JRLQP_OK : hip_fail(e);
+  }
+  hipError_t e = jrlqp::launch_gi_batch(a, cmode, st);
   if(e != hipSuccess) return hip_fail(e);
   return JRLQP_OK;
 }
 
 long jrlqp_gi_batch_warm_lds_bytes(int n, int m, int nb, int * c_in_lds)
 {
-  if(n < 1 || n > JRLQP_BATCH_MAX_N || m < 0 || (nb != 0 && nb != n)) return -1;
+  if(n < 1 || n > JRLQP_BATCH_WAVE_N || m < 0 || (nb != 0 && nb != n)) return -1;
   int cmode = jrlqp::batch_pick_cmode(n, m, nb, 1);
   if(cmode < 0) return -1;
   if(c_in_lds) *c_in_lds = cmode;

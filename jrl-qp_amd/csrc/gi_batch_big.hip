@@ -1,0 +1,700 @@
+// gi_batch_big.hip -- Mode B for 64 < n <= 128: the device-resident batched Goldfarb-Idnani solver when a row of the
+// factors no longer fits one lane-per-row wavefront.
+//
+// Same entry point and same contract as gi_batch.hip (jrlqp_gi_solve_batch: one workgroup solves one QP end to end, the
+// whole dual active-set state machine on the device, inputs read once, results written once, results bit-identical to the
+// CPU oracle), for the sizes the reference's own benchmark families reach (benchmarks/Solvers.cpp:613-623: n up to 100).
+//
+//   reference path restated here (jrl-umi3218/jrl-qp):
+//     DualSolver::solve                      src/DualSolver.cpp:91-168
+//     GoldfarbIdnaniSolver::init_            src/GoldfarbIdnaniSolver.cpp:56-82     (LLT, J = L^-T, x0, f0)
+//     ::selectViolatedConstraint_            :84-134
+//     ::computeStep_ / ::computeStepLength_  :136-219
+//     ::addConstraint_ / ::removeConstraint_ :221-256
+//     ::initActiveSet / addInitialConstraint :268-338
+//     DualSolver::multipliers                src/DualSolver.cpp:38-69
+//
+// Layout.  J (n x n, ld = n|1) lives in LDS -- at n = 128 that is 132 KB of the CU's 160 KB, so one workgroup per CU; the
+// Cholesky factor L shares that array (L is lower, J = L^-T is upper triangular: J is built row by row from the bottom
+// in place, L's diagonal kept aside).  R (upper triangular, packed by columns) lives in LDS when it still fits
+// beside J (n <= 104) and otherwise in a per-workgroup slice of a global workspace (66 KB: L2-resident).  C is streamed
+// from global memory by the scan (one constraint per thread).  The grid is PERSISTENT -- one workgroup per CU slot, each
+// looping over its share of the batch -- so that the workspace is sized by the machine, not by the batch.
+//
+// Work split (256 threads): one thread per row / column / constraint for the O(n^2) parts -- every output element still
+// owns its in-order fma chain (CANON C1), which is what keeps the bits --, one thread for the scalar chains, barriers
+// between the phases.  This kernel is the coverage path for large n: it is written for exactness and simplicity, not for
+// the latency engineering of gi_batch.hip.
+#include <hip/hip_runtime.h>
+
+#include "device_common.h"
+#include "gi_batch.h"
+
+namespace jrlqp
+{
+namespace
+{
+constexpr int WGB = 256;
+constexpr int NONE_B = 0x7fffffff;
+enum : int
+{
+  B_INACTIVE = 0,
+  B_LOWER = 1,
+  B_UPPER = 2,
+  B_EQUALITY = 3,
+  B_LOWER_BOUND = 4,
+  B_UPPER_BOUND = 5,
+  B_FIXED = 6
+};
+enum : int
+{
+  BT_SUCCESS = 0,
+  BT_NON_POS_HESSIAN = 2,
+  BT_INFEASIBLE = 3,
+  BT_MAX_ITER = 4,
+  BT_OVERCONSTRAINED = 6
+};
+
+struct CtlB
+{
+  double red_val[4];
+  double zz, cz, cx, t1, f, rho;
+  double gc, gs, gr; // rotation of the removal step in flight
+  int red_idx[4];
+  int red_stat[4];
+  int l, info, pad0, pad1;
+};
+
+// acc <- chain over k = k0 .. k1-1 (ascending) of fma(+-a[k*sa], b[k*sb], acc); operands a chunk ahead (flat pointers:
+// LDS or global)
+template<bool NEG, int CH = 8>
+__device__ __forceinline__ double chain_asc(const double * a, long sa, const double * b, long sb, int k0, int k1, double acc)
+{
+  int k = k0;
+  for(; k + CH <= k1; k += CH)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      av[u] = a[(k + u) * sa];
+      bv[u] = b[(k + u) * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH; ++u) acc = NEG ? FMA(-av[u], bv[u], acc) : FMA(av[u], bv[u], acc);
+  }
+  for(; k < k1; ++k) acc = NEG ? FMA(-a[k * sa], b[k * sb], acc) : FMA(a[k * sa], b[k * sb], acc);
+  return acc;
+}
+// descending: k = k1-1 .. k0, first operand negated
+template<int CH = 8>
+__device__ __forceinline__ double chain_desc_neg(const double * a, long sa, const double * b, long sb, int k0, int k1, double acc)
+{
+  int k = k1 - 1;
+  for(; k - CH + 1 >= k0; k -= CH)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      av[u] = a[(k - u) * sa];
+      bv[u] = b[(k - u) * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH; ++u) acc = FMA(-av[u], bv[u], acc);
+  }
+  for(; k >= k0; --k) acc = FMA(-a[k * sa], b[k * sb], acc);
+  return acc;
+}
+
+__device__ __forceinline__ void argmin3(double & val, int & idx, int & aux)
+{
+#pragma unroll
+  for(int off = 32; off >= 1; off >>= 1)
+  {
+    const double ov = shfl_xor_d(val, off);
+    const int oi = __shfl_xor(idx, off);
+    const int oa = __shfl_xor(aux, off);
+    const bool take = (oi != NONE_B) && (idx == NONE_B || ov < val || (ov == val && oi < idx));
+    if(take)
+    {
+      val = ov;
+      idx = oi;
+      aux = oa;
+    }
+  }
+}
+
+__global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride, int r_in_lds)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n = A.n, m = A.m, nb = A.nb, mt = m + nb;
+  const int ld = n | 1;
+  const long rlen = (long)n * (n + 1) / 2;
+  const double big = A.big_bnd;
+
+  // LDS carve-up (must match big_lds_bytes below)
+  double * M = smem;                 // L (lower, during init) then J
+  double * xs = M + (long)n * ld;
+  double * zs = xs + n;
+  double * ds = zs + n;
+  double * nps = ds + n;
+  double * us = nps + n;
+  double * rs = us + (n + 2);
+  double * dgl = rs + (n + 2);       // diag(L); later the Givens radii r_{i+1} of an addition
+  double * ccs = dgl + n;
+  double * sss = ccs + n;
+  double * tail = sss + n;
+  double * Rp = r_in_lds ? tail : (ws + (long)blockIdx.x * ws_stride);
+  if(r_in_lds) tail += rlen;
+  CtlB * ctl = reinterpret_cast<CtlB *>(tail);
+  int * act = reinterpret_cast<int *>(ctl + 1);
+  unsigned char * st = reinterpret_cast<unsigned char *>(act + (n + 2));
+  auto RP = [&](int i, int j) -> double & { return Rp[(long)j * (j + 1) / 2 + i]; }; // i <= j
+
+  for(int b = blockIdx.x; b < A.B; b += gridDim.x)
+  {
+    const double * Gg = A.G + (size_t)b * n * n;
+    const double * ag = A.a + (size_t)b * n;
+    const double * Cg = A.C + (size_t)b * n * m;
+    const double * blg = A.bl + (size_t)b * m;
+    const double * bug = A.bu + (size_t)b * m;
+    const double * xlg = nb ? A.xl + (size_t)b * nb : nullptr;
+    const double * xug = nb ? A.xu + (size_t)b * nb : nullptr;
+    __syncthreads(); // (the previous problem's results are out)
+
+    // ---------------------------------------------------------------- load G (lower triangle), reset
+    for(int e = tid; e < n * n; e += WGB)
+    {
+      const int i = e % n, j = e / n;
+      M[i + (long)j * ld] = Gg[e];
+    }
+    for(int i = tid; i < mt; i += WGB) st[i] = 0;
+    if(tid < n) xs[tid] = 0.0;
+    if(tid == 0)
+    {
+      ctl->info = -1;
+      ctl->f = 0.0;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- LLT, left-looking column by column (orc_llt)
+    int info = -1;
+    for(int j = 0; j < n; ++j)
+    {
+      // rows i = j .. n-1 over the threads (two rounds when n - j > 256 never happens: n <= 128)
+      const int i = j + tid;
+      double acc = 0.0;
+      if(i < n) acc = chain_asc<true>(M + i, ld, M + j, ld, 0, j, M[i + (long)j * ld]);
+      if(i == j) ctl->t1 = acc; // pivot before the square root
+      __syncthreads();
+      const double piv = ctl->t1;
+      if(piv <= 0.0)
+      {
+        info = j;
+        break;
+      }
+      const double ljj = __builtin_sqrt(piv);
+      if(i < n) M[i + (long)j * ld] = (i == j) ? ljj : acc / ljj;
+      __syncthreads();
+    }
+    int term = BT_SUCCESS, it = 0, q = 0;
+    if(info >= 0)
+      term = BT_NON_POS_HESSIAN;
+    else
+    {
+      if(A.Lout)
+      {
+        double * Lg = A.Lout + (size_t)b * n * n;
+        for(int e = tid; e < n * n; e += WGB)
+        {
+          const int i = e % n, j = e / n;
+          if(i >= j) Lg[e] = M[i + (long)j * ld];
+        }
+      }
+      // ---------------------------------------------------------------- x0 = -L^-T L^-1 a, f0 (GoldfarbIdnaniSolver.cpp:68-74)
+      // thread i owns x_i; one barrier per substitution step (the pivot travels through LDS)
+      {
+        double xi = (tid < n) ? ag[tid] : 0.0;
+        for(int k = 0; k < n; ++k) // x = L.solve(a)
+        {
+          if(tid == k) zs[k] = xi / M[k + (long)k * ld];
+          __syncthreads();
+          const double v = zs[k];
+          if(tid == k)
+            xi = v;
+          else if(tid > k && tid < n)
+            xi = FMA(-M[tid + (long)k * ld], v, xi);
+        }
+        __syncthreads();
+        for(int k = n - 1; k >= 0; --k) // L^T.solveInPlace(x)
+        {
+          if(tid == k) ds[k] = xi / M[k + (long)k * ld];
+          __syncthreads();
+          const double v = ds[k];
+          if(tid == k)
+            xi = v;
+          else if(tid < k)
+            xi = FMA(-M[k + (long)tid * ld], v, xi);
+        }
+        if(tid < n)
+        {
+          xs[tid] = -xi;
+          dgl[tid] = M[tid + (long)tid * ld];
+        }
+        __syncthreads();
+        if(tid == 0) ctl->f = 0.5 * chain_asc<false>(ag, 1, xs, 1, 0, n, 0.0);
+      }
+      // ---------------------------------------------------------------- J = L^-T in place (orc_inv_lt), row by row from the bottom:
+      // J(i,c) = (delta_ic - sum_{k = c .. i+1, descending} L(k,i) J(k,c)) / L(i,i): column i of L is last read by row i of
+      // J, which only writes the upper triangle -- the two share the array, L's diagonal is in dgl
+      for(int i = n - 1; i >= 0; --i)
+      {
+        const int c = i + tid;
+        if(c < n)
+        {
+          double acc = (c == i) ? 1.0 : 0.0;
+          acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
+          M[i + (long)c * ld] = acc / dgl[i];
+        }
+        __syncthreads();
+      }
+      for(int e = tid; e < n * n; e += WGB) // the strictly lower part of J is zero
+      {
+        const int i = e % n, j = e / n;
+        if(i > j) M[i + (long)j * ld] = 0.0;
+      }
+      __syncthreads();
+    }
+    double * J = M;
+
+    int p = -1, pstat = B_INACTIVE;
+
+    // ---- shared pieces -------------------------------------------------------------------------------------------
+    // n+ of a general constraint -> LDS
+    auto load_np = [&](int pp) {
+      if(pp < m && tid < n) nps[tid] = Cg[(size_t)pp * n + tid];
+    };
+    auto bound_of = [&](int pp, int ps) -> double {
+      const bool lower = (ps == B_LOWER || ps == B_EQUALITY || ps == B_LOWER_BOUND || ps == B_FIXED);
+      if(pp >= m) return lower ? xlg[pp - m] : xug[pp - m];
+      return lower ? blg[pp] : bug[pp];
+    };
+    // computeStep_ + the scalar products of computeStepLength_ (barriers inside: called by every thread)
+    auto compute_step = [&](int pp, int ps) {
+      if(tid < n)
+      {
+        double dj = (pp < m) ? chain_asc<false>(J + (long)tid * ld, 1, nps, 1, 0, n, 0.0) : J[(pp - m) + (long)tid * ld];
+        if(ps == B_UPPER || ps == B_UPPER_BOUND) dj = -dj;
+        ds[tid] = dj;
+      }
+      __syncthreads();
+      if(tid >= 128)
+      {
+        const int i = tid - 128; // z = J2 d2: waves 2-3, one row per thread
+        if(i < n) zs[i] = chain_asc<false>(J + i, ld, ds, 1, q, n, 0.0);
+      }
+      else if(tid < 64)
+      {
+        // r = R^-1 d1 on wave 0, two entries per lane (rows lane and lane + 64), columns k = q-1 .. 0: the quotient of the
+        // pivot row is formed in every lane (same operands, same bits)
+        double r0 = (lane < q) ? ds[lane] : 0.0, r1 = (lane + 64 < q) ? ds[lane + 64] : 0.0;
+        for(int k = q - 1; k >= 0; --k)
+        {
+          const double num = (k < 64) ? bcast_lane(r0, k) : bcast_lane(r1, k - 64);
+          const double v = num / RP(k, k);
+          const double * col = &RP(0, k);
+          if(lane < k) r0 = FMA(-col[lane], v, r0);
+          if(lane + 64 < k) r1 = FMA(-col[lane + 64], v, r1);
+          if(lane == k) r0 = v;
+          if(lane + 64 == k) r1 = v;
+        }
+        if(lane < q) rs[lane] = r0;
+        if(lane + 64 < q) rs[lane + 64] = r1;
+        // t1 = min u_k / r_k over r_k > 0, not EQUALITY/FIXED; status looked up by POSITION (GoldfarbIdnaniSolver.cpp:162)
+        double tk = big;
+        int kk = NONE_B, dummy = 0;
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+        {
+          const int k = lane + 64 * h;
+          const double rk = h ? r1 : r0;
+          if(k < q && rk > 0.0)
+          {
+            const int sk = st[k];
+            const double tt = us[k] / rk;
+            if(sk != B_EQUALITY && sk != B_FIXED && tt < tk)
+            {
+              tk = tt;
+              kk = k;
+            }
+          }
+        }
+        if(kk == NONE_B) tk = big;
+        argmin3(tk, kk, dummy);
+        if(lane == 0)
+        {
+          ctl->t1 = (kk == NONE_B) ? big : tk;
+          ctl->l = (kk == NONE_B) ? 0 : kk;
+        }
+      }
+      __syncthreads();
+      if(tid < 3)
+      {
+        double acc;
+        if(pp < m || tid == 0)
+          acc = chain_asc<false>((tid == 0) ? zs : nps, 1, (tid == 2) ? xs : zs, 1, 0, n, 0.0);
+        else
+          acc = (tid == 1) ? zs[pp - m] : xs[pp - m];
+        if(tid == 0) ctl->zz = acc;
+        if(tid == 1) ctl->cz = acc;
+        if(tid == 2) ctl->cx = acc;
+      }
+      __syncthreads();
+    };
+    // x += t z (if primal), f, u -= t r, u[q] += t   (DualSolver.cpp:136-150)
+    auto apply_step = [&](double t, double dotsc, bool dual_only) {
+      if(!dual_only)
+      {
+        if(tid < n) xs[tid] = FMA(t, zs[tid], xs[tid]);
+        if(tid == 0) ctl->f = FMA(t * dotsc, 0.5 * t + us[q], ctl->f); // uses u[q] BEFORE its update
+      }
+      __syncthreads();
+      if(tid < q) us[tid] = FMA(-t, rs[tid], us[tid]);
+      if(tid == 0) us[q] = us[q] + t;
+      __syncthreads();
+    };
+    // addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237): Givens radii (serial recurrence, wave 0, every lane the same values),
+    // (c_i, s_i) one rotation per thread, sweep of J one row per thread, new column of R
+    auto add_constraint = [&](int pp, int ps) {
+      if(tid < 64)
+      {
+        double rho = ds[n - 1];
+        for(int i = n - 2; i >= q; --i)
+        {
+          if(lane == 0) dgl[i] = rho; // r_{i+1} (the signed d_{n-1} for the first rotation)
+          rho = givens_r_only(ds[i], rho);
+        }
+        if(lane == 0) ctl->rho = rho;
+      }
+      __syncthreads();
+      {
+        const int i = q + tid;
+        if(i <= n - 2)
+        {
+          double c, s, r;
+          make_givens(ds[i], dgl[i], c, s, r);
+          ccs[i] = c;
+          sss[i] = s;
+        }
+      }
+      __syncthreads();
+      if(tid < n)
+      {
+        double carry = J[tid + (long)(n - 1) * ld];
+        for(int i = n - 2; i >= q; --i)
+        {
+          const double xv = J[tid + (long)i * ld];
+          const double c = ccs[i], s = sss[i];
+          J[tid + (long)(i + 1) * ld] = FMA(s, xv, c * carry);
+          carry = FMA(c, xv, -(s * carry));
+        }
+        if(n - 2 >= q) J[tid + (long)q * ld] = carry;
+      }
+      else if(tid >= 128)
+      {
+        const int k = tid - 128;
+        if(k < q)
+          RP(k, q) = ds[k];
+        else if(k == q)
+          RP(q, q) = (n - 2 >= q) ? ctl->rho : ds[q];
+        if(k == 0)
+        {
+          act[q] = pp;
+          st[pp] = (unsigned char)ps;
+        }
+      }
+      __syncthreads();
+    };
+    // removeConstraint (DualSolver.cpp:237-244) + removeConstraint_ (GoldfarbIdnaniSolver.cpp:239-256), orc remove_constraint
+    auto remove_constraint = [&](int l) {
+      const double uv = (tid >= l && tid < q) ? us[tid + 1] : 0.0;
+      const int av = (tid >= l && tid < q - 1) ? act[tid + 1] : 0;
+      const int gone = act[l];
+      __syncthreads();
+      if(tid >= l && tid < q) us[tid] = uv;
+      if(tid >= l && tid < q - 1) act[tid] = av;
+      if(tid == 0) st[gone] = B_INACTIVE;
+      const int qn = q - 1;
+      for(int i = l; i < qn; ++i)
+      {
+        if(tid < i) RP(tid, i) = RP(tid, i + 1);
+        if(tid == 128)
+        {
+          double c, s, r;
+          make_givens(RP(i, i + 1), RP(i + 1, i + 1), c, s, r);
+          ctl->gc = c;
+          ctl->gs = s;
+          ctl->gr = r;
+        }
+        __syncthreads();
+        const double c = ctl->gc, s = ctl->gs;
+        if(tid < n)
+        {
+          const double xv = J[tid + (long)i * ld], yv = J[tid + (long)(i + 1) * ld];
+          J[tid + (long)i * ld] = FMA(c, xv, -(s * yv));
+          J[tid + (long)(i + 1) * ld] = FMA(s, xv, c * yv);
+        }
+        else if(tid >= 128)
+        {
+          const int k = i + 2 + (tid - 128);
+          if(k <= qn)
+          {
+            const double xv = RP(i, k), yv = RP(i + 1, k);
+            RP(i, k) = FMA(c, xv, -(s * yv));
+            RP(i + 1, k) = FMA(s, xv, c * yv);
+          }
+          if(tid == 128) RP(i, i) = ctl->gr;
+        }
+        __syncthreads();
+      }
+      __syncthreads();
+    };
+
+    if(term == BT_SUCCESS)
+    {
+      // ---------------------------------------------------------------- initActiveSet (GoldfarbIdnaniSolver.cpp:268-287)
+      {
+        int cnt = 0;
+        for(int i = tid; i < mt; i += WGB) cnt += ((i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m])) ? 1 : 0;
+        if(tid == 0) ctl->l = 0;
+        __syncthreads();
+        if(cnt) atomicAdd(&ctl->l, cnt);
+        __syncthreads();
+        const int neq = ctl->l;
+        __syncthreads();
+        if(neq > n)
+          term = BT_OVERCONSTRAINED; // UB in the reference; reported (as the oracle does)
+        else if(neq > 0)
+        {
+          for(int i = 0; i < mt; ++i)
+          {
+            const bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
+            if(!eq) continue; // (uniform: every thread reads the same data)
+            p = i;
+            pstat = (i < m) ? B_EQUALITY : B_FIXED;
+            load_np(p);
+            if(tid == 0) us[q] = 0.0;
+            __syncthreads();
+            compute_step(p, pstat);
+            // addInitialConstraint (:295-338): full step, no ratio test
+            const double cz = ctl->cz;
+            double t = 0.0;
+            if(__builtin_sqrt(ctl->zz) > 1e-14) t = (bound_of(p, pstat) - ctl->cx) / cz;
+            apply_step(t, cz, false);
+            add_constraint(p, pstat);
+            ++q;
+          }
+        }
+      }
+    }
+
+    // ---------------------------------------------------------------- main loop (DualSolver.cpp:103-166)
+    if(term == BT_SUCCESS)
+    {
+      bool skip = false;
+      term = BT_MAX_ITER;
+      for(; it < A.max_iter; ++it)
+      {
+        if(!skip)
+        {
+          // selectViolatedConstraint_ (:84-134): most negative slack, general constraints first, lower before upper, first index
+          double bval = 0.0;
+          int bidx = NONE_B, bstat = B_INACTIVE;
+          for(int i = tid; i < m; i += WGB)
+          {
+            if(st[i] != B_INACTIVE) continue;
+            const double cx = chain_asc<false>(Cg + (size_t)i * n, 1, xs, 1, 0, n, 0.0);
+            const double sl = cx - blg[i];
+            if(sl < bval)
+            {
+              bval = sl;
+              bidx = i;
+              bstat = B_LOWER;
+            }
+            else
+            {
+              const double su = bug[i] - cx;
+              if(su < bval)
+              {
+                bval = su;
+                bidx = i;
+                bstat = B_UPPER;
+              }
+            }
+          }
+          for(int i = tid; i < nb; i += WGB)
+          {
+            if(st[m + i] != B_INACTIVE) continue;
+            const double xi = xs[i];
+            const double sl = xi - xlg[i];
+            if(sl < bval)
+            {
+              bval = sl;
+              bidx = m + i;
+              bstat = B_LOWER_BOUND;
+            }
+            else
+            {
+              const double su = xug[i] - xi;
+              if(su < bval)
+              {
+                bval = su;
+                bidx = m + i;
+                bstat = B_UPPER_BOUND;
+              }
+            }
+          }
+          argmin3(bval, bidx, bstat);
+          if(lane == 0)
+          {
+            ctl->red_val[wave] = bval;
+            ctl->red_idx[wave] = bidx;
+            ctl->red_stat[wave] = bstat;
+          }
+          __syncthreads();
+          double v = ctl->red_val[0];
+          int ix = ctl->red_idx[0], sx = ctl->red_stat[0];
+          for(int w = 1; w < 4; ++w)
+          {
+            const double rv = ctl->red_val[w];
+            const int ri = ctl->red_idx[w], rst = ctl->red_stat[w];
+            if(ri != NONE_B && (ix == NONE_B || rv < v || (rv == v && ri < ix)))
+            {
+              v = rv;
+              ix = ri;
+              sx = rst;
+            }
+          }
+          __syncthreads();
+          if(ix == NONE_B)
+          {
+            term = BT_SUCCESS; // DualSolver.cpp:114
+            break;
+          }
+          p = ix;
+          pstat = sx;
+          load_np(p);
+          if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
+          __syncthreads();
+        }
+        compute_step(p, pstat);
+        // computeStepLength_ (:150-219)
+        const double cz = ctl->cz;
+        const double dotsc = (pstat == B_UPPER || pstat == B_UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
+        const double t1 = ctl->t1;
+        const int l = ctl->l;
+        double t2 = big;
+        if(__builtin_sqrt(ctl->zz) > 1e-14) t2 = (bound_of(p, pstat) - ctl->cx) / cz;
+        const double t = (t2 < t1) ? t2 : t1;
+        if(A.trace && tid == 0 && it < A.trace_cap)
+        {
+          jrlqp_trace_rec * tr = A.trace + (size_t)b * A.trace_cap + it;
+          tr->p = p;
+          tr->status = pstat;
+          tr->l = l;
+          tr->kind = (t2 >= big) ? 2 : ((t == t2) ? 0 : 1);
+          tr->t1 = t1;
+          tr->t2 = t2;
+        }
+        if(t >= big)
+        {
+          term = BT_INFEASIBLE; // DualSolver.cpp:131
+          break;
+        }
+        const bool dual_only = (t2 >= big);
+        apply_step(t, dotsc, dual_only);
+        if(!dual_only && t == t2)
+        {
+          add_constraint(p, pstat);
+          ++q;
+          skip = false;
+        }
+        else
+        {
+          remove_constraint(l);
+          --q;
+          skip = true; // same (p, status); u[q] keeps the shifted pending multiplier
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- results (sign-expanded multipliers, DualSolver.cpp:38-69)
+    if(tid < n) A.x[(size_t)b * n + tid] = xs[tid];
+    double * ug = A.u + (size_t)b * mt;
+    int * sg = A.status + (size_t)b * mt;
+    for(int i = tid; i < mt; i += WGB)
+    {
+      ug[i] = 0.0;
+      sg[i] = st[i];
+    }
+    __syncthreads();
+    if(tid < q)
+    {
+      const int i = act[tid];
+      const int s = st[i];
+      ug[i] = (s == B_UPPER || s == B_UPPER_BOUND) ? us[tid] : -us[tid];
+    }
+    if(tid == 0)
+    {
+      A.term[b] = term;
+      A.iters[b] = it;
+      A.f[b] = ctl->f;
+    }
+  }
+}
+
+long big_lds_doubles(int n, int r_in_lds)
+{
+  const long ld = n | 1;
+  long dbl = (long)n * ld + 4L * n + 2L * (n + 2) + 3L * n;
+  if(r_in_lds) dbl += (long)n * (n + 1) / 2;
+  return dbl;
+}
+} // namespace
+
+long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds)
+{
+  for(int rl = 1; rl >= 0; --rl)
+  {
+    const long bytes = ((big_lds_doubles(n, rl) * 8 + (long)sizeof(CtlB) + 4L * (n + 2) + (long)(m + nb)) + 15) & ~15L;
+    if(bytes <= kLdsPerCU)
+    {
+      if(r_in_lds) *r_in_lds = rl;
+      return bytes;
+    }
+  }
+  return -1;
+}
+
+long batch_big_ws_doubles_per_wg(int n)
+{
+  return ((long)n * (n + 1) / 2 + 1) & ~1L;
+}
+
+hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStream_t stream)
+{
+  int r_in_lds = 0;
+  const long lds = batch_big_lds_bytes(a.n, a.m, a.nb, &r_in_lds);
+  if(lds < 0) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL(gi_batch_big_kernel, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, batch_big_ws_doubles_per_wg(a.n), r_in_lds);
+  return hipGetLastError();
+}
+
+} // namespace jrlqp

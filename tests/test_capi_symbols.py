@@ -47,7 +47,12 @@ def test_defaults_and_lds_budget(pkg):
     assert w12 == w16 and c.value == 2  # warm starts are embedded the same way
     lds = lib.jrlqp_gi_batch_lds_bytes(50, 2000, 50, ct.byref(c))
     assert 0 < lds <= 163840 and c.value == 0  # too many constraints: C is streamed
-    assert lib.jrlqp_gi_batch_lds_bytes(65, 10, 0, ct.byref(c)) == -1
+    lds = lib.jrlqp_gi_batch_lds_bytes(100, 200, 0, ct.byref(c))
+    assert 100 * 101 * 8 * 1.5 < lds <= 163840 and c.value == 0  # 64 < n <= 128: J and the packed R in LDS, C streamed
+    lds = lib.jrlqp_gi_batch_lds_bytes(128, 256, 128, ct.byref(c))
+    assert 128 * 129 * 8 < lds <= 163840  # J alone: R goes to the scratch workspace
+    assert lib.jrlqp_gi_batch_warm_lds_bytes(65, 10, 0, ct.byref(c)) == -1  # (no warm start beyond one wavefront of rows)
+    assert lib.jrlqp_gi_batch_lds_bytes(129, 10, 0, ct.byref(c)) == -1
     assert lib.jrlqp_gi_batch_lds_bytes(10, 10, 5, ct.byref(c)) == -1  # nb must be 0 or n
 
 

@@ -1,0 +1,114 @@
+"""GPU parity of the batched path for 64 < n <= 128 (gi_batch_big.hip through jrlqp_gi_solve_batch): the sizes the
+reference's own benchmark families reach (benchmarks/Solvers.cpp:613-623, n = 70 ... 100) and the ABI's ceiling n = 128
+-- termination status, iteration count, activation statuses, x, u, f and the Cholesky factor, bit for bit against the CPU
+oracle; equalities, bounds, double-sided constraints, the other termination statuses and more problems than workgroups
+(the grid is persistent) included."""
+import numpy as np
+import pytest
+
+from test_gpu_batch import assert_bit_identical, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi(pkg):
+    import jrl_qp_amd.capi as capi
+
+    return capi
+
+
+@pytest.fixture(scope="module")
+def P(pkg):
+    import jrl_qp_amd.problems as problems
+
+    return problems
+
+
+BIG_CASES = [
+    dict(nVar=70, nObj=70, nIneq=140, nStrongActIneq=21),  # reference families test1/test3 sizes (30 % active)
+    dict(nVar=80, nObj=80, nIneq=160, nStrongActIneq=40),
+    dict(nVar=100, nObj=100, nIneq=200, nStrongActIneq=30),
+    dict(nVar=128, nObj=128, nIneq=256, nStrongActIneq=38),  # ABI ceiling: R no longer fits in LDS (scratch workspace)
+    dict(nVar=65, nObj=65, nEq=6, nIneq=90, nStrongActIneq=12),  # equalities (initActiveSet)
+    dict(nVar=90, nObj=90, nEq=4, nIneq=100, nStrongActIneq=20, bounds=True, nStrongActBounds=9),  # + bounds
+    dict(nVar=110, nObj=110, nIneq=130, nStrongActIneq=25, doubleSidedIneq=True, nWeakActIneq=6),  # double-sided, weakly active
+    dict(nVar=72, nObj=72),  # unconstrained
+    dict(nVar=128, nObj=128, nEq=10, nIneq=60, nStrongActIneq=15, bounds=True, nStrongActBounds=20, nWeakActBounds=4),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(BIG_CASES)))
+def test_big_n_matches_oracle(capi, P, oracle, ci):
+    ch = P.Characteristics(**BIG_CASES[ci])
+    pb = P.generate_batch(6, ch, first_index=7000 + 20 * ci)
+    hb = ch.bounds
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl if hb else None, pb.xu if hb else None, nthreads=6)
+    gpu = run_gpu(capi, pb, use_bounds=hb, want_factor=True)
+    assert_bit_identical(gpu, ref, f"big case {ci}")
+    assert np.all(ref["term"] == 0)
+    assert np.array_equal(np.tril(gpu["L"].transpose(0, 2, 1)), np.tril(ref["L"].transpose(0, 2, 1)))
+    assert np.max(np.linalg.norm(gpu["x"] - pb.x_star, axis=1)) <= 1e-6 * max(1.0, np.max(np.linalg.norm(pb.x_star, axis=1)))
+    assert int(ref["iters"].max()) > 0 or ch.nIneq + ch.nEq == 0
+
+
+def test_big_n_persistent_grid_more_problems_than_cus(capi, P, oracle):
+    """600 problems at n = 70 on a 256-CU grid: every workgroup solves two or three problems back to back."""
+    pb = P.generate_batch(600, P.benchmark_characteristics(70, 100), first_index=9100)
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=8)
+    gpu = run_gpu(capi, pb)
+    assert_bit_identical(gpu, ref, "n=70 x 600")
+    assert np.all(gpu["term"] == 0)
+
+
+def test_big_n_status_codes_and_trace(capi, P, oracle):
+    n, m = 66, 6
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal(n)
+    C = rng.standard_normal((m, n))
+    bl = np.full(m, -np.inf)
+    mk = lambda G_, bu_, C_=C: P.PackedBatch(n=n, m=m, nb=0, G=G_[None], a=a[None], C=C_[None], bl=bl[None], bu=bu_[None], xl=np.zeros((1, 0)),
+                                             xu=np.zeros((1, 0)), x_star=np.zeros((1, n)), lam_star=np.zeros((1, m)))
+    G = np.eye(n)
+    # MAX_ITER_REACHED, with the per-iteration trace
+    pb = mk(G, np.full(m, -5.0))
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, max_iter=2)
+    gpu = run_gpu(capi, pb, max_iter=2, trace_cap=4)
+    assert_bit_identical(gpu, ref, "max iter")
+    assert gpu["term"][0] == 4 and gpu["iters"][0] == 2
+    r1 = oracle.solve(G, a, C.T, bl, np.full(m, -5.0), max_iter=2, trace_cap=4)
+    for k, rec in enumerate(r1.trace):
+        t = gpu["trace"][0, k]
+        assert (int(t["p"]), int(t["status"]), int(t["l"]), int(t["kind"]), float(t["t1"]), float(t["t2"])) == rec
+    # NON_POS_HESSIAN (first and a later column)
+    for col in (0, 40):
+        Gb = np.eye(n)
+        Gb[col, col] = -1.0
+        pbn = mk(Gb, np.full(m, -5.0))
+        refn = oracle.solve_batch(pbn.G, pbn.a, pbn.C, pbn.bl, pbn.bu)
+        gpun = run_gpu(capi, pbn)
+        assert gpun["term"][0] == refn["term"][0] == 2
+    # INFEASIBLE: x_0 >= 1 and x_0 <= -1
+    C2 = C.copy()
+    C2[0] = 0.0
+    C2[0, 0] = 1.0
+    C2[1] = 0.0
+    C2[1, 0] = -1.0
+    bu2 = np.full(m, 10.0)
+    bu2[0] = bu2[1] = -1.0
+    pbi = mk(G, bu2, C2)
+    refi = oracle.solve_batch(pbi.G, pbi.a, pbi.C, pbi.bl, pbi.bu)
+    gpui = run_gpu(capi, pbi)
+    assert_bit_identical(gpui, refi, "infeasible")
+    assert refi["term"][0] == 3
+
+
+def test_big_n_warm_start_is_refused(capi, P):
+    import torch
+
+    pb = P.generate_batch(2, P.benchmark_characteristics(70, 80), first_index=1)
+    dev = capi.to_device(pb, "cuda:0")
+    s = capi.BatchSolver(pb.n, pb.m, False, pb.B, device="cuda:0")
+    with pytest.raises(capi.JrlqpError):
+        s.solve_warm(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"], guess=None)
+    torch.cuda.synchronize()

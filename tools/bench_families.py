@@ -1,7 +1,7 @@
 """The reference's own benchmark families (benchmarks/Solvers.cpp:613-639: test1 .. test7, 100 random problems per
 size from randomProblem(ProblemCharacteristics(...))) through the batched HIP path, with the CPU
 oracle timed beside it on the same problems and the results compared bit for bit.  Sizes above n = 64 (the families go
-to n = 100) are outside the batched kernel and skipped.  Not the judged bench; writes a table to stdout.
+to n = 100) run through the large-n batched kernel (gi_batch_big.hip).  Not the judged bench; writes a table to stdout.
 
   python tools/bench_families.py [problems-per-size (default 100)] [batch replication (default 20)]
 """
@@ -23,7 +23,7 @@ from oracle_lib import get_oracle
 
 NPROB = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 REP = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-NMAX = 64
+NMAX = 128
 
 
 def families():
