@@ -99,6 +99,13 @@ def main():
     }, open(os.path.join(DST, f"{TAG}_blockgi_c5_batch{nb}_traffic.json"), "w"), indent=1)
     # ---- c2 and the timing logs
     json.dump(first_json_line(os.path.join(SRC, "bench_c2.json")), open(os.path.join(DST, f"{TAG}_bench_line_c2.json"), "w"), indent=1)
+    sq = os.path.join(ROOT, "gpurun_out", "pmc_sq", "summary.json")
+    if os.path.exists(sq):
+        d = json.load(open(sq))
+        d["kernel_source_sha16"], d["commit"] = SHA, COMMIT
+        json.dump(d, open(os.path.join(DST, f"{TAG}_pmc_sq_c3.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(SRC, "families.txt")):
+        shutil.copy(os.path.join(SRC, "families.txt"), os.path.join(DST, f"{TAG}_reference_families.txt"))
     for src, dst in (("c2.log", "c2_dense_timing.txt"), ("time_blockgi.log", "blockgi_timing.txt"), ("time_structured.log", "c5_structured_timing.txt"),
                      ("quick.log", "phase_profile.txt")):
         if os.path.exists(os.path.join(SRC, src)):

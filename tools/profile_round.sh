@@ -17,4 +17,6 @@ python tools/time_dense.py 1024 2048 > $O/c2.log 2>&1
 python tools/time_blockgi.py > $O/time_blockgi.log 2>&1
 python tools/time_structured.py > $O/time_structured.log 2>&1
 python tools/quick_time.py > $O/quick.log 2>&1
+bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1   # SQ counters of the headline kernel: issue / wait split, LDS bank conflicts, instruction mix
+python tools/bench_families.py 64 8 > $O/families.txt 2>&1
 cut -c1-250 $O/bench.json; cut -c1-250 $O/bench_c5.json
