@@ -1843,7 +1843,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         // and the bound.  The LDS-staged extra columns (m > 192) are MAIN's (ws_extras): it has the registers and, after its
         // sweep, the time.
         auto ws_scan = [&](int excl) __attribute__((always_inline)) {
-          constexpr int XG = 8;
+          constexpr int XG = 6;
           static_assert(NR % 2 == 0 || NT == 0, "x is read in pairs");
           const int sbyte = (myc < m) ? st[myc] : 1;
           double cx = 0.0;
