@@ -13,6 +13,9 @@ struct Mailbox
   double uq;            // u[q] before the update (needed by the f update on the host)
   double f0;            // init_
   int llt_info, pad2;
+  // pass tags written LAST by the two blocks of the step kernel (after a system-scope fence): the host state machine polls
+  // them instead of synchronising the stream -- a stream synchronisation wakes up tens of microseconds after the kernel ends
+  volatile int seq0, seq1;
 };
 
 // the caller's problem (device pointers; GoldfarbIdnaniSolver::Problem, GoldfarbIdnaniSolver.h:35-58)
@@ -51,7 +54,7 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
 // spec != nullptr: the Givens coefficient chain of an ADDITION is launched on `spec` as soon as d exists (ev_d), beside
 // z / r / the ratio test on `st`; ev_chain marks its end.  dense_add(..., chain_ready = true) then only commits.
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st,
-                      hipStream_t spec = nullptr, hipEvent_t ev_d = nullptr, hipEvent_t ev_chain = nullptr);
+                      hipStream_t spec = nullptr, hipEvent_t ev_d = nullptr, hipEvent_t ev_chain = nullptr, int tag = 0);
 hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st);
 hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, bool chain_ready = false,
                      hipEvent_t ev_chain = nullptr);

@@ -724,14 +724,29 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
                                                         const double * __restrict__ u, const unsigned char * __restrict__ st, double big,
                                                         const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
                                                         int pb, Mailbox * mb, const int * psel = nullptr, const double * cbase = nullptr, int ldc = 0,
-                                                        int m = 0)
+                                                        int m = 0, int tag = 0)
 {
   extern __shared__ double rs[]; // block 0: the running right-hand side (q) ; block 1: z | x | n+ (3 n)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the pass tag goes out last, behind a system-scope fence: the host polls it (gi_dense_host.cpp)
+  auto post_tag = [&]() {
+    __threadfence_system();
+    if(tid == 0)
+    {
+      if(blockIdx.x == 0)
+        mb->seq0 = tag;
+      else
+        mb->seq1 = tag;
+    }
+  };
   if(psel)
   {
     const int p = psel[0];
-    if(p < 0) return; // nothing violated: the host terminates on the p it reads with this pass's scalars
+    if(p < 0) // nothing violated: the host terminates on the p it reads with this pass's scalars
+    {
+      post_tag();
+      return;
+    }
     cp = (p < m) ? cbase + (size_t)p * ldc : nullptr;
     pb = p - m;
   }
@@ -771,6 +786,7 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
     if(lane == 0) mb->zz = acc;
     if(lane == 1) mb->cz = acc;
     if(lane == 2) mb->cx = acc;
+    post_tag(); // (wave 0 of block 1 wrote the three scalars; thread 0 is one of its lanes)
     return;
   }
 
@@ -895,6 +911,7 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
     mb->l = (kk == NONE) ? 0 : kk;
     mb->uq = u[q];
   }
+  post_tag();
 }
 
 // K9  x += t z ; u[0:q] -= t r ; u[q] += t
@@ -1368,7 +1385,7 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
 }
 
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st, hipStream_t spec,
-                      hipEvent_t ev_d, hipEvent_t ev_chain)
+                      hipEvent_t ev_d, hipEvent_t ev_chain, int tag)
 {
   const int n = v.n;
   const bool dev_p = (p == kSelOnDevice); // (p, status) are read from s.psel by the kernels
@@ -1405,10 +1422,10 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   }
   if(dev_p)
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
-                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m);
+                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag);
   else
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
-                       p - v.m, s.mb, nullptr, nullptr, 0, 0);
+                       p - v.m, s.mb, nullptr, nullptr, 0, 0, tag);
   return hipGetLastError();
 }
 

@@ -5,8 +5,12 @@
 // never leave HBM.  No allocation inside solve(): everything is sized in jrlqp_dense_create.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -33,6 +37,7 @@ struct jrlqp_dense
   hipStream_t spec = nullptr;          // runs the coefficient chain of an addition ahead of the add/drop decision
   hipEvent_t ev_x = nullptr, ev_sel = nullptr, ev_d = nullptr, ev_chain = nullptr;
   bool chain_pending = false;          // a chain launched on `spec` has not been waited for by the main stream yet
+  int tag = 0;                         // pass counter: the step kernel echoes it into the mailbox when its scalars are out
 };
 
 namespace
@@ -47,6 +52,26 @@ namespace
       return JRLQP_ERR_HIP;                      \
     }                                            \
   } while(0)
+
+// Wait for the step kernel of pass `tag` by polling the two tags it writes last into the pinned, host-coherent mailbox.  A
+// stream synchronisation returns tens of microseconds after the kernel has ended; the poll sees the scalars within a few.  The
+// poll gives up after two seconds and lets the caller synchronise the stream (and find the error, if a kernel died).
+inline bool wait_tag(const jrlqp::Mailbox * mb, int tag)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for(unsigned spin = 0;; ++spin)
+  {
+    if(mb->seq0 == tag && mb->seq1 == tag)
+    {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return true;
+    }
+    if((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
 
 template<class T>
 hipError_t dmalloc(T *& p, size_t count)
@@ -87,6 +112,7 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = dmalloc(s.info, 1);
   if(e == hipSuccess) e = dmalloc(s.psel, 2);
   if(e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h->h_mb), sizeof(Mailbox), hipHostMallocMapped);
+  if(e == hipSuccess) std::memset(h->h_mb, 0, sizeof(Mailbox));
   if(e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s.mb), h->h_mb, 0);
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->spec, hipStreamNonBlocking);
@@ -329,12 +355,27 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
     }
   }
 
+  // optional host-side time line of the loop (JRLQP_DENSE_TIMING=1): where the host spends a pass
+  static const bool timing = std::getenv("JRLQP_DENSE_TIMING") != nullptr;
+  double t_launch_step = 0, t_wait = 0, t_rest = 0, t_mark = 0;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  struct Report
+  {
+    const bool & on;
+    double &a, &b, &c;
+    const int & it;
+    ~Report()
+    {
+      if(on) std::fprintf(stderr, "[jrlqp dense] %d passes: launch step %.1f us, wait %.1f us, decide+launch rest %.1f us per pass\n", it, a / (it + 1), b / (it + 1), c / (it + 1));
+    }
+  } report{timing, t_launch_step, t_wait, t_rest, h->it};
   bool skip = false;
   bool prefetched = false; // the scan of this pass already ran on the side stream, beside the previous pass's sweep
   int p = -1, pstat = INACTIVE;
   for(; h->it < o.max_iter; ++h->it)
   {
     const int q = (int)h->active.size();
+    if(timing && t_mark > 0) t_rest += now() - t_mark;
     // ONE host round trip per pass: the selection (on the side stream beside the previous sweep, or here) leaves
     // (p, status) on the device, the step kernels read it there, and the host sees p together with the step's scalars
     if(!skip)
@@ -359,9 +400,19 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
         h->chain_pending = false;
       }
       const bool spec = q < n;
-      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, h->ev_d, h->ev_chain));
+      const int tag = ++h->tag;
+      const double ta = timing ? now() : 0;
+      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, h->ev_d, h->ev_chain, tag));
       h->chain_pending = spec;
-      TRY(hipStreamSynchronize(st));
+      const double tb = timing ? now() : 0;
+      if(!wait_tag(h->h_mb, tag)) TRY(hipStreamSynchronize(st));
+      if(timing)
+      {
+        const double tc = now();
+        t_launch_step += tb - ta;
+        t_wait += tc - tb;
+        t_mark = tc; // (the rest of the pass is closed at the top of the next one)
+      }
       const Mailbox & mb = *h->h_mb;
       if(!skip)
       {
@@ -396,16 +447,19 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
         // x is final once `advance` has run: the next pass's constraint scan (which only reads C, x, bounds and the
         // status bytes) runs on the side stream while the main stream does the Givens sweep; the constraint being
         // activated is excluded explicitly because its status byte is written by the sweep's first kernel
-        if(h->it + 1 < o.max_iter)
+        // (the sweep is on the critical path: it is enqueued first, the side-stream scan behind it -- every launch costs the
+        // host a few microseconds)
+        const bool more = h->it + 1 < o.max_iter;
+        if(more) TRY(hipEventRecord(h->ev_x, st)); // x is final here: the event sits BEFORE the sweep in the main stream
+        TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending, h->ev_chain)); // commit: the chain ran ahead
+        h->chain_pending = false;
+        if(more)
         {
-          TRY(hipEventRecord(h->ev_x, st));
           TRY(hipStreamWaitEvent(h->side, h->ev_x, 0));
           TRY(dense_select(h->v, h->s, p, h->side, q + 1)); // (also u[q+1] = 0 for the next pass: a slot this pass does not touch)
           TRY(hipEventRecord(h->ev_sel, h->side));
           prefetched = true;
         }
-        TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending, h->ev_chain)); // commit: the chain ran ahead
-        h->chain_pending = false;
         activate(p, pstat);
         skip = false;
       }
