@@ -315,3 +315,21 @@ def test_box_and_single_constraint_solver(pkg, oracle):
             assert int(r.term[0]) == 3 and int(r.term[1]) == 0
         else:
             assert int(r.term[0]) == 4
+
+
+@pytest.mark.parametrize("n,m", [(50, 200), (40, 80), (64, 300), (45, 120)])
+def test_iteration_limit_in_the_role_specialised_loop(capi, P, oracle, n, m):
+    """MAX_ITER_REACHED in the hand-off loop of the n >= 40 kernels (every way out of that loop has to release the helper
+    waves): limits 0, 1, 2, 7 and one beyond what the problems need, with the per-iteration trace."""
+    pb = P.generate_batch(48, P.benchmark_characteristics(n, m), first_index=31000 + n)
+    for max_iter in (0, 1, 2, 7, 500):
+        ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, max_iter=max_iter)
+        gpu = run_gpu(capi, pb, max_iter=max_iter, trace_cap=8)
+        assert_bit_identical(gpu, ref, f"n={n} max_iter={max_iter}")
+        if max_iter < 8:
+            assert np.all(gpu["term"] == 4) or max_iter >= int(ref["iters"].max())
+    r0 = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], max_iter=7, trace_cap=8)
+    g = run_gpu(capi, pb, max_iter=7, trace_cap=8)
+    for k, rec in enumerate(r0.trace):
+        t = g["trace"][0, k]
+        assert (int(t["p"]), int(t["status"]), int(t["l"]), int(t["kind"]), float(t["t1"]), float(t["t2"])) == rec
