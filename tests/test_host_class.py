@@ -112,3 +112,10 @@ def test_multiple_uses_no_allocation_and_parity(pkg, oracle, tmp_path):
         assert np.allclose(x, pb.x_star[0], rtol=1e-6, atol=1e-9)
         assert np.allclose(u, pb.lam_star[0], rtol=1e-6, atol=1e-9)
     assert off == len(raw)
+
+
+def test_eigen_adapter_header_parses(tmp_path):
+    """include/jrlqp/EigenAdapter.hpp must be harmless where Eigen is absent (this image) and compile where it is present."""
+    src = tmp_path / "ea.cpp"
+    src.write_text("#include <jrlqp/EigenAdapter.hpp>\n#ifdef JRLQP_HAVE_EIGEN\njrlqp::eigen::GoldfarbIdnaniSolver * s = nullptr;\n#endif\nint main() { return 0; }\n")
+    subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-fsyntax-only", str(src)])
