@@ -455,9 +455,10 @@ __global__ void permute_rows_kernel(double * M, int ldm, int nrhs, int ntot, int
 // which is all the rounding contract fixes, so the result is the bit pattern of the column-by-column reference order,
 // while the critical path is one barrier + one division per COLUMN instead of one LDS round trip per TERM.
 // =========================================================================================================
-__global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
+// (the chain from block i0 on; i0 > 0: the fast kernel below hands over here after a pivot failure at column 0 of block i0,
+// the one failure the reference does not notice -- block i0 as it stands in memory is then the block to go on with)
+__device__ void tri_llt_from(const BlockDesc & D, int i0, double * sm)
 {
-  extern __shared__ double sm[];
   const int tid = threadIdx.x, pb = blockIdx.x;
   int maxb = 0;
   for(int k = 0; k < D.nblk; ++k) maxb = max(maxb, D.bs[k]);
@@ -469,8 +470,8 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
   double * Xs = Ls + (size_t)maxb * ldl;
   double * Ns = Xs + (size_t)maxb * ldl;
   double * diagL = Ns + (size_t)maxb * ldl;
-  load_block(Ls, ldl, D.diag[(size_t)pb * D.nblk], D.ldd[0], D.bs[0], D.bs[0], tid, kTriThreads);
-  for(int i = 0; i < D.nblk; ++i)
+  load_block(Ls, ldl, D.diag[(size_t)pb * D.nblk + i0], D.ldd[i0], D.bs[i0], D.bs[i0], tid, kTriThreads);
+  for(int i = i0; i < D.nblk; ++i)
   {
     const int ni = D.bs[i];
     double * Dg = D.diag[(size_t)pb * D.nblk + i];
@@ -514,6 +515,173 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
       AT(Ns, ldl, r, c) = v;
       AT(D.diag[(size_t)pb * D.nblk + i + 1], D.ldd[i + 1], r, c) = v; // (what a failing factorisation of block i+1 leaves behind)
     }
+    __syncthreads();
+    double * t = Ls; // the updated next block becomes the current one
+    Ls = Ns;
+    Ns = t;
+  }
+}
+
+__global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  tri_llt_from(D, 0, sm);
+}
+
+// acc <- fma(-v, (src of lane LANE), acc) as ONE unit the compiler cannot pull apart: left to itself hipcc hoists the
+// v_readlane pairs of a whole column in front of the fmas and then spills the scalar results through VGPR lanes (four more
+// instructions per term, measured: the register kernel below no faster than the barrier kernel).
+template<int LANE>
+__device__ __forceinline__ void fma_neg_bcast(double & acc, double v, double src)
+{
+  const int lo = __double2loint(src), hi = __double2hiint(src);
+  asm volatile("v_readlane_b32 s90, %2, %4\n\t"
+               "v_readlane_b32 s91, %3, %4\n\t"
+               "s_nop 1\n\t"
+               "v_fma_f64 %0, -%1, s[90:91], %0"
+               : "+v"(acc)
+               : "v"(v), "v"(lo), "v"(hi), "n"(LANE)
+               : "s90", "s91");
+}
+template<int J, int NB, int C = J + 1>
+__device__ __forceinline__ void column_update(double (&a)[NB], double v, double src)
+{
+  if constexpr(C < NB)
+  {
+    fma_neg_bcast<C>(a[C], v, src);
+    column_update<J, NB, C + 1>(a, v, src);
+  }
+}
+
+// column J of the in-register factorisation (lane = row) and the columns after it
+template<int J, int NB>
+__device__ __forceinline__ void llt_columns(double (&a)[NB], int & ret, int lane, int ni, double * Dg, int ldd)
+{
+  if constexpr(J < NB)
+  {
+    if(ret < 0)
+    {
+      const double piv = bcast_lane(a[J], J);
+      if(piv <= 0.0)
+        ret = J;
+      else
+      {
+        const double ljj = __builtin_sqrt(piv);
+        const double lij = (lane == J) ? ljj : a[J] / ljj;
+        a[J] = lij;
+        if(lane >= J && lane < ni && J < ni) AT(Dg, ldd, lane, J) = lij; // (columns before a failing one are final)
+        column_update<J, NB>(a, lij, lij);                               // a[c] -= L(lane, J) * L(c, J) for c > J
+      }
+    }
+    llt_columns<J + 1, NB>(a, ret, lane, ni, Dg, ldd);
+  }
+}
+// column J of X <- X L^-T (lane = row of X, L in the registers a[] of the same lanes) and the columns after it
+template<int J, int NB>
+__device__ __forceinline__ void trsm_columns(double (&x)[NB], const double (&a)[NB])
+{
+  if constexpr(J < NB)
+  {
+    const double xj = x[J] / bcast_lane(a[J], J);
+    x[J] = xj;
+    column_update<J, NB>(x, xj, a[J]); // x[j2] -= x(J) * L(j2, J) for j2 > J
+    trsm_columns<J + 1, NB>(x, a);
+  }
+}
+
+// ---- the same chain for blocks of at most NB rows, the serial part in REGISTERS -----------------------------------------
+// One block costs the barrier-per-column kernel above ~40 us: sixty workgroup barriers around one division each.  Here wave 0
+// keeps its row of the diagonal block in registers (lane = row, a[c] = D(lane, c)), factorises it right-looking -- the pivot
+// and the column entries L(c, j) move by v_readlane, no LDS round trip and no barrier inside a block --, keeps its row of the
+// sub-diagonal block in registers as well for S <- S L^-T, and only the rank update D_{i+1} -= S S^T, which has n^2 independent
+// chains, goes to all four waves through LDS.  Per element the operations and their order are those of block_llt /
+// block_trsm_right_lt (and of the oracle): same bits.  Blocks are padded to NB x NB with the identity (no per-element
+// bounds tests): the padding factorises to the identity and contributes exact zeros.
+template<int NB>
+__global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, pb = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int ldl = NB | 1;
+  double * Ls = sm;                 // the diagonal block being factorised (with its rank update applied)
+  double * Xs = Ls + NB * ldl;      // S_i, then S_i L_i^-T
+  double * Ns = Xs + NB * ldl;      // D_{i+1}
+  __shared__ int s_ret;
+  load_block(Ls, ldl, D.diag[(size_t)pb * D.nblk], D.ldd[0], D.bs[0], D.bs[0], tid, kTriThreads);
+  for(int i = 0; i < D.nblk; ++i)
+  {
+    const int ni = D.bs[i];
+    double * Dg = D.diag[(size_t)pb * D.nblk + i];
+    const int ldd = D.ldd[i];
+    const bool last = (i == D.nblk - 1);
+    const int n1 = last ? 0 : D.bs[i + 1];
+    double * Sg = last ? nullptr : D.side[(size_t)pb * (D.nblk - 1) + i];
+    const int ldsg = last ? 1 : D.lds[i];
+    if(!last)
+    {
+      load_block(Xs, ldl, Sg, ldsg, n1, ni, tid, kTriThreads);
+      load_block(Ns, ldl, D.diag[(size_t)pb * D.nblk + i + 1], D.ldd[i + 1], n1, n1, tid, kTriThreads);
+    }
+    __syncthreads();
+    if(wave == 0)
+    {
+      const bool row = lane < ni;
+      const int rl = row ? lane : 0;
+      double a[NB];
+#pragma unroll
+      for(int c = 0; c < NB; ++c)
+      {
+        const double v = AT(Ls, ldl, rl, (c < ni) ? c : 0);
+        a[c] = (row && c < ni) ? v : ((lane == c) ? 1.0 : 0.0); // identity padding
+      }
+      int ret = -1;
+      llt_columns<0, NB>(a, ret, lane, ni, Dg, ldd);
+      if(lane == 0) s_ret = ret;
+      if(ret < 0 && !last)
+      {
+        // S_i <- S_i L_i^-T, lane = row of S: x(j) = (x(j) - sum_{k<j} x(k) L(j,k)) / L(j,j), right-looking, L from the registers
+        const bool srow = lane < n1;
+        const int sl = srow ? lane : 0;
+        double x[NB];
+#pragma unroll
+        for(int c = 0; c < NB; ++c)
+        {
+          const double v = AT(Xs, ldl, sl, (c < ni) ? c : 0);
+          x[c] = (srow && c < ni) ? v : 0.0;
+        }
+        trsm_columns<0, NB>(x, a);
+#pragma unroll
+        for(int c = 0; c < NB; ++c)
+          if(srow && c < ni)
+          {
+            AT(Xs, ldl, lane, c) = x[c];
+            AT(Sg, ldsg, lane, c) = x[c];
+          }
+      }
+    }
+    __syncthreads();
+    const int ret = s_ret;
+    if(ret > 0) // triBlockDiagLLT.cpp:19,32: the failure the reference reports
+    {
+      if(tid == 0) D.fail[pb] = 1;
+      return;
+    }
+    if(ret == 0) // (a failure at column 0 goes undetected there: the barrier kernel's code reproduces what follows)
+    {
+      __syncthreads();
+      tri_llt_from(D, i, sm);
+      return;
+    }
+    if(last) break;
+    // D_{i+1} -= S_i S_i^T (lower), in LDS: one element per thread, terms in ascending k
+    for(int c = (tid >> 4); c < n1; c += 16)
+      for(int r = (tid & 15); r < n1; r += 16)
+      {
+        if(r < c) continue;
+        const double v = chain2_neg(0, 1, ni, AT(Ns, ldl, r, c), [&](int k) { return AT(Xs, ldl, r, k); }, [&](int k) { return AT(Xs, ldl, c, k); });
+        AT(Ns, ldl, r, c) = v;
+        AT(D.diag[(size_t)pb * D.nblk + i + 1], D.ldd[i + 1], r, c) = v; // (what a failing factorisation of block i+1 leaves behind)
+      }
     __syncthreads();
     double * t = Ls; // the updated next block becomes the current one
     Ls = Ns;
@@ -666,6 +834,24 @@ hipError_t launch_tri_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t 
   hipError_t e = hipMemsetAsync(d.fail, 0, sizeof(int) * nprob, st);
   if(e != hipSuccess) return e;
   const size_t lds = lds_arrow_block(maxb) / 2 * 3 + sizeof(double) * 64;
+  // blocks of at most 48 rows: the register-resident kernel (its LDS must also cover the barrier kernel's, for the hand-over).
+  // It is the LATENCY kernel (one problem: 26 instead of 40 us per block of 30): with 200-300 VGPRs it holds one workgroup per
+  // SIMD group, so that a batch that already fills the chip with the 256-thread barrier kernel stays there (measured: MultiIK
+  // 9 x 43 at batch 1024 251 k vs 229 k factorisation+solves/s; 100 x 30 at batch 64 65 vs 43 us per problem).
+  if(maxb <= 48 && (nprob <= 512 || maxb <= 32))
+  {
+    const int nbk = (maxb <= 32) ? 32 : 48;
+    const size_t l2 = sizeof(double) * 3 * (size_t)nbk * (nbk | 1);
+    const size_t lfast = l2 > lds ? l2 : lds;
+    const void * fn = (nbk == 32) ? reinterpret_cast<const void *>(&tri_llt_fast_kernel<32>) : reinterpret_cast<const void *>(&tri_llt_fast_kernel<48>);
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfast);
+    if(e != hipSuccess) return e;
+    if(nbk == 32)
+      hipLaunchKernelGGL(tri_llt_fast_kernel<32>, dim3(nprob), dim3(kTriThreads), lfast, st, d);
+    else
+      hipLaunchKernelGGL(tri_llt_fast_kernel<48>, dim3(nprob), dim3(kTriThreads), lfast, st, d);
+    return hipGetLastError();
+  }
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_llt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if(e != hipSuccess) return e;
   hipLaunchKernelGGL(tri_llt_kernel, dim3(nprob), dim3(kTriThreads), lds, st, d);
