@@ -158,9 +158,11 @@ public:
   }
 
   /** Same with DEVICE pointers: nothing is copied but the results.  Sizes are those of the last resize().
-   *  Small problems (n <= JRLQP_BATCH_WAVE_N = 64, packed G and C) take the device-resident batched kernel with a batch of one
-   *  -- one launch for the whole solve instead of one host round trip per iteration --, larger ones the host-driven
-   *  hooks (Mode A); both leave the factor in G and give bit-identical results. */
+   *  Problems whose factors fit one CU's LDS (n <= 104, packed G and C) take the device-resident batched kernels with a batch
+   *  of one -- one launch for the whole solve instead of one host round trip per iteration (n = 100: ~2 ms against ~6 ms) --,
+   *  larger ones the host-driven hooks (Mode A); both leave the factor in G and give bit-identical results.  (105 <= n <= 128
+   *  could take the batched path too, but it would bracket the launch with a stream-ordered scratch allocation: Mode A keeps
+   *  the "no allocation once sized" contract to the letter.) */
   TerminationStatus solveDevice(double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl, const double * dbu,
                                 const double * dxl, const double * dxu, hipStream_t stream = nullptr) noexcept
   {
@@ -168,7 +170,7 @@ public:
     jrlqp_options o{options_.maxIter_, options_.bigBnd_};
     int term = int(TerminationStatus::UNKNOWN);
     int cpl = 0;
-    if(n_ <= JRLQP_BATCH_WAVE_N && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
+    if(n_ <= 104 && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
     {
       // dL == dG: the kernel reads G completely before it writes the factor (jrlqp_hip.h), i.e. the reference's in-place contract
       if(!ok(jrlqp_gi_solve_batch(n_, m_, nb_, 1, dG, da, dC, dbl, dbu, dxl, dxu, &o, dx_, du_, dst_, dti_, dti_ + 1, dfv_, dG, nullptr, 0, stream),

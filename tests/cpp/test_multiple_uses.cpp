@@ -101,7 +101,8 @@ static bool rd(std::FILE * f, void * p, size_t bytes)
 
 int main(int argc, char ** argv)
 {
-  CHECK(argc == 3);
+  CHECK(argc == 3 || argc == 4);
+  const bool sizes_mode = (argc == 4); // "sizes": one default-constructed solver over problems of any size, results only
   std::FILE * in = std::fopen(argv[1], "rb");
   CHECK(in);
   int count = 0;
@@ -122,6 +123,38 @@ int main(int argc, char ** argv)
   std::FILE * out = std::fopen(argv[2], "wb");
   CHECK(out);
 
+  if(sizes_mode)
+  {
+    // the three back ends behind the one class: n <= 64 (batched kernel, batch of one), 64 < n <= 104 (large-n batched kernel),
+    // beyond (Mode A); the solver grows as the problems do and then serves the smaller ones again
+    GoldfarbIdnaniSolver any;
+    for(int pass = 0; pass < 2; ++pass)
+      for(Pb p : pbs)
+      {
+        auto st = any.solve({p.G.data(), p.n, p.n, p.n}, {p.a.data(), p.n}, {p.C.data(), p.n, p.m, p.n}, {p.bl.data(), p.m}, {p.bu.data(), p.m},
+                            {p.xl.data(), p.nb}, {p.xu.data(), p.nb});
+        CHECK(any.lastError().empty());
+        if(pass == 1)
+        {
+          const int term = int(st), it = any.iterations();
+          const double f = any.objectiveValue();
+          std::fwrite(&term, 4, 1, out);
+          std::fwrite(&it, 4, 1, out);
+          std::fwrite(&f, 8, 1, out);
+          std::fwrite(any.solution().data(), 8, p.n, out);
+          std::fwrite(any.multipliers().data(), 8, p.m + p.nb, out);
+          std::fwrite(p.G.data(), 8, size_t(p.n) * p.n, out);
+          for(auto s : any.activeSet())
+          {
+            const int v = int(s);
+            std::fwrite(&v, 4, 1, out);
+          }
+        }
+      }
+    std::fclose(out);
+    std::printf("sizes OK\n");
+    return 0;
+  }
   // two pre-sized solvers: the reference's (5, 8, true), which takes the one-launch batched path at these sizes, and one
   // forced through Mode A by a padded leading dimension (solveDevice with ldg > n), so that both back ends are held to
   // the no-allocation contract

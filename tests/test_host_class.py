@@ -68,27 +68,20 @@ def test_multiple_uses_compiles_and_links(pkg, tmp_path):
     _build(str(tmp_path / "multiple_uses"), SRC_MULTI, ("-rdynamic", "-ldl"))
 
 
-@pytest.mark.gpu
-def test_multiple_uses_no_allocation_and_parity(pkg, oracle, tmp_path):
-    """One solver pre-sized (5, 8, true) over the five shapes: no HIP allocation call inside solve() (counted by
-    interposition in the C++ test), SUCCESS, x / multipliers = the planted ones to 1e-6 (the reference's checks), and every
-    output bit-identical to the oracle, the Cholesky factor left in G included."""
+def _write_problems(path, pbs):
     import numpy as np
 
-    import jrl_qp_amd.problems as P
-
-    pbs = [P.generate_batch(1, P.Characteristics(**sh), first_index=3100 + i) for i, sh in enumerate(MULTI_SHAPES)]
-    with open(tmp_path / "problems.bin", "wb") as f:
+    with open(path, "wb") as f:
         np.array([len(pbs)], dtype=np.int32).tofile(f)
         for pb in pbs:
             np.array([pb.n, pb.m, pb.nb], dtype=np.int32).tofile(f)
             for arr in (pb.G[0], pb.a[0], pb.C[0], pb.bl[0], pb.bu[0], pb.xl[0], pb.xu[0]):
                 np.ascontiguousarray(arr, dtype=np.float64).tofile(f)  # G symmetric; C (m, n) C-order == n x m column-major
-    exe = str(tmp_path / "multiple_uses")
-    _build(exe, SRC_MULTI, ("-rdynamic", "-ldl"))
-    out = subprocess.run([exe, str(tmp_path / "problems.bin"), str(tmp_path / "results.bin")], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "multiple uses OK" in out.stdout, out.stdout + out.stderr
-    raw = open(tmp_path / "results.bin", "rb").read()
+
+
+def _check_results(raw, pbs, oracle):
+    import numpy as np
+
     off = 0
     for pb in pbs:
         n, m, nb = pb.n, pb.m, pb.nb
@@ -112,6 +105,44 @@ def test_multiple_uses_no_allocation_and_parity(pkg, oracle, tmp_path):
         assert np.allclose(x, pb.x_star[0], rtol=1e-6, atol=1e-9)
         assert np.allclose(u, pb.lam_star[0], rtol=1e-6, atol=1e-9)
     assert off == len(raw)
+
+
+@pytest.mark.gpu
+def test_host_class_all_three_back_ends(pkg, oracle, tmp_path):
+    """One default-constructed jrlqp::GoldfarbIdnaniSolver over n = 30 (batched kernel, batch of one), n = 80 (large-n batched
+    kernel), n = 120 (Mode A: host-driven hooks), with bounds and equalities, solved twice in a row (growing, then reusing the
+    grown buffers): every output bit-identical to the oracle, the factor left in G included."""
+    import jrl_qp_amd.problems as P
+
+    shapes = [dict(nVar=30, nObj=30, nEq=3, nIneq=40, nStrongActIneq=8, bounds=True, nStrongActBounds=3),
+              dict(nVar=80, nObj=80, nEq=5, nIneq=100, nStrongActIneq=20, bounds=True, nStrongActBounds=6),
+              dict(nVar=120, nObj=120, nIneq=150, nStrongActIneq=30),
+              dict(nVar=12, nObj=12, nIneq=20, nStrongActIneq=4)]
+    pbs = [P.generate_batch(1, P.Characteristics(**sh), first_index=4200 + i) for i, sh in enumerate(shapes)]
+    _write_problems(tmp_path / "problems.bin", pbs)
+    exe = str(tmp_path / "multiple_uses")
+    _build(exe, SRC_MULTI, ("-rdynamic", "-ldl"))
+    out = subprocess.run([exe, str(tmp_path / "problems.bin"), str(tmp_path / "results.bin"), "sizes"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "sizes OK" in out.stdout, out.stdout + out.stderr
+    _check_results(open(tmp_path / "results.bin", "rb").read(), pbs, oracle)
+
+
+@pytest.mark.gpu
+def test_multiple_uses_no_allocation_and_parity(pkg, oracle, tmp_path):
+    """One solver pre-sized (5, 8, true) over the five shapes: no HIP allocation call inside solve() (counted by
+    interposition in the C++ test), SUCCESS, x / multipliers = the planted ones to 1e-6 (the reference's checks), and every
+    output bit-identical to the oracle, the Cholesky factor left in G included."""
+    import numpy as np
+
+    import jrl_qp_amd.problems as P
+
+    pbs = [P.generate_batch(1, P.Characteristics(**sh), first_index=3100 + i) for i, sh in enumerate(MULTI_SHAPES)]
+    _write_problems(tmp_path / "problems.bin", pbs)
+    exe = str(tmp_path / "multiple_uses")
+    _build(exe, SRC_MULTI, ("-rdynamic", "-ldl"))
+    out = subprocess.run([exe, str(tmp_path / "problems.bin"), str(tmp_path / "results.bin")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "multiple uses OK" in out.stdout, out.stdout + out.stderr
+    _check_results(open(tmp_path / "results.bin", "rb").read(), pbs, oracle)
 
 
 def test_eigen_adapter_header_parses(tmp_path):
