@@ -125,7 +125,76 @@ __device__ __forceinline__ void argmin3(double & val, int & idx, int & aux)
   }
 }
 
-__global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride, int r_in_lds)
+// The Givens coefficients of an addition on ONE wave, n up to 128 (GoldfarbIdnaniSolver.cpp:228-231): the radius recurrence
+// r_i = hypot(d_i, r_{i+1}) runs SEEDED and systolically in blocks of 64 steps (device_common.h givens_seed /
+// givens_seeded_step: lane j owns step hi - j, lane 0 is fed the radius the previous block ended on), then every rotation is
+// recomputed from (d_i, r_{i+1}) with the plain formula -- for c_i and s_i, and as the check of the chain: if any radius differs
+// the plain recurrence is run instead.  d, rho (n + 1), ssq (n + 1): LDS; cc, ss receive (c_i, s_i) for i = q .. n-2.
+// Returns the final radius R(q, q).  (The same scheme as add_chain_kernel of gi_dense.hip.)
+__device__ double wave_add_chain(int n, int q, const double * dsm, double * rho, double * ssq, double * cc, double * ss, int lane)
+{
+  double r = 0.0;
+  for(int pass = 0; pass < 2; ++pass)
+  {
+    if(pass == 0)
+    {
+      const int K = (n + 63) / 64; // ssq[i] ~ sum of d_k^2 over k >= i
+      const int c0 = min(lane * K, n), c1 = min(c0 + K, n);
+      double acc = 0.0;
+      for(int i = c1 - 1; i >= c0; --i)
+      {
+        acc = FMA(dsm[i], dsm[i], acc);
+        ssq[i] = acc;
+      }
+      const double above = dpp_shift0_d<0x130>(wave_suffix_sum_approx(acc, lane));
+      for(int i = c0; i < c1; ++i) ssq[i] += above;
+      if(lane == 0) ssq[n] = 0.0;
+      wave_sync();
+      double rprev = dsm[n - 1]; // (signed for the very first rotation, as in the plain loop)
+      for(int hi = n - 2; hi >= q; hi -= 64)
+      {
+        const int lo = (hi - 63 > q) ? (hi - 63) : q;
+        const int cnt = hi - lo + 1;
+        const int mine = hi - lane;
+        const int mi = (mine > 0) ? mine : 0;
+        const GivensSeed g = givens_seed(dsm[mi], ssq[mi + 1]);
+        double rc = 0.0;
+        for(int k = 0; k < cnt; ++k) rc = givens_seeded_step(dpp_shift_d<0x138>(rc, rprev), g);
+        const double rin = dpp_shift_d<0x138>(rc, rprev); // r_{i+1} of this lane's step
+        if(mine >= lo) rho[mine + 1] = rin;
+        rprev = bcast_lane(rc, cnt - 1);
+      }
+      r = rprev;
+    }
+    else
+    {
+      r = dsm[n - 1];
+      for(int i = n - 2; i >= q; --i) // the plain recurrence, every lane the same values
+      {
+        if(lane == 0) rho[i + 1] = r;
+        r = givens_r_only(dsm[i], r);
+      }
+    }
+    wave_sync();
+    bool bad = false;
+    for(int i = q + lane; i <= n - 2; i += 64)
+    {
+      double c, s, rn;
+      make_givens(dsm[i], rho[i + 1], c, s, rn);
+      cc[i] = c;
+      ss[i] = s;
+      if(pass == 0) bad = bad || !(rn == ((i == q) ? r : rho[i])); // the radius this step handed to the next one
+    }
+    if(!__any(bad)) break;
+    wave_sync();
+  }
+  return r;
+}
+
+// RLDS: R lives in LDS (compile-time, so that its accesses are ds_ instructions: with a run-time choice between LDS and the
+// global scratch every access to R is a FLAT load, and the substitution -- two dependent loads per step -- pays ~500 cycles each)
+template<bool RLDS>
+__global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
@@ -147,13 +216,20 @@ __global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A,
   double * dgl = rs + (n + 2);       // diag(L); later the Givens radii r_{i+1} of an addition
   double * ccs = dgl + n;
   double * sss = ccs + n;
-  double * tail = sss + n;
-  double * Rp = r_in_lds ? tail : (ws + (long)blockIdx.x * ws_stride);
-  if(r_in_lds) tail += rlen;
+  double * ssq = sss + n;            // scratch of the coefficient chain (n + 2)
+  double * tail = ssq + (n + 2);
+  double * Rl = tail;                                   // RLDS
+  double * Rg = ws + (long)blockIdx.x * (RLDS ? 0 : ws_stride); // !RLDS (per-workgroup slice of the scratch)
+  if(RLDS) tail += rlen;
   CtlB * ctl = reinterpret_cast<CtlB *>(tail);
   int * act = reinterpret_cast<int *>(ctl + 1);
   unsigned char * st = reinterpret_cast<unsigned char *>(act + (n + 2));
-  auto RP = [&](int i, int j) -> double & { return Rp[(long)j * (j + 1) / 2 + i]; }; // i <= j
+  auto RP = [&](int i, int j) -> double & { // i <= j
+    if constexpr(RLDS)
+      return Rl[j * (j + 1) / 2 + i];
+    else
+      return Rg[(long)j * (j + 1) / 2 + i];
+  };
 
   for(int b = blockIdx.x; b < A.B; b += gridDim.x)
   {
@@ -297,7 +373,17 @@ __global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A,
         const int i = tid - 128; // z = J2 d2: waves 2-3, one row per thread
         if(i < n) zs[i] = chain_asc<false>(J + i, ld, ds, 1, q, n, 0.0);
       }
-      else if(tid < 64)
+      else if(tid >= 64)
+      {
+        // wave 1: the Givens coefficients of a possible ADDITION, speculatively -- they depend on d only, and most passes add
+        // (a pass that drops simply does not use them).  rho in dgl (diag(L) is dead after the prologue).
+        if(n - 2 >= q)
+        {
+          const double rfin = wave_add_chain(n, q, ds, dgl, ssq, ccs, sss, lane);
+          if(lane == 0) ctl->rho = rfin;
+        }
+      }
+      else
       {
         // r = R^-1 d1 on wave 0, two entries per lane (rows lane and lane + 64), columns k = q-1 .. 0: the quotient of the
         // pivot row is formed in every lane (same operands, same bits)
@@ -367,35 +453,32 @@ __global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A,
       if(tid == 0) us[q] = us[q] + t;
       __syncthreads();
     };
-    // addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237): Givens radii (serial recurrence, wave 0, every lane the same values),
-    // (c_i, s_i) one rotation per thread, sweep of J one row per thread, new column of R
+    // addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237): the coefficients come from compute_step (wave 1, speculative); sweep of
+    // J one row per thread, new column of R
     auto add_constraint = [&](int pp, int ps) {
-      if(tid < 64)
-      {
-        double rho = ds[n - 1];
-        for(int i = n - 2; i >= q; --i)
-        {
-          if(lane == 0) dgl[i] = rho; // r_{i+1} (the signed d_{n-1} for the first rotation)
-          rho = givens_r_only(ds[i], rho);
-        }
-        if(lane == 0) ctl->rho = rho;
-      }
-      __syncthreads();
-      {
-        const int i = q + tid;
-        if(i <= n - 2)
-        {
-          double c, s, r;
-          make_givens(ds[i], dgl[i], c, s, r);
-          ccs[i] = c;
-          sss[i] = s;
-        }
-      }
-      __syncthreads();
+      // ((c_i, s_i) and rho: computed beside the step by wave 1, compute_step)
       if(tid < n)
       {
         double carry = J[tid + (long)(n - 1) * ld];
-        for(int i = n - 2; i >= q; --i)
+        int i = n - 2;
+        for(; i - 3 >= q; i -= 4) // four columns per LDS round trip
+        {
+          double xv[4], cv[4], sv[4];
+#pragma unroll
+          for(int u = 0; u < 4; ++u)
+          {
+            xv[u] = J[tid + (long)(i - u) * ld];
+            cv[u] = ccs[i - u];
+            sv[u] = sss[i - u];
+          }
+#pragma unroll
+          for(int u = 0; u < 4; ++u)
+          {
+            J[tid + (long)(i - u + 1) * ld] = FMA(sv[u], xv[u], cv[u] * carry);
+            carry = FMA(cv[u], xv[u], -(sv[u] * carry));
+          }
+        }
+        for(; i >= q; --i)
         {
           const double xv = J[tid + (long)i * ld];
           const double c = ccs[i], s = sss[i];
@@ -517,7 +600,7 @@ __global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A,
           for(int i = tid; i < m; i += WGB)
           {
             if(st[i] != B_INACTIVE) continue;
-            const double cx = chain_asc<false>(Cg + (size_t)i * n, 1, xs, 1, 0, n, 0.0);
+            const double cx = chain_asc<false, 32>(Cg + (size_t)i * n, 1, xs, 1, 0, n, 0.0); // (32 loads in flight: C comes from L2 / HBM)
             const double sl = cx - blg[i];
             if(sl < bval)
             {
@@ -661,7 +744,7 @@ __global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A,
 long big_lds_doubles(int n, int r_in_lds)
 {
   const long ld = n | 1;
-  long dbl = (long)n * ld + 4L * n + 2L * (n + 2) + 3L * n;
+  long dbl = (long)n * ld + 4L * n + 2L * (n + 2) + 3L * n + (n + 2);
   if(r_in_lds) dbl += (long)n * (n + 1) / 2;
   return dbl;
 }
@@ -691,9 +774,13 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
   int r_in_lds = 0;
   const long lds = batch_big_lds_bytes(a.n, a.m, a.nb, &r_in_lds);
   if(lds < 0) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gi_batch_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const void * fn = r_in_lds ? reinterpret_cast<const void *>(&gi_batch_big_kernel<true>) : reinterpret_cast<const void *>(&gi_batch_big_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if(e != hipSuccess) return e;
-  hipLaunchKernelGGL(gi_batch_big_kernel, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, batch_big_ws_doubles_per_wg(a.n), r_in_lds);
+  if(r_in_lds)
+    hipLaunchKernelGGL(gi_batch_big_kernel<true>, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, batch_big_ws_doubles_per_wg(a.n));
+  else
+    hipLaunchKernelGGL(gi_batch_big_kernel<false>, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, batch_big_ws_doubles_per_wg(a.n));
   return hipGetLastError();
 }
 
