@@ -19,6 +19,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_VAR, M_INEQ, BATCH = 50, 200, 4096
+# Rehearsal hook for one-GPU boxes (tests/test_bench_launcher.py): JRLQP_BENCH_SHARED_GPU=1 lets `--gpus N` start its N ranks on
+# cuda:0 with the gloo backend, so that the launcher, the rendezvous, the sharding, the timing protocol and the epilogue
+# collectives of the N > 1 path run end to end.  The line it prints says so ("shared_gpu_rehearsal": true): it is not a
+# scaling number and the driver never sets the variable.
+SHARED_GPU_TEST = os.environ.get("JRLQP_BENCH_SHARED_GPU") == "1"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -149,6 +154,8 @@ def launch_ranks(n, argv):
     import subprocess
 
     have = visible_gpu_count()
+    if SHARED_GPU_TEST and have >= 1:
+        have = n  # rehearsal on a one-GPU box: every rank uses cuda:0, collectives over gloo (never a scaling measurement)
     if have < n:
         print(f"bench.py: --gpus {n} requested but only {have} GPU(s) visible on this node; refusing to run on fewer", file=sys.stderr)
         return 3
@@ -190,13 +197,15 @@ def rank_report(jdist, torch, device, local_solves, elapsed_local, x_local, tota
     ts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(ts, t)
     jdist.all_gather_results(x_local, total)  # warm the communicator / buffers
-    torch.cuda.synchronize(device)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
     dist.barrier()
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
         xa = jdist.all_gather_results(x_local, total)
-    torch.cuda.synchronize(device)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
     ag_ms = (time.perf_counter() - t0) / reps * 1e3
     assert xa.shape[0] == total
     return {"rccl_world_size": world, "backend": dist.get_backend(), "per_rank_solves_per_s": [local_solves / float(v.item()) for v in ts],
@@ -493,13 +502,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
-    if torch.cuda.device_count() < args.gpus:
+    if torch.cuda.device_count() < args.gpus and not SHARED_GPU_TEST:
         print(f"bench.py: --gpus {args.gpus} requested but only {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
         raise SystemExit(3)
-    rank, local_rank, world = jdist.init_process_group()
+    rank, local_rank, world = jdist.init_process_group("gloo" if SHARED_GPU_TEST else None)
     if world != args.gpus:
         raise SystemExit(f"bench.py: process group has {world} rank(s) but --gpus {args.gpus}")
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", local_rank if (world > 1 and not SHARED_GPU_TEST) else 0)
     torch.cuda.set_device(device)
 
     if args.workload == "c5":
@@ -544,8 +553,11 @@ def main():
 
     term = r.term.cpu().numpy()
     iters = r.iters.cpu().numpy()
-    n_ok, sum_it, elapsed = jdist.reduce_stats(int((term == 0).sum()), int(iters.sum()), elapsed, device=device)
-    ranks = rank_report(jdist, torch, device, (hi - lo) * args.steps, elapsed_local, r.x, total)
+    cdev = "cpu" if SHARED_GPU_TEST else device  # (gloo rehearsal: collectives on host tensors)
+    n_ok, sum_it, elapsed = jdist.reduce_stats(int((term == 0).sum()), int(iters.sum()), elapsed, device=cdev)
+    ranks = rank_report(jdist, torch, cdev, (hi - lo) * args.steps, elapsed_local, r.x.cpu() if SHARED_GPU_TEST else r.x, total)
+    if SHARED_GPU_TEST:
+        ranks["shared_gpu_rehearsal"] = True
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -59,3 +59,27 @@ def test_a_failing_rank_fails_the_launch(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     rc = bench.launch_ranks(2, ["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert rc != 0
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_gpu():
+    """The whole N = 2 path of `python bench.py --gpus 2` on the one-GPU box: launcher -> two fresh rank processes -> rendezvous ->
+    each rank generates and solves ITS shard with the HIP solver -> barrier-to-barrier timing, MAX over ranks -> epilogue
+    collectives -> one JSON line from rank 0.  (Both ranks share cuda:0 and talk over gloo: JRLQP_BENCH_SHARED_GPU=1, a rehearsal
+    hook; the line says so and is no scaling measurement.  RCCL itself is exercised by tests/test_gpu_dist.py.)"""
+    import json
+
+    env = dict(_clean_env(), JRLQP_BENCH_SHARED_GPU="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "512"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["requested_gpus"] == 2 and d["steps"] == 3
+    assert d["config"]["total_qps_per_step"] == 1024 and d["config"]["solved"] == 1024
+    rk = d["ranks"]
+    assert rk["rccl_world_size"] == 2 and rk["backend"] == "gloo" and rk["shared_gpu_rehearsal"] is True
+    assert len(rk["per_rank_solves_per_s"]) == 2 and all(v > 0 for v in rk["per_rank_solves_per_s"])
+    assert rk["allgather_x_bytes"] == 1024 * 50 * 8 and rk["allgather_x_ms"] > 0
+    assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline belongs to N = 1 only
