@@ -222,6 +222,17 @@ def test_c3_full_bench_batch(capi, P, oracle, pkg):
     assert np.array_equal(gpu["status"] == 2, pb.lam_star > 0)  # UPPER exactly where the planted multiplier is positive
     assert np.all(gpu["u"] >= 0) and np.max(np.abs(gpu["u"] - pb.lam_star)) <= 1e-6
     assert 25 < gpu["iters"].mean() < 40
+    # the same batch again, several launches back to back on a full chip (three workgroups per CU, every LDS slot re-used by a
+    # later workgroup): the hand-off words of the role-specialised loop must not depend on what a predecessor left behind
+    import torch
+
+    dev = capi.to_device(pb, "cuda:0")
+    s = capi.BatchSolver(pb.n, pb.m, False, pb.B, device="cuda:0")
+    for _ in range(6):
+        r = s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"])
+    torch.cuda.synchronize()
+    assert np.array_equal(r.x.cpu().numpy(), ref["x"]) and np.array_equal(r.iters.cpu().numpy(), ref["iters"])
+    assert np.array_equal(r.u.cpu().numpy(), ref["u"]) and np.array_equal(r.status.cpu().numpy(), ref["status"])
 
 
 def test_trace_matches_oracle(capi, P, oracle):
