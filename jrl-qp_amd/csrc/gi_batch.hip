@@ -60,7 +60,8 @@ enum : int
   T_NON_POS_HESSIAN = 2,
   T_INFEASIBLE = 3,
   T_MAX_ITER = 4,
-  T_OVERCONSTRAINED = 6
+  T_OVERCONSTRAINED = 6,
+  T_UNKNOWN = 7
 };
 
 struct Ctl
@@ -1828,9 +1829,19 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         // (s_wakeup), so the hand-off does not wait for a nap to end.  A wake-up that arrives just before the s_sleep is
         // lost: the nap then bounds the delay.
         constexpr int NAP = 6; // x 64 cycles
-        auto ws_wait = [&](const int * word, int target) __attribute__((always_inline)) {
-          while(__atomic_load_n(word, __ATOMIC_RELAXED) != target) __builtin_amdgcn_s_sleep(NAP);
+        // Every wait is BOUNDED (about a tenth of a second of naps): should a hand-off ever be lost, the waves give up one after
+        // the other, the problem comes back with TerminationStatus UNKNOWN, and the grid drains -- a hung workgroup would hang
+        // the whole launch.
+        constexpr int SPIN_LIMIT = 1 << 19;
+        auto ws_wait = [&](const int * word, int target) __attribute__((always_inline)) -> bool {
+          int spins = 0;
+          while(__atomic_load_n(word, __ATOMIC_RELAXED) != target)
+          {
+            if(++spins > SPIN_LIMIT) return false;
+            __builtin_amdgcn_s_sleep(NAP);
+          }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          return true;
         };
         auto ws_post = [&](int * word, int value) __attribute__((always_inline)) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2073,14 +2084,21 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           int sq = 0, sc = 1;
           int wterm = T_SUCCESS;
           const int rl = (lane < n) ? lane : (n - 1);
+#define WS_WAIT(word, target)      \
+  if(!ws_wait((word), (target)))   \
+  {                                \
+    wterm = T_UNKNOWN;             \
+    goto ws_stop;                  \
+  }
           // first selection: the helpers scan with x = x0
           ws_extras(-1);
-          ws_wait(&ctl->fscan[0], sc);
-          ws_wait(&ctl->fscan[1], sc);
-          ws_wait(&ctl->fscan[2], sc);
-          scan_combine(p, pstat);
+          bool running = ws_wait(&ctl->fscan[0], sc) && ws_wait(&ctl->fscan[1], sc) && ws_wait(&ctl->fscan[2], sc);
+          if(running)
+            scan_combine(p, pstat);
+          else
+            wterm = T_UNKNOWN;
           STAMP3(24)
-          bool running = (p >= 0);
+          running = running && (p >= 0);
           if(running && lane == 0) us[q] = 0.0; // DualSolver.cpp:121
           while(running)
           {
@@ -2149,7 +2167,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             const double t1 = tr_t1;
             const int l = tr_l;
             STAMP3(26)
-            ws_wait(&ctl->fz, sq);
+            WS_WAIT(&ctl->fz, sq)
             STAMP3(27)
             // ---- K8: step length (t2 comes from the z wave)
             const double cz = uniform_d(ctl->cz);
@@ -2180,7 +2198,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             if(add)
             {
               // ---- K10: the coefficients come from the chain wave (speculative since d was published)
-              ws_wait(&ctl->fcs, sq);
+              WS_WAIT(&ctl->fcs, sq)
               STAMP3(29)
               const int qa = uniform(q);
               if(n - 2 >= qa)
@@ -2285,9 +2303,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               ws_extras(p); // (p's status byte is written above, after the helpers may have read it: excluded explicitly)
               STAMP3(30)
               ++sc;
-              ws_wait(&ctl->fscan[0], sc);
-              ws_wait(&ctl->fscan[1], sc);
-              ws_wait(&ctl->fscan[2], sc);
+              WS_WAIT(&ctl->fscan[0], sc)
+              WS_WAIT(&ctl->fscan[1], sc)
+              WS_WAIT(&ctl->fscan[2], sc)
               if(it >= A.max_iter)
               {
                 wterm = T_MAX_ITER; // checked before the next selection (for(; it_ < maxIter_; ...), DualSolver.cpp:103)
@@ -2301,12 +2319,12 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             }
             else
             {
-              ws_wait(&ctl->fdr, sq); // (do_drop hands its rotations on through the vectors d and z)
+              WS_WAIT(&ctl->fdr, sq) // (do_drop hands its rotations on through the vectors d and z)
               do_drop(l);
               q = uniform(q - 1);
               ++it;
               PROF_COUNT3(11)
-              ws_wait(&ctl->fcs, sq); // the chain wave is through with this pass (its chain was abandoned)
+              WS_WAIT(&ctl->fcs, sq) // the chain wave is through with this pass (its chain was abandoned)
               STAMP3(23)
               if(it >= A.max_iter)
               {
@@ -2316,6 +2334,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               // skipStep1: same (p, pstat), u[q] keeps the shifted pending multiplier
             }
           }
+        ws_stop:
+#undef WS_WAIT
           // stop: tell the helpers (they wait either for the next d or for this pass's step)
           if(lane == 0)
           {
@@ -2344,10 +2364,14 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           {
             ++sq;
             // wait for this pass's d (or for the end)
-            int got;
-            while((got = __atomic_load_n(&ctl->fd, __ATOMIC_RELAXED)) != sq && got != -1) __builtin_amdgcn_s_sleep(NAP);
+            int got, spins = 0;
+            while((got = __atomic_load_n(&ctl->fd, __ATOMIC_RELAXED)) != sq && got != -1)
+            {
+              if(++spins > SPIN_LIMIT) break;
+              __builtin_amdgcn_s_sleep(NAP);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if(got == -1) break;
+            if(got != sq) break; // the end, or a hand-off lost (bounded wait)
             const int wp = uniform(ctl->wp), wq = uniform(ctl->wq);
             bool aborted = false;
             if(wave == 0)
@@ -2451,9 +2475,14 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             }
             // ---- the decision
             int fs;
-            while((fs = __atomic_load_n(&ctl->fstep, __ATOMIC_RELAXED)) != sq && fs != -1) __builtin_amdgcn_s_sleep(NAP);
+            spins = 0;
+            while((fs = __atomic_load_n(&ctl->fstep, __ATOMIC_RELAXED)) != sq && fs != -1)
+            {
+              if(++spins > SPIN_LIMIT) break;
+              __builtin_amdgcn_s_sleep(NAP);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if(fs == -1) break;
+            if(fs != sq) break;
             if(uniform(ctl->dec) == 1)
             {
               ++sc;
