@@ -228,7 +228,11 @@ static int gi_batch_common(int warm,
     int dev = 0, ncu = 0;
     if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
       return JRLQP_ERR_NO_DEVICE;
-    const int nwg = B < ncu ? B : ncu;
+    // (as many workgroups per CU as their LDS allows: two up to n = 88, one beyond)
+    const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr);
+    const int per_cu = ldsb > 0 ? (int)(jrlqp::kLdsPerCU / ldsb) : 1;
+    const int slots = ncu * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+    const int nwg = B < slots ? B : slots;
     double * ws = nullptr;
     if(!r_in_lds)
     {

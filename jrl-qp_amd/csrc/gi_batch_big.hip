@@ -194,7 +194,7 @@ __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho,
 // RLDS: R lives in LDS (compile-time, so that its accesses are ds_ instructions: with a run-time choice between LDS and the
 // global scratch every access to R is a FLAT load, and the substitution -- two dependent loads per step -- pays ~500 cycles each)
 template<bool RLDS>
-__global__ __launch_bounds__(WGB, 1) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
+__global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
