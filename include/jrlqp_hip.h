@@ -220,7 +220,7 @@ long jrlqp_gi_batch_warm_lds_bytes(int n, int m, int nb, int * c_placement);
  * upper part untouched) exactly like the reference; C is n x m column-major with leading dimension ldc.
  * Requires n <= JRLQP_DENSE_MAX_N.
  */
-#define JRLQP_DENSE_MAX_N 1024
+#define JRLQP_DENSE_MAX_N 4096
 typedef struct jrlqp_dense jrlqp_dense;
 int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out);
 void jrlqp_dense_destroy(jrlqp_dense * h);

@@ -539,6 +539,7 @@ class BoxAndSingleConstraintSolver:
 
 
 PROFILE_SLOTS, PROFILE_GI_BATCH, PROFILE_BLOCKGI = 32, 0, 1
+DENSE_MAX_N = 4096  # JRLQP_DENSE_MAX_N
 
 
 def set_profile(kernel: int, prof=None):

@@ -1223,26 +1223,42 @@ __global__ __launch_bounds__(128) void rot_apply_kernel(double * J, int ld, int 
     rot_sweep<false>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, lbuf);
 }
 
-// K11 part 1 (one workgroup, thread = NEW column index of R): delete column l of R, restore triangularity with
-// q' - l rotations (q' = q - 1), record (c_i, s_i); shift u; clear the status byte.
+// K11 part 1 (one workgroup; thread tid owns the NEW columns tid + u * blockDim.x, u < NC, of R): delete column l of R,
+// restore triangularity with q' - l rotations (q' = q - 1), record (c_i, s_i); shift u; clear the status byte.
+// NC = 1 up to 1024 active constraints (one column per thread), NC = 4 up to 4096.
+template<int NC>
 __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int q, int l, double * cc, double * ss, double * u, unsigned char * st, int gone)
 {
   __shared__ double gc, gs;
   const int tid = threadIdx.x;
+  const int nt = blockDim.x;
   const int qn = q - 1;
   // u.segment(l, q-l) = u.tail(q-l)   (u has q+1 entries)
-  double uv = 0.0;
-  const bool ush = (tid >= l && tid < q);
-  // columns are handled by threads l .. qn-1 (requires qn - l <= blockDim.x - l; host guarantees q <= 1024)
-  const bool mine = (tid >= l && tid < qn);
-  if(ush) uv = u[tid + 1];
+  double uv[NC];
+#pragma unroll
+  for(int w = 0; w < NC; ++w)
+  {
+    const int k = tid + w * nt;
+    uv[w] = (k >= l && k < q) ? u[k + 1] : 0.0;
+  }
   __syncthreads();
-  if(ush) u[tid] = uv;
+#pragma unroll
+  for(int w = 0; w < NC; ++w)
+  {
+    const int k = tid + w * nt;
+    if(k >= l && k < q) u[k] = uv[w];
+  }
   if(tid == 0) st[gone] = INACTIVE;
   // head rows 0..l-1 of new column k come from old column k+1 (no rotation touches them): thread = row, columns
   // shifted left one after the other (a row is private to its thread: no barrier needed)
-  double carry = mine ? AT(R, ld, l, tid + 1) : 0.0;
-  for(int rr = tid; rr < l; rr += blockDim.x)
+  double carry[NC];
+#pragma unroll
+  for(int w = 0; w < NC; ++w)
+  {
+    const int k = tid + w * nt;
+    carry[w] = (k >= l && k < qn) ? AT(R, ld, l, k + 1) : 0.0;
+  }
+  for(int rr = tid; rr < l; rr += nt)
   {
     // (16 entries of the row requested together, then stored one column to the left: one memory round trip per 16
     // columns instead of one per column; across threads every access is coalesced)
@@ -1251,49 +1267,65 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
     {
       double v[16];
 #pragma unroll
-      for(int u = 0; u < 16; ++u) v[u] = AT(R, ld, rr, k + 1 + u);
+      for(int e = 0; e < 16; ++e) v[e] = AT(R, ld, rr, k + 1 + e);
 #pragma unroll
-      for(int u = 0; u < 16; ++u) AT(R, ld, rr, k + u) = v[u];
+      for(int e = 0; e < 16; ++e) AT(R, ld, rr, k + e) = v[e];
     }
     for(; k < qn; ++k) AT(R, ld, rr, k) = AT(R, ld, rr, k + 1);
   }
   __syncthreads();
-  // Rotation i needs row i+1 of the old R (one entry per column thread, a cache line each): the rows of the next PF
+  // Rotation i needs row i+1 of the old R (one entry per column, a cache line each): the rows of the next PF
   // rotations are requested ahead -- clamped addresses, no predicate -- and the per-rotation hand-off of (c, s) goes
   // through LDS behind LDS-only barriers (a __syncthreads() would drain the prefetches at every step).  A thread only
-  // ever rewrites entries of its own column that it has already consumed.
+  // ever rewrites entries of its own columns that it has already consumed.
   constexpr int PF = 4;
-  const int colr = min(tid + 1, q - 1); // old column this thread reads (clamped for the threads without a column)
-  double yq[PF];
+  int colr[NC]; // old column read for slot w (clamped for the slots without a column)
+  double yq[NC][PF];
 #pragma unroll
-  for(int u = 0; u < PF; ++u) yq[u] = AT(R, ld, min(l + 1 + u, q - 1), colr);
+  for(int w = 0; w < NC; ++w)
+  {
+    colr[w] = min(tid + w * nt + 1, q - 1);
+#pragma unroll
+    for(int e = 0; e < PF; ++e) yq[w][e] = AT(R, ld, min(l + 1 + e, q - 1), colr[w]);
+  }
   for(int i0 = l; i0 < qn; i0 += PF)
   {
 #pragma unroll
-    for(int u = 0; u < PF; ++u)
+    for(int e = 0; e < PF; ++e)
     {
-      const int i = i0 + u;
+      const int i = i0 + e;
       if(i < qn) // (uniform)
       {
-        const double yl = yq[u];
-        yq[u] = AT(R, ld, min(i + 1 + PF, q - 1), colr);
-        const double y = (tid >= i && tid < qn) ? yl : 0.0;
-        if(tid == i)
+        double y[NC];
+#pragma unroll
+        for(int w = 0; w < NC; ++w)
         {
-          double c, s, rho;
-          make_givens(carry, y, c, s, rho);
-          gc = c;
-          gs = s;
-          cc[i] = c;
-          ss[i] = s;
-          AT(R, ld, i, i) = rho;
+          const int k = tid + w * nt;
+          const double yl = yq[w][e];
+          yq[w][e] = AT(R, ld, min(i + 1 + PF, q - 1), colr[w]);
+          y[w] = (k >= i && k < qn) ? yl : 0.0;
+          if(k == i)
+          {
+            double c, s, rho;
+            make_givens(carry[w], y[w], c, s, rho);
+            gc = c;
+            gs = s;
+            cc[i] = c;
+            ss[i] = s;
+            AT(R, ld, i, i) = rho;
+          }
         }
         lds_barrier();
         const double c = gc, s = gs;
-        if(tid > i && tid < qn)
+#pragma unroll
+        for(int w = 0; w < NC; ++w)
         {
-          AT(R, ld, i, tid) = FMA(c, carry, -(s * y));
-          carry = FMA(s, carry, c * y);
+          const int k = tid + w * nt;
+          if(k > i && k < qn)
+          {
+            AT(R, ld, i, k) = FMA(c, carry[w], -(s * y[w]));
+            carry[w] = FMA(s, carry[w], c * y[w]);
+          }
         }
         lds_barrier();
       }
@@ -1314,26 +1346,45 @@ static size_t tail_lds(int n, int q)
 {
   return sizeof(double) * (size_t)((3 * n > q + 2) ? 3 * n : q + 2);
 }
-// step_tail_kernel stages three n-vectors in LDS: beyond 64 KiB (n > 2730) the launch needs the limit raised (once)
-static hipError_t tail_attr(int n)
+// Dynamic LDS beyond the default 64 KiB (step_tail: three n-vectors, n > 2730; rot_apply: the (c, s) pairs of a sweep,
+// more than ~1900 rotations; add_chain: the third vector of the seeded recurrence): the limit is raised once, to the
+// 160 KiB of a gfx950 CU.
+constexpr size_t kLdsDefault = 65536, kLdsMax = 160 * 1024;
+template<class K>
+static hipError_t raise_lds(K kernel, bool & done, size_t need)
 {
-  static bool done = false;
-  if(done || tail_lds(n, 0) <= 65536) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if(done || need <= kLdsDefault) return hipSuccess;
+  if(need > kLdsMax) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
   if(e == hipSuccess) done = true;
   return e;
 }
+static hipError_t tail_attr(int n)
+{
+  static bool done = false;
+  return raise_lds(&step_tail_kernel, done, tail_lds(n, 0));
+}
+static hipError_t rot_attr(int T)
+{
+  static bool done = false;
+  return raise_lds(&rot_apply_kernel, done, rot_lds(T));
+}
 
-// add_chain_kernel: the seeded recurrence needs a third LDS vector; beyond the default 64 KiB it falls back to the plain one
+// add_chain_kernel: the seeded recurrence needs a third LDS vector; beyond a CU's LDS it falls back to the plain one
 static int chain_seeded(int n)
 {
   const int mode = chain_debug_mode();
-  if(mode == 1 || sizeof(double) * (3 * (size_t)n + 2) > 65536) return 0;
+  if(mode == 1 || sizeof(double) * (3 * (size_t)n + 2) > kLdsMax) return 0;
   return mode == 2 ? 2 : 1;
 }
 static size_t chain_lds(int n)
 {
   return sizeof(double) * ((chain_seeded(n) ? 3 : 2) * (size_t)n + 2);
+}
+static hipError_t chain_attr(int n)
+{
+  static bool done = false;
+  return raise_lds(&add_chain_kernel, done, chain_lds(n));
 }
 
 hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st)
@@ -1411,6 +1462,8 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     hipError_t e = hipEventRecord(ev_d, st);
     if(e == hipSuccess) e = hipStreamWaitEvent(spec, ev_d, 0);
     if(e != hipSuccess) return e;
+    if(e == hipSuccess) e = chain_attr(n);
+    if(e != hipSuccess) return e;
     hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
     e = hipEventRecord(ev_chain, spec);
     if(e != hipSuccess) return e;
@@ -1445,7 +1498,15 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
     if(e != hipSuccess) return e;
   }
   else
+  {
+    hipError_t e = chain_attr(n);
+    if(e != hipSuccess) return e;
     hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
+  }
+  {
+    hipError_t e = rot_attr(n);
+    if(e != hipSuccess) return e;
+  }
   if(n - 2 >= q)
     hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
                        CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat});
@@ -1457,9 +1518,18 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st)
 {
   const int n = v.n;
-  const int rthreads = ((q + 63) / 64) * 64; // thread = column (q <= 1024): no more waves at the barriers than columns need
-  hipLaunchKernelGGL(remove_r_kernel, dim3(1), dim3(rthreads), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
+  if(q <= 1024)
+  {
+    const int rthreads = ((q + 63) / 64) * 64; // thread = column: no more waves at the barriers than columns need
+    hipLaunchKernelGGL(remove_r_kernel<1>, dim3(1), dim3(rthreads), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
+  }
+  else // four columns per thread (q <= 4096 = JRLQP_DENSE_MAX_N)
+    hipLaunchKernelGGL(remove_r_kernel<4>, dim3(1), dim3(1024), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
   const int qn = q - 1;
+  {
+    hipError_t e = rot_attr(n);
+    if(e != hipSuccess) return e;
+  }
   if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(qn - l), st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
   return hipGetLastError();
 }

@@ -270,7 +270,7 @@ int jrlqp_dense_add(jrlqp_dense * h, int p, int status, int q, void * stream)
 // active constraints BEFORE the removal, `index` = constraint index of the l-th active constraint
 int jrlqp_dense_remove(jrlqp_dense * h, int l, int q, int index, void * stream)
 {
-  if(!h || !h->bound || l < 0 || l >= q || q > 1024) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(!h || !h->bound || l < 0 || l >= q || q > JRLQP_DENSE_MAX_N) return JRLQP_ERR_INVALID_ARGUMENT;
   TRY(dense_remove(h->v, h->s, l, q, index, static_cast<hipStream_t>(stream)));
   return JRLQP_OK;
 }

@@ -102,6 +102,42 @@ def test_c2_full_size(capi, P, oracle):
     assert int((gpu["status"] != 0).sum()) >= 307
 
 
+def test_dense_beyond_1024(capi, P, oracle):
+    """n = 1400 with 1300 strongly active constraints: more than 1024 columns of R (remove_r_kernel<4>: four columns per
+    thread; 28 of the 183 removals happen there), sweeps of more than 1024 rotations, LDS beyond 64 KiB in rot_apply."""
+    ch = P.Characteristics(nVar=1400, nObj=1400, nIneq=1800, nStrongActIneq=1300)
+    pb = P.generate_batch(1, ch, first_index=77)
+    ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], max_iter=100000, trace_cap=4000)
+    q, deep = 0, 0
+    for (_, _, _, kind, _, _) in ref.trace:
+        if kind == 0:
+            q += 1
+        else:
+            deep += q > 1024
+            q -= 1
+    assert ref.term == 0 and deep >= 10
+    gpu = solve_gpu(capi, pb, 0, False, max_iter=100000)
+    check(gpu, ref, "n=1400")
+    assert np.array_equal(np.tril(gpu["L"]), np.tril(ref.L))
+
+
+def test_dense_n2800(capi, P, oracle):
+    """Beyond 2730 unknowns the step kernel's three staged vectors need more than the default 64 KiB of LDS, the sweep's
+    (c, s) table too, and the coefficient chain its third vector (all raised to the CU's 160 KiB once)."""
+    ch = P.Characteristics(nVar=2800, nObj=2800, nIneq=300, nStrongActIneq=60)
+    pb = P.generate_batch(1, ch, first_index=5)
+    ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], max_iter=100000)
+    gpu = solve_gpu(capi, pb, 0, False, max_iter=100000)
+    check(gpu, ref, "n=2800")
+    assert ref.term == 0 and ref.iters >= 60
+    assert np.array_equal(np.tril(gpu["L"]), np.tril(ref.L))
+
+
+def test_dense_size_limit(capi):
+    with pytest.raises(capi.JrlqpError):
+        capi.DenseSolver(capi.DENSE_MAX_N + 1, 1, False)
+
+
 def test_dense_status_codes(capi, P, oracle):
     n, m = 4, 6
     rng = np.random.default_rng(5)
