@@ -17,6 +17,7 @@
 // Blocks are at most 64 x 64 (one wavefront row-per-lane); the substitutions keep the running column in
 // registers and move pivots with v_readlane, like the dense kernel.  -ffp-contract=off; every fma explicit.
 #include <hip/hip_runtime.h>
+#include <climits>
 
 #include "device_common.h"
 #include "structured.h"
@@ -531,98 +532,232 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
 // acc <- fma(-v, (src of lane LANE), acc) as ONE unit the compiler cannot pull apart: left to itself hipcc hoists the
 // v_readlane pairs of a whole column in front of the fmas and then spills the scalar results through VGPR lanes (four more
 // instructions per term, measured: the register kernel below no faster than the barrier kernel).
-template<int LANE>
+// GUARD: the unit starts with a wait state.  The hardware wants one between a VALU write of a VGPR and a v_readlane of it, the
+// compiler inserts it for its own instructions but cannot see into the unit: a unit issued right behind the v_cndmask that
+// produced `src` read a stale low half (measured: factors off by 1e-8).  The first unit behind a new `src` is guarded.
+template<int LANE, bool GUARD = false>
 __device__ __forceinline__ void fma_neg_bcast(double & acc, double v, double src)
 {
   const int lo = __double2loint(src), hi = __double2hiint(src);
-  asm volatile("v_readlane_b32 s90, %2, %4\n\t"
-               "v_readlane_b32 s91, %3, %4\n\t"
-               "s_nop 1\n\t"
-               "v_fma_f64 %0, -%1, s[90:91], %0"
-               : "+v"(acc)
-               : "v"(v), "v"(lo), "v"(hi), "n"(LANE)
-               : "s90", "s91");
+  if constexpr(GUARD)
+    asm volatile("s_nop 1\n\t"
+                 "v_readlane_b32 s90, %2, %4\n\t"
+                 "v_readlane_b32 s91, %3, %4\n\t"
+                 "s_nop 1\n\t"
+                 "v_fma_f64 %0, -%1, s[90:91], %0\n\t"
+                 "s_nop 0"
+                 : "+v"(acc)
+                 : "v"(v), "v"(lo), "v"(hi), "n"(LANE)
+                 : "s90", "s91");
+  else
+    asm volatile("v_readlane_b32 s90, %2, %4\n\t"
+                 "v_readlane_b32 s91, %3, %4\n\t"
+                 "s_nop 1\n\t"
+                 "v_fma_f64 %0, -%1, s[90:91], %0"
+                 : "+v"(acc)
+                 : "v"(v), "v"(lo), "v"(hi), "n"(LANE)
+                 : "s90", "s91");
 }
-template<int J, int NB, int C = J + 1>
+template<int J, int NB, int C = J + 1, bool FIRST = true>
 __device__ __forceinline__ void column_update(double (&a)[NB], double v, double src)
 {
   if constexpr(C < NB)
   {
-    fma_neg_bcast<C>(a[C], v, src);
-    column_update<J, NB, C + 1>(a, v, src);
+    fma_neg_bcast<C, FIRST>(a[C], v, src);
+    column_update<J, NB, C + 1, false>(a, v, src);
   }
 }
 
-// column J of the in-register factorisation (lane = row) and the columns after it
+// LDS hand-off words between the waves of the register kernel below.  Values only ever grow (they carry the block number), so
+// a word never has to be reset.  A waiting wave naps; the posting wave wakes the sleepers of its workgroup.  Every wait is
+// bounded: a lost hand-off would otherwise hang the launch.
+__device__ __forceinline__ void tri_post(int * word, int value, int lane)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if(lane == 0) __atomic_store_n(word, value, __ATOMIC_RELAXED);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+}
+// The same without the waits, for a wave that posts a word behind LDS stores of its OWN: a wave's LDS operations are carried
+// out in the order it issued them, so the word cannot become visible before the data; the reader polls in short naps.
+__device__ __forceinline__ void tri_post_inorder(int * word, int value, int lane)
+{
+  asm volatile("" ::: "memory");
+  if(lane == 0) __atomic_store_n(word, value, __ATOMIC_RELAXED);
+  asm volatile("" ::: "memory");
+}
+// waits until *word > than; returns the value seen, or INT_MIN after about a tenth of a second
+__device__ __forceinline__ int tri_wait_gt(const int * word, int than)
+{
+  int spins = 0, v;
+  while((v = __atomic_load_n(word, __ATOMIC_RELAXED)) <= than)
+  {
+    if(++spins > (1 << 20)) return INT_MIN;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return v;
+}
+
+// column J of the in-register factorisation (lane = row) and the columns after it.  A finished column goes to LDS at once
+// (Ls, leading dimension NB | 1) and `ready` is raised to base + J + 1: the wave that computes S L^-T follows one column behind.
+// LOOK-AHEAD: the square root and the division of column J + 1 (piv, ljj = sqrt(piv), lq = a[J] / ljj arrive from the column
+// before) are started as soon as column J + 1 has received its term of column J, and the terms of the columns after it are
+// issued in their latency -- per element the operations and their order do not change.
 template<int J, int NB>
-__device__ __forceinline__ void llt_columns(double (&a)[NB], int & ret, int lane, int ni, double * Dg, int ldd)
+__device__ __forceinline__ void llt_columns(double (&a)[NB], int & ret, int lane, double * Ls, int * ready, int base, double piv, double ljj, double lq)
 {
   if constexpr(J < NB)
   {
-    if(ret < 0)
+    if(piv <= 0.0)
     {
-      const double piv = bcast_lane(a[J], J);
-      if(piv <= 0.0)
-        ret = J;
+      ret = J;
+      return;
+    }
+    const double lij = (lane == J) ? ljj : lq;
+    a[J] = lij;
+    if(lane >= J && lane < NB) Ls[lane + J * (NB | 1)] = lij;
+    tri_post_inorder(ready, base + J + 1, lane);
+    // The terms of the columns after J + 1 take L(c, J) back from LDS (one address for the wave: a broadcast; two issue slots
+    // per term where the v_readlane unit takes six).  Order of issue: the reads, then the unit for column J + 1 and the square
+    // root and division of that column -- in the latency of the reads --, then the terms.
+    const double * col = Ls + J * (NB | 1);
+    double lc[NB];
+#pragma unroll
+    for(int c = J + 2; c < NB; ++c) lc[c] = col[c];
+    double pn = 0.0, ln = 0.0, qn = 0.0;
+    if constexpr(J + 1 < NB)
+    {
+      fma_neg_bcast<J + 1, true>(a[J + 1], lij, lij); // a[J+1] -= L(lane, J) * L(J+1, J)  (guarded on both sides: the pivot
+                                                      // is read out of a[J+1] with v_readlane right behind it)
+      pn = bcast_lane(a[J + 1], J + 1);
+      ln = __builtin_sqrt(pn); // (a non-positive pivot gives a NaN nobody uses)
+      qn = a[J + 1] / ln;
+      asm volatile("" : "+v"(ln), "+v"(qn)); // (computed HERE: left alone, the compiler sinks both into the next column's block)
+    }
+#pragma unroll
+    for(int c = J + 2; c < NB; ++c) a[c] = FMA(-lij, lc[c], a[c]); // a[c] -= L(lane, J) * L(c, J)
+#pragma unroll
+    for(int c = J + 2; c < NB; ++c) asm volatile("" : "+v"(a[c])); // (pinned to this column, see trsm_columns)
+    llt_columns<J + 1, NB>(a, ret, lane, Ls, ready, base, pn, ln, qn);
+  }
+}
+// column J of X <- X L^-T (lane = row of X) and the columns after it; column J of L is read from LDS (one address for the whole
+// wave: a broadcast read) as soon as the factorising wave has published it
+template<int J, int NB>
+__device__ __forceinline__ void trsm_columns(double (&x)[NB], const double * Ls, const int * ready, int base, bool & dead)
+{
+  if constexpr(J < NB)
+  {
+    if(!dead)
+    {
+      const int seen = tri_wait_gt(ready, base + J);
+      if(seen > base + NB) // INT_MIN never gets here; base + NB + 1: the factorisation failed, base + NB + 2: timeout elsewhere
+        dead = true;
+      else if(seen == INT_MIN)
+        dead = true;
       else
       {
-        const double ljj = __builtin_sqrt(piv);
-        const double lij = (lane == J) ? ljj : a[J] / ljj;
-        a[J] = lij;
-        if(lane >= J && lane < ni && J < ni) AT(Dg, ldd, lane, J) = lij; // (columns before a failing one are final)
-        column_update<J, NB>(a, lij, lij);                               // a[c] -= L(lane, J) * L(c, J) for c > J
+        const double * col = Ls + J * (NB | 1);
+        double lc[NB];
+#pragma unroll
+        for(int c = J; c < NB; ++c) lc[c] = col[c];
+        const double xj = x[J] / lc[J];
+        x[J] = xj;
+#pragma unroll
+        for(int c = J + 1; c < NB; ++c) x[c] = FMA(-xj, lc[c], x[c]); // x[c] -= x(J) * L(c, J)
+        // The terms are pinned to their column: left alone, the compiler sinks every term to the column that consumes x[c]
+        // -- left-looking, all of L live in registers, hundreds of spills.  (One pin per column END: a pin after every term
+        // also serialises the LDS reads, 40 cycles per term.)
+#pragma unroll
+        for(int c = J + 1; c < NB; ++c) asm volatile("" : "+v"(x[c]));
       }
     }
-    llt_columns<J + 1, NB>(a, ret, lane, ni, Dg, ldd);
-  }
-}
-// column J of X <- X L^-T (lane = row of X, L in the registers a[] of the same lanes) and the columns after it
-template<int J, int NB>
-__device__ __forceinline__ void trsm_columns(double (&x)[NB], const double (&a)[NB])
-{
-  if constexpr(J < NB)
-  {
-    const double xj = x[J] / bcast_lane(a[J], J);
-    x[J] = xj;
-    column_update<J, NB>(x, xj, a[J]); // x[j2] -= x(J) * L(j2, J) for j2 > J
-    trsm_columns<J + 1, NB>(x, a);
+    trsm_columns<J + 1, NB>(x, Ls, ready, base, dead);
   }
 }
 
-// ---- the same chain for blocks of at most NB rows, the serial part in REGISTERS -----------------------------------------
-// One block costs the barrier-per-column kernel above ~40 us: sixty workgroup barriers around one division each.  Here wave 0
-// keeps its row of the diagonal block in registers (lane = row, a[c] = D(lane, c)), factorises it right-looking -- the pivot
-// and the column entries L(c, j) move by v_readlane, no LDS round trip and no barrier inside a block --, keeps its row of the
-// sub-diagonal block in registers as well for S <- S L^-T, and only the rank update D_{i+1} -= S S^T, which has n^2 independent
-// chains, goes to all four waves through LDS.  Per element the operations and their order are those of block_llt /
-// block_trsm_right_lt (and of the oracle): same bits.  Blocks are padded to NB x NB with the identity (no per-element
-// bounds tests): the padding factorises to the identity and contributes exact zeros.
+// ---- the same chain for blocks of at most NB rows, the serial part in REGISTERS, the waves in different roles -----------------
+// One block costs the barrier-per-column kernel above ~40 us: sixty workgroup barriers around one division each.  Here
+//   wave 0 keeps its row of the diagonal block in registers (lane = row, a[c] = D(lane, c)) and factorises it right-looking --
+//          pivot and column entries L(c, j) move by v_readlane, no LDS round trip, no barrier inside a block -- and publishes
+//          every finished column in LDS;
+//   wave 1 keeps its row of the sub-diagonal block in registers and computes S <- S L^-T one column behind wave 0;
+//   waves 2, 3 fetch S_i and D_{i+1} from memory meanwhile;
+// then all four waves store L_i and S_i and apply the rank update D_{i+1} -= S S^T (n^2 independent chains) through LDS.
+// Per element the operations and their order are those of block_llt / block_trsm_right_lt (and of the oracle): same bits.
+// Blocks are padded to NB x NB with the identity (no per-element bounds tests): the padding factorises to the identity and
+// contributes exact zeros.
+// rows x cols block from memory to LDS by ONE wave, lane = row: every load of the block in flight at once (clamped addresses,
+// no predicate), then the stores
+template<int NB>
+__device__ __forceinline__ void load_rows(double * dst, const double * src, int ld, int rows, int cols, int lane)
+{
+  double v[NB];
+  const int r = min(lane, rows - 1);
+#pragma unroll
+  for(int c = 0; c < NB; ++c) v[c] = src[r + (size_t)min(c, cols - 1) * ld];
+#pragma unroll
+  for(int c = 0; c < NB; ++c)
+    if(lane < rows && c < cols) dst[lane + c * (NB | 1)] = v[c];
+}
+
 template<int NB>
 __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDesc D)
 {
   extern __shared__ double sm[];
   const int tid = threadIdx.x, pb = blockIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int ldl = NB | 1;
-  double * Ls = sm;                 // the diagonal block being factorised (with its rank update applied)
-  double * Xs = Ls + NB * ldl;      // S_i, then S_i L_i^-T
-  double * Ns = Xs + NB * ldl;      // D_{i+1}
-  __shared__ int s_ret;
-  load_block(Ls, ldl, D.diag[(size_t)pb * D.nblk], D.ldd[0], D.bs[0], D.bs[0], tid, kTriThreads);
+  int opaque_zero = 0; // (rewritten by an empty asm statement per block, see below)
+  double * Ls = sm;                 // the diagonal block being factorised (with its rank update applied), then L_i
+  double * Ns = Ls + NB * ldl;      // D_{i+1}
+  double * Xa = Ns + NB * ldl;      // S_i, then S_i L_i^-T (blocks with even i)
+  double * Xb = Xa + NB * ldl;      // the same for odd i: S_{i+1} is fetched while block i is factorised
+  __shared__ int s_ret, s_ready, s_lost;
+#ifdef TRI_PROF
+  long long tp_acc[6] = {0, 0, 0, 0, 0, 0}, tp_t = __builtin_amdgcn_s_memtime();
+#define TP(k) { const long long now_ = __builtin_amdgcn_s_memtime(); tp_acc[k] += now_ - tp_t; tp_t = now_; }
+#else
+#define TP(k)
+#endif
+  if(tid == 0)
+  {
+    s_ready = 0;
+    s_lost = 0;
+  }
+  double ** const diag = D.diag + (size_t)pb * D.nblk;
+  double ** const side = D.side + (size_t)pb * (D.nblk - 1);
+  if(wave < 2)
+    load_block(Ls, ldl, diag[0], D.ldd[0], D.bs[0], D.bs[0], tid, 128);
+  else if(wave == 2 && D.nblk > 1)
+    load_rows<NB>(Xa, side[0], D.lds[0], D.bs[1], D.bs[0], lane);
+  __syncthreads();
+  // the descriptors of a block are read one block ahead (scalar loads share their counter with the LDS operations: a load
+  // issued where its value is needed stalls the first LDS wait behind it for a memory round trip)
+  int ni = D.bs[0], ldd = D.ldd[0];
+  double * Dg = diag[0];
+  int n1 = 0, ldn = 1, ldsg = 1;
+  double *Dn = nullptr, *Sg = nullptr;
+  if(D.nblk > 1)
+  {
+    n1 = D.bs[1];
+    ldn = D.ldd[1];
+    Dn = diag[1];
+    Sg = side[0];
+    ldsg = D.lds[0];
+  }
   for(int i = 0; i < D.nblk; ++i)
   {
-    const int ni = D.bs[i];
-    double * Dg = D.diag[(size_t)pb * D.nblk + i];
-    const int ldd = D.ldd[i];
     const bool last = (i == D.nblk - 1);
-    const int n1 = last ? 0 : D.bs[i + 1];
-    double * Sg = last ? nullptr : D.side[(size_t)pb * (D.nblk - 1) + i];
-    const int ldsg = last ? 1 : D.lds[i];
-    if(!last)
-    {
-      load_block(Xs, ldl, Sg, ldsg, n1, ni, tid, kTriThreads);
-      load_block(Ns, ldl, D.diag[(size_t)pb * D.nblk + i + 1], D.ldd[i + 1], n1, n1, tid, kTriThreads);
-    }
-    __syncthreads();
+    const bool more = (i + 2 < D.nblk);
+    // block i + 2 / side block i + 1 (used from the next iteration on)
+    const int n2 = more ? D.bs[i + 2] : 0, ld2 = more ? D.ldd[i + 2] : 1, lds2 = more ? D.lds[i + 1] : 1;
+    double * const D2 = more ? diag[i + 2] : nullptr;
+    double * const S2 = more ? side[i + 1] : nullptr;
+    double * const Xs = (i & 1) ? Xb : Xa;
+    double * const Xn = (i & 1) ? Xa : Xb;
+    const int base = i * (NB + 4);
+    asm volatile("" : "+v"(opaque_zero));
+    TP(5)
     if(wave == 0)
     {
       const bool row = lane < ni;
@@ -635,11 +770,24 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDe
         a[c] = (row && c < ni) ? v : ((lane == c) ? 1.0 : 0.0); // identity padding
       }
       int ret = -1;
-      llt_columns<0, NB>(a, ret, lane, ni, Dg, ldd);
-      if(lane == 0) s_ret = ret;
-      if(ret < 0 && !last)
+      TP(0)
       {
-        // S_i <- S_i L_i^-T, lane = row of S: x(j) = (x(j) - sum_{k<j} x(k) L(j,k)) / L(j,j), right-looking, L from the registers
+        // (the lane number made opaque per block: the per-column lane masks are otherwise hoisted out of the block loop, a
+        // hundred and fifty scalar registers that live in spill lanes and come back with two v_readlane each)
+        const int lz = lane + opaque_zero;
+        const double p0 = bcast_lane(a[0], 0), l0 = __builtin_sqrt(p0);
+        llt_columns<0, NB>(a, ret, lz, Ls, &s_ready, base, p0, l0, a[0] / l0);
+      }
+      TP(1)
+      if(lane == 0) s_ret = ret;
+      if(ret >= 0) tri_post(&s_ready, base + NB + 1, lane); // releases the wave behind
+    }
+    else if(wave == 1)
+    {
+      if(!last)
+      {
+        // S_i <- S_i L_i^-T, lane = row of S: x(j) = (x(j) - sum_{k<j} x(k) L(j,k)) / L(j,j), right-looking
+        TP(0)
         const bool srow = lane < n1;
         const int sl = srow ? lane : 0;
         double x[NB];
@@ -649,44 +797,109 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDe
           const double v = AT(Xs, ldl, sl, (c < ni) ? c : 0);
           x[c] = (srow && c < ni) ? v : 0.0;
         }
-        trsm_columns<0, NB>(x, a);
+        bool dead = false;
+        trsm_columns<0, NB>(x, Ls, &s_ready, base, dead);
+        TP(1)
+        if(!dead)
+        {
+          // (all NB x NB entries, the exact zeros of the padding included: the rank update below runs over NB terms)
 #pragma unroll
-        for(int c = 0; c < NB; ++c)
-          if(srow && c < ni)
-          {
-            AT(Xs, ldl, lane, c) = x[c];
-            AT(Sg, ldsg, lane, c) = x[c];
-          }
+          for(int c = 0; c < NB; ++c)
+            if(lane < NB) AT(Xs, ldl, lane, c) = x[c];
+        }
+        else if(__atomic_load_n(&s_ready, __ATOMIC_RELAXED) <= base + NB)
+        {
+          if(lane == 0) s_lost = 1; // a hand-off never came
+        }
       }
     }
-    __syncthreads();
+    else if(!last)
+    {
+      if(wave == 2)
+      {
+        if(more) load_rows<NB>(Xn, S2, lds2, n2, n1, lane); // S_{i+1}
+      }
+      else
+        load_rows<NB>(Ns, Dn, ldn, n1, n1, lane); // D_{i+1}
+      TP(1)
+    }
+    lds_barrier(); // (LDS only: the stores of the previous block's factor may still be in flight)
+    TP(2)
     const int ret = s_ret;
+    if(s_lost)
+    {
+      if(tid == 0) D.fail[pb] = 1;
+      return;
+    }
+    if(ret == 0) // (a failure at column 0 goes undetected in the reference: the barrier kernel's code reproduces what follows)
+    {
+      __syncthreads(); // block i as the previous rank update stored it is read back from memory
+      tri_llt_from(D, i, sm);
+      return;
+    }
+    // the factor goes to memory: all of the lower triangle on success, the finished columns only on failure
+    const int cols = (ret < 0) ? ni : ret;
+    for(int c = (tid >> 4); c < cols; c += 16)
+      for(int r = (tid & 15); r < ni; r += 16)
+        if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
     if(ret > 0) // triBlockDiagLLT.cpp:19,32: the failure the reference reports
     {
       if(tid == 0) D.fail[pb] = 1;
       return;
     }
-    if(ret == 0) // (a failure at column 0 goes undetected there: the barrier kernel's code reproduces what follows)
-    {
-      __syncthreads();
-      tri_llt_from(D, i, sm);
-      return;
-    }
     if(last) break;
-    // D_{i+1} -= S_i S_i^T (lower), in LDS: one element per thread, terms in ascending k
-    for(int c = (tid >> 4); c < n1; c += 16)
-      for(int r = (tid & 15); r < n1; r += 16)
+    for(int c = (tid >> 4); c < ni; c += 16)
+      for(int r = (tid & 15); r < n1; r += 16) AT(Sg, ldsg, r, c) = AT(Xs, ldl, r, c);
+    // D_{i+1} -= S_i S_i^T (lower), in LDS, terms in ascending k.  The n1 (n1 + 1) / 2 elements are dealt out evenly: column cc
+    // (n1 - cc elements) and column n1 - 1 - cc (cc + 1 elements) form one row of n1 + 1 elements of a rectangle.  Every chain
+    // runs over all NB columns of the padded S L^-T -- the padding contributes exact zeros -- so the loop unrolls into two LDS
+    // reads with immediate offsets and one fma per term.
+    {
+      const int w = n1 + 1, tot = w * ((n1 + 1) >> 1);
+      for(int e = tid; e < tot; e += kTriThreads)
       {
-        if(r < c) continue;
-        const double v = chain2_neg(0, 1, ni, AT(Ns, ldl, r, c), [&](int k) { return AT(Xs, ldl, r, k); }, [&](int k) { return AT(Xs, ldl, c, k); });
-        AT(Ns, ldl, r, c) = v;
-        AT(D.diag[(size_t)pb * D.nblk + i + 1], D.ldd[i + 1], r, c) = v; // (what a failing factorisation of block i+1 leaves behind)
+        const int cc = e / w, rr = e - cc * w;
+        int r, c;
+        if(rr < n1 - cc)
+        {
+          c = cc;
+          r = cc + rr;
+        }
+        else
+        {
+          c = n1 - 1 - cc;
+          r = c + (rr - (n1 - cc));
+          if(c == cc) continue; // (the middle column of an odd n1 is its own partner)
+        }
+        const double * xr = Xs + r;
+        const double * xc = Xs + c;
+        double acc = AT(Ns, ldl, r, c);
+#pragma unroll
+        for(int k = 0; k < NB; ++k) acc = FMA(-xr[k * ldl], xc[k * ldl], acc);
+        AT(Ns, ldl, r, c) = acc;
+        AT(Dn, ldn, r, c) = acc; // (what a failing factorisation of block i+1 leaves behind)
       }
-    __syncthreads();
+    }
+    TP(3)
+    lds_barrier();
+    TP(4)
     double * t = Ls; // the updated next block becomes the current one
     Ls = Ns;
     Ns = t;
+    ni = n1;
+    ldd = ldn;
+    Dg = Dn;
+    n1 = n2;
+    ldn = ld2;
+    Dn = D2;
+    Sg = S2;
+    ldsg = lds2;
   }
+#ifdef TRI_PROF
+  if(pb == 0 && lane == 0)
+    printf("tri wave %d: [0] %lld [1] %lld [2:barrierB] %lld [3:update] %lld [4:barrierC] %lld [5] %lld (cycles)\n", wave, tp_acc[0], tp_acc[1], tp_acc[2],
+           tp_acc[3], tp_acc[4], tp_acc[5]);
+#endif
 }
 
 // triBlockDiagLSolve (triBlockDiagLLT.cpp:37-96): forward block substitution with the zero-window `start`
@@ -841,7 +1054,7 @@ hipError_t launch_tri_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t 
   if(maxb <= 48 && (nprob <= 512 || maxb <= 32))
   {
     const int nbk = (maxb <= 32) ? 32 : 48;
-    const size_t l2 = sizeof(double) * 3 * (size_t)nbk * (nbk | 1);
+    const size_t l2 = sizeof(double) * 4 * (size_t)nbk * (nbk | 1);
     const size_t lfast = l2 > lds ? l2 : lds;
     const void * fn = (nbk == 32) ? reinterpret_cast<const void *>(&tri_llt_fast_kernel<32>) : reinterpret_cast<const void *>(&tri_llt_fast_kernel<48>);
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lfast);
