@@ -306,18 +306,19 @@ __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, dou
 #pragma unroll
       for(int j = 0; j < kAhead; ++j) ln[j] = AT(L, ldl, rl, min(k0 + kAhead + j, n - 1));
     }
+    // One step = quotient of lane k (three dependent operations, computed by EVERY lane on its own entry: no broadcast of
+    // the pivot and its reciprocal), v_readlane of it, one fma, one select.  No branch inside a group: a step beyond n only
+    // rewrites lanes >= n, whose values nobody reads (a uniform branch per step costs a pipeline refill and, worse, a wait
+    // for every load in flight at each step: measured 187 cycles per step against 80).
 #pragma unroll
     for(int j = 0; j < kAhead; ++j)
     {
       const int k = k0 + j;
-      if(k < n)
-      {
-        const double v = div_pre(bcast_lane(xi, k), bcast_lane(dg, k), bcast_lane(rinv, k));
-        const double upd = FMA(-lv[j], v, xi);
-        pre = (lane == k) ? xi : pre;
-        xi = (act && lane > k) ? upd : xi;
-        xi = (lane == k) ? v : xi;
-      }
+      const double vs = div_pre(xi, dg, rinv);
+      const double v = bcast_lane(vs, min(k, 63));
+      const double upd = FMA(-lv[j], v, xi);
+      pre = (lane == k) ? xi : pre;
+      xi = (lane == k) ? vs : ((act && lane > k) ? upd : xi);
     }
   }
   if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
@@ -332,7 +333,7 @@ __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, dou
         xi = FMA(-AT(L, ldl, rl, k), v, xi);
     }
   }
-  return xi;
+  return act ? xi : x0;
 }
 // x <- L^-T x (backward substitution; call sites blockArrowLLT.cpp:211,241,248, triBlockDiagLLT.cpp:139,149)
 __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, double xi, int lane)
@@ -355,18 +356,16 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
 #pragma unroll
       for(int j = 0; j < kAhead; ++j) ln[j] = AT(L, ldl, max(k0 - kAhead - j, 0), rl);
     }
+    // (branch-free steps as in wave_fwd; a step with k < 0 matches no lane)
 #pragma unroll
     for(int j = 0; j < kAhead; ++j)
     {
       const int k = k0 - j;
-      if(k >= 0)
-      {
-        const double v = div_pre(bcast_lane(xi, k), bcast_lane(dg, k), bcast_lane(rinv, k));
-        const double upd = FMA(-lv[j], v, xi);
-        pre = (lane == k) ? xi : pre;
-        xi = (lane < k) ? upd : xi;
-        xi = (lane == k) ? v : xi;
-      }
+      const double vs = div_pre(xi, dg, rinv);
+      const double v = bcast_lane(vs, max(k, 0));
+      const double upd = FMA(-lv[j], v, xi);
+      pre = (lane == k) ? xi : pre;
+      xi = (lane == k) ? vs : ((lane < k) ? upd : xi);
     }
   }
   if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
@@ -381,11 +380,12 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
         xi = FMA(-AT(L, ldl, k, rl), v, xi);
     }
   }
-  return xi;
+  return act ? xi : x0;
 }
 
 // acc <- fma(-a(k), b(k), acc) for k = k0, k0 + step, ... (cnt terms, in that order): the a() operands (HBM/L2) are
-// fetched kAhead terms ahead with unconditional loads (the index is clamped into the valid range)
+// fetched kAhead terms ahead with unconditional loads (the index is clamped into the valid range).  A full group is sixteen
+// plain fmas; only the last, partial group selects per term (no branch per term: see wave_fwd).
 template<class FA, class FB>
 __device__ __forceinline__ double chain_neg8(int k0, int step, int cnt, double acc, FA fa, FB fb)
 {
@@ -402,9 +402,20 @@ __device__ __forceinline__ double chain_neg8(int k0, int step, int cnt, double a
 #pragma unroll
       for(int j = 0; j < kAhead; ++j) an[j] = fa(k0 + step * min(c0 + kAhead + j, cnt - 1));
     }
+    if(c0 + kAhead <= cnt)
+    {
 #pragma unroll
-    for(int j = 0; j < kAhead; ++j)
-      if(c0 + j < cnt) acc = FMA(-av[j], fb(k0 + step * (c0 + j)), acc);
+      for(int j = 0; j < kAhead; ++j) acc = FMA(-av[j], fb(k0 + step * (c0 + j)), acc);
+    }
+    else
+    {
+#pragma unroll
+      for(int j = 0; j < kAhead; ++j)
+      {
+        const double t = FMA(-av[j], fb(k0 + step * min(c0 + j, cnt - 1)), acc);
+        acc = (c0 + j < cnt) ? t : acc;
+      }
+    }
   }
   return acc;
 }
@@ -425,9 +436,20 @@ __device__ __forceinline__ double chain2_neg(int k0, int step, int cnt, double a
       av[j] = fa(k);
       bv[j] = fb(k);
     }
+    if(c0 + W <= cnt)
+    {
 #pragma unroll
-    for(int j = 0; j < W; ++j)
-      if(c0 + j < cnt) acc = FMA(-av[j], bv[j], acc);
+      for(int j = 0; j < W; ++j) acc = FMA(-av[j], bv[j], acc);
+    }
+    else
+    {
+#pragma unroll
+      for(int j = 0; j < W; ++j)
+      {
+        const double t = FMA(-av[j], bv[j], acc);
+        acc = (c0 + j < cnt) ? t : acc;
+      }
+    }
   }
   return acc;
 }
