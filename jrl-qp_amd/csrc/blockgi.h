@@ -49,8 +49,6 @@ struct BgiArgs
   int * active;   // [nprob * qcap]
   double * xu_ws; // [nprob * (n_pad + qcap)]  x and u of the throughput layout (see blockgi_lds_bytes)
   int xu_global;  // 1: x and u live in xu_ws (HBM/L2) instead of LDS, so that two large problems share a CU
-  int tri_stage;  // block tridiagonal, latency layout: largest block size when the blocks of L are staged through LDS by the
-                  // idle waves during the two triangular solves (four buffers of tri_stage x (tri_stage | 1) doubles); else 0
   // outputs
   double *x, *u;
   int *status, *term, *iters;
@@ -65,6 +63,6 @@ constexpr int kBgiMaxN = 3072; // unknowns per structured QP (vectors live in LD
 
 // xu_global = 1 (throughput layout for large problems in large batches): x and u are kept in the HBM workspace, which
 // brings a 3000-unknown problem under half a CU's LDS
-long blockgi_lds_bytes(int n, int m, int nb, int nblk, int xu_global = 0, int tri_stage = 0);
+long blockgi_lds_bytes(int n, int m, int nb, int nblk, int xu_global = 0);
 hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t stream);
 } // namespace jrlqp

@@ -61,8 +61,6 @@ struct Ctx
   double *pool, *Rp;
   SeqRec * desc;
   int *active, *status;
-  double * stage; // block tridiagonal, latency layout: four LDS buffers of stage_mb x (stage_mb | 1) doubles, or nullptr
-  int stage_mb;
 };
 
 // ---- C4 reduction over the workgroup -------------------------------------------------------------------------------
@@ -286,139 +284,6 @@ __device__ __forceinline__ void tri_ltsolve(Ctx & K, double * v)
   __syncthreads();
 }
 
-// ---- the same two solves with the factor STAGED through LDS (latency layout: few problems, blocks that fit) ----------------
-// Read straight from HBM/L2 a block costs six exposed memory latencies (three operand groups of the S v chain, three of the
-// substitution): ~7 us per block of 43, and the chain over the blocks is serial.  Here the waves that have nothing to do in
-// a block tridiagonal solve copy block i + 1 (diagonal block and side block, all loads of a wave in flight at once) into
-// one pair of LDS buffers while wave 0 works on block i out of the other pair: the same operations on the same operands in
-// the same order, only their address changes.
-template<int NHW>
-__device__ __forceinline__ void stage_cols(double * dst, int ldm, const double * src, int ld, int rows, int cols, int hw, int lane)
-{
-  const bool act = lane < rows;
-  const int rl = act ? lane : 0;
-  for(int c0 = hw; c0 < cols; c0 += 4 * NHW)
-  {
-    double v[4];
-#pragma unroll
-    for(int u = 0; u < 4; ++u) v[u] = src[rl + (size_t)min(c0 + u * NHW, cols - 1) * ld];
-#pragma unroll
-    for(int u = 0; u < 4; ++u)
-      if(act && c0 + u * NHW < cols) dst[lane + (c0 + u * NHW) * ldm] = v[u];
-  }
-}
-
-template<int NT>
-__device__ __forceinline__ void tri_lsolve_staged(Ctx & K, double * v, int start)
-{
-  constexpr int NHW = NT / 64 - 1; // helper waves
-  const BgiArgs & A = *K.A;
-  const int lane = K.lane, mb = K.stage_mb, ldm = mb | 1, bsz = mb * ldm;
-  double * Lb[2] = {K.stage, K.stage + 2 * bsz};
-  double * Sb[2] = {K.stage + bsz, K.stage + 3 * bsz};
-  int fb = 0, n = 0; // first block the reference touches: the first with n + ni >= start
-  while(fb < A.nblk && n + K.bm[fb].bs < start)
-  {
-    n += K.bm[fb].bs;
-    ++fb;
-  }
-  if(fb < A.nblk && K.wave > 0) stage_cols<NHW>(Lb[0], ldm, K.bm[fb].diag, K.bm[fb].ldd, K.bm[fb].bs, K.bm[fb].bs, K.wave - 1, lane);
-  __syncthreads();
-  int l = 0, li = 0;
-  if(fb > 0)
-  {
-    li = K.bm[fb - 1].bs;
-    l = n - li;
-  }
-  for(int i = fb; i < A.nblk; ++i)
-  {
-    const int cur = (i - fb) & 1;
-    const int ni = K.bm[i].bs;
-    if(K.wave == 0)
-    {
-      const double * Li = Lb[cur];
-      if(i == fb)
-      {
-        const int rr = n + ni - start, off = ni - rr;
-        double xi = (lane < rr) ? v[start + lane] : 0.0;
-        xi = wave_fwd(Li + off + off * ldm, ldm, rr, xi, lane);
-        if(lane < rr) v[start + lane] = xi;
-      }
-      else
-      {
-        const double * Sg = Sb[cur];
-        double acc = (lane < ni) ? v[n + lane] : 0.0;
-        {
-          const int rl = (lane < ni) ? lane : 0;
-          acc = chain_neg8(0, 1, li, acc, [&](int k) { return Sg[rl + k * ldm]; }, [&](int k) { return v[l + k]; });
-        }
-        acc = wave_fwd(Li, ldm, ni, acc, lane);
-        if(lane < ni) v[n + lane] = acc;
-      }
-    }
-    else if(i + 1 < A.nblk)
-    {
-      const int n1 = K.bm[i + 1].bs;
-      stage_cols<NHW>(Lb[cur ^ 1], ldm, K.bm[i + 1].diag, K.bm[i + 1].ldd, n1, n1, K.wave - 1, lane);
-      stage_cols<NHW>(Sb[cur ^ 1], ldm, K.bm[i].side, K.bm[i].lds, n1, ni, K.wave - 1, lane);
-    }
-    __syncthreads();
-    l = n;
-    li = ni;
-    n += ni;
-  }
-}
-
-template<int NT>
-__device__ __forceinline__ void tri_ltsolve_staged(Ctx & K, double * v)
-{
-  constexpr int NHW = NT / 64 - 1;
-  const BgiArgs & A = *K.A;
-  const int lane = K.lane, mb = K.stage_mb, ldm = mb | 1, bsz = mb * ldm;
-  double * Lb[2] = {K.stage, K.stage + 2 * bsz};
-  double * Sb[2] = {K.stage + bsz, K.stage + 3 * bsz};
-  const int lastb = A.nblk - 1;
-  if(K.wave > 0) stage_cols<NHW>(Lb[0], ldm, K.bm[lastb].diag, K.bm[lastb].ldd, K.bm[lastb].bs, K.bm[lastb].bs, K.wave - 1, lane);
-  __syncthreads();
-  int n = A.n, l = 0, li = 0;
-  for(int i = lastb; i >= 0; --i)
-  {
-    const int cur = (lastb - i) & 1;
-    const int ni = K.bm[i].bs;
-    if(K.wave == 0)
-    {
-      const double * Li = Lb[cur];
-      if(i == lastb)
-      {
-        double xi = (lane < ni) ? v[n - ni + lane] : 0.0;
-        xi = wave_bwd(Li, ldm, ni, xi, lane);
-        if(lane < ni) v[n - ni + lane] = xi;
-      }
-      else
-      {
-        const double * Sg = Sb[cur]; // side block i: n_{i+1} x n_i
-        double acc = (lane < ni) ? v[n - ni + lane] : 0.0;
-        {
-          const int rl = (lane < ni) ? lane : 0;
-          acc = chain_neg8(li - 1, -1, li, acc, [&](int k) { return Sg[k + rl * ldm]; }, [&](int k) { return v[(l - li) + k]; });
-        }
-        acc = wave_bwd(Li, ldm, ni, acc, lane);
-        if(lane < ni) v[n - ni + lane] = acc;
-      }
-    }
-    else if(i > 0)
-    {
-      const int np = K.bm[i - 1].bs;
-      stage_cols<NHW>(Lb[cur ^ 1], ldm, K.bm[i - 1].diag, K.bm[i - 1].ldd, np, np, K.wave - 1, lane);
-      stage_cols<NHW>(Sb[cur ^ 1], ldm, K.bm[i - 1].side, K.bm[i - 1].lds, ni, np, K.wave - 1, lane);
-    }
-    __syncthreads();
-    l = n;
-    li = ni;
-    n -= ni;
-  }
-}
-
 // The up arrow's row permutation (blockArrowLLT.cpp:163-170, :266-271): blockArrowLSolve returns its result in the
 // PERMUTED order (first block moved last) and blockArrowLTransposeSolve expects its argument in that order -- d, and
 // with it the orthonormal sequence, live in permuted coordinates.  forward: v <- [v(n0:), v(:n0)]; backward: the inverse.
@@ -455,12 +320,7 @@ template<int NT>
 __device__ __forceinline__ void sg_lsolve(Ctx & K, double * v, int start, int end, bool permuted = true)
 {
   if(K.A->kind == 2)
-  {
-    if(K.stage)
-      tri_lsolve_staged<NT>(K, v, start);
-    else
-      tri_lsolve(K, v, start);
-  }
+    tri_lsolve(K, v, start);
   else
   {
     arrow_lsolve<NT>(K, v, start, end);
@@ -472,12 +332,7 @@ template<int NT>
 __device__ __forceinline__ void sg_ltsolve(Ctx & K, double * v, bool permuted = true)
 {
   if(K.A->kind == 2)
-  {
-    if(K.stage)
-      tri_ltsolve_staged<NT>(K, v);
-    else
-      tri_ltsolve(K, v);
-  }
+    tri_ltsolve(K, v);
   else
   {
     if(K.A->kind == 1 && permuted) permute_up<NT>(K, v, false);
@@ -924,8 +779,6 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
       bm[b].lds = (b < A.nblk - 1) ? A.lds[b] : 0;
     }
     K.bm = bm;
-    K.stage_mb = A.tri_stage;
-    K.stage = A.tri_stage ? reinterpret_cast<double *>(bm + A.nblk) : nullptr;
   }
   K.pool = A.pool + (size_t)pb * A.max_iter * A.row_len;
   K.Rp = A.Rp + (size_t)pb * A.rlen;
@@ -1349,19 +1202,18 @@ hipError_t launch_one(const BgiArgs & a, int nprob, size_t lds, hipStream_t st)
 }
 } // namespace
 
-long blockgi_lds_bytes(int n, int m, int nb, int nblk, int xu_global, int tri_stage)
+long blockgi_lds_bytes(int n, int m, int nb, int nblk, int xu_global)
 {
   const int n_pad = (n + 3) & ~3;
   int qcap = (n < m + nb ? n : m + nb) + 1;
   qcap = (qcap + 3) & ~3;
   const long vecs = xu_global ? (2L * n_pad + qcap) : (3L * n_pad + 2L * qcap);
-  return (long)sizeof(double) * (vecs + kTri + 32 + 32 + 8) + (long)sizeof(BlkMeta) * nblk
-         + (long)sizeof(double) * 4 * tri_stage * (tri_stage | 1);
+  return (long)sizeof(double) * (vecs + kTri + 32 + 32 + 8) + (long)sizeof(BlkMeta) * nblk;
 }
 
 hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t st)
 {
-  const size_t lds = (size_t)blockgi_lds_bytes(a.n, a.m, a.nb, a.nblk, a.xu_global, a.tri_stage);
+  const size_t lds = (size_t)blockgi_lds_bytes(a.n, a.m, a.nb, a.nblk, a.xu_global);
   // four waves per problem up to 1024 unknowns; eight beyond (the block-parallel phases -- L^-T over ~100 blocks,
   // the constraint scan -- and the per-reflector work scale with the wave count; rule C4 does not depend on it).
   // Throughput layout (xu_global, chosen by the caller for large batches of large problems): four waves and half the

@@ -644,14 +644,6 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.n_pad = h->n_pad; a.qcap = h->qcap; a.row_len = h->row_len;
   a.pool = h->d_pool; a.Rp = h->d_Rp; a.rlen = h->rlen; a.desc = h->d_desc; a.active = h->d_active;
   a.xu_ws = h->d_xu; a.xu_global = h->xu_global;
-  // block tridiagonal, few problems: the factor travels through LDS during the triangular solves (same operations, the
-  // serial chain over the blocks no longer waits for HBM/L2); large batches keep the LDS for occupancy
-  a.tri_stage = 0;
-  if(h->kind == 2 && h->nprob <= 512 && !h->xu_global
-     && jrlqp::blockgi_lds_bytes(h->n, h->m, h->nb, h->nblk, 0, p->maxb) <= jrlqp::kLdsPerCU)
-    a.tri_stage = p->maxb;
-  if(const char * ts = std::getenv("JRLQP_BLOCKGI_TRI_STAGE")) // diagnostic override: "0" off
-    if(ts[0] == '0') a.tri_stage = 0;
   a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
   a.trace = dtrace; a.trace_cap = dtrace ? trace_cap : 0;
   a.prof = g_prof[JRLQP_PROFILE_BLOCKGI].p;

@@ -292,7 +292,6 @@ __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, dou
   const double dg = (n > 0) ? AT(L, ldl, rl, rl) : 1.0;
   const double rinv = recip_refined(dg);
   const double x0 = xi;
-  double pre = 0.0;
   // the operands of group g + 1 are requested before group g is consumed: one exposed memory latency per CALL
   double lv[kAhead], ln[kAhead];
 #pragma unroll
@@ -306,21 +305,23 @@ __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, dou
 #pragma unroll
       for(int j = 0; j < kAhead; ++j) ln[j] = AT(L, ldl, rl, min(k0 + kAhead + j, n - 1));
     }
-    // One step = quotient of lane k (three dependent operations, computed by EVERY lane on its own entry: no broadcast of
-    // the pivot and its reciprocal), v_readlane of it, one fma, one select.  No branch inside a group: a step beyond n only
-    // rewrites lanes >= n, whose values nobody reads (a uniform branch per step costs a pipeline refill and, worse, a wait
-    // for every load in flight at each step: measured 187 cycles per step against 80).
+    // One step: the quotient of lane k -- three dependent operations, computed by EVERY lane on its own entry, so neither
+    // the pivot nor its reciprocal is broadcast --, a v_readlane of it, one fma and one select for the lanes below.  Lane k
+    // itself is left alone: after step k - 1 its entry IS the numerator of x_k, and all quotients are formed together
+    // after the last step.  No branch inside a group (a uniform branch per step costs a pipeline refill and a wait for every
+    // load in flight: 187 cycles per step measured, against ~50): a step beyond n - 1 only touches lanes >= n, whose
+    // values nobody reads.
 #pragma unroll
     for(int j = 0; j < kAhead; ++j)
     {
       const int k = k0 + j;
-      const double vs = div_pre(xi, dg, rinv);
-      const double v = bcast_lane(vs, min(k, 63));
+      const double v = bcast_lane(div_pre(xi, dg, rinv), min(k, 63));
       const double upd = FMA(-lv[j], v, xi);
-      pre = (lane == k) ? xi : pre;
-      xi = (lane == k) ? vs : ((act && lane > k) ? upd : xi);
+      xi = (lane > k) ? upd : xi;
     }
   }
+  const double pre = xi; // the numerators
+  xi = div_pre(pre, dg, rinv);
   if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
   {
     xi = x0;
@@ -343,7 +344,6 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
   const double dg = (n > 0) ? AT(L, ldl, rl, rl) : 1.0;
   const double rinv = recip_refined(dg);
   const double x0 = xi;
-  double pre = 0.0;
   double lv[kAhead], ln[kAhead];
 #pragma unroll
   for(int j = 0; j < kAhead; ++j) ln[j] = (n > 0) ? AT(L, ldl, max(n - 1 - j, 0), rl) : 0.0;
@@ -356,18 +356,18 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
 #pragma unroll
       for(int j = 0; j < kAhead; ++j) ln[j] = AT(L, ldl, max(k0 - kAhead - j, 0), rl);
     }
-    // (branch-free steps as in wave_fwd; a step with k < 0 matches no lane)
+    // (steps as in wave_fwd, mirrored: lanes above k are updated; a step with k < 0 matches no lane)
 #pragma unroll
     for(int j = 0; j < kAhead; ++j)
     {
       const int k = k0 - j;
-      const double vs = div_pre(xi, dg, rinv);
-      const double v = bcast_lane(vs, max(k, 0));
+      const double v = bcast_lane(div_pre(xi, dg, rinv), max(k, 0));
       const double upd = FMA(-lv[j], v, xi);
-      pre = (lane == k) ? xi : pre;
-      xi = (lane == k) ? vs : ((lane < k) ? upd : xi);
+      xi = (lane < k) ? upd : xi;
     }
   }
+  const double pre = xi;
+  xi = div_pre(pre, dg, rinv);
   if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
   {
     xi = x0;
@@ -384,37 +384,51 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
 }
 
 // acc <- fma(-a(k), b(k), acc) for k = k0, k0 + step, ... (cnt terms, in that order): the a() operands (HBM/L2) are
-// fetched kAhead terms ahead with unconditional loads (the index is clamped into the valid range).  A full group is sixteen
-// plain fmas; only the last, partial group selects per term (no branch per term: see wave_fwd).
+// fetched kAhead terms ahead with unconditional loads (the index is clamped into the valid range).  Two operand buffers
+// take turns (no copy between them); a full group is sixteen plain fmas, only the last, partial group selects per term (no
+// branch per term: see wave_fwd).
+template<int G, class FA, class FB>
+__device__ __forceinline__ double chain_group(int k0, int step, int cnt, int c0, double acc, const double (&av)[G], FB fb)
+{
+  if(c0 + G <= cnt)
+  {
+#pragma unroll
+    for(int j = 0; j < G; ++j) acc = FMA(-av[j], fb(k0 + step * (c0 + j)), acc);
+  }
+  else
+  {
+#pragma unroll
+    for(int j = 0; j < G; ++j)
+    {
+      const double t = FMA(-av[j], fb(k0 + step * min(c0 + j, cnt - 1)), acc);
+      acc = (c0 + j < cnt) ? t : acc;
+    }
+  }
+  return acc;
+}
 template<class FA, class FB>
 __device__ __forceinline__ double chain_neg8(int k0, int step, int cnt, double acc, FA fa, FB fb)
 {
   if(cnt <= 0) return acc;
-  double av[kAhead], an[kAhead];
+  double a0[kAhead], a1[kAhead];
 #pragma unroll
-  for(int j = 0; j < kAhead; ++j) an[j] = fa(k0 + step * min(j, cnt - 1));
-  for(int c0 = 0; c0 < cnt; c0 += kAhead)
+  for(int j = 0; j < kAhead; ++j) a0[j] = fa(k0 + step * min(j, cnt - 1));
+  for(int c0 = 0; c0 < cnt; c0 += 2 * kAhead)
   {
-#pragma unroll
-    for(int j = 0; j < kAhead; ++j) av[j] = an[j];
     if(c0 + kAhead < cnt)
     {
 #pragma unroll
-      for(int j = 0; j < kAhead; ++j) an[j] = fa(k0 + step * min(c0 + kAhead + j, cnt - 1));
+      for(int j = 0; j < kAhead; ++j) a1[j] = fa(k0 + step * min(c0 + kAhead + j, cnt - 1));
     }
-    if(c0 + kAhead <= cnt)
+    acc = chain_group<kAhead, FA, FB>(k0, step, cnt, c0, acc, a0, fb);
+    if(c0 + kAhead < cnt)
     {
-#pragma unroll
-      for(int j = 0; j < kAhead; ++j) acc = FMA(-av[j], fb(k0 + step * (c0 + j)), acc);
-    }
-    else
-    {
-#pragma unroll
-      for(int j = 0; j < kAhead; ++j)
+      if(c0 + 2 * kAhead < cnt)
       {
-        const double t = FMA(-av[j], fb(k0 + step * min(c0 + j, cnt - 1)), acc);
-        acc = (c0 + j < cnt) ? t : acc;
+#pragma unroll
+        for(int j = 0; j < kAhead; ++j) a0[j] = fa(k0 + step * min(c0 + 2 * kAhead + j, cnt - 1));
       }
+      acc = chain_group<kAhead, FA, FB>(k0, step, cnt, c0 + kAhead, acc, a1, fb);
     }
   }
   return acc;

@@ -11,6 +11,12 @@ from oracle_lib import get_oracle
 from ikdata import read_arrow, read_tri_block_diag
 from test_gpu_blockgi import KIND
 o = get_oracle()
+PROFILE_LINES = []  # printed by the caller behind the timing line they belong to
+
+
+def flush_profile():
+    while PROFILE_LINES:
+        print(PROFILE_LINES.pop(0), flush=True)
 
 
 def gpu_time(qps, max_iter, reps=5):
@@ -40,8 +46,8 @@ def gpu_time(qps, max_iter, reps=5):
         capi.set_profile(capi.PROFILE_BLOCKGI, None)
         pr = prof.cpu().numpy().astype(np.float64)[0] / 100.0  # us
         names = ["init", "scan", "L^-1 n+", "Q^T d", "Q z", "L^-T z", "R solve", "step length", "update", "add", "drop", "(Q: reflectors", "Q: Givens)"]
-        print("      phase profile, problem 0 (us total; us/iteration): " + "; ".join(f"{nm} {pr[i]:.0f}" for i, nm in enumerate(names))
-              + f"  | sum {pr[:11].sum():.0f} us over {int(r.iters[0])} iterations; core clock {pr[13] / max(pr[14], 1e-9) * 0.1:.2f} GHz", flush=True)
+        PROFILE_LINES.append("      phase profile of the line above, problem 0 (us total): " + "; ".join(f"{nm} {pr[i]:.0f}" for i, nm in enumerate(names))
+              + f"  | sum {pr[:11].sum():.0f} us over {int(r.iters[0])} iterations; core clock {pr[13] / max(pr[14], 1e-9) * 0.1:.2f} GHz")
     return min(ts), r.iters.cpu().numpy(), r.term.cpu().numpy(), s.workspace_bytes
 
 
@@ -76,6 +82,7 @@ if what in ("all", "ik"):
             ms, iters, term, ws = gpu_time([qp] * B, 64)
             print(f"{name}: batch {B:4d}: GPU {ms:8.3f} ms ({ms / B * 1e3:8.1f} us/problem, {B / ms * 1e3:9.0f} solves/s) iters {iters[0]} term {term[0]};  "
                   f"CPU oracle structured {cs:.3f} ms, dense {cd:.3f} ms (1 core)", flush=True)
+            flush_profile()
 if what in ("all", "c5", "c5b64"):
     for sa in (1.0,):
         base = [SP.mpc_arrow_qp(100, 30, 10, seed=s, scale_a=sa) for s in range(2)]
@@ -86,3 +93,4 @@ if what in ("all", "c5", "c5b64"):
             ms, iters, term, ws = gpu_time(qps, 1000, reps=3)
             print(f"   batch {B:3d}: GPU {ms:9.2f} ms  ({ms / B:8.2f} ms/problem, {B / ms * 1e3:7.1f} solves/s)  iters {iters[:2]} term {term[:2]}  "
                   f"{ms / iters.mean() * 1e3:7.1f} us/iteration/batch  workspace {ws / 2**20:.0f} MiB", flush=True)
+            flush_profile()
