@@ -737,6 +737,8 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDe
   double * Dg = diag[0];
   int n1 = 0, ldn = 1, ldsg = 1;
   double *Dn = nullptr, *Sg = nullptr;
+  int n_p = 0, ldd_p = 1, ldsg_p = 1; // the previous block (its factor is stored one iteration late)
+  double *Dg_p = nullptr, *Sg_p = nullptr;
   if(D.nblk > 1)
   {
     n1 = D.bs[1];
@@ -813,14 +815,22 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDe
         }
       }
     }
-    else if(!last)
+    else
     {
+      // waves 2 and 3: the factor of the PREVIOUS block leaves for memory now (its buffers are about to be refilled), then the
+      // next blocks are fetched -- both beside the factorisation, not in the phase every wave waits for
       if(wave == 2)
       {
+        if(i > 0 && lane < ni) // S_{i-1} L_{i-1}^-T: n_i x n_{i-1}
+          for(int c = 0; c < n_p; ++c) AT(Sg_p, ldsg_p, lane, c) = AT(Xn, ldl, lane, c);
         if(more) load_rows<NB>(Xn, S2, lds2, n2, n1, lane); // S_{i+1}
       }
       else
-        load_rows<NB>(Ns, Dn, ldn, n1, n1, lane); // D_{i+1}
+      {
+        if(i > 0 && lane < n_p) // L_{i-1}, lower triangle
+          for(int c = 0; c <= lane; ++c) AT(Dg_p, ldd_p, lane, c) = AT(Ns, ldl, lane, c);
+        if(!last) load_rows<NB>(Ns, Dn, ldn, n1, n1, lane); // D_{i+1}
+      }
       TP(1)
     }
     lds_barrier(); // (LDS only: the stores of the previous block's factor may still be in flight)
@@ -837,19 +847,21 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDe
       tri_llt_from(D, i, sm);
       return;
     }
-    // the factor goes to memory: all of the lower triangle on success, the finished columns only on failure
-    const int cols = (ret < 0) ? ni : ret;
-    for(int c = (tid >> 4); c < cols; c += 16)
-      for(int r = (tid & 15); r < ni; r += 16)
-        if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
-    if(ret > 0) // triBlockDiagLLT.cpp:19,32: the failure the reference reports
+    // the factor goes to memory.  A failing block: its finished columns, now; the last block: now; any other block: by waves
+    // 2 and 3 at the start of the next iteration (above).
+    if(ret > 0 || last)
     {
-      if(tid == 0) D.fail[pb] = 1;
-      return;
+      const int cols = (ret < 0) ? ni : ret;
+      for(int c = (tid >> 4); c < cols; c += 16)
+        for(int r = (tid & 15); r < ni; r += 16)
+          if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+      if(ret > 0) // triBlockDiagLLT.cpp:19,32: the failure the reference reports
+      {
+        if(tid == 0) D.fail[pb] = 1;
+        return;
+      }
+      break;
     }
-    if(last) break;
-    for(int c = (tid >> 4); c < ni; c += 16)
-      for(int r = (tid & 15); r < n1; r += 16) AT(Sg, ldsg, r, c) = AT(Xs, ldl, r, c);
     // D_{i+1} -= S_i S_i^T (lower), in LDS, terms in ascending k.  The n1 (n1 + 1) / 2 elements are dealt out evenly: column cc
     // (n1 - cc elements) and column n1 - 1 - cc (cc + 1 elements) form one row of n1 + 1 elements of a rectangle.  Every chain
     // runs over all NB columns of the padded S L^-T -- the padding contributes exact zeros -- so the loop unrolls into two LDS
@@ -886,6 +898,11 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDe
     double * t = Ls; // the updated next block becomes the current one
     Ls = Ns;
     Ns = t;
+    n_p = ni;
+    ldd_p = ldd;
+    Dg_p = Dg;
+    Sg_p = Sg;
+    ldsg_p = ldsg;
     ni = n1;
     ldd = ldn;
     Dg = Dn;
