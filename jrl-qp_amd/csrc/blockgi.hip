@@ -617,6 +617,7 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
 template<int NT>
 __device__ __forceinline__ void r_solve(Ctx & K, int q)
 {
+  q = __builtin_amdgcn_readfirstlane(q); // (scalar loop counters: see bcast_lane)
   const double * R = K.Rp;
   double *r = K.r, *tri = K.tri;
   for(int k = K.tid; k < q; k += NT) r[k] = K.d[k];
@@ -640,16 +641,18 @@ __device__ __forceinline__ void r_solve(Ctx & K, int q)
       const double x0 = (lane < nc) ? r[c0 + lane] : 0.0;
       const double dg = (lane < nc) ? tri[lane * (lane + 1) / 2 + lane] : 1.0;
       const double rinv = recip_refined(dg);
-      double xi = x0, pre = 0.0;
+      double xi = x0;
+      // (steps as in wave_bwd, device_common.h: the quotient formed by the owning lane, the numerator left in its lane, all
+      // quotients formed after the last step; scalar loop counter)
       for(int k = nc - 1; k >= 0; --k)
       {
         const double * col = tri + k * (k + 1) / 2;
-        const double v = div_pre(bcast_lane(xi, k), bcast_lane(dg, k), bcast_lane(rinv, k));
+        const double v = bcast_lane_s(div_pre(xi, dg, rinv), k);
         const double upd = FMA(-col[min(lane, k)], v, xi);
-        pre = (lane == k) ? xi : pre;
         xi = (lane < k) ? upd : xi;
-        xi = (lane == k) ? v : xi;
       }
+      const double pre = xi;
+      xi = div_pre(pre, dg, rinv);
       if(!__all(lane >= nc || (div_safe_den(dg) && div_safe_num(pre))))
       {
         xi = x0;

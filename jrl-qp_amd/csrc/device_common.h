@@ -27,12 +27,24 @@ __device__ __forceinline__ void lds_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// value of v in lane `src` (src wave-uniform): two v_readlane_b32, no LDS round trip
+// value of v in lane `src` (src wave-uniform): two v_readlane_b32, no LDS round trip.
+// HAZARD NOTE (gfx950, hipcc 7.2, measured): when the compiler cannot prove `src` uniform it fetches the lane number with
+// v_readfirstlane_b32 on the spot and puts the four wait states its hazard table asks for between that VALU write of an SGPR
+// and the v_readlane that selects with it.  In a substitution loop whose counter lived in a VGPR that was not always enough:
+// now and then a stale lane came back (9-18 of 61 parity tests of the batched kernel failing, different problems every run,
+// only in the instantiations whose schedule put exactly four instructions there; with five explicit wait states, or with a
+// scalar counter, every run was clean).  Rule: loops that broadcast by a running index make their bound uniform BEFORE the
+// loop (`uniform()` / v_readfirstlane once), so that the SALU produces every lane number -- bcast_lane_s marks those sites.
 __device__ __forceinline__ double bcast_lane(double v, int src)
 {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
+}
+// the same, at a site whose `src` is a compile-time constant or SALU-produced (see the note above)
+__device__ __forceinline__ double bcast_lane_s(double v, int src)
+{
+  return bcast_lane(v, src);
 }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int mask)
@@ -287,6 +299,7 @@ constexpr int kAhead = 16; // operands of a dependent chain are requested this m
 // A post-hoc range check licenses the hoisted reciprocals; outside it the chain is redone with plain a/b.
 __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, double xi, int lane)
 {
+  n = __builtin_amdgcn_readfirstlane(n); // (scalar loop counters: see bcast_lane)
   const bool act = lane < n;
   const int rl = act ? lane : 0;
   const double dg = (n > 0) ? AT(L, ldl, rl, rl) : 1.0;
@@ -315,7 +328,7 @@ __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, dou
     for(int j = 0; j < kAhead; ++j)
     {
       const int k = k0 + j;
-      const double v = bcast_lane(div_pre(xi, dg, rinv), min(k, 63));
+      const double v = bcast_lane_s(div_pre(xi, dg, rinv), min(k, 63));
       const double upd = FMA(-lv[j], v, xi);
       xi = (lane > k) ? upd : xi;
     }
@@ -339,6 +352,7 @@ __device__ __forceinline__ double wave_fwd(const double * L, int ldl, int n, dou
 // x <- L^-T x (backward substitution; call sites blockArrowLLT.cpp:211,241,248, triBlockDiagLLT.cpp:139,149)
 __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, double xi, int lane)
 {
+  n = __builtin_amdgcn_readfirstlane(n); // (scalar loop counters: see bcast_lane)
   const bool act = lane < n;
   const int rl = act ? lane : 0;
   const double dg = (n > 0) ? AT(L, ldl, rl, rl) : 1.0;
@@ -361,7 +375,7 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
     for(int j = 0; j < kAhead; ++j)
     {
       const int k = k0 - j;
-      const double v = bcast_lane(div_pre(xi, dg, rinv), max(k, 0));
+      const double v = bcast_lane_s(div_pre(xi, dg, rinv), max(k, 0));
       const double upd = FMA(-lv[j], v, xi);
       xi = (lane < k) ? upd : xi;
     }

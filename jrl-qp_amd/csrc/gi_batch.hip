@@ -1220,16 +1220,15 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       // rotation.  Each lane keeps the numerator of its own division (`pre`): the range check that licenses the
       // hoisted reciprocals is made once, after the loop, instead of once per step.
       auto colat = [&](int k) { return R[rl + ((k > 0) ? k : 0) * ld]; };
-      double pre = 0.0;
+      // One step: the quotient of lane k is formed by every lane on its own entry (no broadcast of pivot and reciprocal) and
+      // read with one v_readlane pair; lane k itself is left alone -- after the step before, its entry IS the numerator of
+      // r_k -- and all quotients are formed together after the last step (9 instructions per step instead of 18).
       auto step = [&](int k, double col) __attribute__((always_inline)) {
-        const double num = opaque_v(bcast_lane(rk, k));
-        const double v = div_pre(num, bcast_lane(dg, k), bcast_lane(rinv, k));
+        const double v = bcast_lane_s(div_pre(rk, dg, rinv), k);
         const double upd = FMA(-col, v, rk);
-        pre = (lane == k) ? rk : pre;
         rk = (lane < k) ? upd : rk;
-        rk = (lane == k) ? v : rk;
       };
-      int k = q - 1;
+      int k = uniform(q) - 1; // (a scalar counter: see bcast_lane in device_common.h)
       double c0 = colat(k), c1 = colat(k - 1), c2 = colat(k - 2), c3 = colat(k - 3);
 #pragma unroll 1
       for(; k >= 3; k -= 4)
@@ -1246,6 +1245,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       if(k >= 0) step(k, c0);
       if(k >= 1) step(k - 1, c1);
       if(k >= 2) step(k - 2, c2);
+      const double pre = rk; // the numerators (lanes >= q: 0)
+      rk = div_pre(pre, dg, rinv);
       const bool safe = __all(div_safe_den(dg) && div_safe_num(pre));
       if(!safe)
       {
