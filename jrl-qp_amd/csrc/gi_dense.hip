@@ -362,20 +362,28 @@ __device__ __forceinline__ void blocked_subst(const double * __restrict__ M, int
     {
       const double rk0 = (lane < cnt) ? rs[kb + lane] : 0.0;
       const double rinv = recip_refined(dg);
-      double rk = rk0, pre = 0.0;
+      // Steps as in wave_fwd / wave_bwd (device_common.h): the quotient of lane k is formed by every lane on its own entry
+      // and read with one v_readlane pair, lane k keeps its numerator, all quotients are formed after the last step; no
+      // branch per step (one per group of eight), steps beyond the block are masked.
+      double rk = rk0;
 #pragma unroll
-      for(int kk = 0; kk < 64; ++kk)
+      for(int gg = 0; gg < 8; ++gg)
       {
-        const int k = TRANS ? 63 - kk : kk;
-        if(k < cnt)
+        const int g = TRANS ? 7 - gg : gg;
+        if(g * 8 < cnt)
         {
-          const double v = div_pre(bcast_lane(rk, k), bcast_lane(dg, k), bcast_lane(rinv, k));
-          const double upd = FMA(-blk[k], v, rk);
-          pre = (lane == k) ? rk : pre;
-          rk = ((TRANS ? lane < k : lane > k) && lane < cnt) ? upd : rk;
-          rk = (lane == k) ? v : rk;
+#pragma unroll
+          for(int uu = 0; uu < 8; ++uu)
+          {
+            const int k = g * 8 + (TRANS ? 7 - uu : uu);
+            const double v = bcast_lane(div_pre(rk, dg, rinv), k);
+            const double upd = FMA(-blk[k], v, rk);
+            rk = (k < cnt && (TRANS ? lane < k : lane > k) && lane < cnt) ? upd : rk;
+          }
         }
       }
+      const double pre = rk;
+      rk = div_pre(pre, dg, rinv);
       if(!__all(div_safe_den(dg) && div_safe_num(pre)))
       {
         rk = rk0;
@@ -820,19 +828,26 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
     {
       const double rk0 = (lane < cnt) ? rs[kb + lane] : 0.0;
       const double rinv = recip_refined(dg);
-      double rk = rk0, pre = 0.0;
+      // (steps as in wave_bwd, device_common.h: quotient formed by the owning lane, numerator left in its lane, all quotients
+      // formed after the last step; one branch per group of eight steps, steps beyond the block masked)
+      double rk = rk0;
 #pragma unroll
-      for(int k = 63; k >= 0; --k)
+      for(int g = 7; g >= 0; --g)
       {
-        if(k < cnt)
+        if(g * 8 < cnt)
         {
-          const double v = div_pre(bcast_lane(rk, k), bcast_lane(dg, k), bcast_lane(rinv, k));
-          const double upd = FMA(-blk[k], v, rk);
-          pre = (lane == k) ? rk : pre;
-          rk = (lane < k) ? upd : rk;
-          rk = (lane == k) ? v : rk;
+#pragma unroll
+          for(int u = 7; u >= 0; --u)
+          {
+            const int k = g * 8 + u;
+            const double v = bcast_lane(div_pre(rk, dg, rinv), k);
+            const double upd = FMA(-blk[k], v, rk);
+            rk = (k < cnt && lane < k) ? upd : rk;
+          }
         }
       }
+      const double pre = rk;
+      rk = div_pre(pre, dg, rinv);
       if(!__all(div_safe_den(dg) && div_safe_num(pre)))
       {
         // an operand left the range in which the hoisted reciprocal is provably the compiler's own: redo with a / b
