@@ -529,35 +529,6 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_kernel(const BlockDesc D)
   tri_llt_from(D, 0, sm);
 }
 
-// acc <- fma(-v, (src of lane LANE), acc) as ONE unit the compiler cannot pull apart: left to itself hipcc hoists the
-// v_readlane pairs of a whole column in front of the fmas and then spills the scalar results through VGPR lanes (four more
-// instructions per term, measured: the register kernel below no faster than the barrier kernel).
-// GUARD: the unit starts with a wait state.  The hardware wants one between a VALU write of a VGPR and a v_readlane of it, the
-// compiler inserts it for its own instructions but cannot see into the unit: a unit issued right behind the v_cndmask that
-// produced `src` read a stale low half (measured: factors off by 1e-8).  The first unit behind a new `src` is guarded.
-template<int LANE, bool GUARD = false>
-__device__ __forceinline__ void fma_neg_bcast(double & acc, double v, double src)
-{
-  const int lo = __double2loint(src), hi = __double2hiint(src);
-  if constexpr(GUARD)
-    asm volatile("s_nop 1\n\t"
-                 "v_readlane_b32 s90, %2, %4\n\t"
-                 "v_readlane_b32 s91, %3, %4\n\t"
-                 "s_nop 1\n\t"
-                 "v_fma_f64 %0, -%1, s[90:91], %0\n\t"
-                 "s_nop 0"
-                 : "+v"(acc)
-                 : "v"(v), "v"(lo), "v"(hi), "n"(LANE)
-                 : "s90", "s91");
-  else
-    asm volatile("v_readlane_b32 s90, %2, %4\n\t"
-                 "v_readlane_b32 s91, %3, %4\n\t"
-                 "s_nop 1\n\t"
-                 "v_fma_f64 %0, -%1, s[90:91], %0"
-                 : "+v"(acc)
-                 : "v"(v), "v"(lo), "v"(hi), "n"(LANE)
-                 : "s90", "s91");
-}
 template<int J, int NB, int C = J + 1, bool FIRST = true>
 __device__ __forceinline__ void column_update(double (&a)[NB], double v, double src)
 {
