@@ -440,6 +440,39 @@ __device__ __forceinline__ void llt_reg_columns(double (&a)[N], int & info, int 
   }
 }
 
+// ---- J = L^-T out of registers (one wave, lane = column c of J, acc[i] = the running J_ic) ---------------------------------
+// Row K of J is final once the rows below it are: J_Kc = acc[K] / L_KK; it then gives every row above its term
+// acc[i] -= L_Ki J_Kc (L_Ki: one LDS address for the wave, a broadcast read).  Per element the terms arrive for k = n-1 .. i+1,
+// descending, then one division: the order of the blocked left-looking loop this replaces (rows k > c contribute exact zeros
+// in both).  Terms in groups of sixteen, pinned where they are written (see llt_reg_trail).
+template<int K, int N, int I0>
+__device__ __forceinline__ void jinv_reg_trail(double (&acc)[N], double v, const double * Lrow, int ld)
+{
+  if constexpr(I0 < K)
+  {
+    constexpr int I1 = (I0 + 16 < K) ? I0 + 16 : K;
+    double lr[16];
+#pragma unroll
+    for(int i = I0; i < I1; ++i) lr[i - I0] = Lrow[i * ld];
+#pragma unroll
+    for(int i = I0; i < I1; ++i) acc[i] = FMA(-lr[i - I0], v, acc[i]);
+#pragma unroll
+    for(int i = I0; i < I1; ++i) asm volatile("" : "+v"(acc[i]));
+    jinv_reg_trail<K, N, I1>(acc, v, Lrow, ld);
+  }
+}
+template<int K, int N>
+__device__ __forceinline__ void jinv_reg_rows(double (&acc)[N], int lane, const double * L, double * J, int ld)
+{
+  if constexpr(K >= 0)
+  {
+    const double v = acc[K] / L[K + K * ld];
+    if(lane < N) J[K + lane * ld] = v;
+    jinv_reg_trail<K, N, 0>(acc, v, L + K, ld);
+    jinv_reg_rows<K - 1, N>(acc, lane, L, J, ld);
+  }
+}
+
 template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false, bool BOX = false>
 __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : (NT <= 16 ? 5 : (NT <= 32 ? 4 : 3))) : 1) void gi_batch_kernel(const BatchArgs A)
 {
@@ -866,6 +899,14 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       // for bit as the triangular loop would (x + (+-0) = x, and an accumulator is never -0 here).
       constexpr int JB = 8;
       const int cl = (lane < n) ? lane : (n - 1);
+      if constexpr(NT >= 16)
+      {
+        double acc[NR];
+#pragma unroll
+        for(int i = 0; i < NR; ++i) acc[i] = (i == lane) ? 1.0 : 0.0;
+        jinv_reg_rows<NR - 1, NR>(acc, lane, L, J, ld);
+      }
+      else
       for(int i0 = ((n - 1) / JB) * JB; i0 >= 0; i0 -= JB)
       {
         double acc[JB];
@@ -953,9 +994,38 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       dg = (lane < n) ? dg : 1.0;
       const double rinv = recip_refined(dg);
       const bool den_safe = __all(div_safe_den(dg));
-      for(int pass = 0; pass < 2; ++pass)
+      // First with hoisted reciprocals and the lean step of wave_fwd / wave_bwd (device_common.h): the quotient of lane k formed
+      // by every lane on its own entry and read with one v_readlane pair, the numerator left in its lane, all quotients of a
+      // substitution formed after its last step (so the numerators are checked once per substitution, not once per step).
+      bool lean_ok = false;
       {
-        // pass 0: hoisted reciprocals (div_pre); pass 1 (only if an operand left the safe range): plain a/b
+        double col = L[rl]; // column 0
+        for(int k = 0; k < n; ++k) // x = L.solve(a)
+        {
+          const double coln = L[rl + ((k + 1 < n) ? (k + 1) : k) * ld];
+          const double v = bcast_lane_s(div_pre(xi, dg, rinv), k);
+          const double upd = FMA(-col, v, xi);
+          xi = (lane > k && lane < n) ? upd : xi;
+          col = coln;
+        }
+        const double pre1 = xi;
+        xi = div_pre(pre1, dg, rinv);
+        col = L[(n - 1) + rl * ld]; // row n-1 of L = column n-1 of L^T
+        for(int k = n - 1; k >= 0; --k) // L^T.solveInPlace(x)
+        {
+          const double coln = L[((k > 0) ? (k - 1) : 0) + rl * ld];
+          const double v = bcast_lane_s(div_pre(xi, dg, rinv), k);
+          const double upd = FMA(-col, v, xi);
+          xi = (lane < k) ? upd : xi;
+          col = coln;
+        }
+        const double pre2 = xi;
+        xi = div_pre(pre2, dg, rinv);
+        lean_ok = den_safe && __all(div_safe_num(pre1) && div_safe_num(pre2));
+      }
+      for(int pass = 1; pass < 2 && !lean_ok; ++pass)
+      {
+        // (only if an operand left the range in which the hoisted reciprocal is provably the compiler's quotient): plain a/b
         bool safe = den_safe;
         xi = ai;
         double col = L[rl]; // column 0
