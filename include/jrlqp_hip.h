@@ -59,7 +59,7 @@ enum jrlqp_status
 };
 
 #define JRLQP_BATCH_MAX_N 128 /* largest n of the batched entry points */
-#define JRLQP_BATCH_WAVE_N 64 /* up to here a row of the factors is one lane of a wavefront (gi_batch.hip); beyond it (cold
+#define JRLQP_BATCH_WAVE_N 64 /* up to here a row of the factors is one lane of a wavefront (gi_batch_kernel.h); beyond it (cold
                                  start only) the solver of gi_batch_big.hip: J in LDS, R in LDS or in a stream-ordered scratch
                                  buffer, one workgroup per CU looping over the batch */
 
@@ -338,7 +338,7 @@ int jrlqp_selftest_arith(int n,
 /* Diagnostic: phase profile.  kernel: JRLQP_PROFILE_GI_BATCH (jrlqp_gi_solve_batch[_warm]) or JRLQP_PROFILE_BLOCKGI
  * (jrlqp_blockgi_solve); each keeps a buffer of its own.  When dprof != NULL the following solves of that family run an
  * instrumented build of the kernel that accumulates clock ticks per phase into dprof[b*slots_per_problem + slot], slot <
- * JRLQP_PROFILE_SLOTS (device int64, zero it first; the slots are listed in jrl-qp_amd/csrc/gi_batch.hip / blockgi.hip).
+ * JRLQP_PROFILE_SLOTS (device int64, zero it first; the slots are listed in jrl-qp_amd/csrc/gi_batch_kernel.h / blockgi.hip).
  * slots_per_problem must be >= JRLQP_PROFILE_SLOTS, and a solve of more than nprob problems while a buffer is set returns
  * JRLQP_ERR_INVALID_ARGUMENT instead of writing past it.  dprof == NULL returns to the production kernel.  Never used for
  * quoted times. */

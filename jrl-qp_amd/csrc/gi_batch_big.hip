@@ -1,7 +1,7 @@
 // gi_batch_big.hip -- Mode B for 64 < n <= 128: the device-resident batched Goldfarb-Idnani solver when a row of the
 // factors no longer fits one lane-per-row wavefront.
 //
-// Same entry point and same contract as gi_batch.hip (jrlqp_gi_solve_batch: one workgroup solves one QP end to end, the
+// Same entry point and same contract as gi_batch_kernel.h (jrlqp_gi_solve_batch: one workgroup solves one QP end to end, the
 // whole dual active-set state machine on the device, inputs read once, results written once, results bit-identical to the
 // CPU oracle), for the sizes the reference's own benchmark families reach (benchmarks/Solvers.cpp:613-623: n up to 100).
 //
@@ -24,7 +24,7 @@
 // Work split (256 threads): one thread per row / column / constraint for the O(n^2) parts -- every output element still
 // owns its in-order fma chain (CANON C1), which is what keeps the bits --, one thread for the scalar chains, barriers
 // between the phases.  This kernel is the coverage path for large n: it is written for exactness and simplicity, not for
-// the latency engineering of gi_batch.hip.
+// the latency engineering of gi_batch_kernel.h.
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
