@@ -1624,6 +1624,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
 
     // K11 (wave 0): removeConstraint (DualSolver.cpp:237-244, GoldfarbIdnaniSolver.cpp:239-256)
     auto do_drop = [&](int l) {
+      l = uniform(l); // (scalar loop counters below: the rotation loop broadcasts by a running index, see bcast_lane)
       double uv = (lane >= l && lane < q) ? us[lane + 1] : 0.0;
       int av = (lane >= l && lane < q - 1) ? act[lane + 1] : 0;
       int gone = act[l];
@@ -1631,13 +1632,21 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       if(lane >= l && lane < q) us[lane] = uv;
       if(lane >= l && lane < q - 1) act[lane] = av;
       if(lane == 0) st[gone] = INACTIVE;
-      const int qn = q - 1;
+      const int qn = uniform(q) - 1;
       const bool mine = (lane >= l && lane < qn); // lane = NEW column index; old column = lane + 1
-      for(int rr = 0; rr < l; ++rr)
+      // head rows 0 .. l-1 of the columns behind l move one column to the left: eight rows per round trip (all reads of a round
+      // before its writes: lane j writes the column lane j-1 reads)
+      for(int r0 = 0; r0 < l; r0 += 8)
       {
-        double v = mine ? R[rr + (lane + 1) * ld] : 0.0;
+        double v[8];
+        const double * src = R + (mine ? (lane + 1) : 0) * ld;
+#pragma unroll
+        for(int e = 0; e < 8; ++e) v[e] = src[min(r0 + e, l - 1)];
         wave_sync();
-        if(mine) R[rr + lane * ld] = v;
+#pragma unroll
+        for(int e = 0; e < 8; ++e)
+          if(mine && r0 + e < l) R[(r0 + e) + lane * ld] = v[e];
+        wave_sync();
       }
       double carry = mine ? R[l + (lane + 1) * ld] : 0.0;
       wave_sync();
@@ -1646,7 +1655,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       {
         double ynext = (i + 1 < qn && lane >= i + 1 && lane < qn) ? R[(i + 2) + (lane + 1) * ld] : 0.0;
         GivensHalf h;
-        double rho = givens_r(bcast_lane(carry, i), bcast_lane(y, i), h);
+        double rho = givens_r(bcast_lane_s(carry, i), bcast_lane_s(y, i), h);
         double c, s;
         givens_cs(h, c, s);
         if(lane == 0)
@@ -1668,11 +1677,15 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       {
         double jc = J[lane + l * ld];
         double ynext = J[lane + (l + 1) * ld];
+        double cn = ds[l], sn = zs[l]; // (c, s) of the next rotation requested one step ahead
         for(int i = l; i < qn; ++i)
         {
-          double c = ds[i], s = zs[i];
-          double yy = ynext;
-          if(i + 1 < qn) ynext = J[lane + (i + 2) * ld];
+          const double c = cn, s = sn;
+          const double yy = ynext;
+          const int i1 = (i + 1 < qn) ? (i + 1) : i;
+          cn = ds[i1];
+          sn = zs[i1];
+          ynext = J[lane + (i1 + 1) * ld];
           J[lane + i * ld] = FMA(c, jc, -(s * yy));
           jc = FMA(s, jc, c * yy);
         }
