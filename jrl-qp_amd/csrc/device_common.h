@@ -511,6 +511,77 @@ __device__ __forceinline__ double chain2_neg(int k0, int step, int cnt, double a
   return acc;
 }
 
+// ---- in-register right-looking LLT of the n x n Hessian (n = N compile time), one wave, lane = row -------------------------
+// The same scheme as the block-tridiagonal kernel's (structured.hip): a finished column goes to LDS; the term of column J + 1
+// comes from a v_readlane unit so that the next pivot, its square root and its division start at once; the terms of the columns
+// behind take L(c, J) back from LDS as broadcast reads, sixteen columns at a time (the register budget of this kernel), each
+// group pinned where it is written.  Per element: the terms in ascending k, then one division -- the bits of the left-looking
+// form it replaces (which walked the factored columns out of LDS for every block of eight: 64 k cycles at n = 50, this: 30 k).
+template<int J, int N, int C0>
+__device__ __forceinline__ void llt_reg_trail(double (&a)[N], double lij, const double * col)
+{
+  if constexpr(C0 < N)
+  {
+    constexpr int C1 = (C0 + 16 < N) ? C0 + 16 : N;
+    double lc[16];
+#pragma unroll
+    for(int c = C0; c < C1; ++c) lc[c - C0] = col[c];
+#pragma unroll
+    for(int c = C0; c < C1; ++c) a[c] = FMA(-lij, lc[c - C0], a[c]);
+#pragma unroll
+    for(int c = C0; c < C1; ++c) asm volatile("" : "+v"(a[c]));
+    llt_reg_trail<J, N, C1>(a, lij, col);
+  }
+}
+template<int J, int N>
+__device__ __forceinline__ void llt_reg_columns(double (&a)[N], int & info, int lane, double * L, int ld, double piv, double ljj, double lq)
+{
+  if constexpr(J < N)
+  {
+    if(piv <= 0.0)
+    {
+      info = J;
+      return;
+    }
+    const double lij = (lane == J) ? ljj : lq;
+    a[J] = lij;
+    if(lane >= J && lane < N) L[lane + J * ld] = lij;
+    double pn = 0.0, ln = 0.0, qn = 0.0;
+    if constexpr(J + 1 < N)
+    {
+      fma_neg_bcast<J + 1, true>(a[J + 1], lij, lij);
+      pn = bcast_lane(a[J + 1], J + 1);
+      ln = __builtin_sqrt(opaque_v(pn)); // (a non-positive pivot gives a NaN nobody uses)
+      qn = a[J + 1] / ln;
+      asm volatile("" : "+v"(ln), "+v"(qn)); // (computed HERE: left alone, the compiler sinks both into the next column's block)
+    }
+    llt_reg_trail<J, N, J + 2>(a, lij, L + J * ld);
+    llt_reg_columns<J + 1, N>(a, info, lane, L, ld, pn, ln, qn);
+  }
+}
+
+// X <- X L^-T for one row of X per lane (x[c] = X(lane, c)), L (N x N, lower, leading dimension ld) in LDS: column J of X is
+// final after one division, then gives the columns behind their term x[c] -= x(J) L(c, J) (L(c, J): a broadcast read).  Per
+// element the terms in ascending k, then one division.
+template<int J, int N>
+__device__ __forceinline__ void trsm_reg_columns(double (&x)[N], const double * L, int ld)
+{
+  if constexpr(J < N)
+  {
+    const double * col = L + J * ld;
+    double lc[N];
+#pragma unroll
+    for(int c = J; c < N; ++c) lc[c] = col[c];
+    const double xj = x[J] / lc[J];
+    x[J] = xj;
+#pragma unroll
+    for(int c = J + 1; c < N; ++c) x[c] = FMA(-xj, lc[c], x[c]);
+#pragma unroll
+    for(int c = J + 1; c < N; ++c) asm volatile("" : "+v"(x[c])); // (pinned to this column: see llt_reg_trail)
+    trsm_reg_columns<J + 1, N>(x, L, ld);
+  }
+}
+
 // logical diagonal block i of get<Up> (blockArrowLLT.cpp:22-46)
 __device__ __forceinline__ int dsel(int nblk, int up, int i)
 {

@@ -393,55 +393,6 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
 //         exact-size kernels -- BASELINE c3 among them -- keep nr a compile-time constant and their register allocation
 // BOX   : experimental::BoxAndSingleConstraintSolver -- G = I implicit, A.a holds x0, m == 1, nb == n; the closed-form init_
 //         of src/experimental/BoxAndSingleConstraintSolver.cpp:46-94 replaces LLT / J = L^-T / x0 / initActiveSet
-// ---- in-register right-looking LLT of the n x n Hessian (n = N compile time), one wave, lane = row -------------------------
-// The same scheme as the block-tridiagonal kernel's (structured.hip): a finished column goes to LDS; the term of column J + 1
-// comes from a v_readlane unit so that the next pivot, its square root and its division start at once; the terms of the columns
-// behind take L(c, J) back from LDS as broadcast reads, sixteen columns at a time (the register budget of this kernel), each
-// group pinned where it is written.  Per element: the terms in ascending k, then one division -- the bits of the left-looking
-// form it replaces (which walked the factored columns out of LDS for every block of eight: 64 k cycles at n = 50, this: 30 k).
-template<int J, int N, int C0>
-__device__ __forceinline__ void llt_reg_trail(double (&a)[N], double lij, const double * col)
-{
-  if constexpr(C0 < N)
-  {
-    constexpr int C1 = (C0 + 16 < N) ? C0 + 16 : N;
-    double lc[16];
-#pragma unroll
-    for(int c = C0; c < C1; ++c) lc[c - C0] = col[c];
-#pragma unroll
-    for(int c = C0; c < C1; ++c) a[c] = FMA(-lij, lc[c - C0], a[c]);
-#pragma unroll
-    for(int c = C0; c < C1; ++c) asm volatile("" : "+v"(a[c]));
-    llt_reg_trail<J, N, C1>(a, lij, col);
-  }
-}
-template<int J, int N>
-__device__ __forceinline__ void llt_reg_columns(double (&a)[N], int & info, int lane, double * L, int ld, double piv, double ljj, double lq)
-{
-  if constexpr(J < N)
-  {
-    if(piv <= 0.0)
-    {
-      info = J;
-      return;
-    }
-    const double lij = (lane == J) ? ljj : lq;
-    a[J] = lij;
-    if(lane >= J && lane < N) L[lane + J * ld] = lij;
-    double pn = 0.0, ln = 0.0, qn = 0.0;
-    if constexpr(J + 1 < N)
-    {
-      fma_neg_bcast<J + 1, true>(a[J + 1], lij, lij);
-      pn = bcast_lane(a[J + 1], J + 1);
-      ln = __builtin_sqrt(opaque_v(pn)); // (a non-positive pivot gives a NaN nobody uses)
-      qn = a[J + 1] / ln;
-      asm volatile("" : "+v"(ln), "+v"(qn)); // (computed HERE: left alone, the compiler sinks both into the next column's block)
-    }
-    llt_reg_trail<J, N, J + 2>(a, lij, L + J * ld);
-    llt_reg_columns<J + 1, N>(a, info, lane, L, ld, pn, ln, qn);
-  }
-}
-
 // ---- J = L^-T out of registers (one wave, lane = column c of J, acc[i] = the running J_ic) ---------------------------------
 // Row K of J is final once the rows below it are: J_Kc = acc[K] / L_KK; it then gives every row above its term
 // acc[i] -= L_Ki J_Kc (L_Ki: one LDS address for the wave, a broadcast read).  Per element the terms arrive for k = n-1 .. i+1,

@@ -53,78 +53,68 @@ __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
 // ============================================================================================================
 constexpr int NB = 32; // panel width
 
-// Panel j0, step 1: factor the diagonal block A11 (nb x nb) in LDS (one wave, lane = row), write it back.
-__global__ __launch_bounds__(64) void llt_diag_kernel(double * G, int ldg, int n, int j0, int * info)
+// Panel j0, steps 1 and 2 in ONE launch (round 2): every workgroup (one wave) factorises the diagonal block A11 itself, out of
+// registers (lane = row; llt_reg_columns, device_common.h: look-ahead pivot, the finished columns in LDS), and then computes its
+// 64 rows of L21 = A21 L11^-T out of registers as well (trsm_reg_columns: L11 read back from LDS as broadcasts).  The redundant
+// factorisation costs 6 us per workgroup and saves a dependent launch per panel; workgroup 0 writes L11.  Blocks narrower than
+// NB (the last panel) are padded with the identity, which factorises to itself and contributes exact zeros.  Per element: the
+// terms in ascending k, then one division -- the bits of the two left-looking LDS kernels of round 1 (26 + 23 us per panel;
+// this: 9 us).  A non-positive pivot: *info = its index, nothing at or after that column is written and
+// A21 is left alone, as before.
+__global__ __launch_bounds__(64) void llt_panel_fused_kernel(double * G, int ldg, int n, int j0, int * info)
 {
   __shared__ double L11[NB * (NB + 1)];
   const int lane = threadIdx.x;
   const int nb = min(NB, n - j0);
-  const int ld1 = NB + 1;
+  constexpr int ld1 = NB + 1;
   if(*info >= 0) return;
-  for(int e = lane; e < nb * nb; e += 64)
+  double a[NB];
   {
-    int i = e % nb, j = e / nb;
-    L11[i + j * ld1] = AT(G, ldg, j0 + i, j0 + j);
+    const bool row = lane < nb;
+    const int r = j0 + (row ? lane : 0);
+#pragma unroll
+    for(int c = 0; c < NB; ++c)
+    {
+      const double v = AT(G, ldg, r, j0 + ((c < nb) ? c : 0));
+      a[c] = (row && c < nb) ? v : ((lane == c) ? 1.0 : 0.0);
+    }
   }
-  wave_sync();
-  for(int j = 0; j < nb; ++j)
+  int bad = -1;
   {
-    double acc = 0.0;
-    if(lane >= j && lane < nb)
-    {
-      acc = L11[lane + j * ld1];
-      for(int k = 0; k < j; ++k) acc = FMA(-L11[lane + k * ld1], L11[j + k * ld1], acc);
-    }
-    double piv = bcast_lane(acc, j);
-    if(piv <= 0.0)
-    {
-      if(lane == 0) *info = j0 + j; // Eigen llt_inplace: index of the first non-positive pivot
-      return;                       // nothing is written at or after that column
-    }
-    double ljj = __builtin_sqrt(piv);
-    if(lane == j)
-    {
-      L11[j + j * ld1] = ljj;
-      AT(G, ldg, j0 + j, j0 + j) = ljj;
-    }
-    else if(lane > j && lane < nb)
-    {
-      double v = acc / ljj;
-      L11[lane + j * ld1] = v;
-      AT(G, ldg, j0 + lane, j0 + j) = v;
-    }
-    wave_sync();
+    const double p0 = bcast_lane(a[0], 0), l0 = __builtin_sqrt(opaque_v(p0));
+    llt_reg_columns<0, NB>(a, bad, lane, L11, ld1, p0, l0, a[0] / l0);
   }
-}
-
-// Panel j0, step 2: L21 = A21 L11^-T, 64 rows per workgroup, row per lane (L11 staged in LDS)
-__global__ __launch_bounds__(64) void llt_panel_kernel(double * G, int ldg, int n, int j0, const int * info)
-{
-  __shared__ double L11[NB * (NB + 1)];
-  __shared__ double X[64 * (NB + 1)];
-  const int lane = threadIdx.x;
-  const int nb = min(NB, n - j0);
-  const int ld1 = NB + 1;
-  if(*info >= 0) return;
-  for(int e = lane; e < nb * nb; e += 64)
+  // (llt_reg_columns stores lanes >= J of column J for lane < NB: the padded rows too, harmless)
+  const int cols = (bad < 0) ? nb : bad; // finished columns
+  if(blockIdx.x == 0)
   {
-    int i = e % nb, j = e / nb;
-    L11[i + j * ld1] = AT(G, ldg, j0 + i, j0 + j);
+    if(lane < nb)
+    {
+#pragma unroll
+      for(int c = 0; c < NB; ++c)
+        if(c < cols && lane >= c) AT(G, ldg, j0 + lane, j0 + c) = a[c];
+    }
+    if(bad >= 0 && lane == 0) *info = j0 + bad; // Eigen llt_inplace: index of the first non-positive pivot
   }
+  if(bad >= 0) return;
   wave_sync();
   const int row = j0 + nb + blockIdx.x * 64 + lane;
-  if(row < n)
+  if(j0 + nb >= n) return; // (the last panel has no rows below it)
+  const bool live = row < n;
+  const int rr = live ? row : (n - 1);
+  double x[NB];
+#pragma unroll
+  for(int c = 0; c < NB; ++c)
   {
-    // X is row-major per lane (stride NB+1, odd: conflict-free): X[lane][j]
-    for(int j = 0; j < nb; ++j) X[lane * ld1 + j] = AT(G, ldg, row, j0 + j);
-    for(int j = 0; j < nb; ++j)
-    {
-      double s = X[lane * ld1 + j];
-      for(int k = 0; k < j; ++k) s = FMA(-X[lane * ld1 + k], L11[j + k * ld1], s);
-      s = s / L11[j + j * ld1];
-      X[lane * ld1 + j] = s;
-      AT(G, ldg, row, j0 + j) = s;
-    }
+    const double v = AT(G, ldg, rr, j0 + ((c < nb) ? c : 0));
+    x[c] = (c < nb) ? v : 0.0;
+  }
+  trsm_reg_columns<0, NB>(x, L11, ld1);
+  if(live)
+  {
+#pragma unroll
+    for(int c = 0; c < NB; ++c)
+      if(c < nb) AT(G, ldg, row, j0 + c) = x[c];
   }
 }
 
@@ -1408,10 +1398,9 @@ hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st)
   {
     const int nb = (n - j0 < NB) ? (n - j0) : NB;
     const int rows = n - j0 - nb;
-    hipLaunchKernelGGL(llt_diag_kernel, dim3(1), dim3(64), 0, st, G, ldg, n, j0, d_info);
+    hipLaunchKernelGGL(llt_panel_fused_kernel, dim3(rows > 0 ? (rows + 63) / 64 : 1), dim3(64), 0, st, G, ldg, n, j0, d_info);
     if(rows > 0)
     {
-      hipLaunchKernelGGL(llt_panel_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, G, ldg, n, j0, d_info);
       const int t = (rows + 15) / 16;
       hipLaunchKernelGGL(llt_update_kernel, dim3(t, t), dim3(64), 0, st, G, ldg, n, j0, d_info);
     }
