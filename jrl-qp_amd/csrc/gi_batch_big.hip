@@ -133,6 +133,8 @@ __device__ __forceinline__ void argmin3(double & val, int & idx, int & aux)
 // Returns the final radius R(q, q).  (The same scheme as add_chain_kernel of gi_dense.hip.)
 __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho, double * ssq, double * cc, double * ss, int lane)
 {
+  n = __builtin_amdgcn_readfirstlane(n); // (block bounds and lane numbers from the SALU: see bcast_lane in device_common.h)
+  q = __builtin_amdgcn_readfirstlane(q);
   double r = 0.0;
   for(int pass = 0; pass < 2; ++pass)
   {
@@ -388,7 +390,8 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         // r = R^-1 d1 on wave 0, two entries per lane (rows lane and lane + 64), columns k = q-1 .. 0: the quotient of the
         // pivot row is formed in every lane (same operands, same bits)
         double r0 = (lane < q) ? ds[lane] : 0.0, r1 = (lane + 64 < q) ? ds[lane + 64] : 0.0;
-        for(int k = q - 1; k >= 0; --k)
+        const int qs = __builtin_amdgcn_readfirstlane(q); // (a scalar loop counter: see bcast_lane in device_common.h)
+        for(int k = qs - 1; k >= 0; --k)
         {
           const double num = (k < 64) ? bcast_lane(r0, k) : bcast_lane(r1, k - 64);
           const double v = num / RP(k, k);
