@@ -972,7 +972,11 @@ __global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const doubl
         GivensSeed g = givens_seed(dsm[mi], ssq[mi + 1]);
         if(seeded == 2) g.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
         double rc = 0.0;
-        for(int k = 0; k < cnt; ++k) rc = givens_seeded_step(dpp_shift_d<0x138>(rc, rprev), g);
+        // always 64 sweeps, unrolled: a lane's value is final once the lane above it is and a further sweep reproduces it
+        // (same inputs, same function), so the sweeps past cnt in the last, partial block change nothing -- and the loop has
+        // no counter, compare and branch per sweep (a sweep is 8 dependent operations and a two-instruction DPP shift)
+#pragma unroll 8
+        for(int k = 0; k < 64; ++k) rc = givens_seeded_step(dpp_shift_d<0x138>(rc, rprev), g);
         const double rin = dpp_shift_d<0x138>(rc, rprev); // r_{i+1} of this lane's step
         if(mine >= lo) rho[mine + 1] = rin;
         rprev = bcast_lane(rc, cnt - 1);
