@@ -52,7 +52,13 @@ def pmc_traffic(pattern, key):
     measured on other kernel sources than this tree's (stale numbers are never quoted beside fresh timings)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    import re
+
+    def round_no(path):  # profiles/r<N>_...: newest = highest round NUMBER (a lexicographic sort puts r10 before r2)
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        return (int(m.group(1)) if m else -1, os.path.getmtime(path))
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=round_no)
     if not files:
         return None, "no PMC pass on record (profiles/" + pattern + ")"
     path = files[-1]
@@ -77,11 +83,27 @@ def oracle_build_flags():
     return None
 
 
+def cgroup_cpu_quota():
+    """CPUs the container may use according to its cgroup (v2 cpu.max, v1 cfs quota); None = unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(pb, budget_s=12.0):
-    """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample of the same
-    workload: the first `sample` QPs, solved round after round (G restored from a copy before every solve, as the
-    reference's own benchmark loop does, benchmarks/Solvers.cpp:447-453,:508-520) until about `budget_s` seconds
-    of wall time have passed.  Reported baseline, not the optimisation target."""
+    """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample of the same workload.
+    The timed loop is the reference's own benchmark loop (benchmarks/Solvers.cpp:447-453, :508-520) and runs entirely in C
+    (oracle orc_gi_bench_rounds): one workspace and one G buffer per OpenMP thread, G restored by a per-thread memcpy INSIDE
+    the loop before every solve, outputs preallocated, the clock between two barriers inside the parallel region -- no Python,
+    no serial copy and no allocation inside the timed rounds.  Reported baseline, not the optimisation target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import get_oracle  # cpu_baseline leg only
 
@@ -90,46 +112,43 @@ def cpu_baseline(pb, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))  # the cores this process may actually use
     except AttributeError:
         cores = os.cpu_count() or 1
-    probe = min(64, pb.B)
-    t0 = time.perf_counter()
-    o.solve_batch(pb.G[:probe], pb.a[:probe], pb.C[:probe], pb.bl[:probe], pb.bu[:probe], nthreads=1)
-    per = (time.perf_counter() - t0) / probe
     sample = pb.B
-    args = (pb.G[:sample], pb.a[:sample], pb.C[:sample], pb.bl[:sample], pb.bu[:sample])
-    # the affinity mask can overstate what the container may really use (cgroup quotas): probe thread counts and keep
-    # the fastest; `cores` reports the thread count actually used for the quoted number
-    best_t, best_rate = 1, 0.0
-    t = 1
+    run, _ = o.bench_rounds_fn(pb.G[:sample], pb.a[:sample], pb.C[:sample], pb.bl[:sample], pb.bu[:sample])
+    probe_run, _ = o.bench_rounds_fn(pb.G[:256], pb.a[:256], pb.C[:256], pb.bl[:256], pb.bu[:256])
+    probe_run(1, 1)
+    per = min(probe_run(1, 1) for _ in range(3)) / 256  # single-thread seconds per solve (same loop, same restore)
+    # the affinity mask can overstate what the container may really use (cgroup quotas, SMT siblings): probe thread counts and
+    # keep the fastest; `cores` reports the thread count actually used for the quoted number
+    best_t, best_rate, t, probed = 1, 0.0, 1, {}
     while True:
-        rate = 0.0
-        for _ in range(4):  # the first calls at a new width pay for the OpenMP pool and page faults: keep the best
-            t0 = time.perf_counter()
-            o.solve_batch(*args, nthreads=t)
-            rate = max(rate, sample / (time.perf_counter() - t0))
+        run(1, t)  # the first call at a new width pays for the OpenMP pool and page faults
+        rate = max(sample / run(1, t) for _ in range(3))
+        probed[t] = rate
         if rate > best_rate:
             best_t, best_rate = t, rate
         if t >= cores:
             break
         t = min(cores, t * 2)
     cores_avail, cores = cores, best_t
-    for _ in range(3):
-        o.solve_batch(*args, nthreads=cores)  # settle at the chosen width
-    rounds, t0 = 0, time.perf_counter()
-    while True:
-        o.solve_batch(*args, nthreads=cores)
-        rounds += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or rounds >= 2000:
-            break
+    rounds_per_call = max(1, int(2.0 * best_rate / sample))  # about two seconds per C call
+    rounds, dt = 0, 0.0
+    while dt < budget_s and rounds < 100000:
+        dt += run(rounds_per_call, cores)
+        rounds += rounds_per_call
+    value = sample * rounds / dt
     return {
-        "value": sample * rounds / dt,
+        "value": value,
         "unit": "solves/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{rounds} rounds over the first {sample} QPs of the same workload ({dt:.1f} s), {cores} OpenMP threads "
-                  f"(fastest of 1..{cores_avail} probed; affinity mask has {cores_avail}), one workspace per thread, G restored before "
-                  f"every solve; single-thread probe {per * 1e6:.1f} us/solve",
+        "sample": f"{rounds} rounds over the first {sample} QPs of the same workload ({dt:.1f} s inside the C timing loop), {cores} OpenMP threads "
+                  f"(fastest of {sorted(probed)} probed; affinity mask has {cores_avail}), one workspace + one G buffer per thread, G restored by "
+                  f"memcpy inside the loop before every solve (benchmarks/Solvers.cpp:451); single-thread probe {per * 1e6:.1f} us/solve",
         "single_thread_us_per_solve": per * 1e6,
+        "parallel_efficiency": value * per / cores,  # value / (threads x single-thread rate)
+        "thread_probe_solves_per_s": {str(k): v for k, v in sorted(probed.items())},
+        "cgroup_cpu_quota": cgroup_cpu_quota(),
+        "affinity_cpus": cores_avail,
         "build_flags": oracle_build_flags(),
     }
 
@@ -164,6 +183,9 @@ def launch_ranks(n, argv):
         port = sk.getsockname()[1]
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; without it RCCL's cross-process
+        # buffer registration fails with "hipIpcGetMemHandle: invalid argument".  The image exports it already -- the ranks
+        # inherit whatever the caller set, and get 0 only when the variable is absent (tests/test_bench_launcher.py).
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
@@ -191,7 +213,8 @@ def rank_report(jdist, torch, device, local_solves, elapsed_local, x_local, tota
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
-        return {"rccl_world_size": 1, "backend": None, "per_rank_solves_per_s": [local_solves / elapsed_local], "allgather_x_ms": None}
+        return {"rccl_world_size": 1, "backend": None, "per_rank_solves_per_s": [local_solves / elapsed_local], "allgather_x_ms": None,
+                "allgather_x_bytes": 0, "process_group_initialized": False}
     world = dist.get_world_size()
     t = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
     ts = [torch.empty_like(t) for _ in range(world)]
@@ -209,7 +232,7 @@ def rank_report(jdist, torch, device, local_solves, elapsed_local, x_local, tota
     ag_ms = (time.perf_counter() - t0) / reps * 1e3
     assert xa.shape[0] == total
     return {"rccl_world_size": world, "backend": dist.get_backend(), "per_rank_solves_per_s": [local_solves / float(v.item()) for v in ts],
-            "allgather_x_ms": ag_ms, "allgather_x_bytes": int(xa.numel() * 8)}
+            "allgather_x_ms": ag_ms, "allgather_x_bytes": int(xa.numel() * 8), "process_group_initialized": True}
 
 
 def bench_ik(args, rank, world, device, jdist):
@@ -293,7 +316,7 @@ def bench_ik(args, rank, world, device, jdist):
         torch.distributed.destroy_process_group()
 
 
-def bench_single_large(args, rank, world, device, jdist):
+def bench_single_large(args, rank, world, device, jdist, emit=True):
     """Secondary workload (BASELINE config c2): one dense QP, n = 1024, m = 2048, 307 strongly active, through Mode A
     (jrlqp_dense_solve: state in HBM, host keeps the active-set state machine, one kernel per hook).  The path does not
     shard: at N > 1 every rank solves its own replica.  A step = one solve; G is restored before each
@@ -319,18 +342,22 @@ def bench_single_large(args, rank, world, device, jdist):
     torch.cuda.synchronize(device)
     if world > 1:
         torch.distributed.barrier()
+    per_solve = []
     t0 = time.perf_counter()
     for _ in range(steps):
         G.copy_(G0)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
         r = s.solve(G, a, C, bl, bu)
-    torch.cuda.synchronize(device)
+        torch.cuda.synchronize(device)
+        per_solve.append(time.perf_counter() - t1)
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     n_ok, sum_it, elapsed = jdist.reduce_stats(int(r["term"] == 0), int(r["iters"]), elapsed, device=device)
     # init_ alone (LLT of G, J = L^-T, x0; SURVEY 8(d) asks for it next to the per-iteration time): through the exported hooks
     init_ms = None
-    if rank == 0:
+    if rank == 0 and not getattr(args, "no_secondary", False):  # (counter passes: only whole solves, see tools/profile_round.sh)
         import ctypes as ct
 
         lib = capi.load_library()
@@ -354,22 +381,29 @@ def bench_single_large(args, rank, world, device, jdist):
         per_iter = 8.0 * (n * m + n * n + n * (n - q) + q * q / 2) + 16.0 * n * (n - q)
         alg = 8.0 * (n * n + n + n * m + 2 * m) + it * per_iter
         sec = elapsed / steps
+        traffic, traffic_source = pmc_traffic("r*_c2_dense_traffic.json", "traffic_bytes_per_solve")
         out = {"metric": "dense GI, one large QP (n=1024, m=2048): solves/sec per GPU (replicas)", "value": world * steps / elapsed, "unit": "solves/s",
-               "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 2)), "ms_per_step": sec * 1e3, "higher_is_better": True,
+               "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 2)), "ms_per_step": sec * 1e3,
+               "ms_per_step_min": min(per_solve) * 1e3, "ms_per_step_median": float(np.median(per_solve)) * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "BASELINE configs[1] (c2): one dense QP n=1024, m_ineq=2048, 307 strongly active, Mode A (host-driven hooks); "
                                       "replicas only at N > 1", "iterations": it, "solved": n_ok, "us_per_iteration": sec / max(it, 1) * 1e6, "init_ms": init_ms},
                "roofline": {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "kernel": "per-hook kernels (select / jtn / z / step_tail / add_chain / rot_apply)",
+                            "traffic": traffic, "traffic_source": traffic_source,
+                            "kernel": "per-hook kernels (select / jtn / z / step_tail / add_chain / rot_apply), all launches of one solve",
                             "algorithmic_bytes_per_launch": alg,
                             "note": "streamed-state model (upper bound: J, R, C = 32 MiB stay in the Infinity Cache); the iteration is bound by "
                                     "the serial Givens coefficient chain and the blocked back substitution, not by bandwidth (DESIGN.md 7.1)"}}
+        if not emit:
+            return out
         print(json.dumps(out), flush=True)
+    if not emit:
+        return None
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
-def bench_structured(args, rank, world, device, jdist):
+def bench_structured(args, rank, world, device, jdist, emit=True):
     """Secondary workload (BASELINE config c5): a batch of structured QPs -- block-arrow Hessian (100 stage blocks of 30 +
     head), block-diagonal C with 10 one-sided constraints per stage -- through jrlqp_blockgi_solve (factorisation + the
     device-resident structured GI loop).  A step = one batch; each rank owns its own shard (weak scaling).  The metric of
@@ -456,7 +490,15 @@ def bench_structured(args, rank, world, device, jdist):
                          "note": "frac is against the COMPULSORY bytes of SURVEY 8(d); the kernel is bandwidth-relevant only through its own re-reads "
                                  "(implementation_model), and a single CU per problem is instruction-issue/barrier bound (DESIGN.md 7.3)"},
         }
+        out["ms_per_step_min"], out["ms_per_step_median"] = float(np.min(kern_ms)), float(np.median(kern_ms))
+        if traffic is not None:
+            out["roofline"]["traffic_over_compulsory"] = traffic / compulsory
+            out["roofline"]["traffic_over_implementation_model"] = traffic / reread
+        if not emit:
+            return out
         print(json.dumps(out), flush=True)
+    if not emit:
+        return None
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -470,6 +512,10 @@ def main():
     ap.add_argument("--n", type=int, default=N_VAR)
     ap.add_argument("--m", type=int, default=M_INEQ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline only: skip the ma in {0, 25} rates, the c2 / c5 secondary records and the sustained loop (they run AFTER the "
+                         "timed region and never enter `value`); the profiling scripts use it to keep counter passes short")
+    ap.add_argument("--sustain", type=float, default=2.5, help="seconds of the labelled sustained loop after the timed region (N = 1)")
     ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c2", "ik-tri", "ik-arrow"],
                     help="c3 (default, the BASELINE metric): batch of dense QPs; c5: batch of structured block-arrow QPs "
                          "(100 stages x 30 + head, 10 constraints per stage) through the structured GI solver; "
@@ -510,6 +556,8 @@ def main():
         raise SystemExit(f"bench.py: process group has {world} rank(s) but --gpus {args.gpus}")
     device = torch.device("cuda", local_rank if (world > 1 and not SHARED_GPU_TEST) else 0)
     torch.cuda.set_device(device)
+    # one rank per GPU: keep the rank's host threads on the cores next to that GPU (N = 1: the CPU baseline must keep every core)
+    cpu_binding = jdist.bind_rank_to_gpu_numa(device.index, world) if world > 1 else "not bound (single rank: the CPU baseline uses every core)"
 
     if args.workload == "c5":
         return bench_structured(args, rank, world, device, jdist)
@@ -558,6 +606,8 @@ def main():
     ranks = rank_report(jdist, torch, cdev, (hi - lo) * args.steps, elapsed_local, r.x.cpu() if SHARED_GPU_TEST else r.x, total)
     if SHARED_GPU_TEST:
         ranks["shared_gpu_rehearsal"] = True
+    ranks["rank0_cpu_binding"] = cpu_binding
+    ranks["hsa_enable_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -609,6 +659,56 @@ def main():
                 "note": "latency/LDS-bound kernel (serial Givens/TRSV chains); HBM fraction is low by construction, see DESIGN.md §6",
             },
         }
+        # "min/median of >= 10 repetitions after warm-up" -- per-launch HIP-event times of the K timed steps
+        out["ms_per_step_min"], out["ms_per_step_median"] = float(np.min(kern_ms)), float(np.median(kern_ms))
+        out["value_at_median_step"] = (hi - lo) / (float(np.median(kern_ms)) * 1e-3) * world
+        out["value_at_min_step"] = (hi - lo) / (float(np.min(kern_ms)) * 1e-3) * world
+        if world == 1 and not args.no_secondary:
+            # Everything below runs AFTER the timed region of the headline and never enters `value`.
+            # ---- "also report ma in {0, floor(0.5 n)}" -- the same shape with 0 / 25 strongly active constraints
+            other = {}
+            for ma in (0, n // 2):
+                pb2 = P.generate_batch(hi - lo, P.benchmark_characteristics(n, m, ma), first_index=lo)
+                d2 = capi.to_device(pb2, device)
+                for _ in range(2):
+                    r2 = solver.solve(d2["G"], d2["a"], d2["C"], d2["bl"], d2["bu"], stream=stream)
+                ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for e0, e1 in ev2:
+                    e0.record(stream)
+                    r2 = solver.solve(d2["G"], d2["a"], d2["C"], d2["bl"], d2["bu"], stream=stream)
+                    e1.record(stream)
+                torch.cuda.synchronize(device)
+                k2 = [a.elapsed_time(b) for a, b in ev2]
+                other[f"ma={ma}"] = {"value": (hi - lo) / (float(np.median(k2)) * 1e-3), "unit": "solves/s", "ms_per_step_median": float(np.median(k2)),
+                                     "ms_per_step_min": float(np.min(k2)), "steps": 10, "mean_iterations": float(r2.iters.double().mean().item()),
+                                     "solved": int((r2.term == 0).sum().item())}
+                del d2, pb2
+            out["other_active_fractions"] = other
+            # ---- a clearly labelled SUSTAINED loop: the K timed steps are ~30 ms of kernels, too short for a utilisation sampler to see
+            if args.sustain > 0:
+                torch.cuda.synchronize(device)
+                ts, k = time.perf_counter(), 0
+                while time.perf_counter() - ts < args.sustain:
+                    for _ in range(50):
+                        step()
+                    torch.cuda.synchronize(device)
+                    k += 50
+                dts = time.perf_counter() - ts
+                out["sustained"] = {"what": "back-to-back launches of the headline workload for GPU-utilisation samplers; not part of `value`",
+                                    "seconds": dts, "steps": k, "value": (hi - lo) * k / dts, "unit": "solves/s"}
+            # ---- secondary workloads of BASELINE.json, each with a roofline of its own (c2: Mode A; c5: structured GI batch)
+            sec_args = argparse.Namespace(**vars(args))
+            sec_args.steps, sec_args.warmup, sec_args.batch = 3, 1, BATCH
+            del dev
+            torch.cuda.empty_cache()
+            secondary = {}
+            for name, fn in (("c2", bench_single_large), ("c5", bench_structured)):
+                try:
+                    secondary[name] = fn(sec_args, 0, 1, device, jdist, emit=False)
+                except Exception as e:  # a secondary record must never cost the headline line
+                    secondary[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pb)
         print(json.dumps(out), flush=True)

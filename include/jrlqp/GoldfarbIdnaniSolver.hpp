@@ -8,7 +8,7 @@
 //   auto st = qp.solve(G, a, C, bl, bu, xl, xu);              // HOST views; G is overwritten by its Cholesky factor
 //   qp.solution(), qp.multipliers(), qp.objectiveValue(), qp.iterations(), qp.activeSet()
 //
-// The numerics run on the GPU (libjrlqp_hip.so): n <= 64 through the device-resident batched kernel with a batch of
+// The numerics run on the GPU (libjrlqp_hip.so): n <= 128 through the device-resident batched kernels with a batch of
 // one (one launch per solve), larger problems through Mode A (state in HBM, host-driven active-set loop).  solve() copies
 // the problem to the device and the factor back (the reference's "G is clobbered" contract); solveDevice() takes
 // device pointers and copies nothing.  Contract of the reference kept: no exception leaves the class, and once sized
@@ -107,6 +107,16 @@ public:
       const size_t n = size_t(cn), m = size_t(cm), mt = m + size_t(cb);
       bool a = dev(&dG_, n * n) && dev(&da_, n) && dev(&dC_, n * m) && dev(&dbl_, m) && dev(&dbu_, m) && dev(&dxl_, cb) && dev(&dxu_, cb);
       a = a && dev(&dx_, n) && dev(&du_, mt) && dev(&dfv_, 1) && devi(&dst_, mt) && devi(&dti_, 2);
+      // workspace of the batched path (jrlqp_gi_batch_workspace_bytes; > 0 for 104 < n <= 128 only): sized HERE for the largest
+      // n the capacity admits -- it grows with n --, so that solve() never allocates
+      wsBytes_ = 0;
+      for(int k = (cn < JRLQP_BATCH_MAX_N ? cn : JRLQP_BATCH_MAX_N); k > JRLQP_BATCH_WAVE_N && wsBytes_ == 0; --k)
+      {
+        const long long b = jrlqp_gi_batch_workspace_bytes(k, 0, 0, 1);
+        if(b > 0) wsBytes_ = b;
+        if(b == 0) break;
+      }
+      if(wsBytes_ > 0) a = a && dev(&dws_, size_t(wsBytes_ + 7) / 8);
       if(!a) return;
       x_.reserve(n); u_.reserve(mt); as_.reserve(mt); ias_.reserve(mt);
     }
@@ -158,11 +168,11 @@ public:
   }
 
   /** Same with DEVICE pointers: nothing is copied but the results.  Sizes are those of the last resize().
-   *  Problems whose factors fit one CU's LDS (n <= 104, packed G and C) take the device-resident batched kernels with a batch
-   *  of one -- one launch for the whole solve instead of one host round trip per iteration (n = 100: ~2 ms against ~6 ms) --,
-   *  larger ones the host-driven hooks (Mode A); both leave the factor in G and give bit-identical results.  (105 <= n <= 128
-   *  could take the batched path too, but it would bracket the launch with a stream-ordered scratch allocation: Mode A keeps
-   *  the "no allocation once sized" contract to the letter.) */
+   *  Problems the device-resident batched kernels take (n <= 128, packed G and C) run there with a batch of one -- one launch
+   *  for the whole solve instead of one host round trip per iteration (n = 100: ~2 ms against ~6 ms) --, larger ones through
+   *  the host-driven hooks (Mode A); both leave the factor in G and give bit-identical results.  Beyond n = 104 the batched
+   *  kernel keeps R in a workspace: it was allocated by resize() (jrlqp_gi_batch_workspace_bytes), so a sized solver never
+   *  allocates inside solve() on either path. */
   TerminationStatus solveDevice(double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl, const double * dbu,
                                 const double * dxl, const double * dxu, hipStream_t stream = nullptr) noexcept
   {
@@ -170,11 +180,13 @@ public:
     jrlqp_options o{options_.maxIter_, options_.bigBnd_};
     int term = int(TerminationStatus::UNKNOWN);
     int cpl = 0;
-    if(n_ <= 104 && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
+    const long long wsNeed = (n_ <= JRLQP_BATCH_MAX_N) ? jrlqp_gi_batch_workspace_bytes(n_, m_, nb_, 1) : -1;
+    if(wsNeed >= 0 && wsNeed <= wsBytes_ && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
     {
       // dL == dG: the kernel reads G completely before it writes the factor (jrlqp_hip.h), i.e. the reference's in-place contract
-      if(!ok(jrlqp_gi_solve_batch(n_, m_, nb_, 1, dG, da, dC, dbl, dbu, dxl, dxu, &o, dx_, du_, dst_, dti_, dti_ + 1, dfv_, dG, nullptr, 0, stream),
-             "jrlqp_gi_solve_batch"))
+      if(!ok(jrlqp_gi_solve_batch_ws(0, n_, m_, nb_, 1, dG, da, dC, dbl, dbu, dxl, dxu, nullptr, &o, dx_, du_, dst_, dti_, dti_ + 1, dfv_, dG,
+                                     nullptr, 0, wsNeed > 0 ? dws_ : nullptr, wsNeed > 0 ? wsBytes_ : 0, stream),
+             "jrlqp_gi_solve_batch_ws"))
         return TerminationStatus::UNKNOWN;
       int ti[2] = {int(TerminationStatus::UNKNOWN), 0};
       bool c = hipok(hipMemcpyAsync(x_.data(), dx_, sizeof(double) * n_, hipMemcpyDeviceToHost, stream));
@@ -228,7 +240,8 @@ private:
   {
     if(h_) jrlqp_dense_destroy(h_);
     h_ = nullptr;
-    for(double ** p : {&dG_, &da_, &dC_, &dbl_, &dbu_, &dxl_, &dxu_, &dx_, &du_, &dfv_})
+    wsBytes_ = 0;
+    for(double ** p : {&dG_, &da_, &dC_, &dbl_, &dbu_, &dxl_, &dxu_, &dx_, &du_, &dfv_, &dws_})
     {
       if(*p) (void)hipFree(*p);
       *p = nullptr;
@@ -247,6 +260,8 @@ private:
   double f_ = 0.0;
   double *dG_ = nullptr, *da_ = nullptr, *dC_ = nullptr, *dbl_ = nullptr, *dbu_ = nullptr, *dxl_ = nullptr, *dxu_ = nullptr;
   double *dx_ = nullptr, *du_ = nullptr, *dfv_ = nullptr; // outputs of the batched (B = 1) path
+  double * dws_ = nullptr;                                // its workspace (105 <= n <= 128), wsBytes_ bytes
+  long long wsBytes_ = 0;
   int *dst_ = nullptr, *dti_ = nullptr;                   // activation status; {termination status, iterations}
   std::vector<double> x_, u_;
   std::vector<ActivationStatus> as_;

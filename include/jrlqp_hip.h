@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JRLQP_ABI_VERSION 1
+#define JRLQP_ABI_VERSION 2 /* 2: jrlqp_gi_batch_workspace_bytes / jrlqp_gi_solve_batch_ws; no allocation inside any solve */
 
 /* jrl::qp::ActivationStatus, include/jrl-qp/enums.h:15-23 (same numeric values) */
 enum jrlqp_activation
@@ -60,8 +60,8 @@ enum jrlqp_status
 
 #define JRLQP_BATCH_MAX_N 128 /* largest n of the batched entry points */
 #define JRLQP_BATCH_WAVE_N 64 /* up to here a row of the factors is one lane of a wavefront (gi_batch_kernel.h); beyond it (cold
-                                 start only) the solver of gi_batch_big.hip: J in LDS, R in LDS or in a stream-ordered scratch
-                                 buffer, one workgroup per CU looping over the batch */
+                                 start only) the solver of gi_batch_big.hip: J in LDS, R in LDS or in the caller's workspace
+                                 (jrlqp_gi_batch_workspace_bytes), a persistent grid looping over the batch */
 
 /* jrl::qp::SolverOptions, include/jrl-qp/SolverOptions.h:16-20 (maxIter_ = 500, bigBnd_ = 1e100).  warmStart_ and
  * the logging fields have no GPU counterpart: the production solver resets the active set anyway
@@ -108,8 +108,9 @@ void jrlqp_default_options(jrlqp_options * opts);
  *        dL == dG reproduces the reference's in-place contract (G's lower triangle <- L, upper part untouched).
  *   dtrace optional [B][trace_cap] records.
  * No allocation, no host synchronisation: the call enqueues one kernel on `stream` (a hipStream_t, may be NULL).
- * Requires 1 <= n <= JRLQP_BATCH_MAX_N.  (For 104 < n <= 128 the packed R factor no longer fits in LDS beside J: the call then
- * brackets its kernel with a stream-ordered hipMallocAsync / hipFreeAsync of 66 KB per CU -- still no host synchronisation.)
+ * Requires 1 <= n <= JRLQP_BATCH_MAX_N.  Shapes for which jrlqp_gi_batch_workspace_bytes() > 0 (104 < n <= 128: the packed R
+ * factor no longer fits in LDS beside J) need the caller-owned workspace of jrlqp_gi_solve_batch_ws below; this entry point
+ * then returns JRLQP_ERR_WORKSPACE instead of allocating.
  */
 int jrlqp_gi_solve_batch(int n,
                          int m,
@@ -170,6 +171,45 @@ int jrlqp_gi_solve_batch_warm(int n,
                               int trace_cap,
                               void * stream);
 
+/* Workspace contract of the batched solver -- the counterpart of "a pre-sized solver never allocates inside solve()"
+ * (DualSolver::resize, include/jrl-qp/DualSolver.h:33; internal/Workspace.h:37-43; asserted by
+ * tests/GoldfarbIdnaniSolverTest.cpp:109-116 under set_is_malloc_allowed(false)).
+ *   jrlqp_gi_batch_workspace_bytes: device bytes a batch of B problems of shape (n, m, nb) needs beside its inputs and outputs
+ *     on the CURRENT device: 0 for every shape whose state fits in LDS and registers (all n <= 104), one packed R factor per
+ *     resident workgroup of the persistent grid otherwise (sized by the machine, not by B); -1 if the shape is unsupported.
+ *   jrlqp_gi_solve_batch_ws: jrlqp_gi_solve_batch (warm == 0, das ignored) or jrlqp_gi_solve_batch_warm (warm != 0) with that
+ *     workspace: dworkspace is a 16-byte aligned device pointer to at least workspace_bytes >= the figure above (NULL / 0 when
+ *     that figure is 0).  The workspace is scratch: nothing survives the call, and one workspace must not be shared by solves
+ *     that may run concurrently (different streams).  Too small a workspace returns JRLQP_ERR_WORKSPACE; nothing is launched.
+ * No entry point of this library allocates or frees device or host memory inside a solve. */
+long long jrlqp_gi_batch_workspace_bytes(int n, int m, int nb, int B);
+int jrlqp_gi_solve_batch_ws(int warm,
+                            int n,
+                            int m,
+                            int nb,
+                            int B,
+                            const double * dG,
+                            const double * da,
+                            const double * dC,
+                            const double * dbl,
+                            const double * dbu,
+                            const double * dxl,
+                            const double * dxu,
+                            const int * das,
+                            const jrlqp_options * opts,
+                            double * dx,
+                            double * du,
+                            int * dstatus,
+                            int * dterm,
+                            int * diters,
+                            double * df,
+                            double * dL,
+                            jrlqp_trace_rec * dtrace,
+                            int trace_cap,
+                            void * dworkspace,
+                            long long workspace_bytes,
+                            void * stream);
+
 /* experimental::BoxAndSingleConstraintSolver over a batch.  Replaces B calls of
  *     BoxAndSingleConstraintSolver::solve(x0, c, bl, xl, xu)      (include/jrl-qp/experimental/BoxAndSingleConstraintSolver.h:9-33,
  *                                                                  src/experimental/BoxAndSingleConstraintSolver.cpp:11-44)
@@ -179,7 +219,8 @@ int jrlqp_gi_solve_batch_warm(int n,
  * (multiplier |x0_i - bound_i|, J a permutation, R = diag(+-1)), no factorisation; then the unchanged GI loop.
  *   dx0, dc, dxl, dxu [B][n]; dbl [B].  Outputs: dx [B][n]; du, dstatus [B][1+n] (the general constraint first, then the
  *   bounds); dterm, diters, df [B]; df is 1/2 ||x - x0||^2 itself (the reference's objectiveValue(), constant included).
- * Requires n <= JRLQP_BATCH_MAX_N.  One launch, no allocation, no host synchronisation. */
+ * Requires n <= JRLQP_BATCH_WAVE_N (the closed-form start is one wavefront, lane = variable); larger n returns
+ * JRLQP_ERR_UNSUPPORTED_SIZE.  One launch, no allocation, no host synchronisation. */
 int jrlqp_box_solve_batch(int n,
                           int B,
                           const double * dx0,

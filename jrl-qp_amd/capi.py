@@ -25,6 +25,8 @@ EXPORTED = [
     "jrlqp_default_options",
     "jrlqp_gi_solve_batch",
     "jrlqp_gi_solve_batch_warm",
+    "jrlqp_gi_batch_workspace_bytes",
+    "jrlqp_gi_solve_batch_ws",
     "jrlqp_box_solve_batch",
     "jrlqp_gi_batch_lds_bytes",
     "jrlqp_gi_batch_warm_lds_bytes",
@@ -71,7 +73,15 @@ class TraceRec(ct.Structure):
 
 
 class JrlqpError(RuntimeError):
-    pass
+    """An error code of the ABI itself (enum jrlqp_status); `status` is that code (0 when the library could not be loaded)."""
+
+    def __init__(self, msg, status=0):
+        super().__init__(msg)
+        self.status = status
+
+
+# enum jrlqp_status (include/jrlqp_hip.h)
+ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED_SIZE, ERR_NO_DEVICE, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4, -5
 
 
 _LIB = None
@@ -108,6 +118,11 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_gi_solve_batch_warm.restype = ct.c_int
     lib.jrlqp_gi_solve_batch_warm.argtypes = ([ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 8 + [ct.POINTER(Options)] + [c_dp] * 8
                                               + [ct.c_int, c_dp])
+    lib.jrlqp_gi_batch_workspace_bytes.restype = ct.c_longlong
+    lib.jrlqp_gi_batch_workspace_bytes.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int]
+    lib.jrlqp_gi_solve_batch_ws.restype = ct.c_int
+    lib.jrlqp_gi_solve_batch_ws.argtypes = ([ct.c_int] * 5 + [c_dp] * 8 + [ct.POINTER(Options)] + [c_dp] * 8
+                                            + [ct.c_int, c_dp, ct.c_longlong, c_dp])
     lib.jrlqp_box_solve_batch.restype = ct.c_int
     lib.jrlqp_box_solve_batch.argtypes = [ct.c_int, ct.c_int] + [c_dp] * 5 + [ct.POINTER(Options)] + [c_dp] * 6 + [c_dp, ct.c_int, c_dp]
     lib.jrlqp_gi_solve_batch.restype = ct.c_int
@@ -164,7 +179,7 @@ def check(status: int):
     if status != 0:
         lib = load_library()
         msg = lib.jrlqp_status_string(status).decode()
-        raise JrlqpError(f"jrlqp error {status}: {msg} (hip error {lib.jrlqp_last_hip_error()})")
+        raise JrlqpError(f"jrlqp error {status}: {msg} (hip error {lib.jrlqp_last_hip_error()})", status)
 
 
 def _ptr(t):
@@ -212,6 +227,13 @@ class BatchSolver:
         self.L = torch.zeros((B, n, n), dtype=f64, device=self.device) if want_factor else None
         self.trace_cap = trace_cap
         self.trace = torch.zeros((B, trace_cap, ct.sizeof(TraceRec)), dtype=torch.uint8, device=self.device) if trace_cap else None
+        # the workspace of a pre-sized solver (jrlqp_gi_batch_workspace_bytes): allocated HERE, never inside solve()
+        with torch.cuda.device(self.device):
+            wsb = int(self.lib.jrlqp_gi_batch_workspace_bytes(n, m, self.nb, B))
+        if wsb < 0:
+            raise JrlqpError(f"batched path does not support n={n}, m={m}")
+        self.workspace_bytes = wsb
+        self.workspace = torch.empty((wsb + 7) // 8, dtype=f64, device=self.device) if wsb else None
 
     def solve(self, G, a, C, bl, bu, xl=None, xu=None, stream=None) -> BatchResult:
         """All inputs: contiguous float64 CUDA tensors in the packed layout of include/jrlqp_hip.h
@@ -225,11 +247,11 @@ class BatchSolver:
         if self.nb:
             assert xl.shape == (self.B, self.nb) and xu.shape == (self.B, self.nb)
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        st = self.lib.jrlqp_gi_solve_batch(
-            self.n, self.m, self.nb, self.B, _ptr(G), _ptr(a), _ptr(C), _ptr(bl), _ptr(bu),
-            _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None, ct.byref(self.opts),
+        st = self.lib.jrlqp_gi_solve_batch_ws(
+            0, self.n, self.m, self.nb, self.B, _ptr(G), _ptr(a), _ptr(C), _ptr(bl), _ptr(bu),
+            _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None, None, ct.byref(self.opts),
             _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term), _ptr(self.iters), _ptr(self.f),
-            _ptr(self.L), _ptr(self.trace), self.trace_cap, ct.c_void_p(s.cuda_stream))
+            _ptr(self.L), _ptr(self.trace), self.trace_cap, _ptr(self.workspace), self.workspace_bytes, ct.c_void_p(s.cuda_stream))
         check(st)
         return BatchResult(self.x, self.u, self.status, self.term, self.iters, self.f, self.L, self.trace)
 
@@ -254,11 +276,11 @@ class BatchSolver:
         if self.lib.jrlqp_gi_batch_warm_lds_bytes(self.n, self.m, self.nb, ct.byref(c)) < 0:
             raise JrlqpError(f"warm-started batched path does not support n={self.n}, m={self.m}")
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        st = self.lib.jrlqp_gi_solve_batch_warm(
-            self.n, self.m, self.nb, self.B, _ptr(G), _ptr(a), _ptr(C), _ptr(bl), _ptr(bu),
+        st = self.lib.jrlqp_gi_solve_batch_ws(
+            1, self.n, self.m, self.nb, self.B, _ptr(G), _ptr(a), _ptr(C), _ptr(bl), _ptr(bu),
             _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None, _ptr(guess), ct.byref(self.opts),
             _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term), _ptr(self.iters), _ptr(self.f),
-            _ptr(self.L), _ptr(self.trace), self.trace_cap, ct.c_void_p(s.cuda_stream))
+            _ptr(self.L), _ptr(self.trace), self.trace_cap, _ptr(self.workspace), self.workspace_bytes, ct.c_void_p(s.cuda_stream))
         check(st)
         return BatchResult(self.x, self.u, self.status, self.term, self.iters, self.f, self.L, self.trace)
 

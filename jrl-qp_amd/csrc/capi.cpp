@@ -162,6 +162,32 @@ long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds)
   return jrlqp::batch_lds_bytes(n, m, nb, cmode);
 }
 
+// grid of the persistent kernel of gi_batch_big.hip on the current device (0: no device)
+static int big_grid(int n, int m, int nb, int B)
+{
+  int dev = 0, ncu = 0;
+  if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
+    return 0;
+  const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr);
+  const int per_cu = ldsb > 0 ? (int)(jrlqp::kLdsPerCU / ldsb) : 1;
+  const int slots = ncu * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+  return B < slots ? B : slots;
+}
+
+long long jrlqp_gi_batch_workspace_bytes(int n, int m, int nb, int B)
+{
+  if(n < 1 || n > JRLQP_BATCH_MAX_N || m < 0 || B < 0 || (nb != 0 && nb != n)) return -1;
+  if(n <= JRLQP_BATCH_WAVE_N) return jrlqp::batch_pick_cmode(n, m, nb) < 0 ? -1 : 0;
+  int r_in_lds = 0;
+  if(jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0) return -1;
+  if(r_in_lds || B == 0) return 0;
+  int dev = 0, ncu = 0;
+  if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
+    return -1;
+  // sized by the machine (one slice per resident workgroup of the persistent grid), not by the batch
+  return (long long)sizeof(double) * big_grid(n, m, nb, B) * jrlqp::batch_big_ws_doubles_per_wg(n);
+}
+
 static int gi_batch_common(int warm,
                            const int * das,
                            int n,
@@ -185,6 +211,8 @@ static int gi_batch_common(int warm,
                            double * dL,
                            jrlqp_trace_rec * dtrace,
                            int trace_cap,
+                           void * dws,
+                           long long ws_bytes,
                            void * stream)
 {
   if(n < 1 || m < 0 || B < 0 || (nb != 0 && nb != n)) return JRLQP_ERR_INVALID_ARGUMENT;
@@ -224,29 +252,20 @@ static int gi_batch_common(int warm,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if(bign)
   {
-    // persistent grid: one workgroup per CU (J alone takes most of a CU's LDS), each looping over its share of the batch
-    int dev = 0, ncu = 0;
-    if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
-      return JRLQP_ERR_NO_DEVICE;
-    // (as many workgroups per CU as their LDS allows: two up to n = 88, one beyond)
-    const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr);
-    const int per_cu = ldsb > 0 ? (int)(jrlqp::kLdsPerCU / ldsb) : 1;
-    const int slots = ncu * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
-    const int nwg = B < slots ? B : slots;
+    // persistent grid: as many workgroups per CU as their LDS allows (two up to n = 88, one beyond), each looping over its
+    // share of the batch
+    const int nwg = big_grid(n, m, nb, B);
+    if(nwg < 1) return JRLQP_ERR_NO_DEVICE;
     double * ws = nullptr;
     if(!r_in_lds)
     {
-      // R (packed, 66 KB at n = 128) does not fit beside J: a stream-ordered scratch allocation, returned to the pool by the
-      // same stream right behind the kernel -- no host synchronisation, no race between streams
-      hipError_t ea = hipMallocAsync(reinterpret_cast<void **>(&ws), sizeof(double) * (size_t)nwg * jrlqp::batch_big_ws_doubles_per_wg(n), st);
-      if(ea != hipSuccess) return hip_fail(ea);
+      // R (packed, 66 KB at n = 128) does not fit beside J: it lives in the CALLER's workspace (jrlqp_gi_batch_workspace_bytes)
+      // -- nothing is allocated inside a solve (tests/GoldfarbIdnaniSolverTest.cpp:109-116)
+      const long long need = (long long)sizeof(double) * nwg * jrlqp::batch_big_ws_doubles_per_wg(n);
+      if(!dws || ws_bytes < need || (reinterpret_cast<size_t>(dws) & 15)) return JRLQP_ERR_WORKSPACE;
+      ws = static_cast<double *>(dws);
     }
     hipError_t e = jrlqp::launch_gi_batch_big(a, nwg, ws, st);
-    if(ws)
-    {
-      hipError_t ef = hipFreeAsync(ws, st);
-      if(e == hipSuccess) e = ef;
-    }
     return e == hipSuccess ? JRLQP_OK : hip_fail(e);
   }
   hipError_t e = jrlqp::launch_gi_batch(a, cmode, st);
@@ -269,7 +288,18 @@ int jrlqp_gi_solve_batch(int n, int m, int nb, int B, const double * dG, const d
                          double * df, double * dL, jrlqp_trace_rec * dtrace, int trace_cap, void * stream)
 {
   return gi_batch_common(0, nullptr, n, m, nb, B, dG, da, dC, dbl, dbu, dxl, dxu, opts, dx, du, dstatus, dterm, diters, df,
-                         dL, dtrace, trace_cap, stream);
+                         dL, dtrace, trace_cap, nullptr, 0, stream);
+}
+
+int jrlqp_gi_solve_batch_ws(int warm, int n, int m, int nb, int B, const double * dG, const double * da, const double * dC,
+                            const double * dbl, const double * dbu, const double * dxl, const double * dxu, const int * das,
+                            const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm, int * diters,
+                            double * df, double * dL, jrlqp_trace_rec * dtrace, int trace_cap, void * dworkspace,
+                            long long workspace_bytes, void * stream)
+{
+  if(workspace_bytes < 0 || (workspace_bytes > 0 && !dworkspace)) return JRLQP_ERR_INVALID_ARGUMENT;
+  return gi_batch_common(warm ? 1 : 0, warm ? das : nullptr, n, m, nb, B, dG, da, dC, dbl, dbu, dxl, dxu, opts, dx, du, dstatus, dterm,
+                         diters, df, dL, dtrace, trace_cap, dworkspace, workspace_bytes, stream);
 }
 
 int jrlqp_gi_solve_batch_warm(int n, int m, int nb, int B, const double * dG, const double * da, const double * dC,
@@ -279,7 +309,7 @@ int jrlqp_gi_solve_batch_warm(int n, int m, int nb, int B, const double * dG, co
                               int trace_cap, void * stream)
 {
   return gi_batch_common(1, das, n, m, nb, B, dG, da, dC, dbl, dbu, dxl, dxu, opts, dx, du, dstatus, dterm, diters, df, dL,
-                         dtrace, trace_cap, stream);
+                         dtrace, trace_cap, nullptr, 0, stream);
 }
 
 int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, const double * dbl, const double * dxl,
@@ -290,7 +320,8 @@ int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, c
   if(B == 0) return JRLQP_OK;
   if(!dx0 || !dc || !dbl || !dxl || !dxu || !dx || !du || !dstatus || !dterm || !diters || !df) return JRLQP_ERR_INVALID_ARGUMENT;
   if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
-  if(n > JRLQP_BATCH_MAX_N || jrlqp::batch_lds_bytes(n, 1, n, 1, 0) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  // the closed-form prologue is lane = variable on ONE wavefront (gi_batch_kernel.h, BOX): n <= 64 only
+  if(n > JRLQP_BATCH_WAVE_N || jrlqp::batch_lds_bytes(n, 1, n, 1, 0) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
   jrlqp_options o;
   jrlqp_default_options(&o);
   if(opts) o = *opts;

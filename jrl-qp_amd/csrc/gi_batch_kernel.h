@@ -82,11 +82,12 @@ struct Ctl
   int flag; // sequence number of the last add whose (c, s) coefficients are published (wave 0 -> wave 1 hand-off)
   int nact; // WARM: size of the initial active set
   int over; // WARM: more than n equalities / fixed variables activated
-  int pad;
+  int fack2;        // WS: pass number whose decision wave 2 has read (drop passes: nothing else ties that wave to MAIN)
   // WS (role-specialised main loop): hand-off words between the main wave and the helper waves, see ws_* below
   double rho;       // R(q, q) of the addition whose coefficients are published (chain wave -> main wave)
   int fd;           // pass number whose d (and p, pstat, q below) is published            main -> helpers
-  int fz, fx;       // pass number whose z, z.z / n.x, n.z are published                   z wave, dot wave -> main
+  int fz;           // pass number whose z, z.z, n.z, n.x and t2 are published               z wave -> main
+  int fack0;        // pass number whose decision wave 0 has read (see fack2)
   int fcs;          // pass number whose rotation coefficients are published (or abandoned) chain wave -> main
   int fdr;          // pass number whose d the chain wave has taken into registers          chain wave -> main
   int fstep;        // pass number whose step is taken (x, u final) and whose decision is in dec
@@ -1909,13 +1910,16 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         // ==================================================================================================
         // WS main loop: wave 3 = MAIN, waves 0-2 = HELPERS (see the comment at WS above).  Hand-off words in ctl:
         //   fd    = pass   : d, wp, wps, wq published                       MAIN -> helpers
-        //   fz/fx = pass   : z, z.z  /  n.x, n.z published                  wave 1 / wave 2 -> MAIN
+        //   fz    = pass   : z, z.z, n.z, n.x, t2 published                     wave 1 -> MAIN
         //   fcs   = pass   : (c, s) pairs + rho published, or chain abandoned (also: d no longer read)  wave 0 -> MAIN
         //   fstep = pass   : x, u final, decision in dec                    MAIN -> helpers
         //   fscan[w] = scan number: winner of wave w published              helpers -> MAIN
-        // A word is written after the data it announces (release) and polled by its readers (acquire).  MAIN waits for fz, fx
-        // every pass and for fcs before it overwrites d, so no helper is ever more than one pass behind and `dec` is read
-        // before it is rewritten.
+        //   fack0 / fack2 = pass: wave 0 / wave 2 has read the decision of a DROP pass        helpers -> MAIN
+        // A word is written after the data it announces (release) and polled by its readers (acquire).  The polls test for
+        // equality, so a helper must never be more than one pass behind.  That holds because MAIN, before it leaves a pass,
+        // has heard from every helper AFTER that helper read the pass's decision: wave 1 through fz of the next pass (it only
+        // looks for the next d after the decision), waves 0 and 2 through fscan[w] in a pass that adds and through
+        // fack0 / fack2 in a pass that drops.  So fd, fstep and dec are never rewritten before everybody has read them.
         // ==================================================================================================
         constexpr int MAINW = 3;
         // (c_i, s_i) at csb[2i], csb[2i+1], 16-byte aligned (the dynamic LDS base is): pointer arithmetic only, so that the
@@ -2170,7 +2174,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         };
         if(tid == 0)
         {
-          ctl->fd = 0; ctl->fz = 0; ctl->fx = 0; ctl->fcs = 0; ctl->fdr = 0; ctl->fstep = 0; ctl->dec = 0;
+          ctl->fd = 0; ctl->fz = 0; ctl->fack0 = 0; ctl->fack2 = 0; ctl->fcs = 0; ctl->fdr = 0; ctl->fstep = 0; ctl->dec = 0;
           ctl->fscan[0] = 0; ctl->fscan[1] = 0; ctl->fscan[2] = 0;
           ctl->wit = it; ctl->wterm = T_SUCCESS; ctl->wq = q;
         }
@@ -2422,6 +2426,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               ++it;
               PROF_COUNT3(11)
               WS_WAIT(&ctl->fcs, sq) // the chain wave is through with this pass (its chain was abandoned)
+              WS_WAIT(&ctl->fack0, sq) // waves 0 and 2 have read this pass's decision (long ago: the removal took 9 k cycles)
+              WS_WAIT(&ctl->fack2, sq)
               STAMP3(23)
               if(it >= A.max_iter)
               {
@@ -2588,6 +2594,10 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               ws_post(&ctl->fscan[wave], sc);
               STAMP(7)
             }
+            else if(wave == 0)
+              ws_post(&ctl->fack0, sq);
+            else if(wave == 2)
+              ws_post(&ctl->fack2, sq);
           }
         }
         __syncthreads();

@@ -16,6 +16,8 @@
 // oracle's.  Matrices are column-major; J and R have leading dimension n (Workspace.h, GoldfarbIdnaniSolver.cpp:140-141).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "device_common.h"
 #include "gi_dense.h"
 #include "gi_batch.h"
@@ -1359,23 +1361,34 @@ static size_t tail_lds(int n, int q)
 // more than ~1900 rotations; add_chain: the third vector of the seeded recurrence): the limit is raised once, to the
 // 160 KiB of a gfx950 CU.
 constexpr size_t kLdsDefault = 65536, kLdsMax = 160 * 1024;
-template<class K>
-static hipError_t raise_lds(K kernel, bool & done, size_t need)
+// hipFuncSetAttribute is per DEVICE: the "already raised" flags are one bit per device id, atomically set (one process may
+// drive several GPUs, from several threads); beyond 64 devices the attribute is simply set on every call.
+struct LdsRaised
 {
-  if(done || need <= kLdsDefault) return hipSuccess;
+  std::atomic<unsigned long long> mask{0};
+};
+template<class K>
+static hipError_t raise_lds(K kernel, LdsRaised & done, size_t need)
+{
+  if(need <= kLdsDefault) return hipSuccess;
   if(need > kLdsMax) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-  if(e == hipSuccess) done = true;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if(e != hipSuccess) return e;
+  const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+  if(bit && (done.mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+  if(e == hipSuccess && bit) done.mask.fetch_or(bit, std::memory_order_release);
   return e;
 }
 static hipError_t tail_attr(int n)
 {
-  static bool done = false;
+  static LdsRaised done;
   return raise_lds(&step_tail_kernel, done, tail_lds(n, 0));
 }
 static hipError_t rot_attr(int T)
 {
-  static bool done = false;
+  static LdsRaised done;
   return raise_lds(&rot_apply_kernel, done, rot_lds(T));
 }
 
@@ -1392,7 +1405,7 @@ static size_t chain_lds(int n)
 }
 static hipError_t chain_attr(int n)
 {
-  static bool done = false;
+  static LdsRaised done;
   return raise_lds(&add_chain_kernel, done, chain_lds(n));
 }
 

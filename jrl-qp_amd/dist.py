@@ -73,3 +73,51 @@ def all_gather_results(x_local, total: int):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return torch.cat([o[: e - s] for o, (s, e) in zip(out, sizes)], dim=0)
+
+
+def _parse_cpulist(text: str):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(device_index: int, sysfs: str = "/sys"):
+    """CPUs of the NUMA node GPU `device_index` hangs off (PCI sysfs: <bdf>/numa_node -> node<N>/cpulist), or None when the
+    platform does not say (single-node boxes report -1).  Reads torch's device properties only: no kernel is launched."""
+    import torch
+
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node")).read())
+        if node < 0:
+            return None
+        return _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read()) or None
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+
+
+def bind_rank_to_gpu_numa(device_index: int, local_world: int = 1, sysfs: str = "/sys"):
+    """Pin this rank process to the cores next to its GPU: the launch thread and the pinned mailbox of the host-driven
+    path then stay on the socket the GPU's PCIe root is on.  Intersects with the affinity the process already has (a
+    container's cpuset wins); with several ranks on one NUMA node the node's cores are dealt out evenly.  Returns a short
+    description for the bench line; never raises and never widens the mask."""
+    try:
+        have = os.sched_getaffinity(0)
+    except AttributeError:
+        return "no sched_getaffinity on this platform"
+    near = gpu_numa_cpus(device_index, sysfs)
+    if not near:
+        return f"not bound: no NUMA node reported for GPU {device_index} ({len(have)} cpus allowed)"
+    cpus = sorted(have & near)
+    if not cpus:
+        return f"not bound: none of the {len(near)} NUMA-local cpus is in this process's affinity mask"
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError as e:
+        return f"not bound: sched_setaffinity failed ({e})"
+    return f"bound to {len(cpus)} NUMA-local cpus of GPU {device_index} ({cpus[0]}..{cpus[-1]})"

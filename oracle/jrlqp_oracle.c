@@ -17,6 +17,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <omp.h>
 #include <string.h>
 
 #define FMA(a, b, c) __builtin_fma((a), (b), (c))
@@ -932,6 +933,48 @@ void orc_gi_solve_batch(int B,
     }
     free(work);
   }
+}
+
+/* Timing loop of the CPU baseline (bench.py cpu_baseline leg) -- the reference's own benchmark loop
+ * (benchmarks/Solvers.cpp:447-453 "G = original G" before every solve, :508-520 one solver object per measurement): every
+ * thread owns ONE workspace and ONE n x n buffer; per solve it restores G into that buffer with a memcpy (the reference's
+ * `G = pb.G` copy, inside the loop) and solves.  `rounds` passes over the B problems, static partition.  Nothing is allocated
+ * or copied outside the threads, outputs land in caller-preallocated arrays (overwritten every round).  Returns the wall
+ * seconds of the rounds alone, taken between two barriers INSIDE the parallel region (thread start-up excluded). */
+double orc_gi_bench_rounds(int rounds, int B, int n, int m, int nb, const double * G, const double * a, const double * C,
+                           const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
+                           double big_bnd, double * x, double * u, int * status, int * term, int * iters, double * f,
+                           int nthreads)
+{
+  double t0 = 0.0, t1 = 0.0;
+  if(nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    double * work = (double *)malloc(sizeof(double) * (size_t)orc_gi_work_doubles(n, m, nb));
+    double * Gw = (double *)malloc(sizeof(double) * (size_t)n * n);
+    memset(Gw, 0, sizeof(double) * (size_t)n * n); /* (pages touched before the clock starts) */
+#pragma omp barrier
+#pragma omp master
+    t0 = omp_get_wtime();
+    for(int r = 0; r < rounds; ++r)
+    {
+#pragma omp for schedule(static) nowait
+      for(int b = 0; b < B; ++b)
+      {
+        memcpy(Gw, G + (long)b * n * n, sizeof(double) * (size_t)n * n);
+        term[b] = orc_gi_solve(n, m, nb, Gw, n, a + (long)b * n, C + (long)b * n * m, n, bl + (long)b * m, bu + (long)b * m,
+                               nb ? xl + (long)b * nb : NULL, nb ? xu + (long)b * nb : NULL, max_iter, big_bnd,
+                               x + (long)b * n, u + (long)b * (m + nb), status + (long)b * (m + nb), NULL, NULL, iters + b,
+                               f + b, NULL, 0, work);
+      }
+    }
+#pragma omp barrier
+#pragma omp master
+    t1 = omp_get_wtime();
+    free(Gw);
+    free(work);
+  }
+  return t1 - t0;
 }
 
 /* B warm-started solves; as_in: B x (m+nb) activation-status guesses (may be NULL: no guess). */

@@ -126,6 +126,15 @@ void orc_gi_solve_batch(int B,
                         double * f,
                         int nthreads);
 
+/* Timing loop of bench.py's cpu_baseline leg: the reference's benchmark loop (benchmarks/Solvers.cpp:447-453, :508-520) --
+ * per thread one workspace and one G buffer, G restored by memcpy INSIDE the loop before every solve, `rounds` passes over the
+ * B problems (static partition), outputs into caller-preallocated arrays.  Returns the wall seconds of the rounds alone
+ * (between two barriers inside the parallel region).  G is read-only here. */
+double orc_gi_bench_rounds(int rounds, int B, int n, int m, int nb, const double * G, const double * a, const double * C,
+                           const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
+                           double big_bnd, double * x, double * u, int * status, int * term, int * iters, double * f,
+                           int nthreads);
+
 /* experimental::BoxAndSingleConstraintSolver (src/experimental/BoxAndSingleConstraintSolver.cpp:11-94):
  *   min 1/2 ||x - x0||^2  s.t.  c.x >= bl,  xl <= x <= xu ; closed-form initial point / active set / J / R, then the GI loop.
  *   u, status: 1 + n entries (the general constraint first, then the bounds).  f is 1/2 ||x - x0||^2 itself. */

@@ -2,7 +2,7 @@
 // (include/jrlqp/GoldfarbIdnaniSolver.hpp): ONE solver pre-sized as (5, 8, true) solves five problems of different shapes
 // -- no constraints, equalities, inequalities, both, and bounds -- and, like the reference under
 // set_is_malloc_allowed(false), must not allocate while doing so.  Here "allocate" is every HIP runtime allocation entry
-// point (hipMalloc, hipHostMalloc, hipMallocAsync, hipFree, stream / event creation), counted by interposing them: the
+// point (hipMalloc, hipHostMalloc, hipMallocAsync, hipFreeAsync, hipFree, stream / event creation), counted by interposing them: the
 // definitions below are exported from this executable (-rdynamic), so libjrlqp_hip.so's calls land here as well.
 //
 //   usage: test_multiple_uses <problems.bin> <results.bin>
@@ -61,6 +61,12 @@ hipError_t hipMallocAsync(void ** p, size_t s, hipStream_t st)
   static auto real = next_symbol<hipError_t (*)(void **, size_t, hipStream_t)>("hipMallocAsync");
   if(g_counting) ++g_alloc_calls;
   return real(p, s, st);
+}
+hipError_t hipFreeAsync(void * p, hipStream_t st)
+{
+  static auto real = next_symbol<hipError_t (*)(void *, hipStream_t)>("hipFreeAsync");
+  if(g_counting) ++g_alloc_calls;
+  return real(p, st);
 }
 hipError_t hipStreamCreateWithFlags(hipStream_t * st, unsigned int flags)
 {
@@ -125,14 +131,21 @@ int main(int argc, char ** argv)
 
   if(sizes_mode)
   {
-    // the three back ends behind the one class: n <= 64 (batched kernel, batch of one), 64 < n <= 104 (large-n batched kernel),
-    // beyond (Mode A); the solver grows as the problems do and then serves the smaller ones again
+    // the back ends behind the one class: n <= 64 (batched kernel, batch of one), 64 < n <= 128 (large-n batched kernel; beyond
+    // n = 104 with its R factor in the workspace resize() allocated), beyond (Mode A); the solver grows as the problems do and
+    // then serves the smaller ones again -- in the second pass, with every capacity reached, WITHOUT a single allocation call
+    // (n = 120 included: no hipMallocAsync / hipFreeAsync around the launch)
     GoldfarbIdnaniSolver any;
     for(int pass = 0; pass < 2; ++pass)
       for(Pb p : pbs)
       {
+        g_alloc_calls = 0;
+        g_counting = (pass == 1);
         auto st = any.solve({p.G.data(), p.n, p.n, p.n}, {p.a.data(), p.n}, {p.C.data(), p.n, p.m, p.n}, {p.bl.data(), p.m}, {p.bu.data(), p.m},
                             {p.xl.data(), p.nb}, {p.xu.data(), p.nb});
+        g_counting = false;
+        if(g_alloc_calls != 0) std::printf("solve() made %d allocation-type HIP calls (n=%d m=%d nb=%d)\n", g_alloc_calls, p.n, p.m, p.nb);
+        CHECK(g_alloc_calls == 0);
         CHECK(any.lastError().empty());
         if(pass == 1)
         {

@@ -83,3 +83,64 @@ def test_two_rank_rehearsal_on_one_gpu():
     assert len(rk["per_rank_solves_per_s"]) == 2 and all(v > 0 for v in rk["per_rank_solves_per_s"])
     assert rk["allgather_x_bytes"] == 1024 * 50 * 8 and rk["allgather_x_ms"] > 0
     assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline belongs to N = 1 only
+
+
+def test_ranks_inherit_the_ipc_mode_and_get_dmabuf_by_default(monkeypatch, tmp_path):
+    """launch_ranks gives every rank HSA_ENABLE_IPC_MODE_LEGACY: the caller's value when set, "0" (dmabuf IPC, the only mode
+    the pool's host driver supports -- RCCL fails with hipIpcGetMemHandle otherwise) when absent; and RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    seen = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None):
+            seen.append(env)
+
+        def poll(self):
+            return 0
+
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 2)
+    monkeypatch.setattr("subprocess.Popen", FakeProc)
+    for preset, want in ((None, "0"), ("1", "1")):
+        seen.clear()
+        if preset is None:
+            monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+        else:
+            monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", preset)
+        assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
+        assert [e["RANK"] for e in seen] == ["0", "1"] and all(e["WORLD_SIZE"] == "2" and e["MASTER_ADDR"] == "127.0.0.1" for e in seen)
+        assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == want for e in seen)
+        assert len({e["MASTER_PORT"] for e in seen}) == 1
+
+
+def test_numa_binding_helper(pkg, monkeypatch, tmp_path):
+    """bind_rank_to_gpu_numa: reads <sysfs>/bus/pci/devices/<bdf>/numa_node and node<N>/cpulist, intersects with the mask the
+    process has, never widens it, never raises."""
+    import types
+
+    import torch
+
+    import jrl_qp_amd.dist as jdist
+
+    assert jdist._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    props = types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x75, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: props)
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:75:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    have = sorted(os.sched_getaffinity(0))
+    (node / "cpulist").write_text(f"{have[0]}-{have[0]}\n")
+    try:
+        msg = jdist.bind_rank_to_gpu_numa(0, 8, sysfs=str(tmp_path))
+        assert msg.startswith("bound to 1 NUMA-local") and os.sched_getaffinity(0) == {have[0]}
+    finally:
+        os.sched_setaffinity(0, have)
+    (dev / "numa_node").write_text("-1\n")
+    assert jdist.bind_rank_to_gpu_numa(0, 8, sysfs=str(tmp_path)).startswith("not bound") and os.sched_getaffinity(0) == set(have)
+    (dev / "numa_node").write_text("1\n")
+    (node / "cpulist").write_text("100000\n")
+    assert "none of the" in jdist.bind_rank_to_gpu_numa(0, 8, sysfs=str(tmp_path)) and os.sched_getaffinity(0) == set(have)

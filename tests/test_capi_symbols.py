@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/jrlqp_hip.h but not exported"
     assert sorted(capi.EXPORTED) == decl
-    assert lib.jrlqp_abi_version() == 1
+    assert lib.jrlqp_abi_version() == 2
 
 
 def test_defaults_and_lds_budget(pkg):
@@ -66,6 +66,16 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.jrlqp_gi_solve_batch(4, 1, 0, 0, *args) == 0  # empty batch is a no-op
     assert lib.jrlqp_gi_solve_batch(4, 1, 0, 1, *args) == -1  # null pointers
     assert lib.jrlqp_status_string(-2).decode().startswith("problem size")
+    # the workspace contract (no GPU needed for the shapes that need none)
+    assert lib.jrlqp_gi_batch_workspace_bytes(50, 200, 0, 4096) == 0
+    assert lib.jrlqp_gi_batch_workspace_bytes(100, 200, 0, 64) == 0  # R packed in LDS beside J up to n = 104
+    assert lib.jrlqp_gi_batch_workspace_bytes(129, 10, 0, 1) == -1 and lib.jrlqp_gi_batch_workspace_bytes(10, 10, 5, 1) == -1
+    assert lib.jrlqp_gi_batch_workspace_bytes(128, 10, 0, 0) == 0  # an empty batch needs nothing
+    ws_args = [None] * 8 + [None] + [None] * 8 + [0, None, 0, None]
+    assert lib.jrlqp_gi_solve_batch_ws(0, 4, 1, 0, 0, *ws_args) == 0  # empty batch
+    assert lib.jrlqp_gi_solve_batch_ws(0, 4, 1, 0, 1, *ws_args) == -1  # null pointers
+    ws_bad = [None] * 8 + [None] + [None] * 8 + [0, None, 64, None]
+    assert lib.jrlqp_gi_solve_batch_ws(0, 4, 1, 0, 1, *ws_bad) == -1  # a size without a pointer
 
 
 def test_blockgi_plan_validation_without_gpu(pkg):

@@ -306,6 +306,13 @@ def test_box_and_single_constraint_solver(pkg, oracle):
             assert abs(f[b] - (gi.f + 0.5 * x0[b] @ x0[b])) <= 1e-9 * (1 + abs(f[b]))
             nact += int(status[b, 0] != 0)
         assert nact <= reps and (n < 7 or nact == reps)  # the "active" half ends with the general constraint active
+    # beyond one wavefront of variables the closed-form start does not exist: refused, never a silent wrong answer
+    for n in (65, 96, 128):
+        s = capi.BoxAndSingleConstraintSolver(n, 2)
+        z = torch.zeros((2, n), dtype=torch.float64, device="cuda")
+        with pytest.raises(capi.JrlqpError) as ei:
+            s.solve(z, z + 1.0, torch.zeros(2, dtype=torch.float64, device="cuda"), z - 1.0, z + 1.0)
+        assert ei.value.status == capi.ERR_UNSUPPORTED_SIZE
     # termination statuses other than SUCCESS come out of the same loop: infeasible constraint, iteration limit
     n = 5
     x0 = np.array([[0.5, -2.0, 3.0, 0.1, -0.7]] * 2)

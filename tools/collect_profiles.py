@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r2"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
 sys.path.insert(0, ROOT)
 import subprocess
 
@@ -97,7 +97,27 @@ def main():
         "algorithmic_bytes_per_launch": b5["roofline"].get("algorithmic_bytes_per_launch"),
         "rocprofv3_avg_launch_ns": float(ks5["AverageNs"]),
     }, open(os.path.join(DST, f"{TAG}_blockgi_c5_batch{nb}_traffic.json"), "w"), indent=1)
-    # ---- c2 and the timing logs
+    # ---- c2 (Mode A): every launch of a solve counts; the pass holds two solves (one warm-up, one step)
+    c2_fetch = os.path.join(SRC, "p_c2_fetch", "fetch_counter_collection.csv")
+    if os.path.exists(c2_fetch):
+        def pmc_total(path, counter):
+            tot, disp = 0.0, set()
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] == counter and "jrlqp" in r["Kernel_Name"]:
+                    tot += float(r["Counter_Value"])
+                    disp.add(r["Dispatch_Id"])
+            return tot, len(disp)
+        solves = 2
+        f2, nd = pmc_total(c2_fetch, "FETCH_SIZE")
+        w2, _ = pmc_total(os.path.join(SRC, "p_c2_write", "write_counter_collection.csv"), "WRITE_SIZE")
+        shutil.copy(os.path.join(SRC, "p_c2", "c2_kernel_stats.csv"), os.path.join(DST, f"{TAG}_c2_dense_kernel_stats.csv"))
+        json.dump({
+            "kernels": "all jrlqp:: kernels of jrlqp_dense_solve (Mode A)", "kernel_source_sha16": SHA, "commit": COMMIT, "solves_in_pass": solves,
+            "dispatches_per_solve": nd / solves,
+            "FETCH_SIZE_KB_per_solve": round(f2 / solves, 1), "WRITE_SIZE_KB_per_solve": round(w2 / solves, 1),
+            "correction": "FETCH_SIZE x2 (gfx950 streaming-read under-report, MI355X_MICROARCH.md) + WRITE_SIZE, KiB, separate --pmc passes",
+            "traffic_bytes_per_solve": int(round((2.0 * f2 + w2) * 1024 / solves)),
+        }, open(os.path.join(DST, f"{TAG}_c2_dense_traffic.json"), "w"), indent=1)
     json.dump(first_json_line(os.path.join(SRC, "bench_c2.json")), open(os.path.join(DST, f"{TAG}_bench_line_c2.json"), "w"), indent=1)
     sq = os.path.join(ROOT, "gpurun_out", "pmc_sq", "summary.json")
     if os.path.exists(sq):
