@@ -117,18 +117,26 @@ def cpu_baseline(pb, budget_s=12.0):
     probe_run, _ = o.bench_rounds_fn(pb.G[:256], pb.a[:256], pb.C[:256], pb.bl[:256], pb.bu[:256])
     probe_run(1, 1)
     per = min(probe_run(1, 1) for _ in range(3)) / 256  # single-thread seconds per solve (same loop, same restore)
-    # the affinity mask can overstate what the container may really use (cgroup quotas, SMT siblings): probe thread counts and
-    # keep the fastest; `cores` reports the thread count actually used for the quoted number
-    best_t, best_rate, t, probed = 1, 0.0, 1, {}
+    # The affinity mask can overstate what the container may really use: a cgroup CPU quota throttles a pool that is wider than
+    # the quota, but only once the quota of a scheduling period (100 ms) is spent -- a probe of a few milliseconds runs at the
+    # full width of the host and says nothing about a sustained run.  So every width is probed for >= 0.6 s (several periods),
+    # widths stop at 4 x the quota, and the fastest SUSTAINED width is used; the short-burst rates are reported beside it
+    # (`burst_probe_solves_per_s`: what the host's cores do when the quota does not bind -- an upper bound for a dedicated host).
+    quota = cgroup_cpu_quota()
+    widest = cores if quota is None else max(1, min(cores, int(4 * quota + 0.5)))
+    best_t, best_rate, t, probed, burst = 1, 0.0, 1, {}, {}
     while True:
         run(1, t)  # the first call at a new width pays for the OpenMP pool and page faults
-        rate = max(sample / run(1, t) for _ in range(3))
+        b = sample / run(1, t)
+        burst[t] = b
+        k = max(1, int(0.6 * b / sample + 0.5))
+        rate = sample * k / run(k, t)
         probed[t] = rate
         if rate > best_rate:
             best_t, best_rate = t, rate
-        if t >= cores:
+        if t >= widest:
             break
-        t = min(cores, t * 2)
+        t = min(widest, t * 2)
     cores_avail, cores = cores, best_t
     rounds_per_call = max(1, int(2.0 * best_rate / sample))  # about two seconds per C call
     rounds, dt = 0, 0.0
@@ -142,12 +150,14 @@ def cpu_baseline(pb, budget_s=12.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{rounds} rounds over the first {sample} QPs of the same workload ({dt:.1f} s inside the C timing loop), {cores} OpenMP threads "
-                  f"(fastest of {sorted(probed)} probed; affinity mask has {cores_avail}), one workspace + one G buffer per thread, G restored by "
-                  f"memcpy inside the loop before every solve (benchmarks/Solvers.cpp:451); single-thread probe {per * 1e6:.1f} us/solve",
+                  f"(fastest SUSTAINED width of {sorted(probed)}, each probed for >= 0.6 s; affinity mask has {cores_avail} cpus, cgroup quota "
+                  f"{quota}), one workspace + one G buffer per thread, G restored by memcpy inside the loop before every solve "
+                  f"(benchmarks/Solvers.cpp:451); single-thread probe {per * 1e6:.1f} us/solve",
         "single_thread_us_per_solve": per * 1e6,
         "parallel_efficiency": value * per / cores,  # value / (threads x single-thread rate)
         "thread_probe_solves_per_s": {str(k): v for k, v in sorted(probed.items())},
-        "cgroup_cpu_quota": cgroup_cpu_quota(),
+        "burst_probe_solves_per_s": {str(k): v for k, v in sorted(burst.items())},
+        "cgroup_cpu_quota": quota,
         "affinity_cpus": cores_avail,
         "build_flags": oracle_build_flags(),
     }

@@ -25,6 +25,17 @@ struct ProfBuf
 ProfBuf g_prof[2];
 std::atomic<int> g_chain_mode{0};
 
+// experiment knob (never part of the ABI): JRLQP_TUNE=<bits> in the environment, read once; travels in the upper bits of
+// BatchArgs::chain_mode (gi_batch_kernel.h, "tune")
+int env_tune()
+{
+  static const int v = [] {
+    const char * e = std::getenv("JRLQP_TUNE");
+    return e ? std::atoi(e) : 0;
+  }();
+  return v;
+}
+
 int hip_fail(hipError_t e)
 {
   g_last_hip_error.store(static_cast<int>(e));
@@ -248,7 +259,7 @@ static int gi_batch_common(int warm,
   if(a.prof && B > g_prof[JRLQP_PROFILE_GI_BATCH].nprob) return JRLQP_ERR_INVALID_ARGUMENT;
   a.warm = warm;
   a.as_in = das;
-  a.chain_mode = g_chain_mode.load();
+  a.chain_mode = (g_chain_mode.load() & 255) | (env_tune() << 8);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if(bign)
   {
@@ -338,7 +349,7 @@ int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, c
   a.trace = dtrace;
   a.prof = nullptr; a.prof_stride = 0;
   a.warm = 0; a.as_in = nullptr;
-  a.chain_mode = g_chain_mode.load();
+  a.chain_mode = (g_chain_mode.load() & 255) | (env_tune() << 8);
   hipError_t e = jrlqp::launch_gi_batch_box(a, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }

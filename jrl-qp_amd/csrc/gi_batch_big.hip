@@ -59,6 +59,7 @@ struct CtlB
 {
   double red_val[4];
   double zz, cz, cx, t1, f, rho;
+  double dotp[4]; // the two wave halves of the C4 trees of z.z and n+.z
   double gc, gs, gr; // rotation of the removal step in flight
   int red_idx[4];
   int red_stat[4];
@@ -431,16 +432,29 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         }
       }
       __syncthreads();
-      if(tid < 3)
+      // z.z and n+.z: C4 trees (CANON C5) -- one product per element, elements 0..63 on wave 0 and 64..127 on wave 1, each
+      // wave's adjacent-first tree, then the two halves; n+.x: the C1 chain (the scan's value for that constraint), one lane
+      // of wave 2 beside them
+      if(tid < 128)
       {
-        double acc;
-        if(pp < m || tid == 0)
-          acc = chain_asc<false>((tid == 0) ? zs : nps, 1, (tid == 2) ? xs : zs, 1, 0, n, 0.0);
-        else
-          acc = (tid == 1) ? zs[pp - m] : xs[pp - m];
-        if(tid == 0) ctl->zz = acc;
-        if(tid == 1) ctl->cz = acc;
-        if(tid == 2) ctl->cx = acc;
+        const bool in = tid < n;
+        const double zi = in ? zs[tid] : 0.0;
+        const double ni = (in && pp < m) ? nps[tid] : 0.0;
+        const double pz = wave_sum_tree(FMA(zi, zi, 0.0));
+        const double pc = wave_sum_tree(FMA(ni, zi, 0.0));
+        if(lane == 0)
+        {
+          ctl->dotp[2 * (tid >> 6)] = pz;
+          ctl->dotp[2 * (tid >> 6) + 1] = pc;
+        }
+      }
+      else if(tid == 128)
+        ctl->cx = (pp < m) ? chain_asc<false>(nps, 1, xs, 1, 0, n, 0.0) : xs[pp - m];
+      __syncthreads();
+      if(tid == 0)
+      {
+        ctl->zz = ctl->dotp[0] + ctl->dotp[2];
+        ctl->cz = (pp < m) ? (ctl->dotp[1] + ctl->dotp[3]) : zs[pp - m];
       }
       __syncthreads();
     };

@@ -73,6 +73,7 @@ struct Ctl
   double f;
   double bnd; // bound value b of the selected constraint (bl, bu, xl or xu by status): kept out of global memory on the step path
   double bndw[4]; // CMODE 2: the same per scanning wave (each wave's own winner), see scan_publish
+  double cxw[4];  // WS: n+.x of each scanning wave's winner -- the scan's own C1 chain C.col(p).dot(x), reused by the step length
   int red_idx[4];
   int red_stat[4];
   int info;
@@ -88,12 +89,14 @@ struct Ctl
   int fd;           // pass number whose d (and p, pstat, q below) is published            main -> helpers
   int fz;           // pass number whose z, z.z, n.z, n.x and t2 are published               z wave -> main
   int fack0;        // pass number whose decision wave 0 has read (see fack2)
+  int fx0;          // 1: x0 and f0 are published (overlapped prologue: wave 0 -> everybody)
   int fcs;          // pass number whose rotation coefficients are published (or abandoned) chain wave -> main
   int fdr;          // pass number whose d the chain wave has taken into registers          chain wave -> main
   int fstep;        // pass number whose step is taken (x, u final) and whose decision is in dec
   int dec;          // decision of pass fstep: 1 add, 2 drop, 3 stop
   int fscan[3];     // scan number whose winner is published, per scanning wave
   int wp, wps, wq;  // constraint, status and active-set size of the pass in flight
+  int wfresh;       // 1: p was selected by a scan in this pass (x unchanged since: cxw holds n+.x); 0: the pass follows a removal
   int wit, wterm;   // final iteration count and termination status
   double t2;        // primal step length of the pass in flight (z wave -> main)
 };
@@ -440,6 +443,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ unsigned long long prof_lds[PROF ? 32 : 1];
   if(PROF && threadIdx.x < 32) prof_lds[threadIdx.x] = 0;
+  // (Measured in round 3 and taken out again: dealing the MAIN role out by SIMD.  The hardware starts a workgroup's four waves at a
+  // SIMD of its own choice -- wave 3 lands on every SIMD equally often, so with three workgroups per CU two MAIN waves share a SIMD on
+  // 5 CUs of 8.  Making the wave on SIMD (wave slot mod 4) the MAIN wave puts the three MAIN waves of a CU on three different SIMDs
+  // (HW_ID confirmed it for 4096 of 4096 workgroups) -- and changes nothing: 2.35 M solves/s either way.  The serial wave is bound
+  // by its own dependent latencies, not by issue slots lost to a neighbour.)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = uniform(tid >> 6);
@@ -582,9 +590,20 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     ctl->eq_next = NONE;
     ctl->cnt = 0;
     ctl->flag = 0;
+    // (hand-off words of the role-specialised loop: zeroed HERE, before anybody can post -- with the overlapped prologue the helpers
+    // post their first scan while MAIN is still inside J = L^-T)
+    ctl->fd = 0; ctl->fz = 0; ctl->fack0 = 0; ctl->fack2 = 0; ctl->fcs = 0; ctl->fdr = 0; ctl->fstep = 0; ctl->dec = 0; ctl->fx0 = 0;
+    ctl->fscan[0] = 0; ctl->fscan[1] = 0; ctl->fscan[2] = 0;
+    ctl->wit = 0; ctl->wterm = T_SUCCESS; ctl->wq = 0;
   }
   __syncthreads();
   STAMP(0)
+  if(PROF && lane == 0 && (wave == 3 || wave == 0))
+  {
+    // where the hardware put this wave: HW_ID (SIMD [5:4], CU [11:8], SH [12], SE [15:13]) and XCC_ID -- slots 14 (wave 3) / 15 (wave 0)
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    prof_lds[wave == 3 ? 14 : 15] = ((unsigned long long)xcc << 32) | hw;
+  }
 
   // ---------------------------------------------------------------- K1: LLT in LDS (wave 0), while waves 1-3 stage C
   double * L = R;
@@ -819,6 +838,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   int term = T_SUCCESS;
   int it = 0;
   int q = 0;
+  bool ovl = false; // overlapped prologue (see K2 below)
 
   if(WARM && ctl->over)
   {
@@ -841,11 +861,16 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       }
     }
     // ---------------------------------------------------------------- K2 (wave 1): J = L^-T ; K3 (wave 0): x0, f0
+    // Overlapped prologue (role-specialised kernels, no data equalities -- the pre-activation below needs every wave): J = L^-T runs on
+    // the MAIN wave (wave 3, which owns no constraint column), x0 on wave 0, and there is NO barrier behind them: the helpers go
+    // straight on to fetch their columns and, once wave 0 has posted x0 (fx0), to the first scan -- all of it beside MAIN's J, which
+    // is the longest of the three.
+    ovl = WS && uniform(ctl->eq_next) == NONE && !(A.chain_mode & (8 << 8));
     if constexpr(BOX)
     {
       q = uniform(ctl->nact); // J, R, x, u, f, the active list: all set by the closed form above
     }
-    else if(wave == 1)
+    else if(wave == (ovl ? 3 : 1))
     {
       // J = L^-T by blocks of JB rows from the bottom, lane = column c: J_ic = (delta_ic - sum_{k = c .. i+1,
       // descending} L_ki J_kc) / L_ii.  The JB accumulators of a column stay in registers while the wave walks the
@@ -1016,8 +1041,14 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       double acc = 0.0;
       for(int k = 0; k < n; ++k) acc = FMA(bcast_lane(ai, k), bcast_lane(xi, k), acc);
       if(lane == 0) ctl->f = 0.5 * acc;
+      if(ovl)
+      {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if(lane == 0) __atomic_store_n(&ctl->fx0, 1, __ATOMIC_RELAXED);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+      }
     }
-    __syncthreads();
+    if(!ovl) __syncthreads();
     STAMP(2)
     if(CMODE == 2 && LATE_C && !WS) load_columns();
 
@@ -1289,6 +1320,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     // with lgkmcnt(0) right after issuing the prefetch (measured 267 cycles per step instead of ~130).
     double tr_t1 = 0.0; // (t1, l) of the last trsv_ratio, in every lane of the wave that ran it
     int tr_l = 0;
+    double tr_r = 0.0, tr_u = 0.0, tr_uq = 0.0; // its r_k and the u_k it loaded (lane k < q), and u_q (every lane): WS keeps them for the update
     auto trsv_ratio = [&]() {
       const int rl = (lane < n) ? lane : 0;
       double rk = ds[rl];
@@ -1298,6 +1330,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       const double rk0 = rk;
       const int sk_l = (lane < q) ? st[lane] : INACTIVE; // operands of the ratio test below
       const double u_l = us[rl];
+      tr_uq = us[q]; // (the pending multiplier, a broadcast read in the same round trip; only the WS update uses it)
       const double rinv = recip_refined(dg); // every pivot's reciprocal at once (lane = pivot)
       // Columns are fetched FOUR steps ahead (the LDS is shared with 11 other waves: a one-step prefetch still exposes
       // most of its latency on this chain); the loop is unrolled by four so that the look-ahead registers need no
@@ -1348,6 +1381,8 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         }
       }
       if(lane < q) rs[lane] = rk;
+      tr_r = rk;
+      tr_u = u_l;
       STAMP(16)
       // t1 = min u_k / r_k over r_k > 0 (not EQUALITY/FIXED; status looked up by POSITION, GoldfarbIdnaniSolver.cpp:162)
       // (u and the status byte were fetched before the substitution loop; the quotient is formed in every lane and
@@ -1367,8 +1402,9 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       STAMP(17)
     };
 
-    // K6 + the scalar products of K8: wave 1 computes z, then z.z and c_p.z in two lanes; wave 2 computes c_p.x
-    // (which does not need z) at the same time
+    // K6 + the scalar products of K8: wave 1 computes z, then z.z and n+.z as C4 trees over its lanes (CANON C5: one product per
+    // element, adjacent-first pairwise tree -- four DPP exchanges and three adds instead of two 50-step chains); wave 2 computes
+    // n+.x (a C1 chain: the value the scan computed for the constraint; it does not need z) at the same time
     auto z_and_dots = [&](int pp) {
       const bool general = pp < m;
       if(wave == 2)
@@ -1376,20 +1412,21 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         if(lane == 0) ctl->cx = general ? chain_up(np_ptr(pp), 1, xs, 1, 0, n, 0.0) : xs[pp - m];
         return;
       }
-      if(lane < n) zs[lane] = chain_up(J + lane, ld, ds, 1, q, n, 0.0);
-      wave_sync();
-      if(lane < 2)
+      const int rl = (lane < n) ? lane : 0;
+      const double npv = general ? np_ptr(pp)[rl] : 0.0; // (requested before the chain)
+      double zi = chain_up(J + rl, ld, ds, 1, q, n, 0.0);
+      zi = (lane < n) ? zi : 0.0;
+      if(lane < n) zs[lane] = zi;
+      const double zz = wave_sum_tree(FMA(zi, zi, 0.0));
+      double cz;
+      if(general)
+        cz = wave_sum_tree(FMA(npv, zi, 0.0)); // (lanes >= n: z = 0)
+      else
+        cz = bcast_lane(zi, pp - m);
+      if(lane == 0)
       {
-        double acc;
-        if(general || lane == 0)
-        {
-          const double * pa = (lane == 0) ? zs : np_ptr(pp);
-          acc = chain_up(pa, 1, zs, 1, 0, n, 0.0);
-        }
-        else
-          acc = zs[pp - m];
-        if(lane == 0) ctl->zz = acc;
-        if(lane == 1) ctl->cz = acc;
+        ctl->zz = zz;
+        ctl->cz = cz;
       }
     };
 
@@ -1455,7 +1492,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       gc_d = (lane < n) ? dv : 0.0; // (lanes >= n: zero -- they sit above the chain and must stay at radius 0)
       const double sincl = wave_suffix_sum_approx(gc_d * gc_d, lane);
       gc_seed = givens_seed(gc_d, dpp_shift0_d<0x130>(sincl)); // lane i: sum over k > i
-      if(A.chain_mode == 2) gc_seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
+      if((A.chain_mode & 255) == 2) gc_seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
       gc_rc = gc_d;
       gc_i = n - 2;
     };
@@ -1497,7 +1534,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         GivensHalf h;
         double rex = givens_r(gc_d, gc_kq, h);
         const bool mine = lane >= q && lane <= n - 2;
-        if(A.chain_mode == 1 || __any(mine && !(rex == gc_rc)))
+        if((A.chain_mode & 255) == 1 || __any(mine && !(rex == gc_rc)))
         {
           chain_exact();
           (void)givens_r(gc_d, gc_kq, h);
@@ -2094,6 +2131,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               for(int k = 0; k < NR; ++k) slot[k] = creg[k];
             }
             ctl->bndw[wave] = (bstat == LOWER) ? my_bl : my_bu;
+            ctl->cxw[wave] = cx; // n+.x for the step length: this very chain (GoldfarbIdnaniSolver.cpp:97 and :183-190 are one expression)
           }
           if(wave == 2 && ne <= 64)
           {
@@ -2123,14 +2161,15 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               ctl->red_idx[3] = ei;
               ctl->red_stat[3] = es;
             }
+            if(ei == i && e_on && lane < ne) ctl->cxw[3] = ex;
           }
         };
         // MAIN's share of K4 (only when there are more than 64 extra columns): the LDS-staged extra columns, 64 per round (lane e = column 192 + e0 + e); a lane keeps its
         // first best one (strict <), then the arg-min; the winner goes to slot 3 of the reduction words
         auto ws_extras = [&](int excl) __attribute__((always_inline)) {
           if(ne <= 64) return; // (wave 2 runs them beside its own columns)
-          double ev = 1.0;
-          int ei = NONE, es = INACTIVE;
+          double ev = 1.0, ecx = 0.0;
+          int ei = NONE, es = INACTIVE, mine = NONE;
           for(int e0 = 0; e0 < ne; e0 += 64)
           {
             const int i = CREG_MAX + e0 + lane;
@@ -2150,6 +2189,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
                   ev = sl;
                   ei = i;
                   es = LOWER;
+                  ecx = cxe;
                 }
               }
               else if(su < 0.0 && su < ev)
@@ -2157,9 +2197,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
                 ev = su;
                 ei = i;
                 es = UPPER;
+                ecx = cxe;
               }
             }
           }
+          mine = ei;
           if(ne > 64)
             wave_argmin(ev, ei, es);
           else if(ne > 0)
@@ -2170,21 +2212,28 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             ctl->red_idx[3] = ei;
             ctl->red_stat[3] = es;
           }
+          if(ei != NONE && mine == ei) ctl->cxw[3] = ecx; // (one lane: a constraint belongs to one lane) n+.x of the winner, see ws_scan
           wave_sync();
         };
-        if(tid == 0)
+        if(!ovl)
         {
-          ctl->fd = 0; ctl->fz = 0; ctl->fack0 = 0; ctl->fack2 = 0; ctl->fcs = 0; ctl->fdr = 0; ctl->fstep = 0; ctl->dec = 0;
-          ctl->fscan[0] = 0; ctl->fscan[1] = 0; ctl->fscan[2] = 0;
-          ctl->wit = it; ctl->wterm = T_SUCCESS; ctl->wq = q;
+          if(tid == 0)
+          {
+            ctl->wit = it; ctl->wterm = T_SUCCESS; ctl->wq = q;
+          }
+          __syncthreads();
         }
-        __syncthreads();
+        const int tune = A.chain_mode >> 8; // experiment bits (JRLQP_TUNE): 1 MAIN priority 3, 2 chain wave priority 2, 4 z wave priority 1
         if(wave == MAINW)
         {
           // ------------------------------------------------------------------------------------------ MAIN
+          if(tune & 1) __builtin_amdgcn_s_setprio(3);
           int sq = 0, sc = 1;
           int wterm = T_SUCCESS;
           const int rl = (lane < n) ? lane : (n - 1);
+          // x (lane i: x_i) and f live in MAIN's registers for the whole loop -- only MAIN changes them; xs is written through
+          // for the scans, ctl->f once at the end
+          double x_reg = 0.0, f_reg = 0.0;
 #define WS_WAIT(word, target)      \
   if(!ws_wait((word), (target)))   \
   {                                \
@@ -2192,8 +2241,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     goto ws_stop;                  \
   }
           // first selection: the helpers scan with x = x0
+          if(ovl && !ws_wait(&ctl->fx0, 1)) wterm = T_UNKNOWN; // (overlapped prologue: x0 comes from wave 0 without a barrier)
           ws_extras(-1);
-          bool running = ws_wait(&ctl->fscan[0], sc) && ws_wait(&ctl->fscan[1], sc) && ws_wait(&ctl->fscan[2], sc);
+          bool running = wterm == T_SUCCESS && ws_wait(&ctl->fscan[0], sc) && ws_wait(&ctl->fscan[1], sc) && ws_wait(&ctl->fscan[2], sc);
+          x_reg = xs[rl];
+          f_reg = ctl->f;
           if(running)
             scan_combine(p, pstat);
           else
@@ -2201,6 +2253,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           STAMP3(24)
           running = running && (p >= 0);
           if(running && lane == 0) us[q] = 0.0; // DualSolver.cpp:121
+          bool fresh = true; // p comes from a scan of the current x (false in the pass behind a removal: skipStep1)
           while(running)
           {
             ++sq;
@@ -2259,6 +2312,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
                 ctl->wp = p;
                 ctl->wps = pstat;
                 ctl->wq = q;
+                ctl->wfresh = fresh ? 1 : 0;
               }
             }
             ws_post(&ctl->fd, sq);
@@ -2271,6 +2325,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             WS_WAIT(&ctl->fz, sq)
             STAMP3(27)
             // ---- K8: step length (t2 comes from the z wave)
+            const double zv = zs[rl]; // (requested with the two scalars: one LDS round trip for the whole update)
             const double cz = uniform_d(ctl->cz);
             const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
             const double t2 = uniform_d(ctl->t2);
@@ -2292,7 +2347,20 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             }
             const bool dual_only = (t2 >= big);
             const bool add = !dual_only && (t == t2);
-            apply_step(t, dotsc, dual_only);
+            {
+              // K9 out of registers (DualSolver.cpp:136-150): x += t z, f += t (n+.z) (t/2 + u_q) with u_q BEFORE its update,
+              // u_k -= t r_k, u_q += t.  r, u and u_q (zero behind a fresh selection, the shifted pending multiplier behind a
+              // removal) are still in the registers of trsv_ratio, x and f never left: no load, three stores.
+              const double uq = tr_uq;
+              if(!dual_only)
+              {
+                x_reg = FMA(t, zv, x_reg);
+                if(lane < n) xs[lane] = x_reg;
+                f_reg = FMA(t * dotsc, 0.5 * t + uq, f_reg);
+              }
+              if(lane < q) us[lane] = FMA(-t, tr_r, tr_u);
+              if(lane == 0) us[q] = uq + t;
+            }
             if(lane == 0) ctl->dec = add ? 1 : 2;
             ws_post(&ctl->fstep, sq);
             STAMP3(28)
@@ -2417,9 +2485,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               if(p < 0) break; // SUCCESS (DualSolver.cpp:114)
               if(lane == 0) us[q] = 0.0; // DualSolver.cpp:121
               wave_sync();
+              fresh = true;
             }
             else
             {
+              fresh = false;
               WS_WAIT(&ctl->fdr, sq) // (do_drop hands its rotations on through the vectors d and z)
               do_drop(l);
               q = uniform(q - 1);
@@ -2446,6 +2516,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             ctl->wterm = wterm;
             ctl->wq = q;
             ctl->dec = 3;
+            ctl->f = f_reg;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if(lane == 0)
@@ -2459,7 +2530,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         {
           // ------------------------------------------------------------------------------------------ HELPERS
           load_columns();
+          if(ovl && wave != 0 && !ws_wait(&ctl->fx0, 1)) { /* bounded wait: the scan below then works on a stale x and MAIN reports UNKNOWN */ }
+          if((tune & 2) && wave == 0) __builtin_amdgcn_s_setprio(2);
+          if((tune & 4) && wave == 1) __builtin_amdgcn_s_setprio(1);
           int sq = 0, sc = 0;
+          double cx_next = 0.0; // wave 1: n+.x for the pass behind a removal (same p, x moved by the partial step)
           ++sc;
           ws_scan(-1);
           ws_post(&ctl->fscan[wave], sc);
@@ -2492,7 +2567,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               {
                 const double sincl = wave_suffix_sum_approx(gd * gd, lane);
                 GivensSeed seed = givens_seed(gd, dpp_shift0_d<0x130>(sincl)); // lane i: sum over k > i
-                if(A.chain_mode == 2) seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
+                if((A.chain_mode & 255) == 2) seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
                 double rc = gd;
                 int left = n - 1 - wq; // steps n-2 .. wq
                 while(left > 0)
@@ -2521,7 +2596,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
                   GivensHalf h;
                   const double rex = givens_r(gd, kq, h);
                   const bool mine = lane >= wq && lane <= n - 2;
-                  if(A.chain_mode == 1 || __any(mine && !(rex == rc)))
+                  if((A.chain_mode & 255) == 1 || __any(mine && !(rex == rc)))
                   {
                     double rr = opaque_v(bcast_lane(gd, n - 1));
                     kq = 0.0;
@@ -2548,21 +2623,24 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             }
             else if(wave == 1)
             {
-              // ---- K6: z = J2 d2; then z.z, n+.z, n+.x as three chains in three lanes of ONE instruction stream, and from them
-              // the primal step length t2 (GoldfarbIdnaniSolver.cpp:174-218): MAIN only takes the minimum with t1
+              // ---- K6: z = J2 d2; then z.z and n+.z as C4 trees over the lanes (CANON C5) and, from them and n+.x, the primal
+              // step length t2 (GoldfarbIdnaniSolver.cpp:174-218): MAIN only takes the minimum with t1.  n+.x is not computed here
+              // in a pass that selected p: it is the scan's own chain for that constraint (cxw); behind a removal it was recomputed
+              // beside MAIN's removal (cx_next below), off the critical path.
               const bool general = wp < m;
               const int wps = uniform(ctl->wps);
-              if(lane < n) zs[lane] = chain_up(J + lane, ld, ds, 1, wq, n, 0.0);
-              wave_sync();
-              double acc = 0.0;
-              if(lane < 3)
-              {
-                if(general || lane == 0)
-                  acc = chain_up((lane == 0) ? zs : np_ptr(wp), 1, (lane == 2) ? xs : zs, 1, 0, n, 0.0);
-                else
-                  acc = (lane == 1) ? zs[wp - m] : xs[wp - m];
-              }
-              const double zz = bcast_lane(acc, 0), czv = bcast_lane(acc, 1), cxv = bcast_lane(acc, 2);
+              const int rl = (lane < n) ? lane : 0;
+              const double npv = general ? np_ptr(wp)[rl] : 0.0;
+              double zi = chain_up(J + rl, ld, ds, 1, wq, n, 0.0);
+              zi = (lane < n) ? zi : 0.0;
+              if(lane < n) zs[lane] = zi;
+              const double zz = wave_sum_tree(FMA(zi, zi, 0.0));
+              const double czv = general ? wave_sum_tree(FMA(npv, zi, 0.0)) : bcast_lane(zi, wp - m);
+              double cxv;
+              if(uniform(ctl->wfresh))
+                cxv = general ? uniform_d(ctl->cxw[(wp < CREG_MAX) ? (wp >> 6) : 3]) : uniform_d(xs[wp - m]);
+              else
+                cxv = cx_next;
               double t2v = big;
               if(__builtin_sqrt(zz) > 1e-14) t2v = (uniform_d(bound_of(wp, wps)) - cxv) / czv;
               if(lane == 0)
@@ -2598,6 +2676,12 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               ws_post(&ctl->fack0, sq);
             else if(wave == 2)
               ws_post(&ctl->fack2, sq);
+            else
+            {
+              // wave 1, a pass that removes: the next pass keeps p but x has moved -- n+.x again (C1 chain, every lane the same
+              // chain on broadcast reads), beside MAIN's removal
+              cx_next = (wp < m) ? chain_up(np_ptr(wp), 1, xs, 1, 0, n, 0.0) : xs[wp - m];
+            }
           }
         }
         __syncthreads();

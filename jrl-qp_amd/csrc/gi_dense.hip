@@ -717,9 +717,9 @@ __global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ 
 // while wave 0 was solving, and wave 0 fetches the next diagonal block while they update.  Two LDS-only barriers per
 // column block; the running right-hand side lives in LDS.
 //
-// block 1: z.z, n.z, n.x -- three in-order chains in three lanes of one wave, their operands staged in LDS by the
-// whole workgroup first (a single lane chasing them through global memory pays one L2 latency per eight entries:
-// that, not the arithmetic, was most of this kernel's time).
+// block 1: z.z and n.z as C4 trees over the whole workgroup (CANON C5), n.x as an in-order chain in one lane beside them; the
+// operands are staged in LDS by the whole workgroup first (a single lane chasing them through global memory pays one L2
+// latency per eight entries).
 __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restrict__ R, int ld, int n, int q, const double * __restrict__ d, double * r,
                                                         const double * __restrict__ u, const unsigned char * __restrict__ st, double big,
                                                         const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
@@ -762,30 +762,67 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
       cl[i] = cp ? cp[i] : 0.0;
     }
     __syncthreads();
-    if(wave != 0) return;
-    // lane 0: z.z   lane 1: n.z   lane 2: n.x   (n = C[:,p] for a general constraint, e_pb for a bound)
-    const int which = (lane < 3) ? lane : 0;
-    const double * pa = (which == 0) ? zl : cl;
-    const double * pv = (which == 2) ? xl : zl;
-    double acc = 0.0;
-    int k = 0;
-    for(; k + 16 <= n; k += 16)
+    // z.z and n+.z: C4 trees (CANON C5, oracle orc_dot_tree): element e joins chain e mod 1024, thread t owns chains 2t and
+    // 2t + 1 (ascending e), then the adjacent-first pairwise tree -- the two chains of a thread, the lanes of a wave
+    // (wave_sum_tree), the eight waves.  n+.x: the C1 chain (bit for bit the scan's value for the constraint), one lane of wave 1
+    // beside the trees.
+    double pz0 = 0.0, pz1 = 0.0, pc0 = 0.0, pc1 = 0.0;
+    for(int base = 0; base < n; base += 1024)
     {
-      double av[16], bv[16];
-#pragma unroll
-      for(int t = 0; t < 16; ++t)
+      const int e0 = base + 2 * tid, e1 = e0 + 1;
+      if(e0 < n)
       {
-        av[t] = pa[k + t];
-        bv[t] = pv[k + t];
+        const double zv = zl[e0];
+        pz0 = FMA(zv, zv, pz0);
+        pc0 = FMA(cl[e0], zv, pc0);
       }
-#pragma unroll
-      for(int t = 0; t < 16; ++t) acc = FMA(av[t], bv[t], acc);
+      if(e1 < n)
+      {
+        const double zv = zl[e1];
+        pz1 = FMA(zv, zv, pz1);
+        pc1 = FMA(cl[e1], zv, pc1);
+      }
     }
-    for(; k < n; ++k) acc = FMA(pa[k], pv[k], acc);
-    if(!cp && which != 0) acc = pv[pb];
-    if(lane == 0) mb->zz = acc;
-    if(lane == 1) mb->cz = acc;
-    if(lane == 2) mb->cx = acc;
+    const double sz = wave_sum_tree(pz0 + pz1), sc = wave_sum_tree(pc0 + pc1);
+    double * red = rs + 3 * n; // (inside the dynamic allocation: tail_lds; a static array on top of a raised dynamic limit does not fit)
+    if(lane == 0)
+    {
+      red[wave] = sz;
+      red[8 + wave] = sc;
+    }
+    if(tid == 64)
+    {
+      double acc = 0.0;
+      if(cp)
+      {
+        int k = 0;
+        for(; k + 16 <= n; k += 16)
+        {
+          double av[16], bv[16];
+#pragma unroll
+          for(int t = 0; t < 16; ++t)
+          {
+            av[t] = cl[k + t];
+            bv[t] = xl[k + t];
+          }
+#pragma unroll
+          for(int t = 0; t < 16; ++t) acc = FMA(av[t], bv[t], acc);
+        }
+        for(; k < n; ++k) acc = FMA(cl[k], xl[k], acc);
+      }
+      else
+        acc = xl[pb];
+      mb->cx = acc;
+    }
+    __syncthreads();
+    if(tid == 0)
+    {
+      double w[16];
+#pragma unroll
+      for(int i = 0; i < 16; ++i) w[i] = red[i];
+      mb->zz = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      mb->cz = cp ? (((w[8] + w[9]) + (w[10] + w[11])) + ((w[12] + w[13]) + (w[14] + w[15]))) : zl[pb];
+    }
     post_tag(); // (wave 0 of block 1 wrote the three scalars; thread 0 is one of its lanes)
     return;
   }
@@ -1355,7 +1392,7 @@ static size_t rot_lds(int T)
 }
 static size_t tail_lds(int n, int q)
 {
-  return sizeof(double) * (size_t)((3 * n > q + 2) ? 3 * n : q + 2);
+  return sizeof(double) * (size_t)((3 * n + 16 > q + 2) ? 3 * n + 16 : q + 2); // (+16: the per-wave partial sums of the two C4 trees)
 }
 // Dynamic LDS beyond the default 64 KiB (step_tail: three n-vectors, n > 2730; rot_apply: the (c, s) pairs of a sweep,
 // more than ~1900 rotations; add_chain: the third vector of the seeded recurrence): the limit is raised once, to the

@@ -51,6 +51,18 @@ static void bitrev_init(void)
 double orc_dot_tree(int n, const double * a, const double * b, int phase)
 {
   double p[1024];
+  if(phase == 0 && n <= 1024)
+  {
+    /* every element has a chain of its own (one product): the tree over the first 2^k >= n slots, in natural order.  The slots
+     * beyond are +0.0 and a partial sum is never -0.0 (fma(a, b, +0.0) is not), so leaving them out changes no bit. */
+    int size = 1;
+    while(size < n) size <<= 1;
+    for(int i = 0; i < n; ++i) p[i] = FMA(a[i], b[i], 0.0);
+    for(int i = n; i < size; ++i) p[i] = 0.0;
+    for(int h = 1; h < size; h <<= 1)
+      for(int i = 0; i < size; i += 2 * h) p[i] = p[i] + p[i + h];
+    return n > 0 ? p[0] : 0.0;
+  }
   if(!g_bitrev_ready) bitrev_init();
   memset(p, 0, sizeof p);
   for(int i = 0; i < n; ++i)

@@ -12,6 +12,14 @@
  *       single correctly-rounded IEEE-754 binary64 operation (/, sqrt included), no contraction
  *       (this file must be compiled with -ffp-contract=off and without -ffast-math);
  *   C3  plane rotations:  x' = fma(c, x, -(s*y)),  y' = fma(s, x, c*y).
+ *   C5  the two scalar products of a pass that need the step direction z -- z.z (the ||z|| test, GoldfarbIdnaniSolver.cpp:174,309)
+ *       and n+.z (ConstraintNormal::dot, ConstraintNormal.h:105-123: the step length :183-190, the objective update
+ *       DualSolver.cpp:147, addInitialConstraint :309-321) -- are C4 reductions (orc_dot_tree, blockgi_oracle.c): one product per
+ *       element up to n = 1024 (element e joins chain e mod 1024), combined by the adjacent-first pairwise tree.  Eigen's own
+ *       dot() is a tree of SIMD partial sums as well (packet width unspecified), so this is as faithful to the reference as the
+ *       single chain of C1 was -- and it is the shape a wavefront evaluates in log2(64) exchanges instead of n dependent fmas
+ *       on the critical path of every pass.  n+.x stays the C1 chain: it is bit for bit the value C.col(p).dot(x) the constraint
+ *       scan has just computed for the selected constraint (:97), and the kernels reuse it.
  */
 #include "jrlqp_oracle.h"
 
@@ -247,14 +255,14 @@ long orc_gi_work_doubles(int n, int m, int nb)
   return 2L * n * n + 3L * n + 2L * (m + nb + 2) + m + 1 + 4L * n; /* + b_act, hCoeffs, alpha, beta (warm start) */
 }
 
-/* ConstraintNormal::dot (ConstraintNormal.h:105-123) */
+/* ConstraintNormal::dot (ConstraintNormal.h:105-123) with the step direction z (CANON C5: a C4 tree) */
 static double np_dot(const gi_state * S, int p, int status, const double * v)
 {
   switch(status)
   {
     case ORC_EQUALITY:
-    case ORC_LOWER: return orc_dot(S->n, v, S->C + (long)p * S->ldc);
-    case ORC_UPPER: return -orc_dot(S->n, v, S->C + (long)p * S->ldc);
+    case ORC_LOWER: return orc_dot_tree(S->n, v, S->C + (long)p * S->ldc, 0);
+    case ORC_UPPER: return -orc_dot_tree(S->n, v, S->C + (long)p * S->ldc, 0);
     case ORC_FIXED:
     case ORC_LOWER_BOUND: return v[p - S->m];
     case ORC_UPPER_BOUND: return -v[p - S->m];
@@ -356,12 +364,12 @@ static void add_initial_constraint(gi_state * S, int p, int status)
   u[q] = 0.0;
   compute_step(S, p, status);
   double t = 0.0;
-  if(sqrt(orc_dot(n, z, z)) > 1e-14)
+  if(sqrt(orc_dot_tree(n, z, z, 0)) > 1e-14)
   {
     if(status == ORC_EQUALITY)
     {
       const double * cp = S->C + (long)p * S->ldc;
-      t = (S->bl[p] - orc_dot(n, cp, x)) / orc_dot(n, cp, z);
+      t = (S->bl[p] - orc_dot(n, cp, x)) / orc_dot_tree(n, cp, z, 0);
     }
     else
     {
@@ -786,15 +794,15 @@ main_loop:
         }
       }
       double cz = 0.0;
-      if(sqrt(orc_dot(n, z, z)) > 1e-14)
+      if(sqrt(orc_dot_tree(n, z, z, 0)) > 1e-14) /* CANON C5 */
       {
         double b, cx;
         if(pstatus == ORC_LOWER || pstatus == ORC_UPPER)
         {
           const double * cp = C + (long)p * ldc;
           b = (pstatus == ORC_LOWER) ? bl[p] : bu[p];
-          cx = orc_dot(n, cp, x);
-          cz = orc_dot(n, cp, z);
+          cx = orc_dot(n, cp, x);         /* C1: == cxs[p] of the scan when p was selected in this pass */
+          cz = orc_dot_tree(n, cp, z, 0); /* C5 */
         }
         else
         {

@@ -43,3 +43,14 @@ print("mean cycles per solve", tot.mean(), " mean realtime us", pr[:, 12].mean()
 for i, nm in enumerate(names):
     if nm == '': continue
     print(f"  {nm:18s} {pr[:, i].mean():12.1f}  ({100 * pr[:, i].mean() / tot.mean():5.1f} %)")
+
+# ---- where the hardware put the MAIN wave (slot 14) and wave 0 (slot 15) of every workgroup: SIMD collisions of the serial waves?
+hw3, hw0 = prof[:, 14].cpu().numpy().astype(np.uint64), prof[:, 15].cpu().numpy().astype(np.uint64)
+simd3, simd0 = (hw3 >> np.uint64(4)) & np.uint64(3), (hw0 >> np.uint64(4)) & np.uint64(3)
+cu = ((hw3 >> np.uint64(8)) & np.uint64(15)) | (((hw3 >> np.uint64(12)) & np.uint64(15)) << np.uint64(4)) | ((hw3 >> np.uint64(32)) << np.uint64(8))
+print("MAIN wave SIMD histogram", np.bincount(simd3.astype(np.int64), minlength=4).tolist(), " wave 0 SIMD histogram", np.bincount(simd0.astype(np.int64), minlength=4).tolist())
+print("(MAIN simd - wave0 simd) mod 4 histogram", np.bincount(((simd3.astype(np.int64) - simd0.astype(np.int64)) % 4), minlength=4).tolist())
+print("distinct CU ids seen", len(np.unique(cu)), " wave slots of MAIN", np.bincount((hw3 & np.uint64(15)).astype(np.int64), minlength=16).tolist())
+slot3, slot0 = (hw3 & np.uint64(15)).astype(np.int64), (hw0 & np.uint64(15)).astype(np.int64)
+print("workgroups whose MAIN wave and wave 0 sit in the same wave slot:", int((slot3 == slot0).sum()), "of", len(slot3),
+      "; MAIN on SIMD == slot mod 4:", int((simd3.astype(np.int64) == (slot3 & 3)).sum()))
