@@ -191,12 +191,13 @@ long long jrlqp_gi_batch_workspace_bytes(int n, int m, int nb, int B)
   if(n <= JRLQP_BATCH_WAVE_N) return jrlqp::batch_pick_cmode(n, m, nb) < 0 ? -1 : 0;
   int r_in_lds = 0;
   if(jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0) return -1;
-  if(r_in_lds || B == 0) return 0;
+  if(B == 0) return 0;
   int dev = 0, ncu = 0;
   if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
     return -1;
-  // sized by the machine (one slice per resident workgroup of the persistent grid), not by the batch
-  return (long long)sizeof(double) * big_grid(n, m, nb, B) * jrlqp::batch_big_ws_doubles_per_wg(n);
+  // sized by the machine (one slice per resident workgroup of the persistent grid), not by the batch; the figure covers a
+  // warm start (B = L^-1 N, n x n) as well as a cold one (R alone, and only beyond n = 104)
+  return (long long)sizeof(double) * big_grid(n, m, nb, B) * jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, 1);
 }
 
 static int gi_batch_common(int warm,
@@ -234,9 +235,9 @@ static int gi_batch_common(int warm,
   if(nb > 0 && (!dxl || !dxu)) return JRLQP_ERR_INVALID_ARGUMENT;
   if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
   if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
-  const bool bign = n > JRLQP_BATCH_WAVE_N; // more rows than one lane-per-row wavefront: gi_batch_big.hip (cold start only)
+  const bool bign = n > JRLQP_BATCH_WAVE_N; // more rows than one lane-per-row wavefront: gi_batch_big.hip
   int r_in_lds = 0;
-  if(bign && (warm || jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0)) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  if(bign && jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const int cmode = bign ? 0 : jrlqp::batch_pick_cmode(n, m, nb, warm);
   if(cmode < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
 
@@ -268,11 +269,12 @@ static int gi_batch_common(int warm,
     const int nwg = big_grid(n, m, nb, B);
     if(nwg < 1) return JRLQP_ERR_NO_DEVICE;
     double * ws = nullptr;
-    if(!r_in_lds)
+    const long per_wg = jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, warm);
+    if(per_wg > 0)
     {
-      // R (packed, 66 KB at n = 128) does not fit beside J: it lives in the CALLER's workspace (jrlqp_gi_batch_workspace_bytes)
-      // -- nothing is allocated inside a solve (tests/GoldfarbIdnaniSolverTest.cpp:109-116)
-      const long long need = (long long)sizeof(double) * nwg * jrlqp::batch_big_ws_doubles_per_wg(n);
+      // R (packed, 66 KB at n = 128) when it does not fit beside J, and B = L^-1 N of a warm start, live in the CALLER's workspace
+      // (jrlqp_gi_batch_workspace_bytes) -- nothing is allocated inside a solve (tests/GoldfarbIdnaniSolverTest.cpp:109-116)
+      const long long need = (long long)sizeof(double) * nwg * per_wg;
       if(!dws || ws_bytes < need || (reinterpret_cast<size_t>(dws) & 15)) return JRLQP_ERR_WORKSPACE;
       ws = static_cast<double *>(dws);
     }
@@ -286,6 +288,11 @@ static int gi_batch_common(int warm,
 
 long jrlqp_gi_batch_warm_lds_bytes(int n, int m, int nb, int * c_in_lds)
 {
+  if(n > JRLQP_BATCH_WAVE_N && n <= JRLQP_BATCH_MAX_N && m >= 0 && (nb == 0 || nb == n))
+  {
+    if(c_in_lds) *c_in_lds = 0;
+    return jrlqp::batch_big_lds_bytes(n, m, nb, nullptr); // (B = L^-1 N lives in the workspace, not in LDS)
+  }
   if(n < 1 || n > JRLQP_BATCH_WAVE_N || m < 0 || (nb != 0 && nb != n)) return -1;
   int cmode = jrlqp::batch_pick_cmode(n, m, nb, 1);
   if(cmode < 0) return -1;

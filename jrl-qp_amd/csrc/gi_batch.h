@@ -38,10 +38,10 @@ int batch_pad_size(int n, int warm); // instantiated size a problem of n variabl
 long batch_lds_bytes(int n, int m, int nb, int cmode, int warm = 0);
 int batch_pick_cmode(int n, int m, int nb, int warm = 0); // -1 if unsupported
 hipError_t launch_gi_batch_box(const BatchArgs & a, hipStream_t stream);
-// 64 < n <= JRLQP_BATCH_MAX_N (gi_batch_big.hip): persistent grid of nwg workgroups; ws: nwg * batch_big_ws_doubles_per_wg(n)
-// doubles of global workspace when R does not fit in LDS beside J (*r_in_lds == 0), else unused
+// 64 < n <= JRLQP_BATCH_MAX_N (gi_batch_big.hip): persistent grid of nwg workgroups; ws: nwg * batch_big_ws_doubles_per_wg(...)
+// doubles of global workspace: R when it does not fit in LDS beside J (*r_in_lds == 0), B = L^-1 N of a warm start
 long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds);
-long batch_big_ws_doubles_per_wg(int n);
+long batch_big_ws_doubles_per_wg(int n, int r_in_lds, int warm);
 hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStream_t stream);
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream);
 } // namespace jrlqp

@@ -196,7 +196,11 @@ __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho,
 
 // RLDS: R lives in LDS (compile-time, so that its accesses are ds_ instructions: with a run-time choice between LDS and the
 // global scratch every access to R is a FLAT load, and the substitution -- two dependent loads per step -- pays ~500 cycles each)
-template<bool RLDS>
+// WARM: warm-started solve (experimental::GoldfarbIdnaniSolver, src/experimental/GoldfarbIdnaniSolver.cpp:20-112, :306-487; oracle
+// orc_gi_solve_warm): the initial active set comes from the data equalities plus a guess, J and R from a Householder QR of
+// B = L^-1 N, the start point in closed form, constraints with a negative multiplier purged one at a time; then the same loop.
+// B (n x q) does not fit in LDS beside J: it lives in the workgroup's slice of the global workspace, behind R.
+template<bool RLDS, bool WARM>
 __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -222,7 +226,8 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
   double * ssq = sss + n;            // scratch of the coefficient chain (n + 2)
   double * tail = ssq + (n + 2);
   double * Rl = tail;                                   // RLDS
-  double * Rg = ws + (long)blockIdx.x * (RLDS ? 0 : ws_stride); // !RLDS (per-workgroup slice of the scratch)
+  double * Rg = ws + (long)blockIdx.x * ((RLDS && !WARM) ? 0 : ws_stride); // !RLDS (per-workgroup slice of the scratch)
+  double * Bw = Rg + (RLDS ? 0 : ((rlen + 1) & ~1L));                         // WARM: N -> B = L^-1 N -> its QR factors, n x q, ld = n
   if(RLDS) tail += rlen;
   CtlB * ctl = reinterpret_cast<CtlB *>(tail);
   int * act = reinterpret_cast<int *>(ctl + 1);
@@ -260,9 +265,78 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
     }
     __syncthreads();
 
+    bool over = false;
+    int nact0 = 0;
+    if constexpr(WARM)
+    {
+      // processInitialActiveSet (experimental/GoldfarbIdnaniSolver.cpp:309-386; oracle process_initial_active_set): the decision per
+      // constraint -- data equalities win over the guess; guesses on infinite bounds, FIXED guesses on free variables and
+      // ill-typed entries are ignored --, then the activation ORDER: bounds first, then general constraints, each by increasing
+      // index; beyond n active constraints inequality entries are dropped from the back, i.e. every equality stays and the
+      // first n - #eq inequality entries stay.  More equalities than unknowns: OVERCONSTRAINED, reported before the factorisation.
+      const int * asg = A.as_in ? A.as_in + (size_t)b * mt : nullptr;
+      for(int i = tid; i < mt; i += WGB)
+      {
+        int sdec = B_INACTIVE;
+        const int g = asg ? asg[i] : B_INACTIVE;
+        if(i < m)
+        {
+          const double lo = blg[i], hi = bug[i];
+          if(lo == hi)
+            sdec = B_EQUALITY;
+          else if(g == B_LOWER && !(lo < -big))
+            sdec = B_LOWER;
+          else if(g == B_UPPER && !(hi > big))
+            sdec = B_UPPER;
+          else if(g == B_EQUALITY)
+            sdec = B_EQUALITY; // (:357-371 only filters FIXED: an EQUALITY guess is taken as is)
+        }
+        else
+        {
+          const double lo = xlg[i - m], hi = xug[i - m];
+          if(lo == hi)
+            sdec = B_FIXED;
+          else if(g == B_LOWER_BOUND && !(lo < -big))
+            sdec = B_LOWER_BOUND;
+          else if(g == B_UPPER_BOUND && !(hi > big))
+            sdec = B_UPPER_BOUND;
+        }
+        st[i] = (unsigned char)sdec;
+      }
+      __syncthreads();
+      if(tid == 0)
+      {
+        int neq = 0;
+        for(int i = 0; i < mt; ++i) neq += (st[i] == B_EQUALITY || st[i] == B_FIXED) ? 1 : 0;
+        const int budget = n - neq;
+        int pos = 0, rank = 0;
+        if(budget >= 0)
+          for(int part = 0; part < 2; ++part)
+          {
+            const int lo = (part == 0) ? m : 0, hi = (part == 0) ? mt : m;
+            for(int i = lo; i < hi; ++i)
+            {
+              const int sv = st[i];
+              if(sv == B_INACTIVE) continue;
+              const bool iseq = (sv == B_EQUALITY || sv == B_FIXED);
+              const bool keep = iseq || rank < budget;
+              if(!iseq) ++rank;
+              if(keep)
+                act[pos++] = i;
+              else
+                st[i] = B_INACTIVE;
+            }
+          }
+        ctl->pad0 = (neq > n) ? 1 : 0;
+        ctl->pad1 = pos;
+      }
+      __syncthreads();
+      over = ctl->pad0 != 0;
+      nact0 = ctl->pad1;
+    }
     // ---------------------------------------------------------------- LLT, left-looking column by column (orc_llt)
     int info = -1;
-    for(int j = 0; j < n; ++j)
+    for(int j = 0; j < n && !over; ++j)
     {
       // rows i = j .. n-1 over the threads (two rounds when n - j > 256 never happens: n <= 128)
       const int i = j + tid;
@@ -281,7 +355,9 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       __syncthreads();
     }
     int term = BT_SUCCESS, it = 0, q = 0;
-    if(info >= 0)
+    if(over)
+      term = BT_OVERCONSTRAINED;
+    else if(info >= 0)
       term = BT_NON_POS_HESSIAN;
     else
     {
@@ -294,6 +370,106 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
           if(i >= j) Lg[e] = M[i + (long)j * ld];
         }
       }
+      if constexpr(WARM)
+      {
+        // ---- initializeComputationData (experimental/GoldfarbIdnaniSolver.cpp:388-458; oracle initialize_computation_data)
+        q = nact0;
+        double * bact = ccs; // b_act (free until the first addition of the loop)
+        double * hco = sss;  // Householder coefficients
+        // N (+-C columns / +-unit vectors) and b_act in activation order (:393-418); a -> LDS
+        for(int e = tid; e < q * n; e += WGB)
+        {
+          const int j = e / n, i = e % n;
+          const int idx = act[j];
+          const int sj = st[idx];
+          double v;
+          if(idx < m)
+          {
+            const double c = Cg[(size_t)idx * n + i];
+            v = (sj == B_UPPER) ? -c : c;
+          }
+          else
+            v = (i == idx - m) ? ((sj == B_UPPER_BOUND) ? -1.0 : 1.0) : 0.0;
+          Bw[i + (long)j * n] = v;
+        }
+        for(int j = tid; j < q; j += WGB)
+        {
+          const int idx = act[j];
+          const int sj = st[idx];
+          bact[j] = (idx < m) ? ((sj == B_UPPER) ? -bug[idx] : blg[idx]) : ((sj == B_UPPER_BOUND) ? -xug[idx - m] : xlg[idx - m]);
+        }
+        if(tid < n)
+        {
+          nps[tid] = ag[tid];
+          dgl[tid] = M[tid + (long)tid * ld];
+        }
+        __syncthreads();
+        // B = L^-1 N (:426): wave w takes columns w, w + 4, ...; two rows per lane; per element the terms in ascending k, then
+        // one division (the oracle's forward substitution)
+        for(int j = wave; j < q; j += 4)
+        {
+          double * col = Bw + (long)j * n;
+          double b0 = (lane < n) ? col[lane] : 0.0, b1 = (lane + 64 < n) ? col[lane + 64] : 0.0;
+          const int ns = __builtin_amdgcn_readfirstlane(n);
+          for(int k = 0; k < ns; ++k)
+          {
+            const double num = (k < 64) ? bcast_lane(b0, k) : bcast_lane(b1, k - 64);
+            const double v = num / M[k + (long)k * ld];
+            const double * lk = M + (long)k * ld;
+            if(lane > k && lane < n) b0 = FMA(-lk[lane], v, b0);
+            if(lane + 64 > k && lane + 64 < n) b1 = FMA(-lk[lane + 64], v, b1);
+            if(lane == k) b0 = v;
+            if(lane + 64 == k) b1 = v;
+          }
+          if(lane < n) col[lane] = b0;
+          if(lane + 64 < n) col[lane + 64] = b1;
+        }
+        __syncthreads();
+        // B = Q R, Householder, column by column (:432-440; Eigen makeHouseholder / applyHouseholderOnTheLeft), in place
+        for(int k = 0; k < q; ++k)
+        {
+          double * vk = Bw + (long)k * n;
+          if(wave == 0)
+          {
+            const double tailsq = chain_asc<false>(vk, 1, vk, 1, k + 1, n, 0.0); // (every lane the same chain)
+            const double c0 = vk[k];
+            const bool zero = tailsq <= 2.2250738585072014e-308;
+            double beta = __builtin_sqrt(FMA(c0, c0, tailsq));
+            beta = (c0 >= 0.0) ? -beta : beta;
+            const double den = c0 - beta;
+            double tau = (beta - c0) / beta;
+            tau = zero ? 0.0 : tau;
+            beta = zero ? c0 : beta;
+            const double m0 = (lane > k && lane < n) ? vk[lane] : 0.0, m1 = (lane + 64 > k && lane + 64 < n) ? vk[lane + 64] : 0.0;
+            wave_sync();
+            if(lane > k && lane < n) vk[lane] = zero ? 0.0 : m0 / den;
+            if(lane + 64 > k && lane + 64 < n) vk[lane + 64] = zero ? 0.0 : m1 / den;
+            if(lane == 0)
+            {
+              vk[k] = beta;
+              hco[k] = tau;
+            }
+          }
+          __syncthreads();
+          const double tau = hco[k];
+          if(tau != 0.0 && k + 1 < n)
+          {
+            const int j = k + 1 + tid; // trailing column
+            if(j < q)
+            {
+              double * cj = Bw + (long)j * n;
+              double t = chain_asc<false>(vk, 1, cj, 1, k + 1, n, 0.0);
+              const double top = cj[k];
+              t = t + top;
+              cj[k] = FMA(-tau, t, top);
+              const double stt = tau * t;
+              for(int i = k + 1; i < n; ++i) cj[i] = FMA(-stt, vk[i], cj[i]);
+            }
+          }
+          __syncthreads();
+        }
+      }
+      else
       // ---------------------------------------------------------------- x0 = -L^-T L^-1 a, f0 (GoldfarbIdnaniSolver.cpp:68-74)
       // thread i owns x_i; one barrier per substitution step (the pivot travels through LDS)
       {
@@ -347,6 +523,30 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         if(i > j) M[i + (long)j * ld] = 0.0;
       }
       __syncthreads();
+      if constexpr(WARM)
+      {
+        // J = J Q, Q = H_0 H_1 ... (:443-444): one row of J per thread, reflector after reflector (a row only meets itself)
+        if(tid < n)
+          for(int k = 0; k < q; ++k)
+          {
+            const double tau = sss[k];
+            if(tau == 0.0 || k + 1 >= n) continue;
+            const double * v = Bw + (long)k * n;
+            double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
+            const double jk = M[tid + (long)k * ld];
+            t = t + jk;
+            M[tid + (long)k * ld] = FMA(-tau, t, jk);
+            const double stt = tau * t;
+            for(int j = k + 1; j < n; ++j) M[tid + (long)j * ld] = FMA(-stt, v[j], M[tid + (long)j * ld]);
+          }
+        // R = upper triangle of the factored B
+        for(int e = tid; e < q * q; e += WGB)
+        {
+          const int i = e % q, j = e / q;
+          if(i <= j) RP(i, j) = Bw[i + (long)j * n];
+        }
+        __syncthreads();
+      }
     }
     double * J = M;
 
@@ -564,7 +764,98 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       __syncthreads();
     };
 
-    if(term == BT_SUCCESS)
+    if constexpr(WARM)
+    {
+      // ---- initializePrimalDualPoints (experimental/GoldfarbIdnaniSolver.cpp:462-487), repeated after every purge (:78-109)
+      double * bact = ccs;
+      while(term == BT_SUCCESS)
+      {
+        if(tid < n) ds[tid] = chain_asc<false>(J + (long)tid * ld, 1, nps, 1, 0, n, 0.0); // alpha = J^T a
+        if(wave == 1)
+        {
+          // beta = R^-T b_act: forward substitution, two entries per lane; per element the terms in ascending i, then one division
+          double a0 = (lane < q) ? bact[lane] : 0.0, a1 = (lane + 64 < q) ? bact[lane + 64] : 0.0;
+          const int qs = __builtin_amdgcn_readfirstlane(q);
+          for(int i = 0; i < qs; ++i)
+          {
+            const double num = (i < 64) ? bcast_lane(a0, i) : bcast_lane(a1, i - 64);
+            const double v = num / RP(i, i);
+            if(lane > i && lane < q) a0 = FMA(-RP(i, lane), v, a0);
+            if(lane + 64 > i && lane + 64 < q) a1 = FMA(-RP(i, lane + 64), v, a1);
+            if(lane == i) a0 = v;
+            if(lane + 64 == i) a1 = v;
+          }
+          if(lane < q) rs[lane] = a0;
+          if(lane + 64 < q) rs[lane + 64] = a1;
+        }
+        __syncthreads();
+        if(tid < n) // x = J1 beta - J2 alpha2
+        {
+          double acc = chain_asc<false>(J + tid, ld, rs, 1, 0, q, 0.0);
+          acc = chain_asc<true>(J + tid, ld, ds, 1, q, n, acc);
+          xs[tid] = acc;
+        }
+        else if(wave == 2)
+        {
+          // u = R^-1 (alpha1 + beta), backward substitution, two entries per lane
+          double u0 = (lane < q) ? (ds[lane] + rs[lane]) : 0.0, u1 = (lane + 64 < q) ? (ds[lane + 64] + rs[lane + 64]) : 0.0;
+          const int qs = __builtin_amdgcn_readfirstlane(q);
+          for(int k = qs - 1; k >= 0; --k)
+          {
+            const double num = (k < 64) ? bcast_lane(u0, k) : bcast_lane(u1, k - 64);
+            const double v = num / RP(k, k);
+            const double * col = &RP(0, k);
+            if(lane < k) u0 = FMA(-col[lane], v, u0);
+            if(lane + 64 < k) u1 = FMA(-col[lane + 64], v, u1);
+            if(lane == k) u0 = v;
+            if(lane + 64 == k) u1 = v;
+          }
+          if(lane < q) us[lane] = u0;
+          if(lane + 64 < q) us[lane + 64] = u1;
+          // most negative multiplier of an inequality (first one on ties), threshold -1e-14 (:82-93)
+          double cand = 0.0;
+          int ci = NONE_B, dummy = 0;
+#pragma unroll
+          for(int h = 0; h < 2; ++h)
+          {
+            const int k = lane + 64 * h;
+            const double uk = h ? u1 : u0;
+            if(k < q)
+            {
+              const int sk = st[act[k]];
+              if(uk < -1e-14 && sk != B_FIXED && sk != B_EQUALITY && (ci == NONE_B || uk < cand))
+              {
+                cand = uk;
+                ci = k;
+              }
+            }
+          }
+          argmin3(cand, ci, dummy);
+          if(lane == 0) ctl->l = (ci == NONE_B) ? -1 : ci;
+        }
+        else if(tid == 192)
+        {
+          // f = beta.(0.5 beta + alpha1) - 0.5 |alpha2|^2
+          double f1 = 0.0, f2 = 0.0;
+          for(int k = 0; k < q; ++k) f1 = FMA(rs[k], FMA(0.5, rs[k], ds[k]), f1);
+          for(int k = q; k < n; ++k) f2 = FMA(ds[k], ds[k], f2);
+          ctl->f = FMA(-0.5, f2, f1);
+        }
+        __syncthreads();
+        const int lmin = ctl->l;
+        __syncthreads();
+        if(lmin < 0) break;
+        ++it;
+        const double bv = (tid >= lmin && tid < q - 1) ? bact[tid + 1] : 0.0;
+        __syncthreads();
+        if(tid >= lmin && tid < q - 1) bact[tid] = bv;
+        remove_constraint(lmin); // (its shift of u is harmless: u is recomputed)
+        --q;
+      }
+      if(tid == 0) us[q] = 0.0;
+      __syncthreads();
+    }
+    else if(term == BT_SUCCESS)
     {
       // ---------------------------------------------------------------- initActiveSet (GoldfarbIdnaniSolver.cpp:268-287)
       {
@@ -781,9 +1072,13 @@ long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds)
   return -1;
 }
 
-long batch_big_ws_doubles_per_wg(int n)
+// doubles of global workspace per resident workgroup: the packed R when it does not fit in LDS beside J (r_in_lds == 0), and for
+// a warm start the n x n array of B = L^-1 N / its QR factors behind it
+long batch_big_ws_doubles_per_wg(int n, int r_in_lds, int warm)
 {
-  return ((long)n * (n + 1) / 2 + 1) & ~1L;
+  long d = r_in_lds ? 0 : (((long)n * (n + 1) / 2 + 1) & ~1L);
+  if(warm) d += (long)n * n;
+  return d;
 }
 
 hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStream_t stream)
@@ -791,14 +1086,15 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
   int r_in_lds = 0;
   const long lds = batch_big_lds_bytes(a.n, a.m, a.nb, &r_in_lds);
   if(lds < 0) return hipErrorInvalidValue;
-  const void * fn = r_in_lds ? reinterpret_cast<const void *>(&gi_batch_big_kernel<true>) : reinterpret_cast<const void *>(&gi_batch_big_kernel<false>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if(e != hipSuccess) return e;
-  if(r_in_lds)
-    hipLaunchKernelGGL(gi_batch_big_kernel<true>, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, batch_big_ws_doubles_per_wg(a.n));
-  else
-    hipLaunchKernelGGL(gi_batch_big_kernel<false>, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, batch_big_ws_doubles_per_wg(a.n));
-  return hipGetLastError();
+  const long stride = batch_big_ws_doubles_per_wg(a.n, r_in_lds, a.warm);
+  auto go = [&](auto kern) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, stride);
+    return hipGetLastError();
+  };
+  if(a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, true>) : go(&gi_batch_big_kernel<false, true>);
+  return r_in_lds ? go(&gi_batch_big_kernel<true, false>) : go(&gi_batch_big_kernel<false, false>);
 }
 
 } // namespace jrlqp

@@ -103,12 +103,67 @@ def test_big_n_status_codes_and_trace(capi, P, oracle):
     assert refi["term"][0] == 3
 
 
-def test_big_n_warm_start_is_refused(capi, P):
-    import torch
+BIG_WARM = [
+    dict(nVar=70, nObj=70, nIneq=140, nStrongActIneq=20),
+    dict(nVar=70, nObj=70, nEq=6, nIneq=60, nStrongActIneq=14, bounds=True, nStrongActBounds=6, doubleSidedIneq=True),
+    dict(nVar=100, nObj=100, nIneq=200, nStrongActIneq=30),
+    dict(nVar=100, nObj=100, nEq=10, nIneq=90, nStrongActIneq=20, bounds=True, nStrongActBounds=8),
+    dict(nVar=128, nObj=128, nIneq=160, nStrongActIneq=36),  # R and B = L^-1 N both in the caller's workspace
+    dict(nVar=128, nObj=128, nEq=12, nIneq=100, nStrongActIneq=20, bounds=True, nStrongActBounds=10, doubleSidedIneq=True),
+]
 
-    pb = P.generate_batch(2, P.benchmark_characteristics(70, 80), first_index=1)
-    dev = capi.to_device(pb, "cuda:0")
-    s = capi.BatchSolver(pb.n, pb.m, False, pb.B, device="cuda:0")
-    with pytest.raises(capi.JrlqpError):
-        s.solve_warm(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"], guess=None)
-    torch.cuda.synchronize()
+
+@pytest.mark.parametrize("ci", range(len(BIG_WARM)))
+def test_big_n_warm_start_bit_identical(capi, P, oracle, ci):
+    """jrlqp_gi_solve_batch_warm for 64 < n <= 128 (experimental::GoldfarbIdnaniSolver, src/experimental/GoldfarbIdnaniSolver.cpp:
+    20-112, 306-487; the sizes of the reference's warm-start benchmark, benchmarks/SolversWarmStart.cpp:379-380, go to n = 100):
+    no guess, the exact active set (0 iterations: tests/GoldfarbIdnaniSolverTest.cpp:176,181), stale guesses (purge loop) and an
+    all-lower guess (more than n guesses: trimmed from the back) -- every output bit-identical to the oracle's orc_gi_solve_warm."""
+    from test_gpu_warm import oracle_cold, oracle_warm, perturbed_guess, run_warm
+
+    ch = P.Characteristics(**BIG_WARM[ci])
+    pb = P.generate_batch(12, ch, first_index=5200 + 40 * ci, seed0=0xB16)
+    hb = ch.bounds
+    cold = oracle_cold(oracle, pb, hb)
+    rng = np.random.default_rng(100 + ci)
+    L, LB = 1, 4
+    guesses = {
+        "none": None,
+        "exact": cold["status"],
+        "stale": perturbed_guess(rng, cold["status"], pb.m),
+        "very stale": perturbed_guess(rng, cold["status"], pb.m, flip=0.5, add=0.2),
+        "everything lower": np.where(np.arange(pb.m + pb.nb)[None, :] < pb.m, L, LB).repeat(pb.B, 0).astype(np.int32),
+    }
+    purges = 0
+    for name, g in guesses.items():
+        ref = oracle_warm(oracle, pb, g, hb)
+        gpu = run_warm(capi, pb, g, hb)
+        assert_bit_identical(gpu, ref, f"{BIG_WARM[ci]}, guess '{name}'")
+        if name == "exact" and ch.nEq == 0:
+            assert np.all(ref["iters"][ref["term"] == 0] == 0)  # the reference's warm-start expectation
+        purges += int(np.count_nonzero(ref["iters"]))
+    assert purges > 0
+    # "previous": the solver's own last active set, in place (the reference's as.empty() case)
+    gpu = run_warm(capi, pb, "previous", hb)
+    ref = oracle_warm(oracle, pb, cold["status"], hb)
+    assert_bit_identical(gpu, ref, "previous")
+
+
+def test_big_n_warm_error_paths(capi, P, oracle):
+    """OVERCONSTRAINED (reported before the factorisation), NON_POS_HESSIAN and the iteration limit inside / behind the purge loop."""
+    from test_gpu_warm import oracle_cold, oracle_warm, perturbed_guess, run_warm
+
+    ch = P.Characteristics(nVar=72, nObj=72, nEq=4, nIneq=90, nStrongActIneq=12, bounds=True, nStrongActBounds=4)
+    pb = P.generate_batch(8, ch, first_index=77, seed0=0xE45)
+    pb.bu[1, :73] = pb.bl[1, :73]  # 73 equalities > n
+    pb.G[2, 0, 0] = -1.0
+    pb.bu[3, :73] = pb.bl[3, :73]
+    pb.G[3, 0, 0] = -1.0
+    cold = oracle_cold(oracle, pb, True)
+    g = perturbed_guess(np.random.default_rng(5), cold["status"], pb.m, flip=0.5, add=0.3)
+    for max_iter in (500, 3, 0):
+        ref = oracle_warm(oracle, pb, g, True, max_iter=max_iter)
+        gpu = run_warm(capi, pb, g, True, max_iter=max_iter)
+        assert_bit_identical(gpu, ref, f"max_iter={max_iter}")
+    ref = oracle_warm(oracle, pb, g, True)
+    assert ref["term"][1] == 6 and ref["term"][2] == 2 and ref["term"][3] == 6
