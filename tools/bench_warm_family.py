@@ -1,0 +1,89 @@
+"""The reference's warm-start benchmark family (benchmarks/SolversWarmStart.cpp:31-60, :218-275, :379-380) through the batched HIP path:
+
+    min 1/2 ||x||^2 + a.x   s.t.  -1 <= C x <= 1  (10 n planes tangent to the unit sphere),  -1 <= x <= 1,
+
+a moving along a great circle of the sphere of radius 2 sqrt(n) from p1 to p2 in STEPS steps (a(t) = cos(t alpha) p1 + sin(t alpha) v),
+every step warm-started from the active set of the step before (the reference's GI_EX benchmark: experimental::GoldfarbIdnaniSolver
+with warmStart_, `solver.solve(G, a, C, l, u, xl, xu)` reusing its own active set), n = 10 .. 100.  Here: B such sequences side by
+side as one batch (jrlqp_gi_solve_batch_ws, warm, guess = the solver's previous status vector in place); n <= 64 runs in
+gi_batch_kernel.h, 64 < n <= 128 in gi_batch_big.hip.  Every step is compared bit for bit with the CPU oracle (orc_gi_solve_warm)
+on a sub-sample; the cold solver is timed beside it.  Not the judged bench; prints a table.
+
+  python tools/bench_warm_family.py [sequences per size (default 256)] [steps (default 25)]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+
+from __graft_entry__ import load_package
+
+load_package()
+import jrl_qp_amd.capi as capi
+from oracle_lib import get_oracle
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+CHECK = 8  # sequences compared with the oracle at every step
+
+
+def unit_rows(rng, k, n):
+    v = rng.standard_normal((k, n))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def main():
+    oracle = get_oracle()
+    print(f"# {B} sequences per size, {STEPS} steps each (the reference walks 100 steps per sequence); times per STEP of the whole batch")
+    print(f"{'n':>4s} {'m':>5s} {'warm it/step':>12s} {'cold it/step':>12s} {'warm us/step':>13s} {'cold us/step':>13s} {'warm solves/s':>14s} {'cold solves/s':>14s}  parity (first {CHECK})")
+    for n in range(10, 101, 10):
+        m = 10 * n
+        rng = np.random.default_rng(0x5AB + n)
+        C = np.stack([unit_rows(rng, m, n) for _ in range(B)])  # (B, m, n): row i = constraint i == n x m column-major
+        r = 2.0 * np.sqrt(n)
+        p1, p2 = r * unit_rows(rng, B, n), r * unit_rows(rng, B, n)
+        c = np.sum(p1 * p2, axis=1) / np.sum(p1 * p1, axis=1)
+        v = p2 - c[:, None] * p1
+        v *= (np.linalg.norm(p1, axis=1) / np.linalg.norm(v, axis=1))[:, None]
+        alpha = np.arccos(np.clip(c, -1.0, 1.0))
+        G = np.broadcast_to(np.eye(n), (B, n, n)).copy()
+        bl, bu = -np.ones((B, m)), np.ones((B, m))
+        xl, xu = -np.ones((B, n)), np.ones((B, n))
+        dev = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+        dG, dC, dbl, dbu, dxl, dxu = dev(G), dev(C), dev(bl), dev(bu), dev(xl), dev(xu)
+        warm, cold = capi.BatchSolver(n, m, True, B), capi.BatchSolver(n, m, True, B)
+        tw = tc = 0.0
+        itw = itc = 0
+        same = True
+        guess_ref = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for step in range(STEPS):
+            t = step / STEPS
+            a = np.cos(t * alpha)[:, None] * p1 + np.sin(t * alpha)[:, None] * v
+            da = dev(a)
+            e0.record()
+            rw = warm.solve_warm(dG, da, dC, dbl, dbu, dxl, dxu, guess=("previous" if step else None))
+            e1.record()
+            torch.cuda.synchronize()
+            tw += e0.elapsed_time(e1)
+            e0.record()
+            rc = cold.solve(dG, da, dC, dbl, dbu, dxl, dxu)
+            e1.record()
+            torch.cuda.synchronize()
+            tc += e0.elapsed_time(e1)
+            itw += int(rw.iters.sum().item())
+            itc += int(rc.iters.sum().item())
+            ref = oracle.solve_batch(G[:CHECK], a[:CHECK], C[:CHECK], bl[:CHECK], bu[:CHECK], xl[:CHECK], xu[:CHECK], nthreads=8, warm=True, guess=guess_ref)
+            guess_ref = ref["status"]
+            for k in ("x", "u", "f", "status", "term", "iters"):
+                same = same and np.array_equal(getattr(rw, k).cpu().numpy()[:CHECK], ref[k])
+        print(f"{n:4d} {m:5d} {itw / (B * STEPS):12.2f} {itc / (B * STEPS):12.2f} {tw / STEPS * 1e3:13.1f} {tc / STEPS * 1e3:13.1f} "
+              f"{B * STEPS / tw * 1e3:14.0f} {B * STEPS / tc * 1e3:14.0f}  {'bit-identical' if same else 'DIFFERENT'}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

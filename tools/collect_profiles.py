@@ -126,6 +126,8 @@ def main():
         json.dump(d, open(os.path.join(DST, f"{TAG}_pmc_sq_c3.json"), "w"), indent=1)
     if os.path.exists(os.path.join(SRC, "families.txt")):
         shutil.copy(os.path.join(SRC, "families.txt"), os.path.join(DST, f"{TAG}_reference_families.txt"))
+    if os.path.exists(os.path.join(SRC, "warm_family.txt")):
+        shutil.copy(os.path.join(SRC, "warm_family.txt"), os.path.join(DST, f"{TAG}_reference_warm_family.txt"))
     for src, dst in (("c2.log", "c2_dense_timing.txt"), ("time_blockgi.log", "blockgi_timing.txt"), ("time_structured.log", "c5_structured_timing.txt"),
                      ("quick.log", "phase_profile.txt")):
         if os.path.exists(os.path.join(SRC, src)):

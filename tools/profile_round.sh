@@ -24,4 +24,5 @@ python tools/time_structured.py > $O/time_structured.log 2>&1
 python tools/quick_time.py > $O/quick.log 2>&1
 bash tools/pmc_sq.sh --no-secondary > $O/pmc_sq.log 2>&1   # SQ counters of the headline kernel: issue / wait split, LDS bank conflicts, instruction mix
 python tools/bench_families.py 64 8 > $O/families.txt 2>&1
+python tools/bench_warm_family.py 128 10 > $O/warm_family.txt 2>&1   # the reference's warm-start benchmark family (benchmarks/SolversWarmStart.cpp), n = 10 .. 100
 cut -c1-250 $O/bench.json; cut -c1-250 $O/bench_c5.json
