@@ -289,6 +289,16 @@ int jrlqp_dense_remove(jrlqp_dense * h, int l, int q, int index, void * stream);
 int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
                       const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term,
                       void * stream);
+/* Warm-started variant: experimental::GoldfarbIdnaniSolver::solve(G, a, C, bl, bu, xl, xu, as) with options.warmStart_ = true
+ * (src/experimental/GoldfarbIdnaniSolver.cpp:20-112, :306-487).  as_host: m + nb activation-status guesses on the HOST (general
+ * constraints first, then bounds) -- what jrlqp_dense_results returned in status_host for a previous solve -- or NULL for no
+ * guess.  Same rules as jrlqp_gi_solve_batch_warm: data equalities are activated whatever the guess says, guesses on infinite
+ * bounds and ill-typed entries are ignored, beyond n active constraints inequality guesses are dropped from the back; J and R
+ * come from a Householder QR of L^-1 N (kept in the handle's R buffer, like the reference), constraints with a multiplier
+ * < -1e-14 are dropped one at a time, each counting as one iteration; then the same loop as jrlqp_dense_solve.  No allocation. */
+int jrlqp_dense_solve_warm(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                           const double * dbu, const double * dxl, const double * dxu, const int * as_host, const jrlqp_options * opts,
+                           int * term, void * stream);
 /* host outputs: x[n], sign-expanded multipliers u[m+nb], activation status[m+nb], iterations, objective value */
 int jrlqp_dense_results(jrlqp_dense * h, double * x_host, double * u_host, int * status_host, int * iters, double * f, void * stream);
 

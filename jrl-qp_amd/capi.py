@@ -42,6 +42,7 @@ EXPORTED = [
     "jrlqp_dense_add",
     "jrlqp_dense_remove",
     "jrlqp_dense_solve",
+    "jrlqp_dense_solve_warm",
     "jrlqp_dense_results",
     "jrlqp_blocks_create",
     "jrlqp_blocks_destroy",
@@ -137,6 +138,9 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_dense_last_hip_error.argtypes = [ct.c_void_p]
     lib.jrlqp_dense_solve.restype = ct.c_int
     lib.jrlqp_dense_solve.argtypes = [ct.c_void_p, c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_dp, c_dp, c_dp, c_dp, ct.POINTER(Options), ct.POINTER(ct.c_int), c_dp]
+    lib.jrlqp_dense_solve_warm.restype = ct.c_int
+    lib.jrlqp_dense_solve_warm.argtypes = [ct.c_void_p, c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, ct.POINTER(Options),
+                                           ct.POINTER(ct.c_int), c_dp]
     lib.jrlqp_dense_results.restype = ct.c_int
     lib.jrlqp_dense_results.argtypes = [ct.c_void_p, c_dp, c_dp, c_dp, ct.POINTER(ct.c_int), ct.POINTER(ct.c_double), c_dp]
     lib.jrlqp_blocks_create.restype = ct.c_int
@@ -303,7 +307,7 @@ class DenseSolver:
         check(self.lib.jrlqp_dense_create(n, m, self.nb, ct.byref(h)))
         self.h = h
 
-    def solve(self, G, a, C, bl, bu, xl=None, xu=None):
+    def solve(self, G, a, C, bl, bu, xl=None, xu=None, warm=False, guess=None):
         """G (n,n) symmetric float64 CUDA tensor -- OVERWRITTEN by its Cholesky factor (lower triangle of the
         column-major matrix, i.e. G.T's lower triangle in torch's row-major view); C (m,n): row i = constraint i."""
         import torch
@@ -314,9 +318,16 @@ class DenseSolver:
                 assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
         term = ct.c_int(-1)
         st = ct.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = self.lib.jrlqp_dense_solve(self.h, _ptr(G), n, _ptr(a), _ptr(C) if m else None, n, _ptr(bl) if m else None,
-                                        _ptr(bu) if m else None, _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None,
-                                        ct.byref(self.opts), ct.byref(term), st)
+        common = (self.h, _ptr(G), n, _ptr(a), _ptr(C) if m else None, n, _ptr(bl) if m else None, _ptr(bu) if m else None,
+                  _ptr(xl) if self.nb else None, _ptr(xu) if self.nb else None)
+        if warm:
+            # experimental::GoldfarbIdnaniSolver with warmStart_ (jrlqp_dense_solve_warm): guess = (m + nb) int32 HOST array or None
+            g = None if guess is None else np.ascontiguousarray(guess, dtype=np.int32)
+            assert g is None or g.shape == (m + self.nb,)
+            rc = self.lib.jrlqp_dense_solve_warm(*common, g.ctypes.data_as(ct.c_void_p) if g is not None else None, ct.byref(self.opts),
+                                                 ct.byref(term), st)
+        else:
+            rc = self.lib.jrlqp_dense_solve(*common, ct.byref(self.opts), ct.byref(term), st)
         if rc != 0:
             raise JrlqpError(f"jrlqp_dense_solve failed: {rc} (hip {self.lib.jrlqp_dense_last_hip_error(self.h)})")
         x = np.zeros(n)

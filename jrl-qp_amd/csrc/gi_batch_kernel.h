@@ -1966,11 +1966,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         // get, and a helper waits most of the time); the wave that posts a word wakes the sleepers of its workgroup
         // (s_wakeup), so the hand-off does not wait for a nap to end.  A wake-up that arrives just before the s_sleep is
         // lost: the nap then bounds the delay.
-        constexpr int NAP = 6; // x 64 cycles
+        constexpr int NAP = 24; // x 64 cycles (6, 12, 24, 60 measured in round 3: 24 and 60 are 0.5-1 % ahead of 6 -- fewer polls in the issue slots of the working waves)
         // Every wait is BOUNDED (about a tenth of a second of naps): should a hand-off ever be lost, the waves give up one after
         // the other, the problem comes back with TerminationStatus UNKNOWN, and the grid drains -- a hung workgroup would hang
         // the whole launch.
-        constexpr int SPIN_LIMIT = 1 << 19;
+        constexpr int SPIN_LIMIT = 1 << 17;
         auto ws_wait = [&](const int * word, int target) __attribute__((always_inline)) -> bool {
           int spins = 0;
           while(__atomic_load_n(word, __ATOMIC_RELAXED) != target)
@@ -2881,10 +2881,20 @@ hipError_t launch_one(const BatchArgs & a, long lds, hipStream_t stream)
 template<int NT, int CMODE>
 hipError_t launch_prof(const BatchArgs & a, long lds, hipStream_t stream)
 {
+#ifdef JRLQP_EXP_ONLY_C3 // experimental fast build (tools/ubench/exp_c3.sh): the cold n = 50 kernel alone, never the product library
+  if constexpr(NT != 50)
+    return hipErrorInvalidValue;
+  else
+  {
+    if(a.n != NT || a.warm) return hipErrorInvalidValue;
+    return a.prof ? launch_one<NT, CMODE, true, false>(a, lds, stream) : launch_one<NT, CMODE, false, false>(a, lds, stream);
+  }
+#else
   if(NT > 0 && a.n != NT) // a smaller problem, embedded (no phase-profile build of these)
     return a.warm ? launch_one<NT, CMODE, false, true, true>(a, lds, stream) : launch_one<NT, CMODE, false, false, true>(a, lds, stream);
   if(a.warm) return launch_one<NT, CMODE, false, true>(a, lds, stream); // the phase profile covers the cold path only
   return a.prof ? launch_one<NT, CMODE, true, false>(a, lds, stream) : launch_one<NT, CMODE, false, false>(a, lds, stream);
+#endif
 }
 
 } // namespace

@@ -41,6 +41,8 @@ struct DenseState
   int *pidx, *pstat;
   int * info;         // LLT info (device)
   int * psel;         // {p, status} of the last selection (device copy of the mailbox entries)
+  int * wact;         // warm start: the initial active list (n ints)
+  double *bact, *hco, *beta; // warm start: b_act, Householder coefficients, beta = R^-T b_act (n doubles each)
   Mailbox * mb;       // device view of the mailbox
 };
 
@@ -59,4 +61,9 @@ hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, 
 hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, bool chain_ready = false,
                      hipEvent_t ev_chain = nullptr);
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st);
+// warm start (experimental::GoldfarbIdnaniSolver.cpp:388-487): with the LLT in G, the active list in s.wact and the status bytes in
+// s.st: N -> B = L^-1 N -> Householder QR (in s.R: R is its upper triangle), J = L^-T Q, b_act -> s.bact
+hipError_t dense_warm_factor(const DenseViews & v, DenseState & s, int q, hipStream_t st);
+// initializePrimalDualPoints: alpha = J^T a -> s.d, beta -> s.beta, x, u (q entries), f -> mailbox f0
+hipError_t dense_warm_point(const DenseViews & v, DenseState & s, int q, hipStream_t st);
 } // namespace jrlqp

@@ -1381,6 +1381,220 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
   }
 }
 
+
+// =====================================================================================================================
+// Warm start of Mode A (experimental::GoldfarbIdnaniSolver, src/experimental/GoldfarbIdnaniSolver.cpp:388-487; oracle
+// initialize_computation_data / initialize_primal_dual).  The n x q matrix N -> B = L^-1 N -> its Householder QR factors lives in
+// the solver's R buffer (ld n), exactly where the reference keeps it: afterwards R IS the upper triangle of that array and
+// the Householder vectors below the diagonal are never read again.  Coverage path: every element keeps the oracle's chain, the
+// kernels are simple (one launch per reflector), the cost is a few milliseconds once per solve.
+// =====================================================================================================================
+
+// N (+-C columns / +-unit vectors) and b_act in activation order (:393-418); block j = column j
+__global__ __launch_bounds__(256) void warm_build_kernel(const double * __restrict__ C, int ldc, int n, int m, const int * __restrict__ act,
+                                                         const unsigned char * __restrict__ st, const double * __restrict__ bl,
+                                                         const double * __restrict__ bu, const double * __restrict__ xl,
+                                                         const double * __restrict__ xu, double * N, int ldn, double * bact)
+{
+  const int j = blockIdx.x, idx = act[j], sj = st[idx];
+  double * col = N + (size_t)j * ldn;
+  if(idx < m)
+  {
+    const double * c = C + (size_t)idx * ldc;
+    for(int i = threadIdx.x; i < n; i += 256) col[i] = (sj == UPPER) ? -c[i] : c[i];
+    if(threadIdx.x == 0) bact[j] = (sj == UPPER) ? -bu[idx] : bl[idx];
+  }
+  else
+  {
+    const int v = idx - m;
+    for(int i = threadIdx.x; i < n; i += 256) col[i] = (i == v) ? ((sj == UPPER_BOUND) ? -1.0 : 1.0) : 0.0;
+    if(threadIdx.x == 0) bact[j] = (sj == UPPER_BOUND) ? -xu[v] : xl[v];
+  }
+}
+
+// B = L^-1 N (:426), one workgroup per column: the blocked forward substitution of x0_kernel (same per-element order)
+__global__ __launch_bounds__(512) void warm_fwd_kernel(const double * __restrict__ L, int ldl, int n, double * B, int ldb)
+{
+  extern __shared__ double xs[];
+  double * col = B + (size_t)blockIdx.x * ldb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for(int i = tid; i < n; i += 512) xs[i] = col[i];
+  blocked_subst<false>(L, ldl, n, xs, lane, wave); // (starts and ends with a barrier)
+  for(int i = tid; i < n; i += 512) col[i] = xs[i];
+}
+
+// in-order chain sum_{i = lo}^{hi-1} a[i] * b[i] over LDS operands, every lane of the calling wave the same value
+__device__ __forceinline__ double lds_chain(const double * a, const double * b, int lo, int hi)
+{
+  double acc = 0.0;
+  int k = lo;
+  for(; k + 64 <= hi; k += 64) acc = chain64<1, true>(acc, a + k, b + k, 64);
+  if(k < hi) acc = chain64<1, false>(acc, a + k, b + k, hi - k);
+  return acc;
+}
+
+// Householder vector of column k (:432-440; Eigen makeHouseholder; oracle): tail = sum_{i > k} v_i^2 as ONE in-order chain,
+// beta = -sign(c0) sqrt(c0^2 + tail), v_i /= (c0 - beta), tau = (beta - c0) / beta; v_k <- beta, hco[k] <- tau
+__global__ __launch_bounds__(1024) void warm_hh_make_kernel(double * B, int ldb, int n, int k, double * hco)
+{
+  extern __shared__ double vs[]; // n
+  __shared__ double sh[4];
+  double * vk = B + (size_t)k * ldb;
+  const int tid = threadIdx.x;
+  for(int i = tid; i < n; i += 1024) vs[i] = vk[i];
+  __syncthreads();
+  if(tid < 64)
+  {
+    const double tailsq = lds_chain(vs, vs, k + 1, n);
+    const double c0 = vs[k];
+    const bool zero = tailsq <= 2.2250738585072014e-308;
+    double beta = __builtin_sqrt(FMA(c0, c0, tailsq));
+    beta = (c0 >= 0.0) ? -beta : beta;
+    const double den = c0 - beta;
+    double tau = (beta - c0) / beta;
+    if(tid == 0)
+    {
+      sh[0] = zero ? 0.0 : tau;
+      sh[1] = zero ? c0 : beta;
+      sh[2] = den;
+      sh[3] = zero ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  const double den = sh[2];
+  const bool zero = sh[3] != 0.0;
+  for(int i = k + 1 + tid; i < n; i += 1024) vk[i] = zero ? 0.0 : vs[i] / den;
+  if(tid == 0)
+  {
+    vk[k] = sh[1];
+    hco[k] = sh[0];
+  }
+}
+
+// applyHouseholderOnTheLeft of reflector k on trailing column j = k + 1 + blockIdx.x (one wave per column): t = sum_{i > k} v_i c_i
+// (one in-order chain), t += c_k, c_k = fma(-tau, t, c_k), c_i = fma(-(tau t), v_i, c_i)
+__global__ __launch_bounds__(64) void warm_hh_apply_kernel(double * B, int ldb, int n, int k, const double * __restrict__ hco)
+{
+  extern __shared__ double sm[]; // v (n) | c (n)
+  const double tau = hco[k];
+  if(tau == 0.0 || k + 1 >= n) return;
+  const int lane = threadIdx.x;
+  const double * vk = B + (size_t)k * ldb;
+  double * cj = B + (size_t)(k + 1 + blockIdx.x) * ldb;
+  double * vs = sm;
+  double * cs = sm + n;
+  for(int i = k + lane; i < n; i += 64)
+  {
+    vs[i] = vk[i];
+    cs[i] = cj[i];
+  }
+  wave_sync();
+  double t = lds_chain(vs, cs, k + 1, n);
+  const double top = cs[k];
+  t = t + top;
+  const double stt = tau * t;
+  if(lane == 0) cj[k] = FMA(-tau, t, top);
+  for(int i = k + 1 + lane; i < n; i += 64) cj[i] = FMA(-stt, vs[i], cs[i]);
+}
+
+// J = J Q, Q = H_0 H_1 ... H_{q-1} (:443-444): thread = row of J, reflector after reflector (a row only meets itself); the row's
+// entries come in coalesced across the threads, sixteen in flight per thread
+__global__ __launch_bounds__(64) void warm_jq_kernel(double * J, int ldj, int n, const double * __restrict__ B, int ldb, int q,
+                                                     const double * __restrict__ hco)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int ri = (i < n) ? i : (n - 1);
+  for(int k = 0; k < q; ++k)
+  {
+    const double tau = hco[k];
+    if(tau == 0.0 || k + 1 >= n) continue;
+    const double * v = B + (size_t)k * ldb;
+    double t = 0.0;
+    int j = k + 1;
+    for(; j + 16 <= n; j += 16)
+    {
+      double jv[16], vv[16];
+#pragma unroll
+      for(int u = 0; u < 16; ++u)
+      {
+        jv[u] = J[ri + (size_t)(j + u) * ldj];
+        vv[u] = v[j + u];
+      }
+#pragma unroll
+      for(int u = 0; u < 16; ++u) t = FMA(jv[u], vv[u], t);
+    }
+    for(; j < n; ++j) t = FMA(J[ri + (size_t)j * ldj], v[j], t);
+    const double jk = J[ri + (size_t)k * ldj];
+    t = t + jk;
+    const double stt = tau * t;
+    if(i < n)
+    {
+      J[ri + (size_t)k * ldj] = FMA(-tau, t, jk);
+      for(j = k + 1; j < n; ++j) J[ri + (size_t)j * ldj] = FMA(-stt, v[j], J[ri + (size_t)j * ldj]);
+    }
+  }
+}
+
+// Triangular solves with R (upper, ld) of order q on one workgroup, one barrier per step, element e on thread e mod 1024:
+//   FWD: out = R^-T b   (per element the terms in ascending i, then one division -- the oracle's beta)
+//   else: out = R^-1 (a + b), back substitution (per element the terms in descending k)
+template<bool FWD>
+__global__ __launch_bounds__(1024) void warm_tri_kernel(const double * __restrict__ R, int ld, int q, const double * __restrict__ a,
+                                                       const double * __restrict__ b, double * out)
+{
+  extern __shared__ double ws[]; // the running vector (q) | pivots' quotients (q)
+  double * acc = ws;
+  double * quo = ws + q;
+  const int tid = threadIdx.x;
+  for(int e = tid; e < q; e += 1024) acc[e] = FWD ? b[e] : (a[e] + b[e]);
+  __syncthreads();
+  if(FWD)
+  {
+    for(int i = 0; i < q; ++i)
+    {
+      if(tid == (i & 1023)) quo[i] = acc[i] / R[i + (size_t)i * ld];
+      __syncthreads();
+      const double v = quo[i];
+      for(int e = tid; e < q; e += 1024)
+        if(e > i) acc[e] = FMA(-R[i + (size_t)e * ld], v, acc[e]);
+    }
+  }
+  else
+  {
+    for(int k = q - 1; k >= 0; --k)
+    {
+      if(tid == (k & 1023)) quo[k] = acc[k] / R[k + (size_t)k * ld];
+      __syncthreads();
+      const double v = quo[k];
+      for(int e = tid; e < q; e += 1024)
+        if(e < k) acc[e] = FMA(-R[e + (size_t)k * ld], v, acc[e]);
+    }
+  }
+  __syncthreads();
+  for(int e = tid; e < q; e += 1024) out[e] = quo[e];
+}
+
+// x = J1 beta - J2 alpha2 (:474-476): thread = row, one chain (k ascending)
+__global__ __launch_bounds__(64) void warm_x_kernel(const double * __restrict__ J, int ldj, int n, int q, const double * __restrict__ beta,
+                                                    const double * __restrict__ alpha, double * x)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if(i >= n) return;
+  double acc = 0.0;
+  for(int k = 0; k < q; ++k) acc = FMA(J[i + (size_t)k * ldj], beta[k], acc);
+  for(int k = q; k < n; ++k) acc = FMA(-J[i + (size_t)k * ldj], alpha[k], acc);
+  x[i] = acc;
+}
+
+// f = beta.(0.5 beta + alpha1) - 0.5 |alpha2|^2 (:484-486): two in-order chains
+__global__ void warm_f_kernel(int n, int q, const double * __restrict__ beta, const double * __restrict__ alpha, double * f)
+{
+  if(threadIdx.x != 0) return;
+  double f1 = 0.0, f2 = 0.0;
+  for(int k = 0; k < q; ++k) f1 = FMA(beta[k], FMA(0.5, beta[k], alpha[k]), f1);
+  for(int k = q; k < n; ++k) f2 = FMA(alpha[k], alpha[k], f2);
+  *f = FMA(-0.5, f2, f1);
+}
 } // namespace
 
 // ============================================================================================================
@@ -1589,6 +1803,42 @@ hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int 
     if(e != hipSuccess) return e;
   }
   if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(qn - l), st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
+  return hipGetLastError();
+}
+
+
+// ---- warm start (experimental::GoldfarbIdnaniSolver): see the kernels above ------------------------------------------
+hipError_t dense_warm_factor(const DenseViews & v, DenseState & s, int q, hipStream_t st)
+{
+  const int n = v.n;
+  if(q > 0)
+  {
+    hipLaunchKernelGGL(warm_build_kernel, dim3(q), dim3(256), 0, st, v.C, v.ldc, n, v.m, s.wact, s.st, v.bl, v.bu, v.xl, v.xu, s.R, n, s.bact);
+    hipLaunchKernelGGL(warm_fwd_kernel, dim3(q), dim3(512), sizeof(double) * n, st, v.G, v.ldg, n, s.R, n);
+    static LdsRaised raised;
+    hipError_t e = raise_lds(&warm_hh_apply_kernel, raised, sizeof(double) * 2 * (size_t)n + 16);
+    if(e != hipSuccess) return e;
+    for(int k = 0; k < q; ++k)
+    {
+      hipLaunchKernelGGL(warm_hh_make_kernel, dim3(1), dim3(1024), sizeof(double) * n, st, s.R, n, n, k, s.hco);
+      if(k + 1 < q) hipLaunchKernelGGL(warm_hh_apply_kernel, dim3(q - k - 1), dim3(64), sizeof(double) * 2 * n, st, s.R, n, n, k, s.hco);
+    }
+  }
+  hipError_t e = dense_jinv(v.G, v.ldg, s.J, n, st);
+  if(e != hipSuccess) return e;
+  if(q > 0) hipLaunchKernelGGL(warm_jq_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, s.R, n, q, s.hco);
+  return hipGetLastError();
+}
+
+// initializePrimalDualPoints: alpha -> s.d, beta -> s.beta, x, u, f (into the mailbox's f0)
+hipError_t dense_warm_point(const DenseViews & v, DenseState & s, int q, hipStream_t st)
+{
+  const int n = v.n;
+  hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, v.a, 1.0, s.d, nullptr, nullptr, 0, 0);
+  if(q > 0) hipLaunchKernelGGL(warm_tri_kernel<true>, dim3(1), dim3(1024), sizeof(double) * 2 * q, st, s.R, n, q, s.bact, s.bact, s.beta);
+  hipLaunchKernelGGL(warm_x_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, s.beta, s.d, s.x);
+  if(q > 0) hipLaunchKernelGGL(warm_tri_kernel<false>, dim3(1), dim3(1024), sizeof(double) * 2 * q, st, s.R, n, q, s.d, s.beta, s.u);
+  hipLaunchKernelGGL(warm_f_kernel, dim3(1), dim3(64), 0, st, n, q, s.beta, s.d, &s.mb->f0);
   return hipGetLastError();
 }
 

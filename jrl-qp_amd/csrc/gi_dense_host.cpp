@@ -30,6 +30,8 @@ struct jrlqp_dense
   // host mirror of internal::ActiveSet (src/internal/ActiveSet.cpp): status per constraint + ordered active list
   std::vector<int> status, active;
   std::vector<double> h_bl, h_bu, h_xl, h_xu, h_u;
+  std::vector<double> h_bact;          // warm start: b_act of the initial active set (host copy: shifted by a purge, then uploaded)
+  std::vector<unsigned char> h_stb;    // warm start: the status bytes as uploaded to the device
   int it = 0, term = JRLQP_UNKNOWN;
   double f = 0.0;
   int last_hip = 0;
@@ -111,6 +113,10 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = dmalloc(s.pstat, parts);
   if(e == hipSuccess) e = dmalloc(s.info, 1);
   if(e == hipSuccess) e = dmalloc(s.psel, 2);
+  if(e == hipSuccess) e = dmalloc(s.wact, (size_t)n + 1);
+  if(e == hipSuccess) e = dmalloc(s.bact, n);
+  if(e == hipSuccess) e = dmalloc(s.hco, n);
+  if(e == hipSuccess) e = dmalloc(s.beta, n);
   if(e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h->h_mb), sizeof(Mailbox), hipHostMallocMapped);
   if(e == hipSuccess) std::memset(h->h_mb, 0, sizeof(Mailbox));
   if(e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s.mb), h->h_mb, 0);
@@ -128,6 +134,9 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   h->status.assign(mt, 0);
   h->active.reserve(n + 1);
   h->h_bl.resize(m); h->h_bu.resize(m); h->h_xl.resize(nb); h->h_xu.resize(nb); h->h_u.resize(n + 2);
+  h->h_bact.reserve(n + 1);
+  h->h_stb.assign(mt, 0);
+  h->active.reserve(mt + 1); // (a warm start may list every constraint before it trims the list to n)
   *out = h;
   return JRLQP_OK;
 }
@@ -142,6 +151,7 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   (void)hipFree(s.u); (void)hipFree(s.r); (void)hipFree(s.cc); (void)hipFree(s.ss); (void)hipFree(s.st);
   (void)hipFree(s.cc2); (void)hipFree(s.ss2); (void)hipFree(s.rfin);
   (void)hipFree(s.pval); (void)hipFree(s.pidx); (void)hipFree(s.pstat); (void)hipFree(s.info); (void)hipFree(s.psel);
+  (void)hipFree(s.wact); (void)hipFree(s.bact); (void)hipFree(s.hco); (void)hipFree(s.beta);
   if(h->h_mb) (void)hipHostFree(h->h_mb);
   if(h->side) (void)hipStreamDestroy(h->side);
   if(h->spec) (void)hipStreamDestroy(h->spec);
@@ -163,6 +173,7 @@ int jrlqp_dense_resize(jrlqp_dense * h, int n, int m, int nb)
   h->n = n; h->m = m; h->nb = nb;
   h->bound = false;
   h->status.assign((size_t)m + nb, 0); // (within the capacity reserved at creation: no allocation)
+  h->h_stb.assign((size_t)m + nb, 0);
   h->active.clear();
   h->h_bl.resize(m); h->h_bu.resize(m); h->h_xl.resize(nb); h->h_xu.resize(nb);
   return JRLQP_OK;
@@ -276,9 +287,9 @@ int jrlqp_dense_remove(jrlqp_dense * h, int l, int q, int index, void * stream)
 }
 
 // ---- the complete solve: DualSolver::solve (src/DualSolver.cpp:91-168) on the host ----------------------------
-int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
-                      const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term_out,
-                      void * stream)
+static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                            const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term_out,
+                            void * stream, bool warm, const int * as_host)
 {
   int rc = jrlqp_dense_bind(h, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu);
   if(rc != JRLQP_OK) return rc;
@@ -303,15 +314,18 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
     TRY(hipStreamWaitEvent(st, h->ev_chain, 0));
     h->chain_pending = false;
   }
-  int info = -1;
-  rc = jrlqp_dense_init(h, &info, nullptr, stream);
-  if(rc != JRLQP_OK) return rc;
   auto finish = [&](int term) {
     h->term = term;
     if(term_out) *term_out = term;
     return JRLQP_OK;
   };
-  if(info >= 0) return finish(JRLQP_NON_POS_HESSIAN);
+  int info = -1;
+  if(!warm)
+  {
+    rc = jrlqp_dense_init(h, &info, nullptr, stream);
+    if(rc != JRLQP_OK) return rc;
+    if(info >= 0) return finish(JRLQP_NON_POS_HESSIAN);
+  }
 
   auto bound_value = [&](int p, int status) -> double {
     switch(status)
@@ -327,6 +341,116 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
     h->status[p] = status;
   };
 
+  if(warm)
+  {
+    // ==== experimental::GoldfarbIdnaniSolver::init_ (src/experimental/GoldfarbIdnaniSolver.cpp:65-112; oracle gi_solve_impl warm == 1)
+    TRY(hipStreamSynchronize(st)); // the bounds are on the host
+    DenseState & s = h->s;
+    const int mt = m + nb;
+    // processInitialActiveSet (:309-386): bounds first, then general constraints, each by increasing index; data equalities win over
+    // the guess, guesses on infinite bounds / FIXED guesses on free variables / ill-typed entries are ignored
+    std::fill(h->status.begin(), h->status.end(), 0);
+    h->active.clear();
+    h->f = 0.0;
+    int neq = 0;
+    for(int i = 0; i < nb; ++i)
+    {
+      const int bi = m + i;
+      if(h->h_xl[i] == h->h_xu[i]) { activate(bi, FIXED); ++neq; }
+      else if(as_host && as_host[bi] != INACTIVE)
+      {
+        const int g = as_host[bi];
+        if(g == LOWER_BOUND && !(h->h_xl[i] < -big)) activate(bi, g);
+        if(g == UPPER_BOUND && !(h->h_xu[i] > big)) activate(bi, g);
+      }
+    }
+    for(int i = 0; i < m; ++i)
+    {
+      if(h->h_bl[i] == h->h_bu[i]) { activate(i, EQUALITY); ++neq; }
+      else if(as_host && as_host[i] != INACTIVE)
+      {
+        const int g = as_host[i];
+        if(g == LOWER && !(h->h_bl[i] < -big)) activate(i, g);
+        if(g == UPPER && !(h->h_bu[i] > big)) activate(i, g);
+        if(g == EQUALITY) { activate(i, g); ++neq; } // (:357-371 only filters FIXED: an EQUALITY guess is taken as is)
+      }
+    }
+    TRY(hipMemsetAsync(s.u, 0, sizeof(double) * ((size_t)mt + 2), st));
+    TRY(hipMemsetAsync(s.x, 0, sizeof(double) * n, st));
+    if((int)h->active.size() > n)
+    {
+      if(neq > n)
+      {
+        h->active.clear(); // (the statuses stay, as in the reference; the multipliers are all zero)
+        return finish(JRLQP_OVERCONSTRAINED_PROBLEM);
+      }
+      // work backward, deactivating inequality constraints until n are left (:373-383)
+      int i = (int)h->active.size();
+      while((int)h->active.size() > n)
+      {
+        --i;
+        for(;;)
+        {
+          const int sv = h->status[h->active[i]];
+          if(sv == EQUALITY || sv == FIXED) --i; else break;
+        }
+        h->status[h->active[i]] = INACTIVE;
+        h->active.erase(h->active.begin() + i);
+      }
+    }
+    // the factorisation (:66-71)
+    TRY(hipMemsetAsync(s.info, 0xff, sizeof(int), st));
+    TRY(dense_llt(h->v.G, h->v.ldg, n, s.info, st));
+    TRY(hipMemcpyAsync(&info, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
+    TRY(hipStreamSynchronize(st));
+    if(info >= 0)
+    {
+      h->active.clear();
+      return finish(JRLQP_NON_POS_HESSIAN);
+    }
+    int q = (int)h->active.size();
+    // status bytes, active list and b_act to the device; N -> B = L^-1 N -> QR, J = L^-T Q (initializeComputationData, :388-458)
+    for(int i = 0; i < mt; ++i) h->h_stb[i] = (unsigned char)h->status[i];
+    if(mt) TRY(hipMemcpyAsync(s.st, h->h_stb.data(), (size_t)mt, hipMemcpyHostToDevice, st));
+    if(q) TRY(hipMemcpyAsync(s.wact, h->active.data(), sizeof(int) * q, hipMemcpyHostToDevice, st));
+    h->h_bact.clear();
+    for(int k = 0; k < q; ++k)
+    {
+      const int idx = h->active[k], sv = h->status[idx];
+      h->h_bact.push_back((sv == UPPER || sv == UPPER_BOUND) ? -bound_value(idx, sv) : bound_value(idx, sv));
+    }
+    TRY(dense_warm_factor(h->v, s, q, st));
+    // initializePrimalDualPoints + the purge of the negative multipliers (:78-109), each purge one iteration
+    for(;;)
+    {
+      TRY(dense_warm_point(h->v, s, q, st));
+      if(q) TRY(hipMemcpyAsync(h->h_u.data(), s.u, sizeof(double) * q, hipMemcpyDeviceToHost, st));
+      TRY(hipStreamSynchronize(st));
+      h->f = h->h_mb->f0;
+      double umin = -1e-14;
+      int lmin = -1;
+      for(int l = 0; l < q; ++l)
+      {
+        const int sv = h->status[h->active[l]];
+        if(h->h_u[l] < umin && sv != FIXED && sv != EQUALITY)
+        {
+          umin = h->h_u[l];
+          lmin = l;
+        }
+      }
+      if(lmin < 0) break;
+      ++h->it;
+      h->h_bact.erase(h->h_bact.begin() + lmin);
+      rc = jrlqp_dense_remove(h, lmin, q, h->active[lmin], stream); // (its shift of u is harmless: u is recomputed)
+      if(rc != JRLQP_OK) return rc;
+      h->status[h->active[lmin]] = INACTIVE;
+      h->active.erase(h->active.begin() + lmin);
+      --q;
+      if(q) TRY(hipMemcpyAsync(s.bact, h->h_bact.data(), sizeof(double) * q, hipMemcpyHostToDevice, st));
+    }
+    TRY(hipMemsetAsync(s.u + q, 0, sizeof(double), st)); // u[q] = 0
+  }
+  else
   // initActiveSet (GoldfarbIdnaniSolver.cpp:268-287)
   {
     int neq = 0;
@@ -474,6 +598,20 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
     }
   }
   return finish(JRLQP_MAX_ITER_REACHED);
+}
+
+int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                      const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term_out,
+                      void * stream)
+{
+  return dense_solve_impl(h, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu, opts, term_out, stream, false, nullptr);
+}
+
+int jrlqp_dense_solve_warm(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                           const double * dbu, const double * dxl, const double * dxu, const int * as_host, const jrlqp_options * opts,
+                           int * term_out, void * stream)
+{
+  return dense_solve_impl(h, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu, opts, term_out, stream, true, as_host);
 }
 
 // solution(), multipliers() (sign-expanded, DualSolver.cpp:38-69), activeSet(), iterations(), objectiveValue()

@@ -170,3 +170,78 @@ def test_dense_status_codes(capi, P, oracle):
     ref = oracle.solve(G, a, C2.T, bl, bu2)
     check(solve_gpu(capi, pb2, 0, False), ref, "infeasible")
     assert ref.term == 3
+
+
+def solve_gpu_warm(capi, pb, b, use_bounds, guess, max_iter=500):
+    import torch
+
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    s = capi.DenseSolver(pb.n, pb.m, use_bounds, max_iter=max_iter)
+    r = s.solve(dev(pb.G[b]), dev(pb.a[b]), dev(pb.C[b]), dev(pb.bl[b]), dev(pb.bu[b]), dev(pb.xl[b]) if use_bounds else None,
+                dev(pb.xu[b]) if use_bounds else None, warm=True, guess=guess)
+    torch.cuda.synchronize()
+    return r
+
+
+DENSE_WARM = [
+    dict(nVar=20, nObj=20, nIneq=40, nStrongActIneq=6),
+    dict(nVar=33, nObj=33, nEq=5, nIneq=70, nStrongActIneq=10, bounds=True, nStrongActBounds=4, doubleSidedIneq=True),
+    dict(nVar=129, nObj=129, nEq=7, nIneq=150, nStrongActIneq=40, bounds=True, nStrongActBounds=9),
+    dict(nVar=300, nObj=300, nIneq=400, nStrongActIneq=90),
+    dict(nVar=300, nObj=300, nEq=20, nIneq=260, nStrongActIneq=60, bounds=True, nStrongActBounds=25, doubleSidedIneq=True),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(DENSE_WARM)))
+def test_dense_warm_start_matches_oracle(capi, P, oracle, ci):
+    """jrlqp_dense_solve_warm (experimental::GoldfarbIdnaniSolver with warmStart_, src/experimental/GoldfarbIdnaniSolver.cpp:20-112,
+    306-487) == the oracle's orc_gi_solve_warm, bit for bit: no guess, the exact active set (0 iterations -- the reference's own
+    warm-start expectation, tests/GoldfarbIdnaniSolverTest.cpp:176,181), stale guesses (purge loop + regular loop) and an
+    all-lower guess (more than n guesses: trimmed from the back)."""
+    from test_gpu_warm import perturbed_guess
+
+    ch = P.Characteristics(**DENSE_WARM[ci])
+    pb = P.generate_batch(2, ch, first_index=7700 + 10 * ci, seed0=0xD3A5)
+    hb = ch.bounds
+    L, LB = 1, 4
+    purges = 0
+    for b in range(pb.B):
+        args = (pb.G[b], pb.a[b], pb.C[b].T, pb.bl[b], pb.bu[b], pb.xl[b] if hb else None, pb.xu[b] if hb else None)
+        cold = oracle.solve(*args, max_iter=5000)
+        rng = np.random.default_rng(10 * ci + b)
+        st2 = cold.status[None, :]
+        guesses = {
+            "none": None,
+            "exact": cold.status,
+            "stale": perturbed_guess(rng, st2, pb.m)[0],
+            "very stale": perturbed_guess(rng, st2, pb.m, flip=0.5, add=0.2)[0],
+            "everything lower": np.where(np.arange(pb.m + pb.nb) < pb.m, L, LB).astype(np.int32),
+        }
+        for name, g in guesses.items():
+            ref = oracle.solve(*args, max_iter=5000, warm=True, guess=g)
+            gpu = solve_gpu_warm(capi, pb, b, hb, g, max_iter=5000)
+            check(gpu, ref, f"{DENSE_WARM[ci]} problem {b} guess '{name}'")
+            if name == "exact" and ch.nEq == 0:
+                assert ref.term == 0 and ref.iters == 0
+            purges += ref.iters
+
+
+def test_dense_warm_error_paths(capi, P, oracle):
+    """OVERCONSTRAINED before the factorisation, NON_POS_HESSIAN, the iteration limit inside / behind the purge loop."""
+    from test_gpu_warm import perturbed_guess
+
+    ch = P.Characteristics(nVar=40, nObj=40, nEq=3, nIneq=60, nStrongActIneq=8, bounds=True, nStrongActBounds=3)
+    pb = P.generate_batch(4, ch, first_index=91, seed0=0xE46)
+    pb.bu[1, :41] = pb.bl[1, :41]
+    pb.G[2, 0, 0] = -1.0
+    pb.bu[3, :41] = pb.bl[3, :41]
+    pb.G[3, 0, 0] = -1.0
+    for b in range(4):
+        args = (pb.G[b], pb.a[b], pb.C[b].T, pb.bl[b], pb.bu[b], pb.xl[b], pb.xu[b])
+        cold = oracle.solve(*args)
+        g = perturbed_guess(np.random.default_rng(b), cold.status[None, :], pb.m, flip=0.5, add=0.3)[0]
+        for max_iter in (500, 2, 0):
+            ref = oracle.solve(*args, max_iter=max_iter, warm=True, guess=g)
+            gpu = solve_gpu_warm(capi, pb, b, True, g, max_iter=max_iter)
+            check(gpu, ref, f"problem {b} max_iter={max_iter}")
+    assert oracle.solve(pb.G[1], pb.a[1], pb.C[1].T, pb.bl[1], pb.bu[1], pb.xl[1], pb.xu[1], warm=True).term == 6
