@@ -110,7 +110,7 @@ public:
       // workspace of the batched path (jrlqp_gi_batch_workspace_bytes; > 0 for 104 < n <= 128 only): sized HERE for the largest
       // n the capacity admits -- it grows with n --, so that solve() never allocates
       wsBytes_ = 0;
-      for(int k = (cn < JRLQP_BATCH_MAX_N ? cn : JRLQP_BATCH_MAX_N); k > JRLQP_BATCH_WAVE_N && wsBytes_ == 0; --k)
+      for(int k = (cn < JRLQP_BATCH_LDS_N ? cn : JRLQP_BATCH_LDS_N); k > JRLQP_BATCH_WAVE_N && wsBytes_ == 0; --k)
       {
         const long long b = jrlqp_gi_batch_workspace_bytes(k, 0, 0, 1);
         if(b > 0) wsBytes_ = b;
@@ -180,7 +180,7 @@ public:
     jrlqp_options o{options_.maxIter_, options_.bigBnd_};
     int term = int(TerminationStatus::UNKNOWN);
     int cpl = 0;
-    const long long wsNeed = (n_ <= JRLQP_BATCH_MAX_N) ? jrlqp_gi_batch_workspace_bytes(n_, m_, nb_, 1) : -1;
+    const long long wsNeed = (n_ <= JRLQP_BATCH_LDS_N) ? jrlqp_gi_batch_workspace_bytes(n_, m_, nb_, 1) : -1; // (a lone larger problem: Mode A)
     if(wsNeed >= 0 && wsNeed <= wsBytes_ && ldg == n_ && (m_ == 0 || ldc == n_) && jrlqp_gi_batch_lds_bytes(n_, m_, nb_, &cpl) >= 0)
     {
       // dL == dG: the kernel reads G completely before it writes the factor (jrlqp_hip.h), i.e. the reference's in-place contract

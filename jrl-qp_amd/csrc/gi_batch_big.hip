@@ -59,7 +59,7 @@ struct CtlB
 {
   double red_val[4];
   double zz, cz, cx, t1, f, rho;
-  double dotp[4]; // the two wave halves of the C4 trees of z.z and n+.z
+  double dotp[8]; // per wave: its share of the C4 trees of z.z and n+.z
   double gc, gs, gr; // rotation of the removal step in flight
   int red_idx[4];
   int red_stat[4];
@@ -200,9 +200,14 @@ __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho,
 // orc_gi_solve_warm): the initial active set comes from the data equalities plus a guess, J and R from a Householder QR of
 // B = L^-1 N, the start point in closed form, constraints with a negative multiplier purged one at a time; then the same loop.
 // B (n x q) does not fit in LDS beside J: it lives in the workgroup's slice of the global workspace, behind R.
-template<bool RLDS, bool WARM>
+// WIDE: 128 < n <= 256 (cold start): L / J (up to 526 KB) no longer fit in LDS at all -- they live in the workgroup's slice of the
+// global workspace, behind R (L2 / Infinity-Cache resident: a slice is re-read every pass), LDS keeps the vectors; the wave-level
+// substitutions carry four entries per lane instead of two.  Same code otherwise: every output element still owns its chain.
+template<bool RLDS, bool WARM, bool WIDE = false>
 __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
 {
+  static_assert(!WIDE || (!RLDS && !WARM), "the wide variant keeps R and J in the workspace and is cold-start only");
+  constexpr int EPL = WIDE ? 4 : 2; // entries of a wave-level vector per lane (rows lane, lane + 64, ...)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -213,8 +218,19 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
   const double big = A.big_bnd;
 
   // LDS carve-up (must match big_lds_bytes below)
-  double * M = smem;                 // L (lower, during init) then J
-  double * xs = M + (long)n * ld;
+  double * Rg = ws + (long)blockIdx.x * ((RLDS && !WARM) ? 0 : ws_stride); // !RLDS (per-workgroup slice of the scratch)
+  double * M;                        // L (lower, during init) then J
+  double * xs;
+  if constexpr(WIDE)
+  {
+    M = Rg + ((rlen + 1) & ~1L);
+    xs = smem;
+  }
+  else
+  {
+    M = smem;
+    xs = M + (long)n * ld;
+  }
   double * zs = xs + n;
   double * ds = zs + n;
   double * nps = ds + n;
@@ -226,7 +242,6 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
   double * ssq = sss + n;            // scratch of the coefficient chain (n + 2)
   double * tail = ssq + (n + 2);
   double * Rl = tail;                                   // RLDS
-  double * Rg = ws + (long)blockIdx.x * ((RLDS && !WARM) ? 0 : ws_stride); // !RLDS (per-workgroup slice of the scratch)
   double * Bw = Rg + (RLDS ? 0 : ((rlen + 1) & ~1L));                         // WARM: N -> B = L^-1 N -> its QR factors, n x q, ld = n
   if(RLDS) tail += rlen;
   CtlB * ctl = reinterpret_cast<CtlB *>(tail);
@@ -573,8 +588,8 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       __syncthreads();
       if(tid >= 128)
       {
-        const int i = tid - 128; // z = J2 d2: waves 2-3, one row per thread
-        if(i < n) zs[i] = chain_asc<false>(J + i, ld, ds, 1, q, n, 0.0);
+        // z = J2 d2: waves 2-3, one row per thread (two beyond n = 128)
+        for(int i = tid - 128; i < n; i += 128) zs[i] = chain_asc<false>(J + i, ld, ds, 1, q, n, 0.0);
       }
       else if(tid >= 64)
       {
@@ -588,30 +603,39 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       }
       else
       {
-        // r = R^-1 d1 on wave 0, two entries per lane (rows lane and lane + 64), columns k = q-1 .. 0: the quotient of the
+        // r = R^-1 d1 on wave 0, EPL entries per lane (rows lane, lane + 64, ...), columns k = q-1 .. 0: the quotient of the
         // pivot row is formed in every lane (same operands, same bits)
-        double r0 = (lane < q) ? ds[lane] : 0.0, r1 = (lane + 64 < q) ? ds[lane + 64] : 0.0;
+        double rv[EPL];
+#pragma unroll
+        for(int h = 0; h < EPL; ++h) rv[h] = (lane + 64 * h < q) ? ds[lane + 64 * h] : 0.0;
         const int qs = __builtin_amdgcn_readfirstlane(q); // (a scalar loop counter: see bcast_lane in device_common.h)
         for(int k = qs - 1; k >= 0; --k)
         {
-          const double num = (k < 64) ? bcast_lane(r0, k) : bcast_lane(r1, k - 64);
+          double num = 0.0;
+#pragma unroll
+          for(int h = 0; h < EPL; ++h)
+            if((k >> 6) == h) num = bcast_lane(rv[h], k & 63); // (k is scalar: a uniform branch)
           const double v = num / RP(k, k);
           const double * col = &RP(0, k);
-          if(lane < k) r0 = FMA(-col[lane], v, r0);
-          if(lane + 64 < k) r1 = FMA(-col[lane + 64], v, r1);
-          if(lane == k) r0 = v;
-          if(lane + 64 == k) r1 = v;
+#pragma unroll
+          for(int h = 0; h < EPL; ++h)
+          {
+            const int e = lane + 64 * h;
+            if(e < k) rv[h] = FMA(-col[e], v, rv[h]);
+            if(e == k) rv[h] = v;
+          }
         }
-        if(lane < q) rs[lane] = r0;
-        if(lane + 64 < q) rs[lane + 64] = r1;
+#pragma unroll
+        for(int h = 0; h < EPL; ++h)
+          if(lane + 64 * h < q) rs[lane + 64 * h] = rv[h];
         // t1 = min u_k / r_k over r_k > 0, not EQUALITY/FIXED; status looked up by POSITION (GoldfarbIdnaniSolver.cpp:162)
         double tk = big;
         int kk = NONE_B, dummy = 0;
 #pragma unroll
-        for(int h = 0; h < 2; ++h)
+        for(int h = 0; h < EPL; ++h)
         {
           const int k = lane + 64 * h;
-          const double rk = h ? r1 : r0;
+          const double rk = rv[h];
           if(k < q && rk > 0.0)
           {
             const int sk = st[k];
@@ -632,10 +656,9 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         }
       }
       __syncthreads();
-      // z.z and n+.z: C4 trees (CANON C5) -- one product per element, elements 0..63 on wave 0 and 64..127 on wave 1, each
-      // wave's adjacent-first tree, then the two halves; n+.x: the C1 chain (the scan's value for that constraint), one lane
-      // of wave 2 beside them
-      if(tid < 128)
+      // z.z and n+.z: C4 trees (CANON C5) -- one product per element, element e on thread e: each wave's adjacent-first tree over
+      // its 64 elements, then the waves pairwise ((w0 + w1) + (w2 + w3); up to n = 128 the second pair is exactly +0).  n+.x:
+      // the C1 chain (the scan's value for that constraint), the last lane of wave 3 behind its share of the trees
       {
         const bool in = tid < n;
         const double zi = in ? zs[tid] : 0.0;
@@ -644,17 +667,16 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         const double pc = wave_sum_tree(FMA(ni, zi, 0.0));
         if(lane == 0)
         {
-          ctl->dotp[2 * (tid >> 6)] = pz;
-          ctl->dotp[2 * (tid >> 6) + 1] = pc;
+          ctl->dotp[2 * wave] = pz;
+          ctl->dotp[2 * wave + 1] = pc;
         }
+        if(tid == WGB - 1) ctl->cx = (pp < m) ? chain_asc<false>(nps, 1, xs, 1, 0, n, 0.0) : xs[pp - m];
       }
-      else if(tid == 128)
-        ctl->cx = (pp < m) ? chain_asc<false>(nps, 1, xs, 1, 0, n, 0.0) : xs[pp - m];
       __syncthreads();
       if(tid == 0)
       {
-        ctl->zz = ctl->dotp[0] + ctl->dotp[2];
-        ctl->cz = (pp < m) ? (ctl->dotp[1] + ctl->dotp[3]) : zs[pp - m];
+        ctl->zz = (ctl->dotp[0] + ctl->dotp[2]) + (ctl->dotp[4] + ctl->dotp[6]);
+        ctl->cz = (pp < m) ? ((ctl->dotp[1] + ctl->dotp[3]) + (ctl->dotp[5] + ctl->dotp[7])) : zs[pp - m];
       }
       __syncthreads();
     };
@@ -704,9 +726,9 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         }
         if(n - 2 >= q) J[tid + (long)q * ld] = carry;
       }
-      else if(tid >= 128)
       {
-        const int k = tid - 128;
+        // R.col(q).head(q + 1) = d.head(q) | rho; the active set (threads from the top: up to n = 128 they have no row of J)
+        const int k = WGB - 1 - tid;
         if(k < q)
           RP(k, q) = ds[k];
         else if(k == q)
@@ -748,10 +770,9 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
           J[tid + (long)i * ld] = FMA(c, xv, -(s * yv));
           J[tid + (long)(i + 1) * ld] = FMA(s, xv, c * yv);
         }
-        else if(tid >= 128)
+        if(tid >= 128) // (beyond n = 128 these threads have a row of J as well: one after the other)
         {
-          const int k = i + 2 + (tid - 128);
-          if(k <= qn)
+          for(int k = i + 2 + (tid - 128); k <= qn; k += 128)
           {
             const double xv = RP(i, k), yv = RP(i + 1, k);
             RP(i, k) = FMA(c, xv, -(s * yv));
@@ -1052,7 +1073,8 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
 long big_lds_doubles(int n, int r_in_lds)
 {
   const long ld = n | 1;
-  long dbl = (long)n * ld + 4L * n + 2L * (n + 2) + 3L * n + (n + 2);
+  long dbl = 4L * n + 2L * (n + 2) + 3L * n + (n + 2);
+  if(n <= 128) dbl += (long)n * ld; // J (beyond 128 unknowns it lives in the workspace: WIDE)
   if(r_in_lds) dbl += (long)n * (n + 1) / 2;
   return dbl;
 }
@@ -1060,7 +1082,7 @@ long big_lds_doubles(int n, int r_in_lds)
 
 long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds)
 {
-  for(int rl = 1; rl >= 0; --rl)
+  for(int rl = (n <= 128) ? 1 : 0; rl >= 0; --rl)
   {
     const long bytes = ((big_lds_doubles(n, rl) * 8 + (long)sizeof(CtlB) + 4L * (n + 2) + (long)(m + nb)) + 15) & ~15L;
     if(bytes <= kLdsPerCU)
@@ -1078,6 +1100,7 @@ long batch_big_ws_doubles_per_wg(int n, int r_in_lds, int warm)
 {
   long d = r_in_lds ? 0 : (((long)n * (n + 1) / 2 + 1) & ~1L);
   if(warm) d += (long)n * n;
+  if(n > 128) d += (long)n * (n | 1) + 1; // WIDE: L / J
   return d;
 }
 
@@ -1093,6 +1116,7 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, stride);
     return hipGetLastError();
   };
+  if(a.n > 128) return a.warm ? hipErrorInvalidValue : go(&gi_batch_big_kernel<false, false, true>);
   if(a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, true>) : go(&gi_batch_big_kernel<false, true>);
   return r_in_lds ? go(&gi_batch_big_kernel<true, false>) : go(&gi_batch_big_kernel<false, false>);
 }

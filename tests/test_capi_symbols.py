@@ -53,7 +53,8 @@ def test_defaults_and_lds_budget(pkg):
     assert 128 * 129 * 8 < lds <= 163840  # J alone: R goes to the scratch workspace
     assert lib.jrlqp_gi_batch_warm_lds_bytes(65, 10, 0, ct.byref(c)) > 65 * 65 * 8 and c.value == 0  # (warm starts beyond one wavefront: gi_batch_big)
     assert lib.jrlqp_gi_batch_warm_lds_bytes(129, 10, 0, ct.byref(c)) == -1
-    assert lib.jrlqp_gi_batch_lds_bytes(129, 10, 0, ct.byref(c)) == -1
+    assert 0 < lib.jrlqp_gi_batch_lds_bytes(129, 10, 0, ct.byref(c)) < 40000 and c.value == 0  # 128 < n <= 256: J in the workspace, vectors in LDS
+    assert lib.jrlqp_gi_batch_lds_bytes(257, 10, 0, ct.byref(c)) == -1
     assert lib.jrlqp_gi_batch_lds_bytes(10, 10, 5, ct.byref(c)) == -1  # nb must be 0 or n
 
 
@@ -70,8 +71,8 @@ def test_argument_validation_without_gpu(pkg):
     # the workspace contract (no GPU needed for the shapes that need none)
     assert lib.jrlqp_gi_batch_workspace_bytes(50, 200, 0, 4096) == 0
     assert lib.jrlqp_gi_batch_workspace_bytes(100, 200, 0, 64) != 0  # beyond one wavefront: B = L^-1 N of a warm start (-1 without a device: sized by its CU count)
-    assert lib.jrlqp_gi_batch_workspace_bytes(129, 10, 0, 1) == -1 and lib.jrlqp_gi_batch_workspace_bytes(10, 10, 5, 1) == -1
-    assert lib.jrlqp_gi_batch_workspace_bytes(128, 10, 0, 0) == 0  # an empty batch needs nothing
+    assert lib.jrlqp_gi_batch_workspace_bytes(257, 10, 0, 1) == -1 and lib.jrlqp_gi_batch_workspace_bytes(10, 10, 5, 1) == -1
+    assert lib.jrlqp_gi_batch_workspace_bytes(256, 10, 0, 0) == 0  # an empty batch needs nothing
     ws_args = [None] * 8 + [None] + [None] * 8 + [0, None, 0, None]
     assert lib.jrlqp_gi_solve_batch_ws(0, 4, 1, 0, 0, *ws_args) == 0  # empty batch
     assert lib.jrlqp_gi_solve_batch_ws(0, 4, 1, 0, 1, *ws_args) == -1  # null pointers

@@ -52,6 +52,52 @@ def test_big_n_matches_oracle(capi, P, oracle, ci):
     assert int(ref["iters"].max()) > 0 or ch.nIneq + ch.nEq == 0
 
 
+WIDE_CASES = [
+    dict(nVar=129, nObj=129, nIneq=200, nStrongActIneq=40),  # the first size whose J lives in the workspace
+    dict(nVar=160, nObj=160, nEq=8, nIneq=150, nStrongActIneq=30, bounds=True, nStrongActBounds=12),
+    dict(nVar=200, nObj=200, nIneq=400, nStrongActIneq=60, doubleSidedIneq=True, nWeakActIneq=5),
+    dict(nVar=256, nObj=256, nIneq=300, nStrongActIneq=77),  # the batched ceiling
+    dict(nVar=256, nObj=256, nEq=20, nIneq=120, nStrongActIneq=30, bounds=True, nStrongActBounds=40, nWeakActBounds=3),
+    dict(nVar=192, nObj=192),  # unconstrained
+]
+
+
+@pytest.mark.parametrize("ci", range(len(WIDE_CASES)))
+def test_wide_n_matches_oracle(capi, P, oracle, ci):
+    """128 < n <= 256 (gi_batch_big.hip, WIDE: L / J and R in the caller's workspace, four vector entries per lane): status,
+    iterations, active set, x, u, f and the Cholesky factor bit for bit against the oracle."""
+    ch = P.Characteristics(**WIDE_CASES[ci])
+    pb = P.generate_batch(5, ch, first_index=8000 + 20 * ci)
+    hb = ch.bounds
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl if hb else None, pb.xu if hb else None, nthreads=5)
+    gpu = run_gpu(capi, pb, use_bounds=hb, want_factor=True)
+    assert_bit_identical(gpu, ref, f"wide case {ci}")
+    assert np.all(ref["term"] == 0)
+    assert np.array_equal(np.tril(gpu["L"].transpose(0, 2, 1)), np.tril(ref["L"].transpose(0, 2, 1)))
+    assert np.max(np.linalg.norm(gpu["x"] - pb.x_star, axis=1)) <= 1e-6 * max(1.0, np.max(np.linalg.norm(pb.x_star, axis=1)))
+
+
+def test_wide_n_grid_and_limits(capi, P, oracle):
+    """More problems than resident workgroups at n = 140 (persistent grid: 4 per CU), the iteration limit, and the sizes beyond
+    the ceiling: n = 257 and a warm start at n = 129 are refused."""
+    import torch
+
+    pb = P.generate_batch(1100, P.benchmark_characteristics(140, 160), first_index=9300)
+    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=8)
+    assert_bit_identical(run_gpu(capi, pb), ref, "n=140 x 1100")
+    small = P.generate_batch(4, P.benchmark_characteristics(150, 200), first_index=9400)
+    for max_iter in (0, 3):
+        ref = oracle.solve_batch(small.G, small.a, small.C, small.bl, small.bu, max_iter=max_iter)
+        assert_bit_identical(run_gpu(capi, small, max_iter=max_iter), ref, f"n=150 max_iter={max_iter}")
+    with pytest.raises(capi.JrlqpError):
+        capi.BatchSolver(257, 10, False, 2, device="cuda:0")
+    dev = capi.to_device(small, "cuda:0")
+    s = capi.BatchSolver(small.n, small.m, False, small.B, device="cuda:0")
+    with pytest.raises(capi.JrlqpError):
+        s.solve_warm(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"], guess=None)
+    torch.cuda.synchronize()
+
+
 def test_big_n_persistent_grid_more_problems_than_cus(capi, P, oracle):
     """600 problems at n = 70 on a 256-CU grid: every workgroup solves two or three problems back to back."""
     pb = P.generate_batch(600, P.benchmark_characteristics(70, 100), first_index=9100)
