@@ -120,10 +120,12 @@ def cpu_baseline(pb, budget_s=12.0):
     # The affinity mask can overstate what the container may really use: a cgroup CPU quota throttles a pool that is wider than
     # the quota, but only once the quota of a scheduling period (100 ms) is spent -- a probe of a few milliseconds runs at the
     # full width of the host and says nothing about a sustained run.  So every width is probed for >= 0.6 s (several periods),
-    # widths stop at 4 x the quota, and the fastest SUSTAINED width is used; the short-burst rates are reported beside it
+    # widths stop at the quota, and the fastest SUSTAINED width is used; the short-burst rates are reported beside it
     # (`burst_probe_solves_per_s`: what the host's cores do when the quota does not bind -- an upper bound for a dedicated host).
     quota = cgroup_cpu_quota()
-    widest = cores if quota is None else max(1, min(cores, int(4 * quota + 0.5)))
+    # (no width beyond the quota: threads the cgroup cannot run only add context switches, and a 0.6 s probe of such a width is
+    # noisy enough to win now and then -- a 32-thread pick under a 16-cpu quota cost 10 % of the sustained rate)
+    widest = cores if quota is None else max(1, min(cores, int(quota + 0.5)))
     best_t, best_rate, t, probed, burst = 1, 0.0, 1, {}, {}
     while True:
         run(1, t)  # the first call at a new width pays for the OpenMP pool and page faults
