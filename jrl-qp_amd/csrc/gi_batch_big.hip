@@ -203,9 +203,12 @@ __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho,
 // WIDE: 128 < n <= 256 (cold start): L / J (up to 526 KB) no longer fit in LDS at all -- they live in the workgroup's slice of the
 // global workspace, behind R (L2 / Infinity-Cache resident: a slice is re-read every pass), LDS keeps the vectors; the wave-level
 // substitutions carry four entries per lane instead of two.  Same code otherwise: every output element still owns its chain.
-template<bool RLDS, bool WARM, bool WIDE = false>
-__global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
+template<bool RLDS, bool WARM, bool WIDE = false, bool PROFB = false, int OCC = 1>
+__global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
 {
+  // (launch bounds: OCC = 2 -- two workgroups per CU while their LDS allows it, n <= 88: at most 256 VGPRs, a few spills; OCC = 1
+  // beyond, where one workgroup fills the CU's LDS anyway and the spills would only cost; the wide variant keeps its factors in
+  // memory and lives on occupancy: three waves per SIMD, 168 VGPRs)
   static_assert(!WIDE || (!RLDS && !WARM), "the wide variant keeps R and J in the workspace and is cold-start only");
   constexpr int EPL = WIDE ? 4 : 2; // entries of a wave-level vector per lane (rows lane, lane + 64, ...)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -264,6 +267,20 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
     const double * xlg = nb ? A.xl + (size_t)b * nb : nullptr;
     const double * xug = nb ? A.xu + (size_t)b * nb : nullptr;
     __syncthreads(); // (the previous problem's results are out)
+    // diagnostic phase profile (jrlqp_debug_set_profile, JRLQP_PROFILE_GI_BATCH): thread 0 accumulates shader-clock cycles per phase
+    // -- slots: 0 load, 1 LLT, 2 x0 / J (/ warm factorisation), 3 scan + selection, 4 d = J^T n+, 5 z || R^-1 d || coefficient chain,
+    // 6 scalar products, 7 step, 8 addition (sweep of J), 9 removal, 10 #additions, 11 #removals -- into prof[b * stride + slot]
+    const bool profb = PROFB && A.prof != nullptr && tid == 0; // (PROFB: a build of its own -- the accumulators cost the production kernel 5 %)
+    long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long plast = profb ? clock64() : 0;
+    auto stamp = [&](int slot) {
+      if(profb)
+      {
+        const long long now = clock64();
+        pacc[slot] += now - plast;
+        plast = now;
+      }
+    };
 
     // ---------------------------------------------------------------- load G (lower triangle), reset
     for(int e = tid; e < n * n; e += WGB)
@@ -280,6 +297,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
     }
     __syncthreads();
 
+    stamp(0);
     bool over = false;
     int nact0 = 0;
     if constexpr(WARM)
@@ -369,6 +387,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       if(i < n) M[i + (long)j * ld] = (i == j) ? ljj : acc / ljj;
       __syncthreads();
     }
+    stamp(1);
     int term = BT_SUCCESS, it = 0, q = 0;
     if(over)
       term = BT_OVERCONSTRAINED;
@@ -564,6 +583,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       }
     }
     double * J = M;
+    stamp(2);
 
     int p = -1, pstat = B_INACTIVE;
 
@@ -578,7 +598,9 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       return lower ? blg[pp] : bug[pp];
     };
     // computeStep_ + the scalar products of computeStepLength_ (barriers inside: called by every thread)
-    auto compute_step = [&](int pp, int ps) {
+    // fresh: pp was selected by a scan of the current x -- n+.x is then the scan's own chain value (ctl->cx, written by the thread
+    // that owns the constraint: GoldfarbIdnaniSolver.cpp:97 and :183-190 are one expression) and is not recomputed
+    auto compute_step = [&](int pp, int ps, bool fresh) {
       if(tid < n)
       {
         double dj = (pp < m) ? chain_asc<false>(J + (long)tid * ld, 1, nps, 1, 0, n, 0.0) : J[(pp - m) + (long)tid * ld];
@@ -586,6 +608,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         ds[tid] = dj;
       }
       __syncthreads();
+      stamp(4);
       if(tid >= 128)
       {
         // z = J2 d2: waves 2-3, one row per thread (two beyond n = 128)
@@ -656,6 +679,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         }
       }
       __syncthreads();
+      stamp(5);
       // z.z and n+.z: C4 trees (CANON C5) -- one product per element, element e on thread e: each wave's adjacent-first tree over
       // its 64 elements, then the waves pairwise ((w0 + w1) + (w2 + w3); up to n = 128 the second pair is exactly +0).  n+.x:
       // the C1 chain (the scan's value for that constraint), the last lane of wave 3 behind its share of the trees
@@ -670,7 +694,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
           ctl->dotp[2 * wave] = pz;
           ctl->dotp[2 * wave + 1] = pc;
         }
-        if(tid == WGB - 1) ctl->cx = (pp < m) ? chain_asc<false>(nps, 1, xs, 1, 0, n, 0.0) : xs[pp - m];
+        if(tid == WGB - 1 && !(fresh && pp < m)) ctl->cx = (pp < m) ? chain_asc<false>(nps, 1, xs, 1, 0, n, 0.0) : xs[pp - m];
       }
       __syncthreads();
       if(tid == 0)
@@ -679,6 +703,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         ctl->cz = (pp < m) ? ((ctl->dotp[1] + ctl->dotp[3]) + (ctl->dotp[5] + ctl->dotp[7])) : zs[pp - m];
       }
       __syncthreads();
+      stamp(6);
     };
     // x += t z (if primal), f, u -= t r, u[q] += t   (DualSolver.cpp:136-150)
     auto apply_step = [&](double t, double dotsc, bool dual_only) {
@@ -901,7 +926,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
             load_np(p);
             if(tid == 0) us[q] = 0.0;
             __syncthreads();
-            compute_step(p, pstat);
+            compute_step(p, pstat, false);
             // addInitialConstraint (:295-338): full step, no ratio test
             const double cz = ctl->cz;
             double t = 0.0;
@@ -924,7 +949,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         if(!skip)
         {
           // selectViolatedConstraint_ (:84-134): most negative slack, general constraints first, lower before upper, first index
-          double bval = 0.0;
+          double bval = 0.0, mycx = 0.0;
           int bidx = NONE_B, bstat = B_INACTIVE;
           for(int i = tid; i < m; i += WGB)
           {
@@ -936,6 +961,7 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
               bval = sl;
               bidx = i;
               bstat = B_LOWER;
+              mycx = cx;
             }
             else
             {
@@ -945,9 +971,11 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
                 bval = su;
                 bidx = i;
                 bstat = B_UPPER;
+                mycx = cx;
               }
             }
           }
+          const int mybidx = (bidx < m) ? bidx : NONE_B; // this thread's own best general constraint (before the reduction below)
           for(int i = tid; i < nb; i += WGB)
           {
             if(st[m + i] != B_INACTIVE) continue;
@@ -1000,10 +1028,12 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
           p = ix;
           pstat = sx;
           load_np(p);
+          if(p < m && mybidx == p) ctl->cx = mycx; // (exactly one thread: the owner of constraint p)
           if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
           __syncthreads();
         }
-        compute_step(p, pstat);
+        stamp(3);
+        compute_step(p, pstat, !skip);
         // computeStepLength_ (:150-219)
         const double cz = ctl->cz;
         const double dotsc = (pstat == B_UPPER || pstat == B_UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
@@ -1029,17 +1059,22 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
         }
         const bool dual_only = (t2 >= big);
         apply_step(t, dotsc, dual_only);
+        stamp(7);
         if(!dual_only && t == t2)
         {
           add_constraint(p, pstat);
           ++q;
           skip = false;
+          stamp(8);
+          if(profb) ++pacc[10];
         }
         else
         {
           remove_constraint(l);
           --q;
           skip = true; // same (p, status); u[q] keeps the shifted pending multiplier
+          stamp(9);
+          if(profb) ++pacc[11];
         }
       }
     }
@@ -1067,6 +1102,8 @@ __global__ __launch_bounds__(WGB) void gi_batch_big_kernel(const BatchArgs A, do
       A.iters[b] = it;
       A.f[b] = ctl->f;
     }
+    if(profb)
+      for(int k = 0; k < 12; ++k) A.prof[(size_t)b * A.prof_stride + k] = pacc[k];
   }
 }
 
@@ -1117,6 +1154,9 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
     return hipGetLastError();
   };
   if(a.n > 128) return a.warm ? hipErrorInvalidValue : go(&gi_batch_big_kernel<false, false, true>);
+  if(a.prof && !a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, false, false, true>) : go(&gi_batch_big_kernel<false, false, false, true>);
+  if(2 * lds <= kLdsPerCU && r_in_lds) // two workgroups per CU: the instantiations held to 256 VGPRs
+    return a.warm ? go(&gi_batch_big_kernel<true, true, false, false, 2>) : go(&gi_batch_big_kernel<true, false, false, false, 2>);
   if(a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, true>) : go(&gi_batch_big_kernel<false, true>);
   return r_in_lds ? go(&gi_batch_big_kernel<true, false>) : go(&gi_batch_big_kernel<false, false>);
 }

@@ -22,7 +22,7 @@ from test_gpu_warm import oracle_warm, perturbed_guess, run_warm
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 NLO = int(sys.argv[3]) if len(sys.argv) > 3 else 1    # range of n (default 1 .. 64; e.g. 36 64 for the role-specialised loop,
-NHI = int(sys.argv[4]) if len(sys.argv) > 4 else 64   # 65 128 for the large-n kernel -- cold only there)
+NHI = int(sys.argv[4]) if len(sys.argv) > 4 else 64   # 65 256 for the large-n kernel; warm starts up to n = 128)
 rng = np.random.default_rng(seed)
 oracle = get_oracle()
 terms = {}
@@ -42,7 +42,7 @@ for trial in range(trials):
     ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl if bounds else None, pb.xu if bounds else None, nthreads=8)
     gpu = run_gpu(capi, pb, use_bounds=bounds)
     assert_bit_identical(gpu, ref, f"trial {trial}: {ch}")
-    if trial % 4 == 0 and n <= 64:  # every fourth shape also warm-started, from a stale guess (purge loop + hand-over to the regular loop)
+    if trial % 4 == 0 and n <= 128:  # every fourth shape also warm-started, from a stale guess (purge loop + hand-over to the regular loop)
         g = perturbed_guess(rng, ref["status"], pb.m)
         assert_bit_identical(run_warm(capi, pb, g, use_bounds=bounds), oracle_warm(oracle, pb, g, bounds), f"trial {trial} warm: {ch}")
     for t in ref["term"].tolist():
