@@ -59,8 +59,8 @@ enum jrlqp_status
 };
 
 #define JRLQP_BATCH_MAX_N 256 /* largest n of the batched entry points */
-#define JRLQP_BATCH_LDS_N 128 /* up to here the factor J lives in LDS (gi_batch_big.hip); beyond -- cold start only -- L / J live in the
-                                 caller's workspace too (L2-resident), the same kernel with four vector entries per lane */
+#define JRLQP_BATCH_LDS_N 128 /* up to here the factor J lives in LDS (gi_batch_big.hip); beyond, L / J live in the caller's workspace
+                                 too (L2-resident), the same kernel with four vector entries per lane */
 #define JRLQP_BATCH_WAVE_N 64 /* up to here a row of the factors is one lane of a wavefront (gi_batch_kernel.h); beyond it (cold
                                  start only) the solver of gi_batch_big.hip: J in LDS, R in LDS or in the caller's workspace
                                  (jrlqp_gi_batch_workspace_bytes), a persistent grid looping over the batch */
@@ -110,7 +110,7 @@ void jrlqp_default_options(jrlqp_options * opts);
  *        dL == dG reproduces the reference's in-place contract (G's lower triangle <- L, upper part untouched).
  *   dtrace optional [B][trace_cap] records.
  * No allocation, no host synchronisation: the call enqueues one kernel on `stream` (a hipStream_t, may be NULL).
- * Requires 1 <= n <= JRLQP_BATCH_MAX_N (warm starts: n <= JRLQP_BATCH_LDS_N).  Shapes that need a workspace (cold: n > 104, the
+ * Requires 1 <= n <= JRLQP_BATCH_MAX_N.  Shapes that need a workspace (cold: n > 104, the
  * packed R factor -- and past n = 128 J itself -- no longer fit in LDS; warm: every n > 64) take the caller-owned workspace of
  * jrlqp_gi_solve_batch_ws below; this entry point then returns JRLQP_ERR_WORKSPACE instead of allocating.
  */
@@ -179,7 +179,7 @@ int jrlqp_gi_solve_batch_warm(int n,
  *   jrlqp_gi_batch_workspace_bytes: device bytes a batch of B problems of shape (n, m, nb) needs beside its inputs and outputs
  *     on the CURRENT device, cold or warm-started: 0 for every shape whose state fits in LDS and registers (all n <= 64); beyond,
  *     per resident workgroup of the persistent grid (sized by the machine, not by B), the n x n array B = L^-1 N of a warm
- *     start (n <= 128), past n = 104 the packed R factor, and past n = 128 the factors L / J themselves.  A cold solve needs
+ *     start, past n = 104 the packed R factor, and past n = 128 the factors L / J themselves.  A cold solve needs
  *     only the R / J part (nothing up to n = 104) and accepts a smaller workspace accordingly; -1 if the shape is unsupported.
  *   jrlqp_gi_solve_batch_ws: jrlqp_gi_solve_batch (warm == 0, das ignored) or jrlqp_gi_solve_batch_warm (warm != 0) with that
  *     workspace: dworkspace is a 16-byte aligned device pointer to at least workspace_bytes >= the figure above (NULL / 0 when

@@ -198,7 +198,7 @@ long long jrlqp_gi_batch_workspace_bytes(int n, int m, int nb, int B)
     return -1;
   // sized by the machine (one slice per resident workgroup of the persistent grid), not by the batch; the figure covers a
   // warm start (B = L^-1 N, n x n) as well as a cold one (R alone, and only beyond n = 104)
-  return (long long)sizeof(double) * big_grid(n, m, nb, B) * jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, n <= JRLQP_BATCH_LDS_N ? 1 : 0);
+  return (long long)sizeof(double) * big_grid(n, m, nb, B) * jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, 1);
 }
 
 static int gi_batch_common(int warm,
@@ -238,7 +238,7 @@ static int gi_batch_common(int warm,
   if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const bool bign = n > JRLQP_BATCH_WAVE_N; // more rows than one lane-per-row wavefront: gi_batch_big.hip
   int r_in_lds = 0;
-  if(bign && (jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0 || (warm && n > JRLQP_BATCH_LDS_N))) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  if(bign && jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const int cmode = bign ? 0 : jrlqp::batch_pick_cmode(n, m, nb, warm);
   if(cmode < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
 
@@ -289,7 +289,7 @@ static int gi_batch_common(int warm,
 
 long jrlqp_gi_batch_warm_lds_bytes(int n, int m, int nb, int * c_in_lds)
 {
-  if(n > JRLQP_BATCH_WAVE_N && n <= JRLQP_BATCH_LDS_N && m >= 0 && (nb == 0 || nb == n))
+  if(n > JRLQP_BATCH_WAVE_N && n <= JRLQP_BATCH_MAX_N && m >= 0 && (nb == 0 || nb == n))
   {
     if(c_in_lds) *c_in_lds = 0;
     return jrlqp::batch_big_lds_bytes(n, m, nb, nullptr); // (B = L^-1 N lives in the workspace, not in LDS)

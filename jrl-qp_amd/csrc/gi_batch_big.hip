@@ -200,7 +200,7 @@ __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho,
 // orc_gi_solve_warm): the initial active set comes from the data equalities plus a guess, J and R from a Householder QR of
 // B = L^-1 N, the start point in closed form, constraints with a negative multiplier purged one at a time; then the same loop.
 // B (n x q) does not fit in LDS beside J: it lives in the workgroup's slice of the global workspace, behind R.
-// WIDE: 128 < n <= 256 (cold start): L / J (up to 526 KB) no longer fit in LDS at all -- they live in the workgroup's slice of the
+// WIDE: 128 < n <= 256: L / J (up to 526 KB) no longer fit in LDS at all -- they live in the workgroup's slice of the
 // global workspace, behind R (L2 / Infinity-Cache resident: a slice is re-read every pass), LDS keeps the vectors; the wave-level
 // substitutions carry four entries per lane instead of two.  Same code otherwise: every output element still owns its chain.
 template<bool RLDS, bool WARM, bool WIDE = false, bool PROFB = false, int OCC = 1>
@@ -209,8 +209,16 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
   // (launch bounds: OCC = 2 -- two workgroups per CU while their LDS allows it, n <= 88: at most 256 VGPRs, a few spills; OCC = 1
   // beyond, where one workgroup fills the CU's LDS anyway and the spills would only cost; the wide variant keeps its factors in
   // memory and lives on occupancy: three waves per SIMD, 168 VGPRs)
-  static_assert(!WIDE || (!RLDS && !WARM), "the wide variant keeps R and J in the workspace and is cold-start only");
+  static_assert(!WIDE || !RLDS, "the wide variant keeps R and J in the workspace");
   constexpr int EPL = WIDE ? 4 : 2; // entries of a wave-level vector per lane (rows lane, lane + 64, ...)
+  // entry k (scalar) of such a vector, in every lane
+  auto vec_bcast = [&](const double (&v)[EPL], int k) __attribute__((always_inline)) {
+    double r = 0.0;
+#pragma unroll
+    for(int h = 0; h < EPL; ++h)
+      if((k >> 6) == h) r = bcast_lane(v[h], k & 63); // (k is scalar: a uniform branch)
+    return r;
+  };
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
   double * ssq = sss + n;            // scratch of the coefficient chain (n + 2)
   double * tail = ssq + (n + 2);
   double * Rl = tail;                                   // RLDS
-  double * Bw = Rg + (RLDS ? 0 : ((rlen + 1) & ~1L));                         // WARM: N -> B = L^-1 N -> its QR factors, n x q, ld = n
+  double * Bw = Rg + (RLDS ? 0 : ((rlen + 1) & ~1L)) + (WIDE ? ((long)n * ld + 1) : 0); // WARM: N -> B = L^-1 N -> its QR factors, n x q, ld = n (behind R and, WIDE, behind L / J)
   if(RLDS) tail += rlen;
   CtlB * ctl = reinterpret_cast<CtlB *>(tail);
   int * act = reinterpret_cast<int *>(ctl + 1);
@@ -443,20 +451,25 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         for(int j = wave; j < q; j += 4)
         {
           double * col = Bw + (long)j * n;
-          double b0 = (lane < n) ? col[lane] : 0.0, b1 = (lane + 64 < n) ? col[lane + 64] : 0.0;
+          double bv[EPL];
+#pragma unroll
+          for(int h = 0; h < EPL; ++h) bv[h] = (lane + 64 * h < n) ? col[lane + 64 * h] : 0.0;
           const int ns = __builtin_amdgcn_readfirstlane(n);
           for(int k = 0; k < ns; ++k)
           {
-            const double num = (k < 64) ? bcast_lane(b0, k) : bcast_lane(b1, k - 64);
-            const double v = num / M[k + (long)k * ld];
+            const double v = vec_bcast(bv, k) / M[k + (long)k * ld];
             const double * lk = M + (long)k * ld;
-            if(lane > k && lane < n) b0 = FMA(-lk[lane], v, b0);
-            if(lane + 64 > k && lane + 64 < n) b1 = FMA(-lk[lane + 64], v, b1);
-            if(lane == k) b0 = v;
-            if(lane + 64 == k) b1 = v;
+#pragma unroll
+            for(int h = 0; h < EPL; ++h)
+            {
+              const int e = lane + 64 * h;
+              if(e > k && e < n) bv[h] = FMA(-lk[e], v, bv[h]);
+              if(e == k) bv[h] = v;
+            }
           }
-          if(lane < n) col[lane] = b0;
-          if(lane + 64 < n) col[lane + 64] = b1;
+#pragma unroll
+          for(int h = 0; h < EPL; ++h)
+            if(lane + 64 * h < n) col[lane + 64 * h] = bv[h];
         }
         __syncthreads();
         // B = Q R, Householder, column by column (:432-440; Eigen makeHouseholder / applyHouseholderOnTheLeft), in place
@@ -474,10 +487,13 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             double tau = (beta - c0) / beta;
             tau = zero ? 0.0 : tau;
             beta = zero ? c0 : beta;
-            const double m0 = (lane > k && lane < n) ? vk[lane] : 0.0, m1 = (lane + 64 > k && lane + 64 < n) ? vk[lane + 64] : 0.0;
+            double mv[EPL];
+#pragma unroll
+            for(int h = 0; h < EPL; ++h) mv[h] = (lane + 64 * h > k && lane + 64 * h < n) ? vk[lane + 64 * h] : 0.0;
             wave_sync();
-            if(lane > k && lane < n) vk[lane] = zero ? 0.0 : m0 / den;
-            if(lane + 64 > k && lane + 64 < n) vk[lane + 64] = zero ? 0.0 : m1 / den;
+#pragma unroll
+            for(int h = 0; h < EPL; ++h)
+              if(lane + 64 * h > k && lane + 64 * h < n) vk[lane + 64 * h] = zero ? 0.0 : mv[h] / den;
             if(lane == 0)
             {
               vk[k] = beta;
@@ -820,19 +836,24 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         if(wave == 1)
         {
           // beta = R^-T b_act: forward substitution, two entries per lane; per element the terms in ascending i, then one division
-          double a0 = (lane < q) ? bact[lane] : 0.0, a1 = (lane + 64 < q) ? bact[lane + 64] : 0.0;
+          double av[EPL];
+#pragma unroll
+          for(int h = 0; h < EPL; ++h) av[h] = (lane + 64 * h < q) ? bact[lane + 64 * h] : 0.0;
           const int qs = __builtin_amdgcn_readfirstlane(q);
           for(int i = 0; i < qs; ++i)
           {
-            const double num = (i < 64) ? bcast_lane(a0, i) : bcast_lane(a1, i - 64);
-            const double v = num / RP(i, i);
-            if(lane > i && lane < q) a0 = FMA(-RP(i, lane), v, a0);
-            if(lane + 64 > i && lane + 64 < q) a1 = FMA(-RP(i, lane + 64), v, a1);
-            if(lane == i) a0 = v;
-            if(lane + 64 == i) a1 = v;
+            const double v = vec_bcast(av, i) / RP(i, i);
+#pragma unroll
+            for(int h = 0; h < EPL; ++h)
+            {
+              const int e = lane + 64 * h;
+              if(e > i && e < q) av[h] = FMA(-RP(i, e), v, av[h]);
+              if(e == i) av[h] = v;
+            }
           }
-          if(lane < q) rs[lane] = a0;
-          if(lane + 64 < q) rs[lane + 64] = a1;
+#pragma unroll
+          for(int h = 0; h < EPL; ++h)
+            if(lane + 64 * h < q) rs[lane + 64 * h] = av[h];
         }
         __syncthreads();
         if(tid < n) // x = J1 beta - J2 alpha2
@@ -841,31 +862,36 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           acc = chain_asc<true>(J + tid, ld, ds, 1, q, n, acc);
           xs[tid] = acc;
         }
-        else if(wave == 2)
+        if(wave == 2) // (not `else`: beyond n = 128 these threads have a row of x as well)
         {
           // u = R^-1 (alpha1 + beta), backward substitution, two entries per lane
-          double u0 = (lane < q) ? (ds[lane] + rs[lane]) : 0.0, u1 = (lane + 64 < q) ? (ds[lane + 64] + rs[lane + 64]) : 0.0;
+          double uv[EPL];
+#pragma unroll
+          for(int h = 0; h < EPL; ++h) uv[h] = (lane + 64 * h < q) ? (ds[lane + 64 * h] + rs[lane + 64 * h]) : 0.0;
           const int qs = __builtin_amdgcn_readfirstlane(q);
           for(int k = qs - 1; k >= 0; --k)
           {
-            const double num = (k < 64) ? bcast_lane(u0, k) : bcast_lane(u1, k - 64);
-            const double v = num / RP(k, k);
+            const double v = vec_bcast(uv, k) / RP(k, k);
             const double * col = &RP(0, k);
-            if(lane < k) u0 = FMA(-col[lane], v, u0);
-            if(lane + 64 < k) u1 = FMA(-col[lane + 64], v, u1);
-            if(lane == k) u0 = v;
-            if(lane + 64 == k) u1 = v;
+#pragma unroll
+            for(int h = 0; h < EPL; ++h)
+            {
+              const int e = lane + 64 * h;
+              if(e < k) uv[h] = FMA(-col[e], v, uv[h]);
+              if(e == k) uv[h] = v;
+            }
           }
-          if(lane < q) us[lane] = u0;
-          if(lane + 64 < q) us[lane + 64] = u1;
+#pragma unroll
+          for(int h = 0; h < EPL; ++h)
+            if(lane + 64 * h < q) us[lane + 64 * h] = uv[h];
           // most negative multiplier of an inequality (first one on ties), threshold -1e-14 (:82-93)
           double cand = 0.0;
           int ci = NONE_B, dummy = 0;
 #pragma unroll
-          for(int h = 0; h < 2; ++h)
+          for(int h = 0; h < EPL; ++h)
           {
             const int k = lane + 64 * h;
-            const double uk = h ? u1 : u0;
+            const double uk = uv[h];
             if(k < q)
             {
               const int sk = st[act[k]];
@@ -879,7 +905,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           argmin3(cand, ci, dummy);
           if(lane == 0) ctl->l = (ci == NONE_B) ? -1 : ci;
         }
-        else if(tid == 192)
+        if(tid == 192)
         {
           // f = beta.(0.5 beta + alpha1) - 0.5 |alpha2|^2
           double f1 = 0.0, f2 = 0.0;
@@ -1153,7 +1179,7 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, stride);
     return hipGetLastError();
   };
-  if(a.n > 128) return a.warm ? hipErrorInvalidValue : go(&gi_batch_big_kernel<false, false, true>);
+  if(a.n > 128) return a.warm ? go(&gi_batch_big_kernel<false, true, true>) : go(&gi_batch_big_kernel<false, false, true>);
   if(a.prof && !a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, false, false, true>) : go(&gi_batch_big_kernel<false, false, false, true>);
   if(2 * lds <= kLdsPerCU && r_in_lds) // two workgroups per CU: the instantiations held to 256 VGPRs
     return a.warm ? go(&gi_batch_big_kernel<true, true, false, false, 2>) : go(&gi_batch_big_kernel<true, false, false, false, 2>);

@@ -78,8 +78,8 @@ def test_wide_n_matches_oracle(capi, P, oracle, ci):
 
 
 def test_wide_n_grid_and_limits(capi, P, oracle):
-    """More problems than resident workgroups at n = 140 (persistent grid: 4 per CU), the iteration limit, and the sizes beyond
-    the ceiling: n = 257 and a warm start at n = 129 are refused."""
+    """More problems than resident workgroups at n = 140 (persistent grid: 3 per CU), the iteration limit, and the size beyond
+    the ceiling: n = 257 is refused."""
     import torch
 
     pb = P.generate_batch(1100, P.benchmark_characteristics(140, 160), first_index=9300)
@@ -91,10 +91,6 @@ def test_wide_n_grid_and_limits(capi, P, oracle):
         assert_bit_identical(run_gpu(capi, small, max_iter=max_iter), ref, f"n=150 max_iter={max_iter}")
     with pytest.raises(capi.JrlqpError):
         capi.BatchSolver(257, 10, False, 2, device="cuda:0")
-    dev = capi.to_device(small, "cuda:0")
-    s = capi.BatchSolver(small.n, small.m, False, small.B, device="cuda:0")
-    with pytest.raises(capi.JrlqpError):
-        s.solve_warm(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"], guess=None)
     torch.cuda.synchronize()
 
 
@@ -156,6 +152,9 @@ BIG_WARM = [
     dict(nVar=100, nObj=100, nEq=10, nIneq=90, nStrongActIneq=20, bounds=True, nStrongActBounds=8),
     dict(nVar=128, nObj=128, nIneq=160, nStrongActIneq=36),  # R and B = L^-1 N both in the caller's workspace
     dict(nVar=128, nObj=128, nEq=12, nIneq=100, nStrongActIneq=20, bounds=True, nStrongActBounds=10, doubleSidedIneq=True),
+    dict(nVar=130, nObj=130, nIneq=150, nStrongActIneq=40),  # beyond 128: L / J, R and B all in the workspace, four entries per lane
+    dict(nVar=200, nObj=200, nEq=10, nIneq=150, nStrongActIneq=40, bounds=True, nStrongActBounds=20, doubleSidedIneq=True),
+    dict(nVar=256, nObj=256, nIneq=280, nStrongActIneq=70),
 ]
 
 
@@ -168,7 +167,7 @@ def test_big_n_warm_start_bit_identical(capi, P, oracle, ci):
     from test_gpu_warm import oracle_cold, oracle_warm, perturbed_guess, run_warm
 
     ch = P.Characteristics(**BIG_WARM[ci])
-    pb = P.generate_batch(12, ch, first_index=5200 + 40 * ci, seed0=0xB16)
+    pb = P.generate_batch(12 if ch.nVar <= 128 else 5, ch, first_index=5200 + 40 * ci, seed0=0xB16)
     hb = ch.bounds
     cold = oracle_cold(oracle, pb, hb)
     rng = np.random.default_rng(100 + ci)

@@ -42,7 +42,7 @@ for trial in range(trials):
     ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl if bounds else None, pb.xu if bounds else None, nthreads=8)
     gpu = run_gpu(capi, pb, use_bounds=bounds)
     assert_bit_identical(gpu, ref, f"trial {trial}: {ch}")
-    if trial % 4 == 0 and n <= 128:  # every fourth shape also warm-started, from a stale guess (purge loop + hand-over to the regular loop)
+    if trial % 4 == 0:  # every fourth shape also warm-started, from a stale guess (purge loop + hand-over to the regular loop)
         g = perturbed_guess(rng, ref["status"], pb.m)
         assert_bit_identical(run_warm(capi, pb, g, use_bounds=bounds), oracle_warm(oracle, pb, g, bounds), f"trial {trial} warm: {ch}")
     for t in ref["term"].tolist():
