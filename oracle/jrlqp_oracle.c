@@ -43,10 +43,32 @@ double orc_dot(int n, const double * a, const double * b)
 }
 
 /* out[j] = orc_dot(n, M + j*ldm, v) for j < ncols: same per-output chain as orc_dot (bit-identical), eight
- * independent chains in flight so that the CPU baseline is not bound by fma latency. */
+ * independent chains in flight so that the CPU baseline is not bound by fma latency.  When the column stride is a multiple
+ * of 4 KiB (n = 1024: BASELINE c2) eight column streams plus v land in one set of an 8-way L1 and evict each other -- the
+ * baseline would run 4x slower than at n = 1000 for no algorithmic reason -- so that case walks six columns at a time. */
 static void multi_dot(int n, const double * M, long ldm, int ncols, const double * v, double * out)
 {
   int j = 0;
+  if((ldm * (long)sizeof(double)) % 4096 == 0)
+  {
+    for(; j + 6 <= ncols; j += 6)
+    {
+      const double * c0 = M + (long)j * ldm;
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+      for(int k = 0; k < n; ++k)
+      {
+        double vk = v[k];
+        a0 = FMA(c0[k], vk, a0);
+        a1 = FMA(c0[k + ldm], vk, a1);
+        a2 = FMA(c0[k + 2 * ldm], vk, a2);
+        a3 = FMA(c0[k + 3 * ldm], vk, a3);
+        a4 = FMA(c0[k + 4 * ldm], vk, a4);
+        a5 = FMA(c0[k + 5 * ldm], vk, a5);
+      }
+      out[j] = a0; out[j + 1] = a1; out[j + 2] = a2; out[j + 3] = a3; out[j + 4] = a4; out[j + 5] = a5;
+    }
+    for(; j < ncols; ++j) out[j] = orc_dot(n, M + (long)j * ldm, v);
+  }
   for(; j + 8 <= ncols; j += 8)
   {
     const double * c0 = M + (long)j * ldm;
@@ -74,27 +96,50 @@ static void multi_dot(int n, const double * M, long ldm, int ncols, const double
  * nothing is written at or after that column.  Only the lower triangle is read/written. */
 int orc_llt(int n, double * A, int lda)
 {
+  /* Element (i, j) is A(i,j) minus L(i,k) L(j,k) for k = 0 .. j-1, one fma per k IN THAT ORDER, then the division by the pivot.
+   * The loops below walk k outside and i inside, so that every access is down a column (the row-wise form runs through memory
+   * with a stride of lda: at lda = 1024 every step of a chain falls in the same cache set); column j is built in a
+   * scratch vector and only stored once its pivot is known to be positive. */
+  double tmp_small[128];
+  double * tmp = (n <= 128) ? tmp_small : (double *)malloc(sizeof(double) * (size_t)n);
+  int info = -1;
   for(int j = 0; j < n; ++j)
   {
-    double acc = A[j + (long)j * lda];
-    for(int k = 0; k < j; ++k) acc = FMA(-A[j + (long)k * lda], A[j + (long)k * lda], acc);
-    if(acc <= 0.0) return j;
-    double ljj = sqrt(acc);
-    A[j + (long)j * lda] = ljj;
-    for(int i = j + 1; i < n; ++i)
+    double * cj = A + (long)j * lda;
+    const int len = n - j;
+    for(int i = 0; i < len; ++i) tmp[i] = cj[j + i];
+    for(int k = 0; k < j; ++k)
     {
-      double s = A[i + (long)j * lda];
-      for(int k = 0; k < j; ++k) s = FMA(-A[i + (long)k * lda], A[j + (long)k * lda], s);
-      A[i + (long)j * lda] = s / ljj;
+      const double * ck = A + (long)k * lda + j;
+      const double ljk = ck[0];
+      for(int i = 0; i < len; ++i) tmp[i] = FMA(-ck[i], ljk, tmp[i]);
     }
+    if(tmp[0] <= 0.0)
+    {
+      info = j;
+      break;
+    }
+    const double ljj = sqrt(tmp[0]);
+    cj[j] = ljj;
+    for(int i = 1; i < len; ++i) cj[j + i] = tmp[i] / ljj;
   }
-  return -1;
+  if(tmp != tmp_small) free(tmp);
+  return info;
 }
 
 /* J.setIdentity(); L.transpose().solveInPlace(J)  (GoldfarbIdnaniSolver.cpp:64-66).
  * Backward substitution per column; entries below the diagonal are exact zeros. */
 void orc_inv_lt(int n, const double * L, int ldl, double * J, int ldj)
 {
+  /* (the update of col[0 .. k) by row k of L runs down a column of a transposed copy of L: same operations, unit stride) */
+  double lt_small[64 * 64];
+  double * LT = (n <= 64) ? lt_small : (double *)malloc(sizeof(double) * (size_t)n * n);
+  for(int i0 = 0; i0 < n; i0 += 32)
+    for(int k = i0; k < n; ++k)
+    {
+      const int i1 = (i0 + 32 < k) ? i0 + 32 : k;
+      for(int i = i0; i < i1; ++i) LT[i + (long)k * n] = L[k + (long)i * ldl];
+    }
   for(int c = 0; c < n; ++c)
   {
     double * col = J + (long)c * ldj;
@@ -103,9 +148,11 @@ void orc_inv_lt(int n, const double * L, int ldl, double * J, int ldj)
     {
       double v = col[k] / L[k + (long)k * ldl];
       col[k] = v;
-      for(int i = 0; i < k; ++i) col[i] = FMA(-L[k + (long)i * ldl], v, col[i]);
+      const double * lk = LT + (long)k * n;
+      for(int i = 0; i < k; ++i) col[i] = FMA(-lk[i], v, col[i]);
     }
   }
+  if(LT != lt_small) free(LT);
 }
 
 /* Eigen::JacobiRotation<double>::makeGivens(p, q, &r), real case (call sites
