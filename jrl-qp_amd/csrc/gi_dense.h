@@ -12,10 +12,26 @@ struct Mailbox
   double t1, zz, cz, cx; // t1, z.z, n.z, n.x
   double uq;            // u[q] before the update (needed by the f update on the host)
   double f0;            // init_
-  int llt_info, pad2;
+  int llt_info;
+  volatile int sync_err; // a device-side wait of the pass hand-off (PassSync) gave up: the results of this solve are void
   // pass tags written LAST by the two blocks of the step kernel (after a system-scope fence): the host state machine polls
   // them instead of synchronising the stream -- a stream synchronisation wakes up tens of microseconds after the kernel ends
   volatile int seq0, seq1;
+};
+
+// Device-side hand-off between the kernels of a pass that run on DIFFERENT streams (the coefficient chain beside z / r / the ratio
+// test, the next pass's constraint scan beside the Givens sweep).  A producer publishes the pass tag with release semantics once
+// its data are out (several workgroups: the last one to arrive at the counter); a consumer -- always enqueued AFTER its producer
+// by the host, on whatever hardware queue its stream maps to, so the producer is never stuck behind it -- spins on the tag with
+// acquire loads.  This replaces hipEventRecord / hipStreamWaitEvent pairs: a cross-queue event dependency costs 7-13 us of idle
+// GPU per edge on this stack (four edges per pass; kernel trace in profiles/), a tag a fraction of a microsecond.
+struct PassSync
+{
+  int d_cnt, d_tag;   // d = J^T n+ is complete            (jtn / jrow -> add_chain)
+  int chain_tag;      // (c_i, s_i), the last radius        (add_chain -> rot_apply / add_commit; -> the next jtn after a drop)
+  int x_cnt, x_tag;   // x, u advanced                      (advance -> the prefetched select)
+  int sel_tag;        // psel = {p, status} of the NEXT pass (select_final -> jtn)
+  int pad[2];
 };
 
 // the caller's problem (device pointers; GoldfarbIdnaniSolver::Problem, GoldfarbIdnaniSolver.h:35-58)
@@ -44,6 +60,7 @@ struct DenseState
   int * wact;         // warm start: the initial active list (n ints)
   double *bact, *hco, *beta; // warm start: b_act, Householder coefficients, beta = R^-T b_act (n doubles each)
   Mailbox * mb;       // device view of the mailbox
+  PassSync * sync;    // pass hand-off tags (zeroed at creation; tags only grow)
 };
 
 constexpr int kSelOnDevice = -2; // dense_step: take (p, status) from DenseState::psel instead of the arguments
@@ -51,15 +68,20 @@ constexpr int kSelOnDevice = -2; // dense_step: take (p, status) from DenseState
 hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st);
 hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st);
 hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st);
-// zero_u >= 0: also clears u[zero_u] (the multiplier slot of the constraint this selection is for; saves a memset launch)
-hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u = -1);
-// spec != nullptr: the Givens coefficient chain of an ADDITION is launched on `spec` as soon as d exists (ev_d), beside
-// z / r / the ratio test on `st`; ev_chain marks its end.  dense_add(..., chain_ready = true) then only commits.
+// zero_u >= 0: also clears u[zero_u] (the multiplier slot of the constraint this selection is for; saves a memset launch).
+// wait_x_tag != 0: the scan first waits for PassSync::x_tag == wait_x_tag (it runs on another stream than `advance`);
+// post_sel_tag != 0: the selection publishes PassSync::sel_tag = post_sel_tag behind psel.
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u = -1, int wait_x_tag = 0, int post_sel_tag = 0);
+// spec != nullptr: the Givens coefficient chain of an ADDITION is launched on `spec` at once and starts as soon as d exists
+// (PassSync::d_tag == tag), beside z / r / the ratio test on `st`; it publishes chain_tag = tag.  dense_add(..., wait_chain_tag = tag)
+// then only commits.  wait_sel_tag / wait_chain_tag != 0: the first kernel waits for the selection made on the side stream / for a
+// discarded chain of an earlier pass that may still be reading d.
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st,
-                      hipStream_t spec = nullptr, hipEvent_t ev_d = nullptr, hipEvent_t ev_chain = nullptr, int tag = 0);
-hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st);
-hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, bool chain_ready = false,
-                     hipEvent_t ev_chain = nullptr);
+                      hipStream_t spec = nullptr, int tag = 0, int wait_sel_tag = 0, int wait_chain_tag = 0);
+// post_x_tag != 0: publishes PassSync::x_tag = post_x_tag once x and u are advanced
+hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st, int post_x_tag = 0);
+// wait_chain_tag != 0: the chain already ran on the side (dense_step with spec); the sweep waits for its tag and commits
+hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, int wait_chain_tag = 0);
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st);
 // warm start (experimental::GoldfarbIdnaniSolver.cpp:388-487): with the LLT in G, the active list in s.wact and the status bytes in
 // s.st: N -> B = L^-1 N -> Householder QR (in s.R: R is its upper triangle), J = L^-T Q, b_act -> s.bact

@@ -50,6 +50,45 @@ __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
   }
 }
 
+// ---- pass hand-off tags (PassSync, gi_dense.h) -----------------------------------------------------------------------------
+// Whole workgroup.  The wait gives up after ~1 s (a producer that never ran: a dead stream), says so in the host-visible mailbox
+// and lets the kernel run on -- the host voids the solve; nothing spins for ever.
+__device__ __forceinline__ void flag_wait(const int * flag, int tag, Mailbox * mb)
+{
+  if(threadIdx.x == 0)
+  {
+    int spins = 0;
+    // (relaxed polls: an acquire per poll would invalidate this XCD's cached lines under the kernels running beside it)
+    while(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag)
+    {
+      __builtin_amdgcn_s_sleep(4);
+      if(++spins > (1 << 20))
+      {
+        if(mb) mb->sync_err = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // every wave drops what its caches may hold of the producer's buffers
+}
+// after the workgroup's last global store; total = number of workgroups that arrive (the counter is left at zero again)
+__device__ __forceinline__ void flag_post(int * cnt, int * flag, int total, int tag)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if(threadIdx.x == 0)
+  {
+    bool last = true;
+    if(total > 1)
+    {
+      last = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1);
+      if(last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if(last) __hip_atomic_store(flag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ============================================================================================================
 // K1  blocked right-looking Cholesky
 // ============================================================================================================
@@ -506,51 +545,84 @@ __device__ __forceinline__ double tile_column_dot(const double * __restrict__ M,
 
 // psel != nullptr: the vector is the column of `vbase` the last selection picked (psel = {p, status} on the DEVICE): the
 // host launches the step without having seen p, and reads it only once per pass, together with the step's scalars
+// Hand-off of d (PassSync): what a jtn / jrow launch waits for before it touches psel and d, and what it publishes behind d
+struct DSync
+{
+  PassSync * sync; // nullptr: plain launch
+  Mailbox * mb;
+  int wait_sel, wait_chain; // tags (0: none)
+  int post, total;          // d_tag = post once `total` workgroups (of jtn and jrow together) have arrived
+};
+
 __global__ __launch_bounds__(64) void jtn_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign, double * out,
-                                                 const int * psel = nullptr, const double * vbase = nullptr, int ldv = 0, int m = 0)
+                                                 const int * psel = nullptr, const double * vbase = nullptr, int ldv = 0, int m = 0,
+                                                 DSync ds = DSync{nullptr, nullptr, 0, 0, 0, 0})
 {
   extern __shared__ double sh[]; // vector (n) | tile (CT x (KT+1))
+  if(ds.sync)
+  {
+    if(ds.wait_sel) flag_wait(&ds.sync->sel_tag, ds.wait_sel, ds.mb);
+    if(ds.wait_chain) flag_wait(&ds.sync->chain_tag, ds.wait_chain, ds.mb);
+  }
+  bool live = true;
   if(psel)
   {
     const int p = psel[0];
-    if(p < 0 || p >= m) return; // none selected, or a bound (jrow_kernel)
-    v = vbase + (size_t)p * ldv;
-    sign = (psel[1] == UPPER) ? -1.0 : 1.0;
+    live = !(p < 0 || p >= m); // none selected, or a bound (jrow_kernel)
+    if(live)
+    {
+      v = vbase + (size_t)p * ldv;
+      sign = (psel[1] == UPPER) ? -1.0 : 1.0;
+    }
   }
-  double * vs = sh;
-  double * tile = sh + n;
-  const int lane = threadIdx.x;
-  for(int i = lane; i < n; i += 64) vs[i] = v[i];
-  const int col0 = blockIdx.x * CT;
-  const int nc = min(CT, ncols - col0);
-  double acc = tile_column_dot(M, ld, n, col0, nc, vs, tile, lane);
-  if(lane < nc) out[col0 + lane] = (sign < 0.0) ? -acc : acc;
+  if(live)
+  {
+    double * vs = sh;
+    double * tile = sh + n;
+    const int lane = threadIdx.x;
+    for(int i = lane; i < n; i += 64) vs[i] = v[i];
+    const int col0 = blockIdx.x * CT;
+    const int nc = min(CT, ncols - col0);
+    double acc = tile_column_dot(M, ld, n, col0, nc, vs, tile, lane);
+    if(lane < nc) out[col0 + lane] = (sign < 0.0) ? -acc : acc;
+  }
+  if(ds.sync && ds.post) flag_post(&ds.sync->d_cnt, &ds.sync->d_tag, ds.total, ds.post);
 }
 
 // bound constraint: d = +-row pb of J
-__global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb, double sign, double * out, const int * psel = nullptr, int m = 0)
+__global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb, double sign, double * out, const int * psel = nullptr, int m = 0,
+                            DSync ds = DSync{nullptr, nullptr, 0, 0, 0, 0})
 {
+  if(ds.sync)
+  {
+    if(ds.wait_sel) flag_wait(&ds.sync->sel_tag, ds.wait_sel, ds.mb);
+    if(ds.wait_chain) flag_wait(&ds.sync->chain_tag, ds.wait_chain, ds.mb);
+  }
+  bool live = true;
   if(psel)
   {
     const int p = psel[0];
-    if(p < m) return; // none selected, or a general constraint (jtn_kernel)
+    live = !(p < m); // none selected, or a general constraint (jtn_kernel)
     pb = p - m;
     sign = (psel[1] == UPPER_BOUND) ? -1.0 : 1.0;
   }
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if(j < n)
+  if(live && j < n)
   {
     double v = AT(J, ld, pb, j);
     out[j] = (sign < 0.0) ? -v : v;
   }
+  if(ds.sync && ds.post) flag_post(&ds.sync->d_cnt, &ds.sync->d_tag, ds.total, ds.post);
 }
 
 // K4 partial: per CT constraints the first-index arg-min of min(c.x - bl, bu - c.x) below 0
 __global__ __launch_bounds__(64) void select_partial_kernel(const double * __restrict__ C, int ldc, int n, int m, const double * __restrict__ x,
                                                             const double * __restrict__ bl, const double * __restrict__ bu,
-                                                            const unsigned char * __restrict__ st, int excl, double * pval, int * pidx, int * pstat)
+                                                            const unsigned char * __restrict__ st, int excl, double * pval, int * pidx, int * pstat,
+                                                            const PassSync * sync = nullptr, int wait_x = 0, Mailbox * mb = nullptr)
 {
   extern __shared__ double sh[];
+  if(sync && wait_x) flag_wait(&sync->x_tag, wait_x, mb); // x of this pass comes from `advance` on another stream
   double * vs = sh;
   double * tile = sh + n;
   const int lane = threadIdx.x;
@@ -594,8 +666,9 @@ __global__ __launch_bounds__(64) void select_partial_kernel(const double * __res
 __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const double * pval, const int * pidx, const int * pstat, int m, int nb,
                                                           const double * __restrict__ x, const double * __restrict__ xl,
                                                           const double * __restrict__ xu, const unsigned char * __restrict__ st, int excl, Mailbox * mb,
-                                                          int * psel, double * uq = nullptr)
+                                                          int * psel, double * uq = nullptr, PassSync * sync = nullptr, int wait_x = 0, int post_sel = 0)
 {
+  if(sync && wait_x) flag_wait(&sync->x_tag, wait_x, mb); // (m == 0: no partial kernel ran ahead of this one)
   if(uq && threadIdx.x == 0) *uq = 0.0; // u[q] = 0 for the constraint about to be selected (DualSolver.cpp:121)
   __shared__ double sv[4];
   __shared__ int si[4], ss[4];
@@ -660,6 +733,7 @@ __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const dou
     psel[0] = (ix == NONE) ? -1 : ix; // device copy: the step kernels of this pass read it without a host round trip
     psel[1] = sx;
   }
+  if(sync && post_sel) flag_post(nullptr, &sync->sel_tag, 1, post_sel);
 }
 
 // K6  z = J2 d2.  A workgroup (one wave) owns 16 rows; all 64 lanes load (lane = (column offset, row): 4 columns x 16
@@ -959,12 +1033,14 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
 }
 
 // K9  x += t z ; u[0:q] -= t r ; u[q] += t
-__global__ void advance_kernel(int n, int q, double t, int primal, const double * __restrict__ z, double * x, const double * __restrict__ r, double * u)
+__global__ void advance_kernel(int n, int q, double t, int primal, const double * __restrict__ z, double * x, const double * __restrict__ r, double * u,
+                               PassSync * sync = nullptr, int post_x = 0)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if(primal && i < n) x[i] = FMA(t, z[i], x[i]);
   if(i < q) u[i] = FMA(-t, r[i], u[i]);
   if(i == q) u[q] = u[q] + t;
+  if(sync && post_x) flag_post(&sync->x_cnt, &sync->x_tag, gridDim.x, post_x);
 }
 
 // K10 part 1 (one wave): the Givens coefficient recurrence on d (i = n-2 .. q), then all (c_i, s_i) in parallel.  Reads d
@@ -974,9 +1050,11 @@ __global__ void advance_kernel(int n, int q, double t, int primal, const double 
 // step instead of 26), systolically in blocks of 64 steps -- lane j owns step hi - j, its radius moves one lane up per
 // sweep (DPP), lane 0 is fed the radius the previous block ended on.  The second pass, which recomputes every rotation
 // from (d_i, r_{i+1}) with the plain formula anyway, compares the radii; any difference reruns the plain recurrence.
-__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const double * d, double * cc, double * ss, double * rfin, int seeded)
+__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const double * d, double * cc, double * ss, double * rfin, int seeded,
+                                                       PassSync * sync = nullptr, int tag = 0, Mailbox * mb = nullptr)
 {
   extern __shared__ double sm[]; // d (n) | rho (n + 1) | suffix sums of d^2 (n + 1, seeded only)
+  if(sync && tag) flag_wait(&sync->d_tag, tag, mb); // launched beside jtn on another stream: d of THIS pass
   double * dsm = sm;
   double * rho = sm + n;
   double * ssq = rho + (n + 1);
@@ -1057,12 +1135,14 @@ __global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const doubl
     wave_sync();
   }
   if(lane == 0) *rfin = r;
+  if(sync && tag) flag_post(nullptr, &sync->chain_tag, 1, tag);
 }
 
 // K10 part 1b: R(:, q) = d(0:q) with the new diagonal; status byte of the activated constraint (GoldfarbIdnaniSolver.cpp:233)
 __global__ __launch_bounds__(256) void add_commit_kernel(int q, const double * d, const double * rfin, double * R, int ld, unsigned char * st, int p,
-                                                         int pstat)
+                                                         int pstat, const PassSync * sync = nullptr, int wait_chain = 0, Mailbox * mb = nullptr)
 {
+  if(sync && wait_chain) flag_wait(&sync->chain_tag, wait_chain, mb); // rfin comes from the chain on the side stream
   const int k = blockIdx.x * 256 + threadIdx.x;
   if(k < q) AT(R, ld, k, q) = d[k];
   if(k == q)
@@ -1244,12 +1324,16 @@ struct CommitArgs
   double * R;
   unsigned char * st;
   int q, ld, p, pstat;
+  const PassSync * sync; // wait_chain != 0: (c_i, s_i) and rfin come from the chain on the side stream (PassSync::chain_tag)
+  int wait_chain;
+  Mailbox * mb;
 };
 
 __global__ __launch_bounds__(128) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
-                                                        const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0})
+                                                        const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr})
 {
   extern __shared__ double rsm[]; // two chunk buffers | (c_i, s_i) pairs (T)
+  if(cm.sync && cm.wait_chain) flag_wait(&cm.sync->chain_tag, cm.wait_chain, cm.mb);
   if(cm.d && blockIdx.x == 0)
   {
     for(int k = threadIdx.x; k < cm.q; k += 128) AT(cm.R, cm.ld, k, cm.q) = cm.d[k];
@@ -1696,49 +1780,53 @@ hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double *
   return hipGetLastError();
 }
 
-hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u)
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u, int wait_x_tag, int post_sel_tag)
 {
   const int parts = (v.m + CT - 1) / CT;
   if(parts > 0)
     hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * (v.n + CT * (KT + 1)), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
-                       excl, s.pval, s.pidx, s.pstat);
+                       excl, s.pval, s.pidx, s.pstat, s.sync, wait_x_tag, s.mb);
   hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb, s.psel,
-                     zero_u >= 0 ? s.u + zero_u : nullptr);
+                     zero_u >= 0 ? s.u + zero_u : nullptr, s.sync, parts > 0 ? 0 : wait_x_tag, post_sel_tag);
   return hipGetLastError();
 }
 
-hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st, hipStream_t spec,
-                      hipEvent_t ev_d, hipEvent_t ev_chain, int tag)
+hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st, hipStream_t spec, int tag,
+                      int wait_sel_tag, int wait_chain_tag)
 {
   const int n = v.n;
   const bool dev_p = (p == kSelOnDevice); // (p, status) are read from s.psel by the kernels
   const double sign = (pstat == UPPER || pstat == UPPER_BOUND) ? -1.0 : 1.0;
   const double * cp = nullptr;
+  const bool chain = spec && q < n;
+  const int jt_wgs = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;
   if(dev_p)
   {
+    // (with general constraints AND bounds both kernels run -- each returns at once unless the selection is of its kind -- and both
+    // arrive at the d counter; the second one is behind the first in the stream: it has nothing left to wait for)
+    DSync ds{s.sync, s.mb, wait_sel_tag, wait_chain_tag, chain ? tag : 0, (v.m > 0 ? jt_wgs : 0) + (v.nb > 0 ? jr_wgs : 0)};
     if(v.m > 0)
-      hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C,
-                         v.ldc, v.m);
-    if(v.nb > 0) hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, 0, 1.0, s.d, s.psel, v.m);
+    {
+      hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc, v.m, ds);
+      ds.wait_sel = ds.wait_chain = 0;
+    }
+    if(v.nb > 0) hipLaunchKernelGGL(jrow_kernel, dim3(jr_wgs), dim3(256), 0, st, s.J, n, n, 0, 1.0, s.d, s.psel, v.m, ds);
   }
   else if(p < v.m)
   {
     cp = v.C + (size_t)p * v.ldc;
-    hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0);
+    hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
+                       DSync{s.sync, s.mb, 0, wait_chain_tag, chain ? tag : 0, jt_wgs});
   }
   else
-    hipLaunchKernelGGL(jrow_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d, nullptr, 0);
-  if(spec && q < n)
+    hipLaunchKernelGGL(jrow_kernel, dim3(jr_wgs), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d, nullptr, 0,
+                       DSync{s.sync, s.mb, 0, wait_chain_tag, chain ? tag : 0, jr_wgs});
+  if(chain)
   {
-    // d is all the coefficient recurrence needs: it starts now, beside z, r and the ratio test
-    hipError_t e = hipEventRecord(ev_d, st);
-    if(e == hipSuccess) e = hipStreamWaitEvent(spec, ev_d, 0);
+    // d is all the coefficient recurrence needs: it is enqueued now, on its own stream, and starts when d_tag says d is complete
+    hipError_t e = chain_attr(n);
     if(e != hipSuccess) return e;
-    if(e == hipSuccess) e = chain_attr(n);
-    if(e != hipSuccess) return e;
-    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
-    e = hipEventRecord(ev_chain, spec);
-    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n), s.sync, tag, s.mb);
   }
   hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
   {
@@ -1754,26 +1842,21 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   return hipGetLastError();
 }
 
-hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st)
+hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st, int post_x_tag)
 {
   const int cnt = (v.n > q + 1) ? v.n : (q + 1);
-  hipLaunchKernelGGL(advance_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, v.n, q, t, primal ? 1 : 0, s.z, s.x, s.r, s.u);
+  hipLaunchKernelGGL(advance_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, v.n, q, t, primal ? 1 : 0, s.z, s.x, s.r, s.u, s.sync, post_x_tag);
   return hipGetLastError();
 }
 
-hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, bool chain_ready, hipEvent_t ev_chain)
+hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, int wait_chain_tag)
 {
   const int n = v.n;
-  if(chain_ready)
-  {
-    hipError_t e = hipStreamWaitEvent(st, ev_chain, 0);
-    if(e != hipSuccess) return e;
-  }
-  else
+  if(!wait_chain_tag)
   {
     hipError_t e = chain_attr(n);
     if(e != hipSuccess) return e;
-    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n));
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n), nullptr, 0, nullptr);
   }
   {
     hipError_t e = rot_attr(n);
@@ -1781,9 +1864,9 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
   }
   if(n - 2 >= q)
     hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
-                       CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat});
+                       CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat, s.sync, wait_chain_tag, s.mb});
   else // q = n - 1: nothing to rotate
-    hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat);
+    hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat, s.sync, wait_chain_tag, s.mb);
   return hipGetLastError();
 }
 

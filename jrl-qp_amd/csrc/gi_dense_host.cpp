@@ -37,8 +37,7 @@ struct jrlqp_dense
   int last_hip = 0;
   hipStream_t side = nullptr;          // runs the next pass's constraint scan beside the Givens sweep
   hipStream_t spec = nullptr;          // runs the coefficient chain of an addition ahead of the add/drop decision
-  hipEvent_t ev_x = nullptr, ev_sel = nullptr, ev_d = nullptr, ev_chain = nullptr;
-  bool chain_pending = false;          // a chain launched on `spec` has not been waited for by the main stream yet
+  int chain_pending = 0;               // tag of a chain launched on `spec` that no kernel of the main stream has waited for yet (0: none)
   int tag = 0;                         // pass counter: the step kernel echoes it into the mailbox when its scalars are out
 };
 
@@ -122,10 +121,8 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&s.mb), h->h_mb, 0);
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->spec, hipStreamNonBlocking);
-  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_d, hipEventDisableTiming);
-  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming);
-  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming);
-  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming);
+  if(e == hipSuccess) e = dmalloc(s.sync, 1);
+  if(e == hipSuccess) e = hipMemset(s.sync, 0, sizeof(PassSync));
   if(e != hipSuccess)
   {
     jrlqp_dense_destroy(h);
@@ -155,10 +152,7 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   if(h->h_mb) (void)hipHostFree(h->h_mb);
   if(h->side) (void)hipStreamDestroy(h->side);
   if(h->spec) (void)hipStreamDestroy(h->spec);
-  if(h->ev_d) (void)hipEventDestroy(h->ev_d);
-  if(h->ev_chain) (void)hipEventDestroy(h->ev_chain);
-  if(h->ev_x) (void)hipEventDestroy(h->ev_x);
-  if(h->ev_sel) (void)hipEventDestroy(h->ev_sel);
+  (void)hipFree(s.sync);
   delete h;
 }
 
@@ -309,11 +303,12 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
 
   h->it = 0;
   h->term = JRLQP_UNKNOWN;
-  if(h->chain_pending) // a discarded chain of the previous solve may still be reading d
+  if(h->chain_pending) // a discarded chain of the previous solve may still be reading d (it ended long ago: this returns at once)
   {
-    TRY(hipStreamWaitEvent(st, h->ev_chain, 0));
-    h->chain_pending = false;
+    TRY(hipStreamSynchronize(h->spec));
+    h->chain_pending = 0;
   }
+  h->h_mb->sync_err = 0;
   auto finish = [&](int term) {
     h->term = term;
     if(term_out) *term_out = term;
@@ -502,11 +497,13 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
     if(timing && t_mark > 0) t_rest += now() - t_mark;
     // ONE host round trip per pass: the selection (on the side stream beside the previous sweep, or here) leaves
     // (p, status) on the device, the step kernels read it there, and the host sees p together with the step's scalars
+    const int tag = ++h->tag;
+    int wait_sel = 0;
     if(!skip)
     {
       if(prefetched)
       {
-        TRY(hipStreamWaitEvent(st, h->ev_sel, 0));
+        wait_sel = tag; // the first kernel of the step waits for the side stream's selection (PassSync::sel_tag)
         prefetched = false;
       }
       else
@@ -517,17 +514,11 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
     {
       // computeStep_ with the coefficient chain of a possible addition started on the side as soon as d exists: most
       // passes add, and the chain (n - q dependent radius steps) is as long as z, r and the ratio test together.  A
-      // chain that is still reading d must have ended before d is overwritten: the main stream waits for it here.
-      if(h->chain_pending)
-      {
-        TRY(hipStreamWaitEvent(st, h->ev_chain, 0));
-        h->chain_pending = false;
-      }
+      // chain that is still reading d must have ended before d is overwritten: the kernel that writes d waits for its tag.
       const bool spec = q < n;
-      const int tag = ++h->tag;
       const double ta = timing ? now() : 0;
-      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, h->ev_d, h->ev_chain, tag));
-      h->chain_pending = spec;
+      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, h->chain_pending));
+      h->chain_pending = spec ? tag : 0;
       const double tb = timing ? now() : 0;
       if(!wait_tag(h->h_mb, tag)) TRY(hipStreamSynchronize(st));
       if(timing)
@@ -538,6 +529,11 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
         t_mark = tc; // (the rest of the pass is closed at the top of the next one)
       }
       const Mailbox & mb = *h->h_mb;
+      if(mb.sync_err) // a device-side wait between the streams gave up (gi_dense.h, PassSync): nothing of this solve can be trusted
+      {
+        h->last_hip = (int)hipErrorLaunchTimeOut;
+        return JRLQP_ERR_HIP;
+      }
       if(!skip)
       {
         p = mb.p;
@@ -563,8 +559,9 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
     }
     else
     {
-      rc = jrlqp_dense_advance(h, t, q, 1, stream);
-      if(rc != JRLQP_OK) return rc;
+      const bool more = h->it + 1 < o.max_iter;
+      const bool prefetch = (t == t2) && more;
+      TRY(dense_advance(h->v, h->s, t, q, true, st, prefetch ? tag : 0)); // (x_tag: the side stream's scan reads the new x)
       h->f = std::fma(t * dotsc, 0.5 * t + uq, h->f);
       if(t == t2)
       {
@@ -573,15 +570,11 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
         // activated is excluded explicitly because its status byte is written by the sweep's first kernel
         // (the sweep is on the critical path: it is enqueued first, the side-stream scan behind it -- every launch costs the
         // host a few microseconds)
-        const bool more = h->it + 1 < o.max_iter;
-        if(more) TRY(hipEventRecord(h->ev_x, st)); // x is final here: the event sits BEFORE the sweep in the main stream
-        TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending, h->ev_chain)); // commit: the chain ran ahead
-        h->chain_pending = false;
-        if(more)
+        TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending)); // commit: the chain ran ahead (the sweep waits for chain_tag)
+        h->chain_pending = 0;
+        if(prefetch)
         {
-          TRY(hipStreamWaitEvent(h->side, h->ev_x, 0));
-          TRY(dense_select(h->v, h->s, p, h->side, q + 1)); // (also u[q+1] = 0 for the next pass: a slot this pass does not touch)
-          TRY(hipEventRecord(h->ev_sel, h->side));
+          TRY(dense_select(h->v, h->s, p, h->side, q + 1, tag, tag + 1)); // (also u[q+1] = 0 for the next pass: a slot this pass does not touch)
           prefetched = true;
         }
         activate(p, pstat);
