@@ -31,7 +31,7 @@ struct PassSync
   int chain_tag;      // (c_i, s_i), the last radius        (add_chain -> rot_apply / add_commit; -> the next jtn after a drop)
   int x_cnt, x_tag;   // x, u advanced                      (advance -> the prefetched select)
   int sel_tag;        // psel = {p, status} of the NEXT pass (select_final -> jtn)
-  int pad[2];
+  int z_cnt, z_tag;   // z = J2 d2 is complete              (z_rows on the side stream -> the scalar products of step_tail)
 };
 
 // the caller's problem (device pointers; GoldfarbIdnaniSolver::Problem, GoldfarbIdnaniSolver.h:35-58)
@@ -75,9 +75,10 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
 // spec != nullptr: the Givens coefficient chain of an ADDITION is launched on `spec` at once and starts as soon as d exists
 // (PassSync::d_tag == tag), beside z / r / the ratio test on `st`; it publishes chain_tag = tag.  dense_add(..., wait_chain_tag = tag)
 // then only commits.  wait_sel_tag / wait_chain_tag != 0: the first kernel waits for the selection made on the side stream / for a
-// discarded chain of an earlier pass that may still be reading d.
+// discarded chain of an earlier pass that may still be reading d.  zside != nullptr (with a tag): z = J2 d2 runs on `zside`, beside the
+// back substitution on `st` (both need d only); the scalar products of the step wait for PassSync::z_tag.
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st,
-                      hipStream_t spec = nullptr, int tag = 0, int wait_sel_tag = 0, int wait_chain_tag = 0);
+                      hipStream_t spec = nullptr, int tag = 0, int wait_sel_tag = 0, int wait_chain_tag = 0, hipStream_t zside = nullptr);
 // post_x_tag != 0: publishes PassSync::x_tag = post_x_tag once x and u are advanced
 hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st, int post_x_tag = 0);
 // wait_chain_tag != 0: the chain already ran on the side (dense_step with spec); the sweep waits for its tag and commits

@@ -739,10 +739,12 @@ __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const dou
 // K6  z = J2 d2.  A workgroup (one wave) owns 16 rows; all 64 lanes load (lane = (column offset, row): 4 columns x 16
 // rows per instruction, 128 contiguous bytes per column), the 16 x 64 tile lands in LDS, lanes 0..15 run the
 // in-order chains over columns q .. n-1.
-__global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ J, int ld, int n, int q, const double * __restrict__ d, double * z)
+__global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ J, int ld, int n, int q, const double * __restrict__ d, double * z,
+                                                    PassSync * sync = nullptr, int wait_d = 0, int post_z = 0, Mailbox * mb = nullptr)
 {
   __shared__ double tile[64 * 17]; // [column in tile][row], padded
   __shared__ double dsm[64];
+  if(sync && wait_d) flag_wait(&sync->d_tag, wait_d, mb); // on its own stream, beside the substitution: d (and with it J) of this pass
   const int lane = threadIdx.x;
   const int r0 = blockIdx.x * 16;
   const int rr = lane & 15, cg = lane >> 4; // row in tile, column group
@@ -779,6 +781,7 @@ __global__ __launch_bounds__(64) void z_rows_kernel(const double * __restrict__ 
   for(int s = 0; s < NPRE; ++s)
     if(jb + s * 64 < n) consume(ring[s], dring[s], jb + s * 64);
   if(lane < 16 && r0 + lane < n) z[r0 + lane] = acc;
+  if(sync && post_z) flag_post(&sync->z_cnt, &sync->z_tag, gridDim.x, post_z);
 }
 
 // K7 + K8, two workgroups of 8 waves.
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
                                                         const double * __restrict__ u, const unsigned char * __restrict__ st, double big,
                                                         const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
                                                         int pb, Mailbox * mb, const int * psel = nullptr, const double * cbase = nullptr, int ldc = 0,
-                                                        int m = 0, int tag = 0)
+                                                        int m = 0, int tag = 0, const PassSync * zsync = nullptr, int wait_z = 0)
 {
   extern __shared__ double rs[]; // block 0: the running right-hand side (q) ; block 1: z | x | n+ (3 n)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -831,39 +834,12 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
     double * cl = rs + 2 * n;
     for(int i = tid; i < n; i += 512)
     {
-      zl[i] = z[i];
       xl[i] = x[i];
       cl[i] = cp ? cp[i] : 0.0;
     }
     __syncthreads();
-    // z.z and n+.z: C4 trees (CANON C5, oracle orc_dot_tree): element e joins chain e mod 1024, thread t owns chains 2t and
-    // 2t + 1 (ascending e), then the adjacent-first pairwise tree -- the two chains of a thread, the lanes of a wave
-    // (wave_sum_tree), the eight waves.  n+.x: the C1 chain (bit for bit the scan's value for the constraint), one lane of wave 1
-    // beside the trees.
-    double pz0 = 0.0, pz1 = 0.0, pc0 = 0.0, pc1 = 0.0;
-    for(int base = 0; base < n; base += 1024)
-    {
-      const int e0 = base + 2 * tid, e1 = e0 + 1;
-      if(e0 < n)
-      {
-        const double zv = zl[e0];
-        pz0 = FMA(zv, zv, pz0);
-        pc0 = FMA(cl[e0], zv, pc0);
-      }
-      if(e1 < n)
-      {
-        const double zv = zl[e1];
-        pz1 = FMA(zv, zv, pz1);
-        pc1 = FMA(cl[e1], zv, pc1);
-      }
-    }
-    const double sz = wave_sum_tree(pz0 + pz1), sc = wave_sum_tree(pc0 + pc1);
-    double * red = rs + 3 * n; // (inside the dynamic allocation: tail_lds; a static array on top of a raised dynamic limit does not fit)
-    if(lane == 0)
-    {
-      red[wave] = sz;
-      red[8 + wave] = sc;
-    }
+    // n+.x: the C1 chain (bit for bit the scan's value for the constraint), one lane of wave 1 -- it needs neither z nor r, and runs
+    // while z is still being computed (zsync: z_rows runs on another stream, beside the substitution of block 0)
     if(tid == 64)
     {
       double acc = 0.0;
@@ -887,6 +863,36 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
       else
         acc = xl[pb];
       mb->cx = acc;
+    }
+    if(zsync && wait_z) flag_wait(&zsync->z_tag, wait_z, mb);
+    for(int i = tid; i < n; i += 512) zl[i] = z[i];
+    __syncthreads();
+    // z.z and n+.z: C4 trees (CANON C5, oracle orc_dot_tree): element e joins chain e mod 1024, thread t owns chains 2t and
+    // 2t + 1 (ascending e), then the adjacent-first pairwise tree -- the two chains of a thread, the lanes of a wave
+    // (wave_sum_tree), the eight waves.
+    double pz0 = 0.0, pz1 = 0.0, pc0 = 0.0, pc1 = 0.0;
+    for(int base = 0; base < n; base += 1024)
+    {
+      const int e0 = base + 2 * tid, e1 = e0 + 1;
+      if(e0 < n)
+      {
+        const double zv = zl[e0];
+        pz0 = FMA(zv, zv, pz0);
+        pc0 = FMA(cl[e0], zv, pc0);
+      }
+      if(e1 < n)
+      {
+        const double zv = zl[e1];
+        pz1 = FMA(zv, zv, pz1);
+        pc1 = FMA(cl[e1], zv, pc1);
+      }
+    }
+    const double sz = wave_sum_tree(pz0 + pz1), sc = wave_sum_tree(pc0 + pc1);
+    double * red = rs + 3 * n; // (inside the dynamic allocation: tail_lds; a static array on top of a raised dynamic limit does not fit)
+    if(lane == 0)
+    {
+      red[wave] = sz;
+      red[8 + wave] = sc;
     }
     __syncthreads();
     if(tid == 0)
@@ -1792,19 +1798,21 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
 }
 
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st, hipStream_t spec, int tag,
-                      int wait_sel_tag, int wait_chain_tag)
+                      int wait_sel_tag, int wait_chain_tag, hipStream_t zside)
 {
   const int n = v.n;
   const bool dev_p = (p == kSelOnDevice); // (p, status) are read from s.psel by the kernels
   const double sign = (pstat == UPPER || pstat == UPPER_BOUND) ? -1.0 : 1.0;
   const double * cp = nullptr;
   const bool chain = spec && q < n;
+  const bool zs = zside && tag;            // z = J2 d2 on its own stream, beside the substitution (both only need d)
+  const int dpost = (chain || zs) ? tag : 0; // d_tag is published for whoever runs beside the main stream
   const int jt_wgs = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;
   if(dev_p)
   {
     // (with general constraints AND bounds both kernels run -- each returns at once unless the selection is of its kind -- and both
     // arrive at the d counter; the second one is behind the first in the stream: it has nothing left to wait for)
-    DSync ds{s.sync, s.mb, wait_sel_tag, wait_chain_tag, chain ? tag : 0, (v.m > 0 ? jt_wgs : 0) + (v.nb > 0 ? jr_wgs : 0)};
+    DSync ds{s.sync, s.mb, wait_sel_tag, wait_chain_tag, dpost, (v.m > 0 ? jt_wgs : 0) + (v.nb > 0 ? jr_wgs : 0)};
     if(v.m > 0)
     {
       hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc, v.m, ds);
@@ -1816,11 +1824,11 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   {
     cp = v.C + (size_t)p * v.ldc;
     hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
-                       DSync{s.sync, s.mb, 0, wait_chain_tag, chain ? tag : 0, jt_wgs});
+                       DSync{s.sync, s.mb, 0, wait_chain_tag, dpost, jt_wgs});
   }
   else
     hipLaunchKernelGGL(jrow_kernel, dim3(jr_wgs), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d, nullptr, 0,
-                       DSync{s.sync, s.mb, 0, wait_chain_tag, chain ? tag : 0, jr_wgs});
+                       DSync{s.sync, s.mb, 0, wait_chain_tag, dpost, jr_wgs});
   if(chain)
   {
     // d is all the coefficient recurrence needs: it is enqueued now, on its own stream, and starts when d_tag says d is complete
@@ -1828,17 +1836,20 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     if(e != hipSuccess) return e;
     hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n), s.sync, tag, s.mb);
   }
-  hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
+  if(zs)
+    hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, zside, s.J, n, n, q, s.d, s.z, s.sync, tag, tag, s.mb);
+  else
+    hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
   {
     hipError_t e = tail_attr(n);
     if(e != hipSuccess) return e;
   }
   if(dev_p)
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
-                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag);
+                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag, s.sync, zs ? tag : 0);
   else
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
-                       p - v.m, s.mb, nullptr, nullptr, 0, 0, tag);
+                       p - v.m, s.mb, nullptr, nullptr, 0, 0, tag, s.sync, zs ? tag : 0);
   return hipGetLastError();
 }
 

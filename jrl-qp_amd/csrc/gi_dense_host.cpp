@@ -517,7 +517,7 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
       // chain that is still reading d must have ended before d is overwritten: the kernel that writes d waits for its tag.
       const bool spec = q < n;
       const double ta = timing ? now() : 0;
-      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, h->chain_pending));
+      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, h->chain_pending, h->side));
       h->chain_pending = spec ? tag : 0;
       const double tb = timing ? now() : 0;
       if(!wait_tag(h->h_mb, tag)) TRY(hipStreamSynchronize(st));
