@@ -1158,24 +1158,30 @@ __global__ __launch_bounds__(256) void add_commit_kernel(int q, const double * d
   }
 }
 
-// K10 part 2 / K11 part 2: apply the rotation sequence to the columns of J, one workgroup of TWO waves per 64 rows.
+// K10 part 2 / K11 part 2: apply the rotation sequence to the columns of J, one workgroup of THREE waves per 64 rows.
 //   descending (add):   i = i_hi .. i_lo, columns (i, i+1), carry = column i+1
 //   ascending (remove): i = i_lo .. i_hi, columns (i, i+1), carry = column i
 // A row's sweep is one carry chain (two dependent ops per rotation); the point of this kernel is that the chain never
-// waits for memory.  gfx9 counts loads AND stores in one in-order counter (vmcnt): a wave that streams a row in and
-// out waits, for every group of loads, for the write acknowledgements of the stores issued before them -- the sweep
-// used to cost a full memory round trip per 16 rotations, however the loads were scheduled (deeper rings and double
-// buffers were measured slower).  So the two directions of the stream get a wave each:
-//   wave 0 loads (three chunks of 32 columns in flight in registers, clamped addresses, no branch in the steady state:
-//          its vmcnt only ever counts loads), rotates, and leaves the rotated columns in an LDS buffer;
-//   wave 1 copies the buffer of the previous chunk to memory while wave 0 rotates the next one (its vmcnt only counts
-//          stores, which nobody waits for).
-// One LDS-only barrier per chunk; (c_i, s_i) of the whole sweep are staged in LDS once.
-constexpr int RC = 32;      // columns per chunk
-constexpr int RLD = 65;     // leading dimension of a chunk buffer (lane = row: conflict-free)
+// waits for memory.  gfx9 counts loads AND stores in one in-order counter (vmcnt), and a wave that keeps three chunks of
+// columns in flight in registers has none left for the (c, s) pairs -- hipcc then parks a chunk in AGPRs at the top of the
+// steady loop behind an s_waitcnt vmcnt(0), i.e. every load in flight is waited for once per pass (round 2: 36 us per sweep of
+// 870 rotations, of which ~10 us are the chain).  So each direction of the stream, and the chain, get a wave of their own:
+//   wave 2 (loader)  streams the columns into LDS with LDS-direct loads (global_load_lds_dwordx4: no registers, 1 KiB = two
+//                    columns of 64 rows per instruction), up to three chunks of 32 columns in flight in a ring of four slots;
+//                    it alone waits for vmcnt, with the constant that lets the NEXT chunk land;
+//   wave 0 (chain)   reads column values and (c, s) pairs out of LDS eight columns ahead of the rotations, rotates, and leaves the
+//                    rotated columns in one of two LDS buffers -- it never has a memory operation outstanding in the loop;
+//   wave 1 (storer)  copies the buffer of the previous chunk to memory while wave 0 rotates the next one (its vmcnt only counts
+//                    stores, which nobody waits for).
+// One LDS-only barrier per chunk for all three; (c_i, s_i) of the whole sweep are staged in LDS once.
+constexpr int RC = 32;          // columns per chunk
+constexpr int RSLOTS = 4;       // ring of chunk slots the loader fills (64 rows x RC columns each, column after column)
+constexpr int RSLOT = RC * 64;  // doubles per slot
+constexpr int RCB = 8;          // columns whose operands the chain wave requests per batch
+constexpr int ROT_THREADS = 192;
 
 template<bool DESC, bool FULL>
-__device__ __forceinline__ void rot_chunk(double (&x)[RC], double & carry, const double2 * csl, int t0, int T, double * obuf, int lane)
+__device__ __forceinline__ void rot_chunk(const double * xs, double & carry, const double2 * csl, int t0, int T, double * obuf, int lane)
 {
   // rotation number t = t0 + u; its (c, s) pair sits at index (DESC ? T-1-t : t) of the staged array: for a full chunk
   // that is one base address and immediate offsets
@@ -1185,117 +1191,130 @@ __device__ __forceinline__ void rot_chunk(double (&x)[RC], double & carry, const
     const int t = min(t0 + u, T - 1);
     return csl[DESC ? (T - 1 - t) : t];
   };
-  // the pairs are requested 16 at a time, the second half before the first half's rotations (scheduling barriers: left
+  // operands are requested RCB columns at a time, one batch ahead of the rotations that use them (scheduling barriers: left
   // alone, hipcc requests each pair two rotations ahead and the chain waits for LDS at every step)
-  constexpr int H = RC / 2;
-  double2 cs0[H], cs1[H];
+  double2 csb[2][RCB];
+  double xb[2][RCB];
 #pragma unroll
-  for(int u = 0; u < H; ++u) cs0[u] = csat(u);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for(int u = 0; u < H; ++u) cs1[u] = csat(H + u);
+  for(int u = 0; u < RCB; ++u)
+  {
+    csb[0][u] = csat(u);
+    xb[0][u] = xs[u * 64 + lane];
+  }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for(int u = 0; u < RC; ++u)
   {
-    const double c = (u < H) ? cs0[u % H].x : cs1[u % H].x, sn = (u < H) ? cs0[u % H].y : cs1[u % H].y;
+    if(u % RCB == 0 && u + RCB < RC)
+    {
+#pragma unroll
+      for(int w = 0; w < RCB; ++w)
+      {
+        csb[((u / RCB) + 1) & 1][w] = csat(u + RCB + w);
+        xb[((u / RCB) + 1) & 1][w] = xs[(u + RCB + w) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const double c = csb[(u / RCB) & 1][u % RCB].x, sn = csb[(u / RCB) & 1][u % RCB].y, xv = xb[(u / RCB) & 1][u % RCB];
     double out, nc;
     if(DESC)
     {
-      out = FMA(sn, x[u], c * carry);
-      nc = FMA(c, x[u], -(sn * carry));
+      out = FMA(sn, xv, c * carry);
+      nc = FMA(c, xv, -(sn * carry));
     }
     else
     {
-      out = FMA(c, carry, -(sn * x[u]));
-      nc = FMA(sn, carry, c * x[u]);
+      out = FMA(c, carry, -(sn * xv));
+      nc = FMA(sn, carry, c * xv);
     }
-    obuf[u * RLD + lane] = out;
+    obuf[u * 64 + lane] = out;
     carry = (FULL || t0 + u < T) ? nc : carry;
   }
 }
 
 template<bool DESC>
-__device__ __forceinline__ void rot_sweep(double * J, int ld, int n, int row0, int i_lo, int i_hi, const double2 * csl, double * lbuf)
+__device__ __forceinline__ void rot_sweep(double * J, int ld, int n, int row0, int i_lo, int i_hi, const double2 * csl, double * slots, double * obufs)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = i_hi - i_lo + 1;
   const int nchunk = (T + RC - 1) / RC, nfull = T / RC;
   const int row = min(row0 + lane, n - 1);
-  // rotation t consumes column fcol(t) and produces column wcol(t); consecutive rotations are one column apart:
-  // pointers step by +-ld, no per-access address arithmetic
+  // rotation t consumes column fcol(t) and produces column wcol(t); consecutive rotations are one column apart
   auto fcol = [&](int t) { return DESC ? i_hi - t : i_lo + t + 1; };
   auto wcol = [&](int t) { return DESC ? i_hi - t + 1 : i_lo + t; };
   const ptrdiff_t cstep = DESC ? -(ptrdiff_t)ld : (ptrdiff_t)ld;
-  if(wave == 0)
+  // Every wave passes the same nchunk + 1 barriers B_0 .. B_nchunk.  Chunk k is in its slot before B_k (loader), rotated between
+  // B_k and B_k+1 (chain), stored after B_k+1 (storer); slot (k + 3) mod 4 -- last read for chunk k - 1 -- is refilled after B_k.
+  if(wave == 2)
   {
-    double carry = DESC ? AT(J, ld, row, i_hi + 1) : AT(J, ld, row, i_lo);
-    double ring[3][RC];
-    auto gload = [&](double (&dst)[RC], int k) {
-      if(k < nfull) // (uniform) a full chunk: one pointer, stepped
+    // lane l fetches rows 2 (l mod 32), + 1 of column 2 i + (l div 32) of the chunk: 16 bytes; instruction i lands as 1 KiB at
+    // slot + 2 i columns.  Rows past n are fetched from the block's first row pair instead (never used); the last pair of an odd
+    // n reads one double past its column (the next column's first row; past the LAST column that is the slack J is allocated with).
+    const int pr = 2 * (lane & 31), half = lane >> 5;
+    const int lrow = (row0 + pr < n) ? row0 + pr : row0;
+    auto issue = [&](int k) {
+      double * slot = slots + (k % RSLOTS) * RSLOT;
+      if(k < nfull)
       {
-        const double * p = &AT(J, ld, row, fcol(k * RC));
+        const double * p = &AT(J, ld, lrow, fcol(k * RC + half));
 #pragma unroll
-        for(int u = 0; u < RC; ++u)
+        for(int i = 0; i < RC / 2; ++i)
         {
-          dst[u] = *p;
-          p += cstep;
+          __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)(slot + i * 128), 16, 0, 0);
+          p += 2 * cstep;
         }
       }
       else
       {
 #pragma unroll
-        for(int u = 0; u < RC; ++u) dst[u] = AT(J, ld, row, fcol(min(k * RC + u, T - 1)));
+        for(int i = 0; i < RC / 2; ++i)
+        {
+          const double * p = &AT(J, ld, lrow, fcol(min(k * RC + 2 * i + half, T - 1)));
+          __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)(slot + i * 128), 16, 0, 0);
+        }
       }
     };
-#pragma unroll
-    for(int s3 = 0; s3 < 3; ++s3) gload(ring[s3], s3);
-    int k = 0;
-#pragma unroll 1
-    for(; k + 6 <= nfull; k += 3) // (three more FULL chunks exist beyond the three consumed here: the refill needs no clamp)
+    for(int k = 0; k < 3 && k < nchunk; ++k) issue(k);
+    for(int k = 0; k < nchunk; ++k)
     {
-#pragma unroll
-      for(int s3 = 0; s3 < 3; ++s3)
-      {
-        rot_chunk<DESC, true>(ring[s3], carry, csl, (k + s3) * RC, T, lbuf + ((k + s3) & 1) * (RC * RLD), lane);
-        const double * p = &AT(J, ld, row, fcol((k + s3 + 3) * RC));
-#pragma unroll
-        for(int u = 0; u < RC; ++u)
-        {
-          ring[s3][u] = *p;
-          p += cstep;
-        }
-        lds_barrier();
-      }
+      // chunk k has landed when at most the loads of the chunks behind it are outstanding (16 per chunk, in order)
+      if(k + 2 < nchunk)
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if(k + 1 < nchunk)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier(); // B_k
+      if(k + 3 < nchunk) issue(k + 3);
     }
-    // the rest: chunk by chunk, refills through the general (clamping) path
-    for(; k < nchunk; k += 3)
+    lds_barrier(); // B_nchunk
+  }
+  else if(wave == 0)
+  {
+    double carry = DESC ? AT(J, ld, row, i_hi + 1) : AT(J, ld, row, i_lo);
+    for(int k = 0; k < nchunk; ++k)
     {
-#pragma unroll
-      for(int s3 = 0; s3 < 3; ++s3)
-      {
-        if(k + s3 < nchunk)
-        {
-          if(k + s3 < nfull)
-            rot_chunk<DESC, true>(ring[s3], carry, csl, (k + s3) * RC, T, lbuf + ((k + s3) & 1) * (RC * RLD), lane);
-          else
-            rot_chunk<DESC, false>(ring[s3], carry, csl, (k + s3) * RC, T, lbuf + ((k + s3) & 1) * (RC * RLD), lane);
-          if(k + s3 + 3 < nchunk) gload(ring[s3], k + s3 + 3);
-          lds_barrier();
-        }
-      }
+      lds_barrier(); // B_k: chunk k is in its slot, the storer is done with the buffer of chunk k - 2
+      const double * xs = slots + (k % RSLOTS) * RSLOT;
+      double * ob = obufs + (k & 1) * RSLOT;
+      if(k < nfull)
+        rot_chunk<DESC, true>(xs, carry, csl, k * RC, T, ob, lane);
+      else
+        rot_chunk<DESC, false>(xs, carry, csl, k * RC, T, ob, lane);
     }
+    lds_barrier(); // B_nchunk
     if(row0 + lane < n) AT(J, ld, row, DESC ? i_lo : i_hi + 1) = carry;
   }
   else
   {
+    lds_barrier(); // B_0
     for(int k = 0; k < nchunk; ++k)
     {
-      lds_barrier(); // chunk k is in its buffer
-      const double * ib = lbuf + (k & 1) * (RC * RLD);
+      lds_barrier(); // B_k+1: chunk k is in its buffer
+      const double * ib = obufs + (k & 1) * RSLOT;
       double v[RC];
 #pragma unroll
-      for(int u = 0; u < RC; ++u) v[u] = ib[u * RLD + lane];
+      for(int u = 0; u < RC; ++u) v[u] = ib[u * 64 + lane];
       if(row0 + lane < n)
       {
         double * p = &AT(J, ld, row, wcol(k * RC));
@@ -1335,14 +1354,14 @@ struct CommitArgs
   Mailbox * mb;
 };
 
-__global__ __launch_bounds__(128) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
-                                                        const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr})
+__global__ __launch_bounds__(ROT_THREADS) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
+                                                                const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr})
 {
-  extern __shared__ double rsm[]; // two chunk buffers | (c_i, s_i) pairs (T)
+  extern __shared__ double rsm[]; // four chunk slots | two chunk buffers | (c_i, s_i) pairs (T)
   if(cm.sync && cm.wait_chain) flag_wait(&cm.sync->chain_tag, cm.wait_chain, cm.mb);
   if(cm.d && blockIdx.x == 0)
   {
-    for(int k = threadIdx.x; k < cm.q; k += 128) AT(cm.R, cm.ld, k, cm.q) = cm.d[k];
+    for(int k = threadIdx.x; k < cm.q; k += ROT_THREADS) AT(cm.R, cm.ld, k, cm.q) = cm.d[k];
     if(threadIdx.x == 0)
     {
       AT(cm.R, cm.ld, cm.q, cm.q) = *cm.rfin;
@@ -1351,14 +1370,15 @@ __global__ __launch_bounds__(128) void rot_apply_kernel(double * J, int ld, int 
   }
   if(i_hi < i_lo) return;
   const int T = i_hi - i_lo + 1;
-  double * lbuf = rsm;
-  double2 * csl = reinterpret_cast<double2 *>(rsm + 2 * RC * RLD);
-  for(int k = threadIdx.x; k < T; k += 128) csl[k] = make_double2(cc[i_lo + k], ss[i_lo + k]);
+  double * slots = rsm;
+  double * obufs = rsm + RSLOTS * RSLOT;
+  double2 * csl = reinterpret_cast<double2 *>(obufs + 2 * RSLOT);
+  for(int k = threadIdx.x; k < T; k += ROT_THREADS) csl[k] = make_double2(cc[i_lo + k], ss[i_lo + k]);
   __syncthreads();
   if(descending)
-    rot_sweep<true>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, lbuf);
+    rot_sweep<true>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, slots, obufs);
   else
-    rot_sweep<false>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, lbuf);
+    rot_sweep<false>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, slots, obufs);
 }
 
 // K11 part 1 (one workgroup; thread tid owns the NEW columns tid + u * blockDim.x, u < NC, of R): delete column l of R,
@@ -1692,7 +1712,7 @@ __global__ void warm_f_kernel(int n, int q, const double * __restrict__ beta, co
 // ============================================================================================================
 static size_t rot_lds(int T)
 {
-  return sizeof(double) * (size_t)(2 * RC * RLD + 2 * T);
+  return sizeof(double) * (size_t)((RSLOTS + 2) * RSLOT + 2 * T); // (T = 4095: 163 824 of the CU's 163 840 bytes)
 }
 static size_t tail_lds(int n, int q)
 {
@@ -1874,7 +1894,7 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
     if(e != hipSuccess) return e;
   }
   if(n - 2 >= q)
-    hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
+    hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(ROT_THREADS), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
                        CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat, s.sync, wait_chain_tag, s.mb});
   else // q = n - 1: nothing to rotate
     hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat, s.sync, wait_chain_tag, s.mb);
@@ -1896,7 +1916,7 @@ hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int 
     hipError_t e = rot_attr(n);
     if(e != hipSuccess) return e;
   }
-  if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(128), rot_lds(qn - l), st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
+  if(qn > l) hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(ROT_THREADS), rot_lds(qn - l), st, s.J, n, n, l, qn - 1, 0, s.cc, s.ss);
   return hipGetLastError();
 }
 

@@ -93,7 +93,7 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   h->cap_n = n; h->cap_m = m; h->cap_nb = nb;
   const size_t mt = (size_t)m + nb;
   DenseState & s = h->s;
-  hipError_t e = dmalloc(s.J, (size_t)n * n);
+  hipError_t e = dmalloc(s.J, (size_t)n * n + 2); // (+2: the sweep's 16-byte loads may read one double past the last column, gi_dense.hip rot_sweep)
   if(e == hipSuccess) e = dmalloc(s.R, (size_t)n * n);
   if(e == hipSuccess) e = dmalloc(s.d, n);
   if(e == hipSuccess) e = dmalloc(s.z, n);
