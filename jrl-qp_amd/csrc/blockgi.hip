@@ -512,7 +512,6 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
               snn = sp[ix];
             }
             const double y = on ? w[i0 + 1 + lane] : 0.0;
-            const double sy = sn * y;
             S[lane] = sn;
             B[lane] = c * y;
             wave_sync();
@@ -534,15 +533,16 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
                 xc = (j0 + u < cnt) ? nx : xc;
               }
             }
-            if(on) w[i0 + lane] = FMA(c, tin, -sy);
+            if(on) w[i0 + lane] = FMA(-sn, y, c * tin);
             wave_sync();
           }
           if(lane == 0) w[sz] = xc;
         }
         else
         {
-          // descending i: (w_i, w_i+1) <- (c w_i + s w_i+1, -s w_i + c w_i+1); carried: the new w_i.  Here a step is
-          // mul + fma on three operands: the systolic form is the faster one -- lane j owns rotation j, the carry
+          // descending i: (w_i, w_i+1) <- (c w_i + s w_i+1, -s w_i + c w_i+1); carried: the new w_i = fma(s, w_i+1, c w_i)
+          // (CANON C6: the product WITHOUT the carried operand is the rounded one, so a step is one fma on the carry -- c w_i is
+          // the lane's own constant).  The systolic form is the faster one -- lane j owns rotation j, the carry
           // travels lane to lane with one DPP wave shift per step, every lane recomputes its step each time and lane
           // j's result is final from step j on.  The chunk is aligned to the TOP lanes (rotation i1-1 on lane 63); the
           // entry lane's result is known up front and it is given coefficients that reproduce it whatever arrives.
@@ -570,15 +570,16 @@ __device__ __forceinline__ void q_apply(Ctx & K, double * v, int nseq, long long
             double cl = c, xl = xv, sl = sn;
             if(lane == 63)
             {
-              xl = FMA(c, xv, sn * yc);
+              xl = FMA(sn, yc, c * xv);
               cl = 1.0;
               sl = 0.0;
             }
+            const double pl = cl * xl;
             double out = 0.0, t = 0.0;
             for(int step = 0; step < cnt; ++step)
             {
               t = dpp_shift0_d<0x130>(out); // wave_shl:1 -- lane j takes lane j+1's carry
-              out = FMA(cl, xl, sl * t);
+              out = FMA(sl, t, pl);
             }
             t = (lane == 63) ? yc : t;
             if(on) w[i0 + j + 1] = FMA(-sn, xv, c * t);
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
                 if(valid)
                 {
                   const double y = RP(R, i + 1, k);
-                  const double xn = FMA(c, xc, -(s * y));
+                  const double xn = FMA(-s, y, c * xc);
                   xc = FMA(s, xc, c * y);
                   RP(R, i, k - 1) = xn;
                 }
@@ -1137,7 +1138,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
               else if(valid && lane > jj)
               {
                 const double y = RP(R, i + 1, k);
-                const double xn = FMA(c, xc, -(s * y));
+                const double xn = FMA(-s, y, c * xc);
                 xc = FMA(s, xc, c * y);
                 RP(R, i, k - 1) = xn;
               }

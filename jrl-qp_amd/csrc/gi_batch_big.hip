@@ -755,7 +755,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           for(int u = 0; u < 4; ++u)
           {
             J[tid + (long)(i - u + 1) * ld] = FMA(sv[u], xv[u], cv[u] * carry);
-            carry = FMA(cv[u], xv[u], -(sv[u] * carry));
+            carry = FMA(-sv[u], carry, cv[u] * xv[u]);
           }
         }
         for(; i >= q; --i)
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           const double xv = J[tid + (long)i * ld];
           const double c = ccs[i], s = sss[i];
           J[tid + (long)(i + 1) * ld] = FMA(s, xv, c * carry);
-          carry = FMA(c, xv, -(s * carry));
+          carry = FMA(-s, carry, c * xv);
         }
         if(n - 2 >= q) J[tid + (long)q * ld] = carry;
       }
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         if(tid < n)
         {
           const double xv = J[tid + (long)i * ld], yv = J[tid + (long)(i + 1) * ld];
-          J[tid + (long)i * ld] = FMA(c, xv, -(s * yv));
+          J[tid + (long)i * ld] = FMA(-s, yv, c * xv);
           J[tid + (long)(i + 1) * ld] = FMA(s, xv, c * yv);
         }
         if(tid >= 128) // (beyond n = 128 these threads have a row of J as well: one after the other)
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           for(int k = i + 2 + (tid - 128); k <= qn; k += 128)
           {
             const double xv = RP(i, k), yv = RP(i + 1, k);
-            RP(i, k) = FMA(c, xv, -(s * yv));
+            RP(i, k) = FMA(-s, yv, c * xv);
             RP(i + 1, k) = FMA(s, xv, c * yv);
           }
           if(tid == 128) RP(i, i) = ctl->gr;

@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         for(int u = 0; u < 4; ++u)
         {
           J[rl + (i - u + 1) * ld] = FMA(sv[u], xv[u], cv[u] * carry);
-          carry = FMA(cv[u], xv[u], -(sv[u] * carry));
+          carry = FMA(-sv[u], carry, cv[u] * xv[u]);
         }
       }
 #pragma unroll 1
@@ -1606,7 +1606,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         const double xv = J[rl + i * ld];
         const double c2 = zs[i], s2 = rs[i];
         J[rl + (i + 1) * ld] = FMA(s2, xv, c2 * carry);
-        carry = FMA(c2, xv, -(s2 * carry));
+        carry = FMA(-s2, carry, c2 * xv);
       }
       J[rl + qa * ld] = carry;
     };
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           R[i + i * ld] = rho;
         else if(lane > i && lane < qn)
         {
-          R[i + lane * ld] = FMA(c, carry, -(s * y));
+          R[i + lane * ld] = FMA(-s, y, c * carry);
           carry = FMA(s, carry, c * y);
         }
         y = ynext;
@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           cn = ds[i1];
           sn = zs[i1];
           ynext = J[lane + (i1 + 1) * ld];
-          J[lane + i * ld] = FMA(c, jc, -(s * yy));
+          J[lane + i * ld] = FMA(-s, yy, c * jc);
           jc = FMA(s, jc, c * yy);
         }
         J[lane + qn * ld] = jc;
@@ -2405,7 +2405,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
                     {
                       const int i = NR - 2 - AB * b - u;
                       J[rl + (i + 1) * ld] = FMA(sq2[u], xq[u], cq[u] * carry);
-                      carry = FMA(cq[u], xq[u], -(sq2[u] * carry));
+                      carry = FMA(-sq2[u], carry, cq[u] * xq[u]);
                     }
                   };
                   int inext = NR - 2;
@@ -2437,7 +2437,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
                     const double xv = J[rl + i * ld];
                     const double2 cs2 = *reinterpret_cast<const double2 *>(csb + 2 * i);
                     J[rl + (i + 1) * ld] = FMA(cs2.y, xv, cs2.x * carry);
-                    carry = FMA(cs2.x, xv, -(cs2.y * carry));
+                    carry = FMA(-cs2.y, carry, cs2.x * xv);
                   }
                 }
                 else
@@ -2447,7 +2447,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
                     const double xv = J[rl + i * ld];
                     const double c2 = csb[2 * i], s2 = csb[2 * i + 1];
                     J[rl + (i + 1) * ld] = FMA(s2, xv, c2 * carry);
-                    carry = FMA(c2, xv, -(s2 * carry));
+                    carry = FMA(-s2, carry, c2 * xv);
                   }
                 }
                 J[rl + qa * ld] = carry;

@@ -89,4 +89,5 @@ hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int 
 hipError_t dense_warm_factor(const DenseViews & v, DenseState & s, int q, hipStream_t st);
 // initializePrimalDualPoints: alpha = J^T a -> s.d, beta -> s.beta, x, u (q entries), f -> mailbox f0
 hipError_t dense_warm_point(const DenseViews & v, DenseState & s, int q, hipStream_t st);
+void dense_rot_profile_dump(); // diagnostic build (-DJRLQP_ROT_PROF) only: prints the sweep's time line to stderr; otherwise nothing
 } // namespace jrlqp

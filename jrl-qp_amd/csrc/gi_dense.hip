@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdio>
 
 #include "device_common.h"
 #include "gi_dense.h"
@@ -50,6 +51,15 @@ __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
   }
 }
 
+#ifdef JRLQP_ROT_PROF
+// diagnostic build only (EXTRA=-DJRLQP_ROT_PROF): where workgroup 0 of the sweep spends its time, in 10 ns ticks summed over launches
+__device__ unsigned long long g_rotprof[32];
+#define ROTP(slot, expr) do { if(blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_rotprof[slot], (unsigned long long)(expr)); } while(0)
+#define ROTT() wall_clock64()
+#else
+#define ROTP(slot, expr) do { (void)sizeof(expr); } while(0)
+#define ROTT() 0ull
+#endif
 // ---- pass hand-off tags (PassSync, gi_dense.h) -----------------------------------------------------------------------------
 // Whole workgroup.  The wait gives up after ~1 s (a producer that never ran: a dead stream), says so in the host-visible mailbox
 // and lets the kernel run on -- the host voids the solve; nothing spins for ever.
@@ -499,52 +509,98 @@ __global__ __launch_bounds__(512) void x0_kernel(const double * __restrict__ L, 
   }
 }
 
-constexpr int NPRE = 3; // tiles requested ahead of the one being consumed (one tile's chains last ~0.45 us, an L2 round trip ~1 us)
+constexpr int NPRE = 3; // z_rows: tiles requested ahead of the one being consumed (registers)
 
-__device__ __forceinline__ double tile_column_dot(const double * __restrict__ M, int ld, int n, int col0, int ncols, const double * vs, double * tile,
-                                                  int lane)
+// ---- column dots out of an LDS-direct tile stream (jtn: d = J^T n+; select_partial: C^T x) ------------------------------------
+// A workgroup of TWO waves owns CT = 16 columns of M and runs their in-order chains over the n rows, 64 rows (a tile) at a time:
+//   wave 1 (loader) streams the tiles into a ring of TS_NS LDS slots with global_load_lds_dwordx4 -- lane l fetches rows
+//          2 (l mod 32), + 1 of column 2 i + (l div 32): an instruction moves two columns x 64 rows = 1 KiB, eight instructions a
+//          tile, no registers -- up to TS_NS - 1 tiles ahead (round 2 kept three tiles in registers, two ahead: a tile's loads took
+//          ~1.7 us to come back, the chains of a tile last 0.4 us, and the wave waited 0.9 us per tile); it alone waits for vmcnt;
+//   wave 0 (chain)  lane c < 16 owns column c: one ds_read2_b64 fetches two rows of its column, the vector comes as broadcasts.
+// A slot is [column pair][column in pair][row]: 1 KiB per pair as the loads deliver it, pairs 16 bytes apart so that the sixteen
+// lanes of a step hit eight distinct bank groups (the two columns of a pair are 512 bytes apart: a two-way conflict, 2 cycles).
+// One LDS-only barrier per tile.  Rows past n (last tile) are fetched from clamped addresses and never used; with an odd n the
+// pair that starts at row n - 1 would read one double past its column -- possibly past the caller's buffer -- so it is fetched
+// from rows n - 2, n - 1 instead and the loader then writes element n - 1 of its sixteen columns in place itself.
+constexpr int TS_NS = 6;                 // slots
+constexpr int TS_PAIR = 128 + 2;         // doubles between the column pairs of a slot
+constexpr int TS_SLOT = (CT / 2) * TS_PAIR;
+constexpr int TILE_THREADS = 128;
+static_assert(8 * (TS_NS - 1) <= 63, "vmcnt");
+
+__device__ __forceinline__ void tile_loader(const double * __restrict__ M, size_t ld, int n, int col0, int ncols, double * slots, int lane)
 {
-  double acc = 0.0;
-  const int kk = lane; // row inside the tile this lane loads
-  // Software pipeline: the global loads of tiles t+1 .. t+NPRE are in flight while the chains consume tile t out of LDS.
-  // Addresses are CLAMPED instead of predicated and the steady-state loop has no branch: a predicated load sits in its
-  // own exec-mask region, and hipcc then waits with vmcnt(0) -- for EVERY tile in flight -- at each use (that, one L2
-  // round trip per tile, was 2/3 of this kernel's time).  Rows past n only feed chain steps that are never taken,
-  // columns past ncols only feed lanes whose result is dropped.
-  double ring[NPRE][CT];
-  const size_t cmax = (size_t)(col0 + ((ncols > 0) ? ncols - 1 : 0));
-  auto gload = [&](double (&dst)[CT], int k0) {
-    const int row = min(k0 + kk, n - 1);
+  const int ntiles = (n + KT - 1) / KT;
+  const int kp = lane & 31, half = lane >> 5;
+  const int cmax = col0 + ((ncols > 0) ? ncols - 1 : 0);
+  auto issue = [&](int t) {
+    if(n < 2) return; // (a single row: the odd-n path below fetches it; a 16-byte load could leave the caller's buffer)
+    double * slot = slots + (t % TS_NS) * TS_SLOT;
+    int row = t * KT + 2 * kp;
+    if(row + 1 >= n) row = n - 2; // past the end, or the pair that starts at the last row of an odd n (see above)
 #pragma unroll
-    for(int c = 0; c < CT; ++c) dst[c] = M[min((size_t)(col0 + c), cmax) * ld + row];
+    for(int i = 0; i < CT / 2; ++i)
+    {
+      const double * src = M + (size_t)min(col0 + 2 * i + half, cmax) * ld + row;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(slot + i * TS_PAIR), 16, 0, 0);
+    }
   };
-  auto consume = [&](double (&buf)[CT], int k0) {
-    const int cnt = min(KT, n - k0);
-    wave_sync();
-#pragma unroll
-    for(int c = 0; c < CT; ++c) tile[c * (KT + 1) + kk] = buf[c];
-    wave_sync();
-    gload(buf, k0 + NPRE * KT);
-    const double * tc = tile + min(lane, CT - 1) * (KT + 1);
-    const double nx = (cnt == KT) ? chain64<1, true>(acc, tc, vs + k0, cnt) : chain64<1, false>(acc, tc, vs + k0, cnt);
-    acc = (lane < ncols) ? nx : acc;
-  };
-#pragma unroll
-  for(int s = 0; s < NPRE; ++s) gload(ring[s], s * KT);
-  int kb = 0;
-  for(; kb + NPRE * KT <= n; kb += NPRE * KT)
+  for(int t = 0; t < TS_NS - 1 && t < ntiles; ++t) issue(t);
+  for(int t = 0; t < ntiles; ++t)
   {
-#pragma unroll
-    for(int s = 0; s < NPRE; ++s) consume(ring[s], kb + s * KT);
+    if(t + TS_NS - 2 < ntiles) // the TS_NS - 2 tiles behind tile t are all requested: tile t has landed once only they are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (TS_NS - 2)) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if((n & 1) && t == ntiles - 1 && lane < CT)
+    {
+      // odd n: element n - 1 of column `lane` (its pair was fetched one row low)
+      const double vlast = M[(size_t)min(col0 + lane, cmax) * ld + (n - 1)];
+      slots[(t % TS_NS) * TS_SLOT + (lane >> 1) * TS_PAIR + (lane & 1) * 64 + (n - 1 - t * KT)] = vlast;
+    }
+    lds_barrier(); // B_t
+    if(t + TS_NS - 1 < ntiles) issue(t + TS_NS - 1);
   }
-#pragma unroll
-  for(int s = 0; s < NPRE; ++s)
-    if(kb + s * KT < n) consume(ring[s], kb + s * KT);
+}
+
+// the chain wave's side: acc of lane c < 16 = in-order chain of column col0 + c against vs (n entries, LDS)
+__device__ __forceinline__ double tile_chain(int n, const double * vs, const double * slots, int lane)
+{
+  const int ntiles = (n + KT - 1) / KT;
+  const int c = min(lane, CT - 1);
+  const int coff = (c >> 1) * TS_PAIR + (c & 1) * 64;
+  double acc = 0.0;
+  for(int t = 0; t < ntiles; ++t)
+  {
+    lds_barrier(); // B_t: tile t is in its slot
+    const double * a = slots + (t % TS_NS) * TS_SLOT + coff;
+    const int k0 = t * KT, cnt = min(KT, n - k0);
+    acc = (cnt == KT) ? chain64<1, true>(acc, a, vs + k0, cnt) : chain64<1, false>(acc, a, vs + k0, cnt);
+  }
   return acc;
 }
 
-// psel != nullptr: the vector is the column of `vbase` the last selection picked (psel = {p, status} on the DEVICE): the
-// host launches the step without having seen p, and reads it only once per pass, together with the step's scalars
+// wave-level wait for a pass tag (the chain wave of a two-wave kernel: the loader wave must not be held up)
+__device__ __forceinline__ void flag_wait_wave(const int * flag, int tag, Mailbox * mb, int lane)
+{
+  if(lane == 0)
+  {
+    int spins = 0;
+    while(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag)
+    {
+      __builtin_amdgcn_s_sleep(4);
+      if(++spins > (1 << 20))
+      {
+        if(mb) mb->sync_err = 1;
+        break;
+      }
+    }
+  }
+  wave_sync();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // Hand-off of d (PassSync): what a jtn / jrow launch waits for before it touches psel and d, and what it publishes behind d
 struct DSync
 {
@@ -554,37 +610,48 @@ struct DSync
   int post, total;          // d_tag = post once `total` workgroups (of jtn and jrow together) have arrived
 };
 
-__global__ __launch_bounds__(64) void jtn_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign, double * out,
-                                                 const int * psel = nullptr, const double * vbase = nullptr, int ldv = 0, int m = 0,
-                                                 DSync ds = DSync{nullptr, nullptr, 0, 0, 0, 0})
+__global__ __launch_bounds__(TILE_THREADS) void jtn_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign,
+                                                           double * out, const int * psel = nullptr, const double * vbase = nullptr, int ldv = 0, int m = 0,
+                                                           DSync ds = DSync{nullptr, nullptr, 0, 0, 0, 0})
 {
-  extern __shared__ double sh[]; // vector (n) | tile (CT x (KT+1))
-  if(ds.sync)
+  extern __shared__ double sh[]; // vector (n) | tile slots
+  double * vs = sh;
+  double * slots = sh + n + (n & 1); // (16-byte aligned: the loads deliver 16 bytes per lane)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * CT;
+  const int nc = min(CT, ncols - col0);
+  if(wave == 1)
+    tile_loader(M, (size_t)ld, n, col0, nc, slots, lane); // (M is complete when the kernel starts: the tiles do not wait for the selection)
+  else
   {
-    if(ds.wait_sel) flag_wait(&ds.sync->sel_tag, ds.wait_sel, ds.mb);
-    if(ds.wait_chain) flag_wait(&ds.sync->chain_tag, ds.wait_chain, ds.mb);
-  }
-  bool live = true;
-  if(psel)
-  {
-    const int p = psel[0];
-    live = !(p < 0 || p >= m); // none selected, or a bound (jrow_kernel)
-    if(live)
+    const unsigned long long tj0 = ROTT();
+    if(ds.sync)
     {
-      v = vbase + (size_t)p * ldv;
-      sign = (psel[1] == UPPER) ? -1.0 : 1.0;
+      if(ds.wait_sel) flag_wait_wave(&ds.sync->sel_tag, ds.wait_sel, ds.mb, lane);
+      if(ds.wait_chain) flag_wait_wave(&ds.sync->chain_tag, ds.wait_chain, ds.mb, lane);
     }
-  }
-  if(live)
-  {
-    double * vs = sh;
-    double * tile = sh + n;
-    const int lane = threadIdx.x;
-    for(int i = lane; i < n; i += 64) vs[i] = v[i];
-    const int col0 = blockIdx.x * CT;
-    const int nc = min(CT, ncols - col0);
-    double acc = tile_column_dot(M, ld, n, col0, nc, vs, tile, lane);
-    if(lane < nc) out[col0 + lane] = (sign < 0.0) ? -acc : acc;
+    const unsigned long long tj1 = ROTT();
+    bool live = true;
+    if(psel)
+    {
+      const int p = psel[0];
+      live = !(p < 0 || p >= m); // none selected, or a bound (jrow_kernel)
+      if(live)
+      {
+        v = vbase + (size_t)p * ldv;
+        sign = (psel[1] == UPPER) ? -1.0 : 1.0;
+      }
+    }
+    if(live)
+      for(int i = lane; i < n; i += 64) vs[i] = v[i];
+    const unsigned long long tj2 = ROTT();
+    const double acc = tile_chain(n, vs, slots, lane); // (not live: the chains run on whatever LDS holds -- the loader's barriers need their partner)
+    if(live && lane < nc) out[col0 + lane] = (sign < 0.0) ? -acc : acc;
+    const unsigned long long tj3 = ROTT();
+    ROTP(16, tj1 - tj0); // jtn: waiting for the selection / a discarded chain
+    ROTP(17, tj2 - tj1); // jtn: psel, the constraint's column into LDS
+    ROTP(18, tj3 - tj2); // jtn: the tiles
+    ROTP(20, 1);
   }
   if(ds.sync && ds.post) flag_post(&ds.sync->d_cnt, &ds.sync->d_tag, ds.total, ds.post);
 }
@@ -616,20 +683,25 @@ __global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb
 }
 
 // K4 partial: per CT constraints the first-index arg-min of min(c.x - bl, bu - c.x) below 0
-__global__ __launch_bounds__(64) void select_partial_kernel(const double * __restrict__ C, int ldc, int n, int m, const double * __restrict__ x,
-                                                            const double * __restrict__ bl, const double * __restrict__ bu,
-                                                            const unsigned char * __restrict__ st, int excl, double * pval, int * pidx, int * pstat,
-                                                            const PassSync * sync = nullptr, int wait_x = 0, Mailbox * mb = nullptr)
+__global__ __launch_bounds__(TILE_THREADS) void select_partial_kernel(const double * __restrict__ C, int ldc, int n, int m, const double * __restrict__ x,
+                                                                      const double * __restrict__ bl, const double * __restrict__ bu,
+                                                                      const unsigned char * __restrict__ st, int excl, double * pval, int * pidx, int * pstat,
+                                                                      const PassSync * sync = nullptr, int wait_x = 0, Mailbox * mb = nullptr)
 {
   extern __shared__ double sh[];
-  if(sync && wait_x) flag_wait(&sync->x_tag, wait_x, mb); // x of this pass comes from `advance` on another stream
   double * vs = sh;
-  double * tile = sh + n;
-  const int lane = threadIdx.x;
-  for(int i = lane; i < n; i += 64) vs[i] = x[i];
+  double * slots = sh + n + (n & 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col0 = blockIdx.x * CT;
   const int nc = min(CT, m - col0);
-  const double cx = tile_column_dot(C, ldc, n, col0, nc, vs, tile, lane);
+  if(wave == 1)
+  {
+    tile_loader(C, (size_t)ldc, n, col0, nc, slots, lane); // (C is the caller's: its tiles start at once, beside the wait for x)
+    return;
+  }
+  if(sync && wait_x) flag_wait_wave(&sync->x_tag, wait_x, mb, lane); // x of this pass comes from `advance` on another stream
+  for(int i = lane; i < n; i += 64) vs[i] = x[i];
+  const double cx = tile_chain(n, vs, slots, lane);
   const int i = col0 + lane;
   double bval = 0.0;
   int bidx = NONE, bstat = INACTIVE;
@@ -1158,7 +1230,7 @@ __global__ __launch_bounds__(256) void add_commit_kernel(int q, const double * d
   }
 }
 
-// K10 part 2 / K11 part 2: apply the rotation sequence to the columns of J, one workgroup of THREE waves per 64 rows.
+// K10 part 2 / K11 part 2: apply the rotation sequence to the columns of J, one workgroup of FOUR waves per 64 rows.
 //   descending (add):   i = i_hi .. i_lo, columns (i, i+1), carry = column i+1
 //   ascending (remove): i = i_lo .. i_hi, columns (i, i+1), carry = column i
 // A row's sweep is one carry chain (two dependent ops per rotation); the point of this kernel is that the chain never
@@ -1171,14 +1243,13 @@ __global__ __launch_bounds__(256) void add_commit_kernel(int q, const double * d
 //                    it alone waits for vmcnt, with the constant that lets the NEXT chunk land;
 //   wave 0 (chain)   reads column values and (c, s) pairs out of LDS eight columns ahead of the rotations, rotates, and leaves the
 //                    rotated columns in one of two LDS buffers -- it never has a memory operation outstanding in the loop;
-//   wave 1 (storer)  copies the buffer of the previous chunk to memory while wave 0 rotates the next one (its vmcnt only counts
-//                    stores, which nobody waits for).
-// One LDS-only barrier per chunk for all three; (c_i, s_i) of the whole sweep are staged in LDS once.
+//   waves 1, 3 (storers) copy the buffers of the finished chunks to memory, alternately, while wave 0 rotates the next ones.
+// One LDS-only barrier per chunk for all four; (c_i, s_i) of the whole sweep are staged in LDS once.
 constexpr int RC = 32;          // columns per chunk
 constexpr int RSLOTS = 4;       // ring of chunk slots the loader fills (64 rows x RC columns each, column after column)
 constexpr int RSLOT = RC * 64;  // doubles per slot
 constexpr int RCB = 8;          // columns whose operands the chain wave requests per batch
-constexpr int ROT_THREADS = 192;
+constexpr int ROT_THREADS = 256;
 
 template<bool DESC, bool FULL>
 __device__ __forceinline__ void rot_chunk(const double * xs, double & carry, const double2 * csl, int t0, int T, double * obuf, int lane)
@@ -1220,11 +1291,11 @@ __device__ __forceinline__ void rot_chunk(const double * xs, double & carry, con
     if(DESC)
     {
       out = FMA(sn, xv, c * carry);
-      nc = FMA(c, xv, -(sn * carry));
+      nc = FMA(-sn, carry, c * xv);
     }
     else
     {
-      out = FMA(c, carry, -(sn * xv));
+      out = FMA(-sn, xv, c * carry);
       nc = FMA(sn, carry, c * xv);
     }
     obuf[u * 64 + lane] = out;
@@ -1278,13 +1349,17 @@ __device__ __forceinline__ void rot_sweep(double * J, int ld, int n, int row0, i
     for(int k = 0; k < nchunk; ++k)
     {
       // chunk k has landed when at most the loads of the chunks behind it are outstanding (16 per chunk, in order)
+      const unsigned long long tw = ROTT();
       if(k + 2 < nchunk)
         asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
       else if(k + 1 < nchunk)
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long tx = ROTT();
+      ROTP(4, tx - tw); // loader: waiting for a chunk to land
       lds_barrier(); // B_k
+      ROTP(5, ROTT() - tx); // loader: waiting at the barrier
       if(k + 3 < nchunk) issue(k + 3);
     }
     lds_barrier(); // B_nchunk
@@ -1294,7 +1369,10 @@ __device__ __forceinline__ void rot_sweep(double * J, int ld, int n, int row0, i
     double carry = DESC ? AT(J, ld, row, i_hi + 1) : AT(J, ld, row, i_lo);
     for(int k = 0; k < nchunk; ++k)
     {
+      const unsigned long long tb = ROTT();
       lds_barrier(); // B_k: chunk k is in its slot, the storer is done with the buffer of chunk k - 2
+      ROTP(k == 0 ? 6 : 7, ROTT() - tb); // chain: waiting at B_0 (the first chunk) / at the other barriers
+      ROTP(8, 1);
       const double * xs = slots + (k % RSLOTS) * RSLOT;
       double * ob = obufs + (k & 1) * RSLOT;
       if(k < nfull)
@@ -1307,37 +1385,55 @@ __device__ __forceinline__ void rot_sweep(double * J, int ld, int n, int row0, i
   }
   else
   {
+    // Two storer waves (1 and 3), alternate chunks.  A wave has at most 63 memory operations outstanding (vmcnt, stores included on
+    // gfx9), and a write acknowledgement takes a microsecond or two: one wave storing a column (512 bytes) per instruction moved one
+    // chunk per microsecond and the whole workgroup waited for it at every barrier.  Here an instruction stores two columns (lane =
+    // (column, row pair): 16 bytes), the two waves share the chunks, and a wave fetches a chunk out of its buffer right behind
+    // the barrier that completes it but issues the stores only behind the NEXT barrier -- a stalled store holds nobody up.
+    const int sidx = (wave == 1) ? 0 : 1;
+    const int pr = 2 * (lane & 31), half = lane >> 5;
+    const bool two = row0 + pr + 1 < n, one = row0 + pr < n;
+    const int srow = min(row0 + pr, n - 1);
+    double2 v[RC / 2];
+    auto fetch = [&](int k) {
+      const double * ib = obufs + (k & 1) * RSLOT + half * 64 + pr;
+#pragma unroll
+      for(int i = 0; i < RC / 2; ++i) v[i] = *reinterpret_cast<const double2 *>(ib + i * 128);
+    };
+    auto store = [&](int k) {
+      double * p = &AT(J, ld, srow, wcol(k * RC + half));
+#pragma unroll
+      for(int i = 0; i < RC / 2; ++i)
+      {
+        if(k < nfull || k * RC + 2 * i + half < T)
+        {
+          if(two)
+            *reinterpret_cast<double2 *>(p) = v[i];
+          else if(one)
+            *p = v[i].x;
+        }
+        p += 2 * cstep;
+      }
+    };
     lds_barrier(); // B_0
+    int held = -1;
     for(int k = 0; k < nchunk; ++k)
     {
+      const unsigned long long tb = ROTT();
       lds_barrier(); // B_k+1: chunk k is in its buffer
-      const double * ib = obufs + (k & 1) * RSLOT;
-      double v[RC];
-#pragma unroll
-      for(int u = 0; u < RC; ++u) v[u] = ib[u * 64 + lane];
-      if(row0 + lane < n)
+      if(sidx == 0) ROTP(9, ROTT() - tb); // storer A: waiting at the barriers
+      if((k & 1) == sidx)
       {
-        double * p = &AT(J, ld, row, wcol(k * RC));
-        if(k < nfull)
-        {
-#pragma unroll
-          for(int u = 0; u < RC; ++u)
-          {
-            *p = v[u];
-            p += cstep;
-          }
-        }
-        else
-        {
-#pragma unroll
-          for(int u = 0; u < RC; ++u)
-          {
-            if(k * RC + u < T) *p = v[u];
-            p += cstep;
-          }
-        }
+        fetch(k);
+        held = k;
+      }
+      else if(held >= 0)
+      {
+        store(held);
+        held = -1;
       }
     }
+    if(held >= 0) store(held);
   }
 }
 
@@ -1358,7 +1454,9 @@ __global__ __launch_bounds__(ROT_THREADS) void rot_apply_kernel(double * J, int 
                                                                 const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr})
 {
   extern __shared__ double rsm[]; // four chunk slots | two chunk buffers | (c_i, s_i) pairs (T)
+  const unsigned long long tk0 = ROTT();
   if(cm.sync && cm.wait_chain) flag_wait(&cm.sync->chain_tag, cm.wait_chain, cm.mb);
+  const unsigned long long tk1 = ROTT();
   if(cm.d && blockIdx.x == 0)
   {
     for(int k = threadIdx.x; k < cm.q; k += ROT_THREADS) AT(cm.R, cm.ld, k, cm.q) = cm.d[k];
@@ -1375,10 +1473,18 @@ __global__ __launch_bounds__(ROT_THREADS) void rot_apply_kernel(double * J, int 
   double2 * csl = reinterpret_cast<double2 *>(obufs + 2 * RSLOT);
   for(int k = threadIdx.x; k < T; k += ROT_THREADS) csl[k] = make_double2(cc[i_lo + k], ss[i_lo + k]);
   __syncthreads();
+  const unsigned long long tk2 = ROTT();
   if(descending)
     rot_sweep<true>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, slots, obufs);
   else
     rot_sweep<false>(J, ld, n, blockIdx.x * 64, i_lo, i_hi, csl, slots, obufs);
+  if(threadIdx.x == 0)
+  {
+    ROTP(0, tk1 - tk0);    // waiting for the chain's tag
+    ROTP(1, tk2 - tk1);    // commit + staging the (c, s) pairs
+    ROTP(2, ROTT() - tk2); // the sweep, as the chain wave sees it
+    ROTP(3, 1);            // launches
+  }
 }
 
 // K11 part 1 (one workgroup; thread tid owns the NEW columns tid + u * blockDim.x, u < NC, of R): delete column l of R,
@@ -1481,7 +1587,7 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
           const int k = tid + w * nt;
           if(k > i && k < qn)
           {
-            AT(R, ld, i, k) = FMA(c, carry[w], -(s * y[w]));
+            AT(R, ld, i, k) = FMA(-s, y[w], c * carry[w]);
             carry[w] = FMA(s, carry[w], c * y[w]);
           }
         }
@@ -1714,6 +1820,10 @@ static size_t rot_lds(int T)
 {
   return sizeof(double) * (size_t)((RSLOTS + 2) * RSLOT + 2 * T); // (T = 4095: 163 824 of the CU's 163 840 bytes)
 }
+static size_t tile_lds(int n)
+{
+  return sizeof(double) * (size_t)(n + (n & 1) + TS_NS * TS_SLOT); // the vector | the tile slots (jtn, select_partial)
+}
 static size_t tail_lds(int n, int q)
 {
   return sizeof(double) * (size_t)((3 * n + 16 > q + 2) ? 3 * n + 16 : q + 2); // (+16: the per-wave partial sums of the two C4 trees)
@@ -1746,6 +1856,12 @@ static hipError_t tail_attr(int n)
 {
   static LdsRaised done;
   return raise_lds(&step_tail_kernel, done, tail_lds(n, 0));
+}
+static hipError_t tile_attr(int n) // (n > ~1800: the vector and six slots pass the default 64 KiB)
+{
+  static LdsRaised done_j, done_s;
+  hipError_t e = raise_lds(&jtn_kernel, done_j, tile_lds(n));
+  return e == hipSuccess ? raise_lds(&select_partial_kernel, done_s, tile_lds(n)) : e;
 }
 static hipError_t rot_attr(int T)
 {
@@ -1809,8 +1925,12 @@ hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double *
 hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u, int wait_x_tag, int post_sel_tag)
 {
   const int parts = (v.m + CT - 1) / CT;
+  {
+    hipError_t e = tile_attr(v.n);
+    if(e != hipSuccess) return e;
+  }
   if(parts > 0)
-    hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(64), sizeof(double) * (v.n + CT * (KT + 1)), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
+    hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(TILE_THREADS), tile_lds(v.n), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
                        excl, s.pval, s.pidx, s.pstat, s.sync, wait_x_tag, s.mb);
   hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb, s.psel,
                      zero_u >= 0 ? s.u + zero_u : nullptr, s.sync, parts > 0 ? 0 : wait_x_tag, post_sel_tag);
@@ -1828,6 +1948,10 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   const bool zs = zside && tag;            // z = J2 d2 on its own stream, beside the substitution (both only need d)
   const int dpost = (chain || zs) ? tag : 0; // d_tag is published for whoever runs beside the main stream
   const int jt_wgs = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;
+  {
+    hipError_t e = tile_attr(n);
+    if(e != hipSuccess) return e;
+  }
   if(dev_p)
   {
     // (with general constraints AND bounds both kernels run -- each returns at once unless the selection is of its kind -- and both
@@ -1835,7 +1959,7 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     DSync ds{s.sync, s.mb, wait_sel_tag, wait_chain_tag, dpost, (v.m > 0 ? jt_wgs : 0) + (v.nb > 0 ? jr_wgs : 0)};
     if(v.m > 0)
     {
-      hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc, v.m, ds);
+      hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc, v.m, ds);
       ds.wait_sel = ds.wait_chain = 0;
     }
     if(v.nb > 0) hipLaunchKernelGGL(jrow_kernel, dim3(jr_wgs), dim3(256), 0, st, s.J, n, n, 0, 1.0, s.d, s.psel, v.m, ds);
@@ -1843,7 +1967,7 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   else if(p < v.m)
   {
     cp = v.C + (size_t)p * v.ldc;
-    hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
+    hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
                        DSync{s.sync, s.mb, 0, wait_chain_tag, dpost, jt_wgs});
   }
   else
@@ -1901,6 +2025,20 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
   return hipGetLastError();
 }
 
+void dense_rot_profile_dump()
+{
+#ifdef JRLQP_ROT_PROF
+  unsigned long long h[32] = {0};
+  if(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rotprof), sizeof(h)) != hipSuccess || h[3] == 0) return;
+  const double L = (double)h[3], us = 0.01;
+  std::fprintf(stderr, "[rot prof] %llu launches, %.1f chunks each; per launch (us): wait chain tag %.2f, commit+stage %.2f, sweep %.2f | loader: wait data %.2f, at barriers %.2f | chain: wait B_0 %.2f, other barriers %.2f | storer A at barriers %.2f\n",
+               h[3], h[8] / L, h[0] * us / L, h[1] * us / L, h[2] * us / L, h[4] * us / L, h[5] * us / L, h[6] * us / L, h[7] * us / L, h[9] * us / L);
+  if(h[20])
+    std::fprintf(stderr, "[jtn prof] %llu launches (workgroup 0); per launch (us): wait tags %.2f, stage the column %.2f, tiles %.2f, publish d %.2f\n", h[20],
+                 h[16] * us / h[20], h[17] * us / h[20], h[18] * us / h[20], h[19] * us / h[20]);
+#endif
+}
+
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st)
 {
   const int n = v.n;
@@ -1948,7 +2086,11 @@ hipError_t dense_warm_factor(const DenseViews & v, DenseState & s, int q, hipStr
 hipError_t dense_warm_point(const DenseViews & v, DenseState & s, int q, hipStream_t st)
 {
   const int n = v.n;
-  hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(64), sizeof(double) * (n + CT * (KT + 1)), st, s.J, n, n, n, v.a, 1.0, s.d, nullptr, nullptr, 0, 0);
+  {
+    hipError_t e = tile_attr(n);
+    if(e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, v.a, 1.0, s.d, nullptr, nullptr, 0, 0);
   if(q > 0) hipLaunchKernelGGL(warm_tri_kernel<true>, dim3(1), dim3(1024), sizeof(double) * 2 * q, st, s.R, n, q, s.bact, s.bact, s.beta);
   hipLaunchKernelGGL(warm_x_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, s.beta, s.d, s.x);
   if(q > 0) hipLaunchKernelGGL(warm_tri_kernel<false>, dim3(1), dim3(1024), sizeof(double) * 2 * q, st, s.R, n, q, s.d, s.beta, s.u);

@@ -144,6 +144,7 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   DenseState & s = h->s;
   if(h->spec) (void)hipStreamSynchronize(h->spec);
   if(h->side) (void)hipStreamSynchronize(h->side);
+  dense_rot_profile_dump();
   (void)hipFree(s.J); (void)hipFree(s.R); (void)hipFree(s.d); (void)hipFree(s.z); (void)hipFree(s.x);
   (void)hipFree(s.u); (void)hipFree(s.r); (void)hipFree(s.cc); (void)hipFree(s.ss); (void)hipFree(s.st);
   (void)hipFree(s.cc2); (void)hipFree(s.ss2); (void)hipFree(s.rfin);

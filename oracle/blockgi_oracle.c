@@ -168,7 +168,7 @@ static void sg_solve_lt(const bgi * S, double * v)
 static inline void rot(double c, double s, double * x, double * y)
 {
   double xv = *x, yv = *y;
-  *x = FMA(c, xv, -(s * yv));
+  *x = FMA(-s, yv, c * xv); /* (CANON C3 / C6, as in jrlqp_oracle.c) */
   *y = FMA(s, xv, c * yv);
 }
 

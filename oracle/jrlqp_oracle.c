@@ -196,8 +196,9 @@ void orc_givens(double p, double q, double * c, double * s, double * r)
 static inline void rot(double c, double s, double * x, double * y)
 {
   double xv = *x, yv = *y;
-  *x = FMA(c, xv, -(s * yv));
-  *y = FMA(s, xv, c * yv);
+  *x = FMA(-s, yv, c * xv); /* CANON C6: in each output the product of the OTHER operand's partner is rounded first -- c x here, */
+  *y = FMA(s, xv, c * yv);  /* c y there -- so that a sweep's carried value (y in a descending sweep, x in an ascending one)
+                             * enters one fma per rotation and nothing else */
 }
 
 /* ------------------------------------------------------------------------------------------- */
