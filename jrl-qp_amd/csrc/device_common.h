@@ -168,6 +168,50 @@ __device__ __forceinline__ void make_givens(double p, double q, double & c, doub
   }
 }
 
+// ---- CANON C7 (oracle/jrlqp_oracle.c orc_givens_chain): the coefficients of an addition's sweep from a suffix sum of squares ----
+// value of lane + off (lanes whose partner is past lane 63 get their own value back: callers mask them)
+__device__ __forceinline__ double shfl_down_d(double v, int off)
+{
+  int lo = __shfl_down(__double2loint(v), off);
+  int hi = __shfl_down(__double2hiint(v), off);
+  return __hiloint2double(hi, lo);
+}
+// may every entry of the chain be squared?  (0, or 2^-500 <= |d| <= 2^500; NaN / Inf: no)
+__device__ __forceinline__ bool c7_in_range(double d)
+{
+  const double a = fabs(d);
+  return a == 0.0 || (a >= 0x1p-500 && a <= 0x1p500);
+}
+// One block of the scan on a wave whose lane `lane` holds entry j = top - lane of the block (top = the block's lane of j = 0, i.e. the
+// HIGHEST index k of the block sits in lane `top`; lanes above `top` are not part of the block): x_j += x_{j-off} <=> lane += lane + off.
+__device__ __forceinline__ double c7_block_scan(double e, int lane, int top)
+{
+#pragma unroll
+  for(int off = 1; off < 64; off <<= 1)
+  {
+    const double o = shfl_down_d(e, off);
+    e = (lane + off <= top) ? e + o : e;
+  }
+  return e;
+}
+// The whole chain on one wave when n <= 64 (lane = index k, dk = d_k, anything in lanes >= n): rotation k's (c, s) for q <= k <= n-2
+// and rq = r_q.  false: an entry is out of range -- nothing is computed, the caller runs the serial recurrence.
+__device__ __forceinline__ bool c7_wave(double dk, int lane, int n, int q, double & c, double & s, double & rq)
+{
+  const bool in = lane >= q && lane < n;
+  if(!__all(!in || c7_in_range(dk))) return false;
+  const double S = c7_block_scan(in ? dk * dk : 0.0, lane, n - 1);
+  double rho = __builtin_sqrt(S);
+  rho = (lane == n - 1) ? dk : rho; // rho_0: the signed last entry, as the first makeGivens sees it
+  const double rup = dpp_shift0_d<0x130>(rho); // lane k takes lane k+1's radius
+  const bool z = (rho == 0.0);
+  const double cq = dk / rho, sq = (-rup) / rho;
+  c = z ? 1.0 : cq;
+  s = z ? 0.0 : sq;
+  rq = bcast_lane(rho, q);
+  return true;
+}
+
 // sqrt(x) for x in [1, 2] (x = 1 + t^2, |t| <= 1): the Goldschmidt sequence hipcc expands __builtin_sqrt(double)
 // into, minus its range scaling (ldexp by 0 here) and its inf/zero class fix-up -- bit-identical on this range,
 // 9 dependent ops instead of 16 and no VALU->SALU round trip.

@@ -126,70 +126,56 @@ __device__ __forceinline__ void argmin3(double & val, int & idx, int & aux)
   }
 }
 
-// The Givens coefficients of an addition on ONE wave, n up to 128 (GoldfarbIdnaniSolver.cpp:228-231): the radius recurrence
-// r_i = hypot(d_i, r_{i+1}) runs SEEDED and systolically in blocks of 64 steps (device_common.h givens_seed /
-// givens_seeded_step: lane j owns step hi - j, lane 0 is fed the radius the previous block ended on), then every rotation is
-// recomputed from (d_i, r_{i+1}) with the plain formula -- for c_i and s_i, and as the check of the chain: if any radius differs
-// the plain recurrence is run instead.  d, rho (n + 1), ssq (n + 1): LDS; cc, ss receive (c_i, s_i) for i = q .. n-2.
-// Returns the final radius R(q, q).  (The same scheme as add_chain_kernel of gi_dense.hip.)
+// The Givens coefficients of an addition on ONE wave, n up to 256 (GoldfarbIdnaniSolver.cpp:228-231), CANON C7 (oracle
+// orc_givens_chain; device_common.h): the squares of d are scanned from the END of d in blocks of 64 (lane 63 = the block's highest
+// index), the blocks chained by one addition each, then every lane takes a square root and two divisions per rotation.  Entries that
+// cannot be squared: the serial recurrence r_i = hypot(d_i, r_{i+1}) with the plain makeGivens per rotation, as the oracle does.
+// d, rho (n + 1), ssq (n + 1): LDS; cc, ss receive (c_i, s_i) for i = q .. n-2.  Returns the final radius R(q, q).
 __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho, double * ssq, double * cc, double * ss, int lane)
 {
   n = __builtin_amdgcn_readfirstlane(n); // (block bounds and lane numbers from the SALU: see bcast_lane in device_common.h)
   q = __builtin_amdgcn_readfirstlane(q);
-  double r = 0.0;
-  for(int pass = 0; pass < 2; ++pass)
+  if(n - 1 <= q) return dsm[n - 1]; // a single entry: no rotation
+  bool ok = true;
+  for(int k = q + lane; k < n; k += 64) ok = ok && c7_in_range(dsm[k]);
+  if(__all(ok))
   {
-    if(pass == 0)
+    double carry = 0.0;
+    for(int ktop = n - 1; ktop >= q; ktop -= 64)
     {
-      const int K = (n + 63) / 64; // ssq[i] ~ sum of d_k^2 over k >= i
-      const int c0 = min(lane * K, n), c1 = min(c0 + K, n);
-      double acc = 0.0;
-      for(int i = c1 - 1; i >= c0; --i)
-      {
-        acc = FMA(dsm[i], dsm[i], acc);
-        ssq[i] = acc;
-      }
-      const double above = dpp_shift0_d<0x130>(wave_suffix_sum_approx(acc, lane));
-      for(int i = c0; i < c1; ++i) ssq[i] += above;
-      if(lane == 0) ssq[n] = 0.0;
-      wave_sync();
-      double rprev = dsm[n - 1]; // (signed for the very first rotation, as in the plain loop)
-      for(int hi = n - 2; hi >= q; hi -= 64)
-      {
-        const int lo = (hi - 63 > q) ? (hi - 63) : q;
-        const int cnt = hi - lo + 1;
-        const int mine = hi - lane;
-        const int mi = (mine > 0) ? mine : 0;
-        const GivensSeed g = givens_seed(dsm[mi], ssq[mi + 1]);
-        double rc = 0.0;
-        for(int k = 0; k < cnt; ++k) rc = givens_seeded_step(dpp_shift_d<0x138>(rc, rprev), g);
-        const double rin = dpp_shift_d<0x138>(rc, rprev); // r_{i+1} of this lane's step
-        if(mine >= lo) rho[mine + 1] = rin;
-        rprev = bcast_lane(rc, cnt - 1);
-      }
-      r = rprev;
-    }
-    else
-    {
-      r = dsm[n - 1];
-      for(int i = n - 2; i >= q; --i) // the plain recurrence, every lane the same values
-      {
-        if(lane == 0) rho[i + 1] = r;
-        r = givens_r_only(dsm[i], r);
-      }
+      const int k = ktop - 63 + lane;
+      const bool in = k >= q;
+      const double dk = dsm[in ? k : q];
+      const double S = c7_block_scan(in ? dk * dk : 0.0, lane, 63) + carry;
+      if(in) ssq[k] = S;
+      carry = bcast_lane(S, 0); // (the entry 63 places from the block's end; only a full block has a successor)
     }
     wave_sync();
-    bool bad = false;
+    for(int k = q + lane; k < n; k += 64) rho[k] = (k == n - 1) ? dsm[k] : __builtin_sqrt(ssq[k]);
+    wave_sync();
     for(int i = q + lane; i <= n - 2; i += 64)
     {
-      double c, s, rn;
-      make_givens(dsm[i], rho[i + 1], c, s, rn);
-      cc[i] = c;
-      ss[i] = s;
-      if(pass == 0) bad = bad || !(rn == ((i == q) ? r : rho[i])); // the radius this step handed to the next one
+      const double ri = rho[i], rup = rho[i + 1];
+      const bool z = (ri == 0.0);
+      const double cq = dsm[i] / ri, sq = (-rup) / ri;
+      cc[i] = z ? 1.0 : cq;
+      ss[i] = z ? 0.0 : sq;
     }
-    if(!__any(bad)) break;
-    wave_sync();
+    return rho[q];
+  }
+  double r = dsm[n - 1];
+  for(int i = n - 2; i >= q; --i) // the serial recurrence, every lane the same values
+  {
+    if(lane == 0) rho[i + 1] = r;
+    r = givens_r_only(dsm[i], r);
+  }
+  wave_sync();
+  for(int i = q + lane; i <= n - 2; i += 64)
+  {
+    double c, s, rn;
+    make_givens(dsm[i], rho[i + 1], c, s, rn);
+    cc[i] = c;
+    ss[i] = s;
   }
   return r;
 }

@@ -1444,74 +1444,17 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     };
 
     // K10 (wave 0): addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237).
-    // Three phases so that only the irreducible recurrence r_i = f(d_i, r_{i+1}) is serial:
-    //   1. coefficient chain: every lane runs the recurrence (uniform values); lane i keeps r_{i+1}
-    //   2. lane i recomputes rotation i from (d_i, r_{i+1}) -- same function, same bits -- and derives (c_i, s_i):
-    //      all the 1/u divisions happen at once instead of inside the chain
-    //   3. lane = row of J: sweep i = n-2 .. q applying the rotations, operands prefetched one step ahead
-    // wave 0: phases 1 and 2; publishes (c_i, s_i) in LDS (z and r are dead after the primal/dual update) and raises
+    //   1. the coefficients (CANON C7, device_common.h c7_wave): lane i forms d_i^2, a six-step scan gives every lane the squared
+    //      norm of d(i:n), and (c_i, s_i) are one square root and two divisions per lane -- no serial chain (rounds 1-3 ran the
+    //      radius recurrence r_i = hypot(d_i, r_{i+1}) here: n - q dependent steps, seeded and systolic at best).  Entries too large
+    //      or too small to be squared take the serial recurrence instead (chain_exact), as the oracle does;
+    //   2. lane = row of J: sweep i = n-2 .. q applying the rotations, operands prefetched one step ahead
+    // wave 0: phase 1; publishes (c_i, s_i) in LDS (z and r are dead after the primal/dual update) and raises
     // the flag wave 1 is waiting on; then the new column of R and the active-set bookkeeping
-    // chain state (registers of the wave that runs it): d (lane i holds d_i), running radius, r_{i+1} kept by lane i,
-    // next rotation index
     double gc_d = 0.0, gc_rho = 0.0, gc_kq = 0.0;
-    int gc_i = -1;
-    // The recurrence runs SEEDED and systolically (device_common.h givens_seed / givens_seeded_step): lane i owns step i,
-    // gc_rc is its radius r_i, one loop-invariant sweep per step.  chain_finish checks every step against the plain
-    // formula and falls back to the plain recurrence (chain_exact) if any radius differs.
-    GivensSeed gc_seed;
-    double gc_rc = 0.0;
-    constexpr bool GC_LDS = (CMODE == 2); // chain state parked in LDS between the slices (see gsc above)
-    auto chain_park = [&]() {
-      if(!GC_LDS) return;
-      gsc[lane] = gc_seed.Pn;
-      gsc[64 + lane] = gc_seed.Pu;
-      gsc[128 + lane] = gc_seed.W;
-      gsc[192 + lane] = gc_seed.G;
-      gsc[256 + lane] = gc_seed.h;
-      gsc[320 + lane] = gc_rc;
-    };
-    auto chain_unpark = [&](bool seeds) {
-      const int rl = (lane < n) ? lane : (n - 1);
-      const double dv = ds[rl];
-      gc_d = (lane < n) ? dv : 0.0;
-      if(!GC_LDS) return;
-      gc_seed.a = fabs(gc_d);
-      if(seeds)
-      {
-        gc_seed.Pn = gsc[lane];
-        gc_seed.Pu = gsc[64 + lane];
-        gc_seed.W = gsc[128 + lane];
-        gc_seed.G = gsc[192 + lane];
-        gc_seed.h = gsc[256 + lane];
-      }
-      gc_rc = gsc[320 + lane];
-    };
-    auto chain_begin = [&]() {
-      const int rl = (lane < n) ? lane : (n - 1);
-      const double dv = ds[rl];
-      gc_d = (lane < n) ? dv : 0.0; // (lanes >= n: zero -- they sit above the chain and must stay at radius 0)
-      const double sincl = wave_suffix_sum_approx(gc_d * gc_d, lane);
-      gc_seed = givens_seed(gc_d, dpp_shift0_d<0x130>(sincl)); // lane i: sum over k > i
-      if((A.chain_mode & 255) == 2) gc_seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
-      gc_rc = gc_d;
-      gc_i = n - 2;
-    };
-    // up to `count` more steps of the coefficient recurrence (rotation indices n-2 .. q)
-    auto chain_run = [&](int count) {
-      const int stop = (gc_i - count + 1 > q) ? (gc_i - count + 1) : q;
-      for(int i = gc_i; i >= stop; --i) gc_rc = givens_seeded_step(dpp_shift0_d<0x130>(gc_rc), gc_seed);
-      gc_i = (gc_i >= stop) ? (stop - 1) : gc_i;
-    };
-    // one slice of the chain: state from / to LDS when the chain is interleaved with the other waves' phases
-    auto chain_steps = [&](int count, bool first = false) {
-      if(first)
-        chain_begin();
-      else
-        chain_unpark(true);
-      chain_run(count);
-      chain_park();
-    };
-    // the plain recurrence: every lane runs it (uniform values); lane i keeps r_{i+1}
+    // (the slices of the old serial chain, interleaved with the other waves' phases: nothing left to interleave)
+    auto chain_steps = [&](int, bool = false) {};
+    // the serial recurrence: every lane runs it (uniform values); lane i keeps r_{i+1}
     auto chain_exact = [&]() {
       gc_rho = opaque_v(bcast_lane(gc_d, n - 1));
       gc_kq = 0.0;
@@ -1524,26 +1467,26 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     };
     auto chain_finish = [&](int pp, int ps, int token) {
       STAMP(13)
-      chain_unpark(false);
+      {
+        const int rl = (lane < n) ? lane : (n - 1);
+        const double dv = ds[rl];
+        gc_d = (lane < n) ? dv : 0.0;
+      }
       gc_rho = bcast_lane(gc_d, n - 1);
       if(n - 2 >= q)
       {
-        // lane i: r_{i+1} is its upper neighbour's radius (the SIGNED d_{n-1} for the first rotation)
-        gc_kq = dpp_shift0_d<0x130>(gc_rc);
-        gc_kq = (lane == n - 2) ? gc_rho : gc_kq;
-        GivensHalf h;
-        double rex = givens_r(gc_d, gc_kq, h);
         const bool mine = lane >= q && lane <= n - 2;
-        if((A.chain_mode & 255) == 1 || __any(mine && !(rex == gc_rc)))
+        double cl, sl, rq;
+        if(c7_wave(gc_d, lane, n, q, cl, sl, rq))
+          gc_rho = rq;
+        else
         {
           chain_exact();
+          GivensHalf h;
           (void)givens_r(gc_d, gc_kq, h);
+          givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
           if(PROF && CMODE == 2 && lane == 0) atomicAdd(&prof_lds[13], 1ULL); // (slot 13 is idle when wave 3 runs the chain)
         }
-        else
-          gc_rho = bcast_lane(gc_rc, q);
-        double cl, sl;
-        givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
         if(mine)
         {
           zs[lane] = cl;
@@ -2565,57 +2508,30 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
               double rho = bcast_lane(gd, n - 1);
               if(n - 2 >= wq)
               {
-                const double sincl = wave_suffix_sum_approx(gd * gd, lane);
-                GivensSeed seed = givens_seed(gd, dpp_shift0_d<0x130>(sincl)); // lane i: sum over k > i
-                if((A.chain_mode & 255) == 2) seed.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
-                double rc = gd;
-                int left = n - 1 - wq; // steps n-2 .. wq
-                while(left > 0)
+                // CANON C7 (device_common.h c7_wave): a six-step scan of the squares, a square root and two divisions per lane; the
+                // serial recurrence only for entries that cannot be squared
+                const bool mine = lane >= wq && lane <= n - 2;
+                double cl, sl, rq;
+                if(c7_wave(gd, lane, n, wq, cl, sl, rq))
+                  rho = rq;
+                else
                 {
-                  const int fs = __atomic_load_n(&ctl->fstep, __ATOMIC_RELAXED); // (requested before the slice, looked at after)
-#pragma unroll
-                  for(int u = 0; u < 8; ++u) rc = givens_seeded_step(dpp_shift0_d<0x130>(rc), seed); // (steps past wq: idempotent)
-                  left -= 8;
-                  if(uniform(fs) == sq || uniform(fs) == -1)
+                  double rr = opaque_v(bcast_lane(gd, n - 1));
+                  double kq = 0.0;
+                  for(int i = n - 2; i >= wq; --i)
                   {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    if(uniform(ctl->dec) != 1)
-                    {
-                      aborted = true;
-                      break;
-                    }
+                    const double p_i = opaque_v(bcast_lane(gd, i));
+                    kq = (lane == i) ? rr : kq;
+                    rr = givens_r_only(p_i, rr);
                   }
+                  rho = rr;
+                  GivensHalf h;
+                  (void)givens_r(gd, kq, h);
+                  givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
+                  PROF_COUNT(13)
                 }
                 STAMP(4)
-                if(!aborted)
-                {
-                  // lane i: r_{i+1} is its upper neighbour's radius (the SIGNED d_{n-1} for the first rotation); recompute the
-                  // rotation with the plain formula and compare radii: all equal <=> the seeded chain IS the plain chain
-                  double kq = dpp_shift0_d<0x130>(rc);
-                  kq = (lane == n - 2) ? rho : kq;
-                  GivensHalf h;
-                  const double rex = givens_r(gd, kq, h);
-                  const bool mine = lane >= wq && lane <= n - 2;
-                  if((A.chain_mode & 255) == 1 || __any(mine && !(rex == rc)))
-                  {
-                    double rr = opaque_v(bcast_lane(gd, n - 1));
-                    kq = 0.0;
-                    for(int i = n - 2; i >= wq; --i)
-                    {
-                      const double p_i = opaque_v(bcast_lane(gd, i));
-                      kq = (lane == i) ? rr : kq;
-                      rr = givens_r_only(p_i, rr);
-                    }
-                    rho = rr;
-                    (void)givens_r(gd, kq, h);
-                    PROF_COUNT(13)
-                  }
-                  else
-                    rho = bcast_lane(rc, wq);
-                  double cl, sl;
-                  givens_cs(h, cl, sl); // lane i now holds (c_i, s_i)
-                  if(mine) *reinterpret_cast<double2 *>(csb + 2 * lane) = make_double2(cl, sl);
-                }
+                if(mine) *reinterpret_cast<double2 *>(csb + 2 * lane) = make_double2(cl, sl);
               }
               if(!aborted && lane == 0) ctl->rho = rho;
               ws_post(&ctl->fcs, sq);

@@ -1121,98 +1121,110 @@ __global__ void advance_kernel(int n, int q, double t, int primal, const double 
   if(sync && post_x) flag_post(&sync->x_cnt, &sync->x_tag, gridDim.x, post_x);
 }
 
-// K10 part 1 (one wave): the Givens coefficient recurrence on d (i = n-2 .. q), then all (c_i, s_i) in parallel.  Reads d
-// only and writes only its own outputs, so it can run ahead of the add/drop decision beside z / r / the ratio test.
-//
-// seeded != 0: the recurrence runs from seeds (device_common.h givens_seed / givens_seeded_step: 8 dependent ops per
-// step instead of 26), systolically in blocks of 64 steps -- lane j owns step hi - j, its radius moves one lane up per
-// sweep (DPP), lane 0 is fed the radius the previous block ended on.  The second pass, which recomputes every rotation
-// from (d_i, r_{i+1}) with the plain formula anyway, compares the radii; any difference reruns the plain recurrence.
-__global__ __launch_bounds__(64) void add_chain_kernel(int n, int q, const double * d, double * cc, double * ss, double * rfin, int seeded,
-                                                       PassSync * sync = nullptr, int tag = 0, Mailbox * mb = nullptr)
+// K10 part 1 (one workgroup of four waves): the Givens coefficients (c_i, s_i), i = n-2 .. q, of an addition and the final radius
+// from d -- CANON C7 (oracle orc_givens_chain; device_common.h).  The squares of d are scanned from the END of d in blocks of 64 (a
+// wave per block, lane 63 = the block's highest index: six shuffle-and-add steps), wave 0 chains the blocks (one addition each),
+// then every thread takes a square root and two divisions per rotation.  Rounds 1-3 ran the radius recurrence r_i = hypot(d_i,
+// r_{i+1}) here -- n - q dependent steps, 36 us at n = 1024 with seeds and a systolic wave: the longest kernel of a pass, and on its
+// critical path.  Entries that cannot be squared (beyond 2^+-500, not finite) take the serial recurrence on wave 0, as the oracle does.
+// Reads d only and writes only its own outputs, so it can run ahead of the add/drop decision beside z / r / the ratio test.
+constexpr int CHAIN_THREADS = 256;
+__global__ __launch_bounds__(CHAIN_THREADS) void add_chain_kernel(int n, int q, const double * d, double * cc, double * ss, double * rfin, int unused,
+                                                                  PassSync * sync = nullptr, int tag = 0, Mailbox * mb = nullptr)
 {
-  extern __shared__ double sm[]; // d (n) | rho (n + 1) | suffix sums of d^2 (n + 1, seeded only)
+  extern __shared__ double sm[]; // d (n) | S, then rho (n + 1) | block carries (64) | flag
   if(sync && tag) flag_wait(&sync->d_tag, tag, mb); // launched beside jtn on another stream: d of THIS pass
   double * dsm = sm;
-  double * rho = sm + n;
-  double * ssq = rho + (n + 1);
-  const int lane = threadIdx.x;
-  for(int i = lane; i < n; i += 64) dsm[i] = d[i];
-  wave_sync();
-  double r = 0.0;
-  for(int pass = seeded ? 0 : 1; pass < 2; ++pass)
+  double * S = sm + n;
+  double * carry = S + (n + 1);
+  int * okf = reinterpret_cast<int *>(carry + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if(tid == 0) *okf = 1;
+  for(int i = tid; i < n; i += CHAIN_THREADS) dsm[i] = d[i];
+  __syncthreads();
+  if(n - 1 <= q) // a single entry: no rotation, the radius is the entry itself
   {
-    if(pass == 0)
+    if(tid == 0) *rfin = dsm[n - 1];
+    if(sync && tag) flag_post(nullptr, &sync->chain_tag, 1, tag);
+    return;
+  }
+  bool ok = true;
+  for(int k = q + tid; k < n; k += CHAIN_THREADS) ok = ok && c7_in_range(dsm[k]);
+  if(!__all(ok) && lane == 0) *okf = 0;
+  __syncthreads();
+  if(*okf)
+  {
+    const int nblk = (n - q + 63) >> 6;
+    for(int b = wave; b < nblk; b += CHAIN_THREADS / 64)
     {
-      // ssq[i] ~ sum of d_k^2 over k >= i (lane = chunk of consecutive entries, then a suffix sum over the chunk totals)
-      const int K = (n + 63) / 64;
-      const int c0 = min(lane * K, n), c1 = min(c0 + K, n);
-      double acc = 0.0;
-      for(int i = c1 - 1; i >= c0; --i)
-      {
-        acc = FMA(dsm[i], dsm[i], acc);
-        ssq[i] = acc;
-      }
-      const double above = dpp_shift0_d<0x130>(wave_suffix_sum_approx(acc, lane)); // chunks of the lanes above this one
-      for(int i = c0; i < c1; ++i) ssq[i] += above;
-      if(lane == 0) ssq[n] = 0.0;
-      wave_sync();
-      double rprev = dsm[n - 1]; // r_{hi+1} of the current block (signed for the very first rotation, as in the plain loop)
-      for(int hi = n - 2; hi >= q; hi -= 64)
-      {
-        const int lo = (hi - 63 > q) ? (hi - 63) : q;
-        const int cnt = hi - lo + 1;
-        const int mine = hi - lane; // lane j owns step i = hi - j
-        const int mi = (mine > 0) ? mine : 0;
-        GivensSeed g = givens_seed(dsm[mi], ssq[mi + 1]);
-        if(seeded == 2) g.G *= 1.0 + 0x1p-20; // debug: spoiled seed -> verification fails -> fallback
-        double rc = 0.0;
-        // always 64 sweeps, unrolled: a lane's value is final once the lane above it is and a further sweep reproduces it
-        // (same inputs, same function), so the sweeps past cnt in the last, partial block change nothing -- and the loop has
-        // no counter, compare and branch per sweep (a sweep is 8 dependent operations and a two-instruction DPP shift)
-#pragma unroll 8
-        for(int k = 0; k < 64; ++k) rc = givens_seeded_step(dpp_shift_d<0x138>(rc, rprev), g);
-        const double rin = dpp_shift_d<0x138>(rc, rprev); // r_{i+1} of this lane's step
-        if(mine >= lo) rho[mine + 1] = rin;
-        rprev = bcast_lane(rc, cnt - 1);
-      }
-      r = rprev;
+      const int k = (n - 1 - 64 * b) - 63 + lane;
+      const bool in = k >= q;
+      const double dk = dsm[in ? k : q];
+      const double x = c7_block_scan(in ? dk * dk : 0.0, lane, 63);
+      if(in) S[k] = x;
+      if(lane == 0) carry[b] = x; // the block's total (only read for a full block)
     }
-    else
+    __syncthreads();
+    if(wave == 0)
     {
-      r = opaque_v(dsm[n - 1]);
-      // The loop body must stay free of stores and exec-mask regions (they stall the in-order wave: measured +40 % on
-      // the batched kernel's chain).  The d values of the next 64 steps sit in a register (lane = step inside the
-      // block, read with v_readlane); lane (i mod 64) keeps r_{i+1}; both are exchanged with LDS once per 64 steps.
-      double kq = 0.0;
-      for(int hi = n - 2; hi >= q; hi -= 64)
+      // carry_0 = 0, carry_b+1 = S_(64 b + 63) = x_(64 b + 63) + carry_b: lane b ends up with carry_b
+      const double tb = (lane < nblk) ? carry[lane] : 0.0;
+      double cy = 0.0, mine = 0.0;
+      for(int b = 0; b < nblk; ++b)
       {
-        const int lo = (hi - 63 > q) ? (hi - 63) : q; // this block: i = hi .. lo
-        const int mine = hi - lane;                   // lane j handles step i = hi - j
-        const double dblk = (mine >= lo) ? dsm[mine] : 0.0;
-        for(int i = hi; i >= lo; --i)
-        {
-          const double di = opaque_v(bcast_lane(dblk, hi - i));
-          kq = (lane == hi - i) ? r : kq; // r_{i+1}
-          r = givens_r_only(di, r);
-        }
-        if(mine >= lo) rho[mine + 1] = kq;
+        mine = (lane == b) ? cy : mine;
+        cy = bcast_lane(tb, b) + cy;
       }
+      if(lane < nblk) carry[lane] = mine;
+    }
+    __syncthreads();
+    for(int k = q + tid; k < n; k += CHAIN_THREADS)
+    {
+      const int b = (n - 1 - k) >> 6;
+      S[k] = (k == n - 1) ? dsm[k] : __builtin_sqrt(S[k] + carry[b]); // rho
+    }
+    __syncthreads();
+    for(int i = q + tid; i <= n - 2; i += CHAIN_THREADS)
+    {
+      const double ri = S[i], rup = S[i + 1];
+      const bool z = (ri == 0.0);
+      const double cq = dsm[i] / ri, sq = (-rup) / ri;
+      cc[i] = z ? 1.0 : cq;
+      ss[i] = z ? 0.0 : sq;
+    }
+    if(tid == 0) *rfin = S[q];
+  }
+  else if(wave == 0)
+  {
+    // the serial recurrence.  The loop body must stay free of stores and exec-mask regions (they stall the in-order wave: measured
+    // +40 % on the batched kernel's chain).  The d values of the next 64 steps sit in a register (lane = step inside the block,
+    // read with v_readlane); lane (i mod 64) keeps r_{i+1}; both are exchanged with LDS once per 64 steps.
+    double * rho = S;
+    double r = opaque_v(dsm[n - 1]);
+    double kq = 0.0;
+    for(int hi = n - 2; hi >= q; hi -= 64)
+    {
+      const int lo = (hi - 63 > q) ? (hi - 63) : q; // this block: i = hi .. lo
+      const int mine = hi - lane;                   // lane j handles step i = hi - j
+      const double dblk = (mine >= lo) ? dsm[mine] : 0.0;
+      for(int i = hi; i >= lo; --i)
+      {
+        const double di = opaque_v(bcast_lane(dblk, hi - i));
+        kq = (lane == hi - i) ? r : kq; // r_{i+1}
+        r = givens_r_only(di, r);
+      }
+      if(mine >= lo) rho[mine + 1] = kq;
     }
     wave_sync();
-    bool bad = false;
     for(int i = q + lane; i <= n - 2; i += 64)
     {
       double c, s, rn;
       make_givens(dsm[i], rho[i + 1], c, s, rn);
       cc[i] = c;
       ss[i] = s;
-      if(pass == 0) bad = bad || !(rn == ((i == q) ? r : rho[i])); // the radius this step handed to the next one
     }
-    if(!__any(bad)) break;
-    wave_sync();
+    if(lane == 0) *rfin = r;
   }
-  if(lane == 0) *rfin = r;
   if(sync && tag) flag_post(nullptr, &sync->chain_tag, 1, tag);
 }
 
@@ -1870,15 +1882,9 @@ static hipError_t rot_attr(int T)
 }
 
 // add_chain_kernel: the seeded recurrence needs a third LDS vector; beyond a CU's LDS it falls back to the plain one
-static int chain_seeded(int n)
-{
-  const int mode = chain_debug_mode();
-  if(mode == 1 || sizeof(double) * (3 * (size_t)n + 2) > kLdsMax) return 0;
-  return mode == 2 ? 2 : 1;
-}
 static size_t chain_lds(int n)
 {
-  return sizeof(double) * ((chain_seeded(n) ? 3 : 2) * (size_t)n + 2);
+  return sizeof(double) * (2 * (size_t)n + 1 + 64 + 2); // d | S / rho | block carries | flag
 }
 static hipError_t chain_attr(int n)
 {
@@ -1978,7 +1984,7 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     // d is all the coefficient recurrence needs: it is enqueued now, on its own stream, and starts when d_tag says d is complete
     hipError_t e = chain_attr(n);
     if(e != hipSuccess) return e;
-    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n), s.sync, tag, s.mb);
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(CHAIN_THREADS), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, 0, s.sync, tag, s.mb);
   }
   if(zs)
     hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, zside, s.J, n, n, q, s.d, s.z, s.sync, tag, tag, s.mb);
@@ -2011,7 +2017,7 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
   {
     hipError_t e = chain_attr(n);
     if(e != hipSuccess) return e;
-    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(64), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, chain_seeded(n), nullptr, 0, nullptr);
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(CHAIN_THREADS), chain_lds(n), st, n, q, s.d, s.cc2, s.ss2, s.rfin, 0, nullptr, 0, nullptr);
   }
   {
     hipError_t e = rot_attr(n);

@@ -23,6 +23,7 @@
  */
 #include "jrlqp_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <omp.h>
@@ -361,6 +362,80 @@ static void compute_step(gi_state * S, int p, int status)
   }
 }
 
+/* CANON C7 -- the coefficients of an ADDITION's Givens sweep (GoldfarbIdnaniSolver.cpp:225-232: for i = n-2 .. q
+ * makeGivens(d_i, d_{i+1}) with the radius left in d_i).  The radius r_i = hypot(d_i, r_{i+1}) is the norm of d[i .. n-1], and with
+ * it c_i = d_i / r_i, s_i = -r_{i+1} / r_i (makeGivens' result, JacobiRotation.h, for a non-negative second argument).  The
+ * recurrence is n - q dependent makeGivens evaluations -- the longest serial chain of a pass on a GPU -- whereas the norms are a
+ * suffix sum: C7 fixes the radii as the square roots of a suffix sum of the squares taken in a fixed, parallel order, and every
+ * coefficient as one division by its radius.
+ *   j = n-1-k counts from the END of d;  e_j = d_k * d_k;  blocks of 64 consecutive j;  inside a block the Hillis-Steele
+ *   inclusive scan  x_j += x_{j-off}  (off = 1, 2, 4, .. 32; all j of the block with j mod 64 >= off at once, from the values of
+ *   the step before);  S_j = x_j + carry_b,  carry_0 = 0,  carry_{b+1} = S_{64 b + 63};
+ *   rho_0 = d_{n-1} (signed, as the first makeGivens sees it),  rho_j = sqrt(S_j);
+ *   rotation i = n-1-j (j >= 1):  rho_j == 0 ? (c, s) = (1, 0)  :  c = d_i / rho_j,  s = (-rho_{j-1}) / rho_j;   r_q = rho_{n-1-q}.
+ * Squares leave the double range where makeGivens (which only forms ratios) does not: when an entry is beyond 2^500 in magnitude,
+ * or a non-zero one below 2^-500, or anything is not finite, the serial recurrence is used instead -- the decision is a pure
+ * function of d, so the kernels take the same branch.  Returns 1 for the tree, 0 for the recurrence. */
+int orc_givens_chain(int n, int q, const double * d, double * c, double * s, double * rfin)
+{
+  const int m = n - q; /* entries d[q .. n-1]; rotations i = n-2 .. q */
+  if(m <= 0) return 1;
+  if(m == 1)
+  {
+    *rfin = d[n - 1];
+    return 1;
+  }
+  double amax = 0.0, amin = INFINITY;
+  int finite = 1;
+  for(int k = q; k < n; ++k)
+  {
+    const double a = fabs(d[k]);
+    if(!(a <= DBL_MAX)) finite = 0;
+    if(a > amax) amax = a;
+    if(a != 0.0 && a < amin) amin = a;
+  }
+  if(!finite || amax > 0x1p500 || amin < 0x1p-500)
+  {
+    double r = d[n - 1];
+    for(int i = n - 2; i >= q; --i) orc_givens(d[i], r, &c[i], &s[i], &r);
+    *rfin = r;
+    return 0;
+  }
+  double x_small[256];
+  double * x = (m <= 256) ? x_small : (double *)malloc(sizeof(double) * (size_t)m);
+  for(int j = 0; j < m; ++j) x[j] = d[n - 1 - j] * d[n - 1 - j];
+  double carry = 0.0;
+  for(int b0 = 0; b0 < m; b0 += 64)
+  {
+    const int cnt = (m - b0 < 64) ? m - b0 : 64;
+    double * xb = x + b0;
+    for(int off = 1; off < 64; off <<= 1)
+      for(int j = cnt - 1; j >= off; --j) xb[j] = xb[j] + xb[j - off]; /* descending j: xb[j - off] is still the old value */
+    for(int j = 0; j < cnt; ++j) xb[j] = xb[j] + carry;
+    if(cnt == 64) carry = xb[63];
+  }
+  double rho_prev = d[n - 1]; /* rho_0 */
+  for(int j = 1; j < m; ++j)
+  {
+    const int i = n - 1 - j;
+    const double rho = sqrt(x[j]);
+    if(rho == 0.0)
+    {
+      c[i] = 1.0;
+      s[i] = 0.0;
+    }
+    else
+    {
+      c[i] = d[i] / rho;
+      s[i] = (-rho_prev) / rho;
+    }
+    rho_prev = rho;
+  }
+  *rfin = rho_prev;
+  if(x != x_small) free(x);
+  return 1;
+}
+
 /* addConstraint (DualSolver.cpp:231-235) + addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237) */
 static void add_constraint(gi_state * S, int p, int status)
 {
@@ -368,14 +443,20 @@ static void add_constraint(gi_state * S, int p, int status)
   orc_as_activate(&S->A, p, status);
   const int q = S->A.nact; /* already counts the new constraint */
   double *d = S->d, *J = S->J;
+  double cs_small[2 * 256];
+  double * cc = (n <= 256) ? cs_small : (double *)malloc(sizeof(double) * 2 * (size_t)n);
+  double * ss = cc + n;
+  double rfin = d[q - 1];
+  orc_givens_chain(n, q - 1, d, cc, ss, &rfin); /* C7: all coefficients from d, then the sweep */
   for(int i = n - 2; i >= q - 1; --i)
   {
-    double c, s;
-    orc_givens(d[i], d[i + 1], &c, &s, &d[i]);
     double *ci = J + (long)i * n, *cj = J + (long)(i + 1) * n;
-    for(int rr = 0; rr < n; ++rr) rot(c, s, &ci[rr], &cj[rr]);
+    const double c = cc[i], sn = ss[i];
+    for(int rr = 0; rr < n; ++rr) rot(c, sn, &ci[rr], &cj[rr]);
   }
+  d[q - 1] = rfin;
   for(int k = 0; k < q; ++k) S->R[k + (long)(q - 1) * n] = d[k];
+  if(cc != cs_small) free(cc);
 }
 
 /* removeConstraint_ (GoldfarbIdnaniSolver.cpp:239-256) preceded by A_.deactivate(l) */

@@ -164,6 +164,8 @@ void orc_gi_solve_batch_warm(int B, int n, int m, int nb, double * G, const doub
 int orc_llt(int n, double * A, int lda);                         /* -1 ok, else failing column (Eigen llt_inplace) */
 void orc_inv_lt(int n, const double * L, int ldl, double * J, int ldj); /* J = L^-T, dense n x n */
 void orc_givens(double p, double q, double * c, double * s, double * r);
+/* CANON C7: the coefficients (c_i, s_i), i = n-2 .. q, of an addition's sweep and the final radius, from d[q .. n-1] (jrlqp_oracle.c) */
+int orc_givens_chain(int n, int q, const double * d, double * c, double * s, double * rfin);
 double orc_dot(int n, const double * a, const double * b);
 
 /* ActiveSet restatement (ActiveSet.cpp:45-168) driven through a flat API for the integer-sequence test. */
