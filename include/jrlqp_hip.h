@@ -401,10 +401,10 @@ int jrlqp_selftest_arith(int n,
 #define JRLQP_PROFILE_GI_BATCH 0
 #define JRLQP_PROFILE_BLOCKGI 1
 int jrlqp_debug_set_profile(int kernel, long long * dprof, int slots_per_problem, int nprob);
-/* Diagnostic: how the Givens radius recurrence of an addition (GoldfarbIdnaniSolver.cpp:228-231) is run by the batched
- * kernel and by jrlqp_dense_step/add.  0 (default): seeded and verified, plain recurrence only on a failed check;
- * 1: plain recurrence always; 2: seeded with deliberately spoiled seeds, so that every sweep fails its check and takes
- * the fallback.  All three give bit-identical results (tests/test_gpu_chain_modes.py). */
+/* Retired diagnostic, kept for ABI stability: rounds 1-3 ran the Givens radius recurrence of an addition
+ * (GoldfarbIdnaniSolver.cpp:228-231) from seeds with a verified fallback and this switch selected among the variants.  The
+ * coefficients now come from a suffix sum of squares (CANON C7; the serial recurrence only for entries
+ * that cannot be squared -- a function of the data, tests/test_gpu_chain_modes.py).  The value is stored and ignored. */
 int jrlqp_debug_set_chain_mode(int mode);
 /* D(16x16) = A(16x4) * B(4x16) + C(16x16), row-major, one MFMA instruction on one wave */
 int jrlqp_selftest_mfma_f64(const double * dA, const double * dB, const double * dC, double * dD, void * stream);

@@ -78,7 +78,10 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
 // discarded chain of an earlier pass that may still be reading d.  zside != nullptr (with a tag): z = J2 d2 runs on `zside`, beside the
 // back substitution on `st` (both need d only); the scalar products of the step wait for PassSync::z_tag.
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st,
-                      hipStream_t spec = nullptr, int tag = 0, int wait_sel_tag = 0, int wait_chain_tag = 0, hipStream_t zside = nullptr);
+                      hipStream_t spec = nullptr, int tag = 0, int wait_sel_tag = 0, int wait_chain_tag = 0, hipStream_t zside = nullptr,
+                      hipEvent_t ev_d = nullptr, hipEvent_t ev_chain = nullptr);
+// ev_d / ev_chain != nullptr: EVENT MODE -- the chain is ordered behind d by events instead of tags and z stays on `st`; no tag is waited
+// for or published (for environments in which kernels of different streams do not run side by side: dense_probe_concurrency).
 // post_x_tag != 0: publishes PassSync::x_tag = post_x_tag once x and u are advanced
 hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st, int post_x_tag = 0);
 // wait_chain_tag != 0: the chain already ran on the side (dense_step with spec); the sweep waits for its tag and commits
@@ -89,5 +92,7 @@ hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int 
 hipError_t dense_warm_factor(const DenseViews & v, DenseState & s, int q, hipStream_t st);
 // initializePrimalDualPoints: alpha = J^T a -> s.d, beta -> s.beta, x, u (q entries), f -> mailbox f0
 hipError_t dense_warm_point(const DenseViews & v, DenseState & s, int q, hipStream_t st);
+// see gi_dense.hip: do kernels of streams a and b run side by side?  dscratch2: two ints of device memory
+hipError_t dense_probe_concurrency(int * dscratch2, hipStream_t a, hipStream_t b, bool * concurrent);
 void dense_rot_profile_dump(); // diagnostic build (-DJRLQP_ROT_PROF) only: prints the sweep's time line to stderr; otherwise nothing
 } // namespace jrlqp

@@ -1944,15 +1944,17 @@ hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStrea
 }
 
 hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, int q, double big, hipStream_t st, hipStream_t spec, int tag,
-                      int wait_sel_tag, int wait_chain_tag, hipStream_t zside)
+                      int wait_sel_tag, int wait_chain_tag, hipStream_t zside, hipEvent_t ev_d, hipEvent_t ev_chain)
 {
   const int n = v.n;
   const bool dev_p = (p == kSelOnDevice); // (p, status) are read from s.psel by the kernels
   const double sign = (pstat == UPPER || pstat == UPPER_BOUND) ? -1.0 : 1.0;
   const double * cp = nullptr;
   const bool chain = spec && q < n;
-  const bool zs = zside && tag;            // z = J2 d2 on its own stream, beside the substitution (both only need d)
-  const int dpost = (chain || zs) ? tag : 0; // d_tag is published for whoever runs beside the main stream
+  const bool events = (ev_d != nullptr);   // event mode (kernels of different streams cannot run side by side: see PassSync): no tags
+  const bool zs = zside && tag && !events; // z = J2 d2 on its own stream, beside the substitution (both only need d)
+  const int dpost = (!events && (chain || zs)) ? tag : 0; // d_tag is published for whoever runs beside the main stream
+  if(events) wait_sel_tag = wait_chain_tag = 0;
   const int jt_wgs = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;
   {
     hipError_t e = tile_attr(n);
@@ -1984,7 +1986,18 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     // d is all the coefficient recurrence needs: it is enqueued now, on its own stream, and starts when d_tag says d is complete
     hipError_t e = chain_attr(n);
     if(e != hipSuccess) return e;
-    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(CHAIN_THREADS), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, 0, s.sync, tag, s.mb);
+    if(events)
+    {
+      e = hipEventRecord(ev_d, st);
+      if(e == hipSuccess) e = hipStreamWaitEvent(spec, ev_d, 0);
+      if(e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(add_chain_kernel, dim3(1), dim3(CHAIN_THREADS), chain_lds(n), spec, n, q, s.d, s.cc2, s.ss2, s.rfin, 0, s.sync, events ? 0 : tag, s.mb);
+    if(events)
+    {
+      e = hipEventRecord(ev_chain, spec);
+      if(e != hipSuccess) return e;
+    }
   }
   if(zs)
     hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, zside, s.J, n, n, q, s.d, s.z, s.sync, tag, tag, s.mb);
@@ -2013,7 +2026,9 @@ hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, 
 hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, int wait_chain_tag)
 {
   const int n = v.n;
-  if(!wait_chain_tag)
+  const bool ran_ahead = (wait_chain_tag != 0);
+  if(wait_chain_tag < 0) wait_chain_tag = 0; // event mode: the chain ran ahead and the stream is already ordered behind it
+  if(!ran_ahead)
   {
     hipError_t e = chain_attr(n);
     if(e != hipSuccess) return e;
@@ -2043,6 +2058,42 @@ void dense_rot_profile_dump()
     std::fprintf(stderr, "[jtn prof] %llu launches (workgroup 0); per launch (us): wait tags %.2f, stage the column %.2f, tiles %.2f, publish d %.2f\n", h[20],
                  h[16] * us / h[20], h[17] * us / h[20], h[18] * us / h[20], h[19] * us / h[20]);
 #endif
+}
+
+// Can a kernel on one stream run while a kernel on another stream is running?  The pass tags (PassSync) rely on a consumer that was
+// enqueued AFTER its producer never being executed BEFORE it; tools that let one kernel at a time onto the device and pick among the
+// queues in an order of their own (rocprofv3 --pmc serialises every dispatch) break that.  The probe enqueues a waiting kernel on `a`
+// and THEN the kernel it waits for on `b`: side by side the wait ends in microseconds; serialised, it gives up after ~2 ms and says so.
+namespace
+{
+__global__ void probe_wait_kernel(const int * flag, int * seen)
+{
+  int ok = 0;
+  for(int spins = 0; spins < 8192 && !ok; ++spins)
+  {
+    ok = (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1);
+    if(!ok) __builtin_amdgcn_s_sleep(8);
+  }
+  *seen = ok;
+}
+__global__ void probe_post_kernel(int * flag)
+{
+  __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+} // namespace
+hipError_t dense_probe_concurrency(int * dscratch2, hipStream_t a, hipStream_t b, bool * concurrent)
+{
+  hipError_t e = hipMemsetAsync(dscratch2, 0, 2 * sizeof(int), a);
+  if(e == hipSuccess) e = hipStreamSynchronize(a);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, a, dscratch2, dscratch2 + 1);
+  hipLaunchKernelGGL(probe_post_kernel, dim3(1), dim3(1), 0, b, dscratch2);
+  e = hipStreamSynchronize(a);
+  if(e == hipSuccess) e = hipStreamSynchronize(b);
+  int seen = 0;
+  if(e == hipSuccess) e = hipMemcpy(&seen, dscratch2 + 1, sizeof(int), hipMemcpyDeviceToHost);
+  *concurrent = (seen == 1);
+  return e;
 }
 
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st)

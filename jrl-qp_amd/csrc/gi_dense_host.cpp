@@ -38,6 +38,12 @@ struct jrlqp_dense
   hipStream_t side = nullptr;          // runs the next pass's constraint scan beside the Givens sweep
   hipStream_t spec = nullptr;          // runs the coefficient chain of an addition ahead of the add/drop decision
   int chain_pending = 0;               // tag of a chain launched on `spec` that no kernel of the main stream has waited for yet (0: none)
+  // Hand-off between the streams of a pass: device-side tags (PassSync) where kernels of different streams run side by side -- the
+  // normal case --, events where they do not (a profiler collecting counters serialises every dispatch and picks among the queues in
+  // its own order: a consumer spinning on a tag would then run before its producer).  Decided once, at creation
+  // (dense_probe_concurrency); JRLQP_DENSE_SYNC=events|tags overrides.
+  bool use_events = false;
+  hipEvent_t ev_x = nullptr, ev_sel = nullptr, ev_d = nullptr, ev_chain = nullptr;
   int tag = 0;                         // pass counter: the step kernel echoes it into the mailbox when its scalars are out
 };
 
@@ -123,6 +129,24 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->spec, hipStreamNonBlocking);
   if(e == hipSuccess) e = dmalloc(s.sync, 1);
   if(e == hipSuccess) e = hipMemset(s.sync, 0, sizeof(PassSync));
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_d, hipEventDisableTiming);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming);
+  if(e == hipSuccess)
+  {
+    const char * mode = std::getenv("JRLQP_DENSE_SYNC");
+    if(mode && std::strcmp(mode, "events") == 0)
+      h->use_events = true;
+    else if(mode && std::strcmp(mode, "tags") == 0)
+      h->use_events = false;
+    else
+    {
+      bool side_by_side = true;
+      e = dense_probe_concurrency(s.psel, h->side, h->spec, &side_by_side); // (psel: two ints, rewritten by every selection)
+      h->use_events = !side_by_side;
+    }
+  }
   if(e != hipSuccess)
   {
     jrlqp_dense_destroy(h);
@@ -154,6 +178,10 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   if(h->side) (void)hipStreamDestroy(h->side);
   if(h->spec) (void)hipStreamDestroy(h->spec);
   (void)hipFree(s.sync);
+  if(h->ev_d) (void)hipEventDestroy(h->ev_d);
+  if(h->ev_chain) (void)hipEventDestroy(h->ev_chain);
+  if(h->ev_x) (void)hipEventDestroy(h->ev_x);
+  if(h->ev_sel) (void)hipEventDestroy(h->ev_sel);
   delete h;
 }
 
@@ -504,7 +532,10 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
     {
       if(prefetched)
       {
-        wait_sel = tag; // the first kernel of the step waits for the side stream's selection (PassSync::sel_tag)
+        if(h->use_events)
+          TRY(hipStreamWaitEvent(st, h->ev_sel, 0));
+        else
+          wait_sel = tag; // the first kernel of the step waits for the side stream's selection (PassSync::sel_tag)
         prefetched = false;
       }
       else
@@ -518,7 +549,13 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
       // chain that is still reading d must have ended before d is overwritten: the kernel that writes d waits for its tag.
       const bool spec = q < n;
       const double ta = timing ? now() : 0;
-      TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, h->chain_pending, h->side));
+      if(h->use_events)
+      {
+        if(h->chain_pending) TRY(hipStreamWaitEvent(st, h->ev_chain, 0)); // a discarded chain may still be reading d
+        TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, 0, 0, nullptr, h->ev_d, h->ev_chain));
+      }
+      else
+        TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, h->chain_pending, h->side));
       h->chain_pending = spec ? tag : 0;
       const double tb = timing ? now() : 0;
       if(!wait_tag(h->h_mb, tag)) TRY(hipStreamSynchronize(st));
@@ -562,7 +599,7 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
     {
       const bool more = h->it + 1 < o.max_iter;
       const bool prefetch = (t == t2) && more;
-      TRY(dense_advance(h->v, h->s, t, q, true, st, prefetch ? tag : 0)); // (x_tag: the side stream's scan reads the new x)
+      TRY(dense_advance(h->v, h->s, t, q, true, st, (prefetch && !h->use_events) ? tag : 0)); // (x_tag: the side stream's scan reads the new x)
       h->f = std::fma(t * dotsc, 0.5 * t + uq, h->f);
       if(t == t2)
       {
@@ -571,11 +608,26 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
         // activated is excluded explicitly because its status byte is written by the sweep's first kernel
         // (the sweep is on the critical path: it is enqueued first, the side-stream scan behind it -- every launch costs the
         // host a few microseconds)
-        TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending)); // commit: the chain ran ahead (the sweep waits for chain_tag)
+        if(h->use_events)
+        {
+          if(prefetch) TRY(hipEventRecord(h->ev_x, st)); // x is final here: the event sits BEFORE the sweep in the main stream
+          if(h->chain_pending) TRY(hipStreamWaitEvent(st, h->ev_chain, 0));
+          TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending ? -1 : 0)); // (-1: the chain ran ahead, ordered by the event)
+        }
+        else
+          TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending)); // commit: the chain ran ahead (the sweep waits for chain_tag)
         h->chain_pending = 0;
         if(prefetch)
         {
-          TRY(dense_select(h->v, h->s, p, h->side, q + 1, tag, tag + 1)); // (also u[q+1] = 0 for the next pass: a slot this pass does not touch)
+          // (also u[q+1] = 0 for the next pass: a slot this pass does not touch)
+          if(h->use_events)
+          {
+            TRY(hipStreamWaitEvent(h->side, h->ev_x, 0));
+            TRY(dense_select(h->v, h->s, p, h->side, q + 1));
+            TRY(hipEventRecord(h->ev_sel, h->side));
+          }
+          else
+            TRY(dense_select(h->v, h->s, p, h->side, q + 1, tag, tag + 1));
           prefetched = true;
         }
         activate(p, pstat);

@@ -84,6 +84,19 @@ def test_dense_n300(capi, P, oracle):
     assert ref.term == 0 and np.linalg.norm(gpu["x"] - pb.x_star[0]) <= 1e-6
 
 
+@pytest.mark.parametrize("mode", ["events", "tags"])
+def test_dense_stream_handoff_modes(capi, P, oracle, monkeypatch, mode):
+    """The hand-off between the three streams of a pass: device-side tags (PassSync) or, where kernels of different streams do not run
+    side by side (a counter-collecting profiler serialises the dispatches), events.  The handle probes at creation;
+    JRLQP_DENSE_SYNC forces either.  Same bits both ways, bounds and general constraints, drops included."""
+    monkeypatch.setenv("JRLQP_DENSE_SYNC", mode)
+    ch = P.Characteristics(nVar=150, nObj=150, nEq=4, nIneq=260, nStrongActIneq=30, bounds=True, nStrongActBounds=12, doubleSidedIneq=True)
+    pb = P.generate_batch(1, ch, first_index=8800)
+    ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], pb.xl[0], pb.xu[0], max_iter=3000)
+    assert ref.term == 0 and ref.iters > 20
+    check(solve_gpu(capi, pb, 0, True, max_iter=3000), ref, f"hand-off by {mode}")
+
+
 def test_c2_full_size(capi, P, oracle):
     """BASELINE configs[1] (c2) at full size: n = 1024, m = 2048, 307 strongly active, through jrlqp_dense_solve --
     termination status, iteration count, activation statuses, x, u, f and the Cholesky factor left in G, bit for bit
