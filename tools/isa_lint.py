@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA lint over EVERY kernel of libjrlqp_hip.so (gfx950): the two read-lane hazards this code base has met on hardware.
+"""ISA lint over EVERY kernel of libjrlqp_hip.so (gfx950): the VALU-written-SGPR hazards this code base has met on hardware.
 
   R1  lane select too close to its producer.  `v_readlane_b32 D, vS, sN` / `v_writelane_b32 vD, X, sN` whose lane-select SGPR
       sN was written by a VALU instruction (v_readfirstlane_b32, v_readlane_b32, a v_cmp / carry-out into SGPRs) FEWER THAN
@@ -10,7 +10,15 @@
       own instructions; it cannot see into inline-assembly units (device_common.h fma_neg_bcast), and a unit issued right behind
       the producer of its source read a stale half (measured: factors off by 1e-8).
 
-Both are checked on the DISASSEMBLY of the built objects (every instruction, compiler-emitted and inline assembly alike), in
+  R3  memory instruction addressed through an SGPR too close to the VALU write of that SGPR.  `global_load_dwordx2 v, vOFF, s[0:1]`
+      (or any global_ / flat_ / scratch_ / buffer_ / s_load_ / s_buffer_ instruction naming an SGPR) whose SGPR was written by a VALU
+      instruction -- in practice the v_readlane_b32 that reloads a spilled SGPR pair -- FEWER THAN EIGHT wait states earlier.  The
+      hazard table asks for five and hipcc emits exactly five (`s_nop 4`); round 3 caught an embedded-size instantiation of the
+      batched kernel (the ones with SGPR spills) faulting about once in 150 launches on `global_load_dwordx2 v[132:133], v123,
+      s[0:1]` five wait states behind `v_readlane_b32 s1, v205, 31`, at addresses made of whatever s[0:1] held BEFORE the reload
+      (rocgdb, precise memory mode: tools/gdb_fault.sh).
+
+All are checked on the DISASSEMBLY of the built objects (every instruction, compiler-emitted and inline assembly alike), in
 straight-line order inside each function: a taken branch only adds time between producer and consumer.
 
 usage: isa_lint.py [--min-states 5] [--objdir jrl-qp_amd/csrc] [--list] [objects...]      exit status 1 on any finding
@@ -32,6 +40,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 INSN = re.compile(r"^\s+([a-z][a-z0-9_]+)(?:\s+(.*?))?\s*(?://.*|;.*)?$")  # llvm-objdump ("// addr: bytes") and hipcc -S ("; comment") lines
 FUNC = re.compile(r"^[0-9a-f]+ <(.+)>:$")
+MEM_STATES = 8  # R3: wait states between a VALU write of an SGPR and a memory instruction addressed through it (hazard table: 5)
 CARRY_OUT = ("v_add_co_u32", "v_sub_co_u32", "v_subrev_co_u32", "v_addc_co_u32", "v_subb_co_u32", "v_subbrev_co_u32",
              "v_div_scale_f32", "v_div_scale_f64", "v_mad_u64_u32", "v_mad_i64_i32")
 
@@ -122,6 +131,24 @@ def lint_listing(text, min_states, name, fix_out=None):
                             stats["fixed"] = stats.get("fixed", 0) + 1
                         else:
                             findings.append((name, func, "R1", f"{states} wait states between '{sgpr_valu_write[s][1]}' and '{line.strip().split('//')[0].strip()}'"))
+        # R3: a memory instruction that names a VALU-written SGPR (address base / offset / resource)
+        if mn.startswith(("global_", "flat_", "scratch_", "buffer_", "s_load_", "s_buffer_", "s_scratch_", "tbuffer_")):
+            used = set()
+            for t in ops[(1 if (mn.startswith("s_load_") or mn.startswith("s_buffer_")) else 0):]:
+                used |= regs_of(t.split()[0] if t else t, "s")
+            worst = None
+            for sreg in used:
+                if sreg in sgpr_valu_write:
+                    states = clock - sgpr_valu_write[sreg][0]
+                    if states < MEM_STATES and (worst is None or states < worst[0]):
+                        worst = (states, sgpr_valu_write[sreg][1])
+            if worst is not None:
+                if fix_out is not None:
+                    fix_out.insert(len(fix_out) - 1, f"\ts_nop {MEM_STATES - worst[0] - 1} ; isa_lint R3")
+                    clock += MEM_STATES - worst[0]
+                    stats["fixed"] = stats.get("fixed", 0) + 1
+                else:
+                    findings.append((name, func, "R3", f"{worst[0]} wait states between '{worst[1]}' and '{line.strip().split('//')[0].strip()}'"))
         # ---- producers
         written_s = set()
         if is_valu and ops:
