@@ -6,7 +6,7 @@ little: this test solves the n = 40 / 50 / 60 / 64 parity sets -- equalities, bo
 extra columns, the role-specialised loop -- TWENTY-FOUR times back to back in one process, with other launches of the same
 kernels in flight on a second stream, and requires every repetition to be bit-identical to the oracle (and therefore to every
 other repetition).  The static half of the same item is tools/isa_lint.py (run by build(): five wait states at every
-VALU-written lane select of every kernel)."""
+VALU-written lane select of every kernel, eight in front of every memory instruction addressed through a VALU-written SGPR)."""
 import numpy as np
 import pytest
 
@@ -22,6 +22,10 @@ SETS = [
     dict(nVar=64, nObj=64, nIneq=256, nStrongActIneq=25),
     dict(nVar=64, nObj=64, nEq=5, nIneq=190, nStrongActIneq=12, bounds=True, nStrongActBounds=6, doubleSidedIneq=True),
     dict(nVar=45, nObj=45, nEq=5, nIneq=90, nStrongActIneq=12, bounds=True, nStrongActBounds=5, doubleSidedIneq=True),  # embedded in 50
+    # embedded in 60 / 64, role-specialised loop: the instantiations with SGPR spills.  Round 3: a load addressed through an SGPR pair five
+    # wait states behind its v_readlane reload faulted about once in 150 launches of the first one (isa_lint R3 pads such sites to eight)
+    dict(nVar=55, nObj=55, nIneq=110, nStrongActIneq=16),
+    dict(nVar=61, nObj=61, nIneq=157, nStrongActIneq=20),
 ]
 
 
