@@ -699,6 +699,33 @@ def main():
                                      "solved": int((r2.term == 0).sum().item())}
                 del d2, pb2
             out["other_active_fractions"] = other
+            # ---- how much of a launch is its first and last round: the same problems tiled to 2 B and 4 B (4096 workgroups are 5.33 rounds
+            # of the 768 resident ones; the marginal rate between two batch sizes is what the kernel sustains once the machine is full)
+            try:
+                scal = {"B": [], "ms_per_launch_min": []}
+                for mult in (1, 2, 4):
+                    dm = {k: (torch.cat([v] * mult) if mult > 1 else v) for k, v in dev.items() if k in ("G", "a", "C", "bl", "bu")}
+                    sm = capi.BatchSolver(n, m, False, (hi - lo) * mult, device=device)
+                    for _ in range(2):
+                        sm.solve(dm["G"], dm["a"], dm["C"], dm["bl"], dm["bu"], stream=stream)
+                    evm = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+                    for e0, e1 in evm:
+                        e0.record(stream)
+                        sm.solve(dm["G"], dm["a"], dm["C"], dm["bl"], dm["bu"], stream=stream)
+                        e1.record(stream)
+                    torch.cuda.synchronize(device)
+                    scal["B"].append((hi - lo) * mult)
+                    scal["ms_per_launch_min"].append(float(min(a.elapsed_time(b) for a, b in evm)))
+                    del dm, sm
+                tms, bs = scal["ms_per_launch_min"], scal["B"]
+                scal["solves_per_s"] = [b_ / (t_ * 1e-3) for b_, t_ in zip(bs, tms)]
+                scal["marginal_solves_per_s"] = (bs[2] - bs[0]) / ((tms[2] - tms[0]) * 1e-3)
+                scal["launch_overhead_ms"] = tms[0] - bs[0] / scal["marginal_solves_per_s"] * 1e3
+                scal["what"] = ("the headline problems tiled to 2 B and 4 B per launch, best of 8 launches each; marginal = (4 B - B) / (t(4 B) - t(B)): "
+                                "the rate once every CU holds its three workgroups; not part of `value`")
+                out["batch_scaling"] = scal
+            except Exception as e:  # (an extra: never let it take the bench line down)
+                out["batch_scaling"] = {"error": repr(e)}
             # ---- a clearly labelled SUSTAINED loop: the K timed steps are ~30 ms of kernels, too short for a utilisation sampler to see
             if args.sustain > 0:
                 torch.cuda.synchronize(device)
