@@ -84,6 +84,36 @@ def test_dense_n300(capi, P, oracle):
     assert ref.term == 0 and np.linalg.norm(gpu["x"] - pb.x_star[0]) <= 1e-6
 
 
+def test_two_handles_on_two_threads(capi, P, oracle):
+    """Two Mode A handles driven from two host threads at the same time, each on a stream of its own: every handle has its own pass
+    tags, side streams and mailbox, so the solves must not see each other (ctypes releases the GIL inside jrlqp_dense_solve)."""
+    import threading
+
+    import torch
+
+    chs = [P.benchmark_characteristics(260, 400), P.Characteristics(nVar=200, nObj=200, nEq=5, nIneq=300, nStrongActIneq=40, bounds=True, nStrongActBounds=15)]
+    pbs = [P.generate_batch(1, ch, first_index=9100 + i) for i, ch in enumerate(chs)]
+    refs = []
+    for pb, ch in zip(pbs, chs):
+        hb = ch.bounds
+        refs.append(oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], pb.xl[0] if hb else None, pb.xu[0] if hb else None, max_iter=4000))
+    out = [None, None]
+
+    def work(i):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(3):  # (repeated: the handle's tags keep counting across solves)
+                out[i] = solve_gpu(capi, pbs[i], 0, chs[i].bounds, max_iter=4000)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert refs[i].term == 0
+        check(out[i], refs[i], f"handle {i} beside the other")
+
+
 @pytest.mark.parametrize("mode", ["events", "tags"])
 def test_dense_stream_handoff_modes(capi, P, oracle, monkeypatch, mode):
     """The hand-off between the three streams of a pass: device-side tags (PassSync) or, where kernels of different streams do not run
