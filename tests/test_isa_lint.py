@@ -1,0 +1,64 @@
+"""tools/isa_lint.py on small hand-written listings: each rule flags its hazard and the fix pass pads it away (CPU only).
+
+R1  a lane select (v_readlane / v_writelane) by an SGPR that a VALU instruction wrote fewer than five wait states earlier
+R2  a v_readlane of a VGPR right behind the VALU instruction that wrote it
+R3  a memory instruction addressed through an SGPR that a VALU instruction wrote fewer than eight wait states earlier -- the
+    hazard table asks for five, hipcc emits exactly five behind an SGPR-spill reload, and that faulted on hardware"""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+lint = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(lint)
+
+
+def listing(body):
+    return "0000000000001000 <kernel_under_test>:\n" + "\n".join("\t" + l for l in body) + "\n"
+
+
+def rules(text):
+    findings, _ = lint.lint_listing(text, 5, "unit")
+    return sorted(f[2] for f in findings)
+
+
+def fixed(text):
+    out = []
+    lint.lint_listing(text, 5, "unit", out)
+    return "\n".join(out)
+
+
+def test_r3_five_wait_states_behind_a_spill_reload_are_flagged_and_padded():
+    # the sequence rocgdb stopped on: reload of an address pair from spill lanes, s_nop 4, the load through it
+    bad = listing(["v_readlane_b32 s0, v205, 30", "v_lshlrev_b32_e32 v123, 3, v0", "v_readlane_b32 s1, v205, 31", "s_nop 4",
+                   "global_load_dwordx2 v[132:133], v123, s[0:1]", "s_endpgm"])
+    assert rules(bad) == ["R3"]
+    out = fixed(bad)
+    assert "isa_lint R3" in out and rules(out.replace("; isa_lint R3", "")) == []
+    # eight wait states are enough; an SALU write of the pair in between supersedes the VALU write
+    ok8 = listing(["v_readlane_b32 s1, v205, 31", "s_nop 7", "global_load_dwordx2 v[2:3], v1, s[0:1]"])  # (s_nop N = N + 1 wait states)
+    assert rules(ok8) == []
+    salu = listing(["v_readlane_b32 s1, v205, 31", "s_mov_b64 s[0:1], s[4:5]", "global_load_dwordx2 v[2:3], v1, s[0:1]"])
+    assert rules(salu) == []
+    # scalar loads and stores through a VALU-written base count as well
+    smem = listing(["v_readfirstlane_b32 s4, v7", "v_readfirstlane_b32 s5, v8", "s_load_dwordx2 s[8:9], s[4:5], 0x0"])
+    assert rules(smem) == ["R3"]
+    st = listing(["v_readlane_b32 s3, v9, 2", "s_nop 1", "global_store_dwordx2 v1, v[4:5], s[2:3]"])
+    assert rules(st) == ["R3"]
+
+
+def test_r1_lane_select_and_r2_back_to_back_readlane():
+    r1 = listing(["v_readfirstlane_b32 s6, v3", "s_nop 3", "v_readlane_b32 s8, v10, s6"])  # four wait states: what hipcc emits
+    assert rules(r1) == ["R1"]
+    assert rules(fixed(r1).replace("; isa_lint R1", "")) == []
+    ok = listing(["v_readfirstlane_b32 s6, v3", "s_nop 4", "v_readlane_b32 s8, v10, s6"])
+    assert rules(ok) == []
+    r2 = listing(["v_add_f64 v[10:11], v[2:3], v[4:5]", "v_readlane_b32 s8, v10, 3"])
+    assert rules(r2) == ["R2"]
+    assert rules(fixed(r2).replace("; isa_lint R2", "")) == []
+
+
+def test_scopes_do_not_leak_between_functions():
+    two = ("0000000000001000 <first>:\n\tv_readlane_b32 s1, v205, 31\n\ts_endpgm\n"
+           "0000000000002000 <second>:\n\tglobal_load_dwordx2 v[2:3], v1, s[0:1]\n")
+    assert rules(two) == []
