@@ -230,11 +230,19 @@ __global__ __launch_bounds__(256) void jinv_block_kernel(const double * __restri
   const int cmax = min(n - 1, c0 + 63);
   const int ncol = cmax - c0 + 1;
   const bool live = c < n;
-  constexpr int RW = NB / 4; // rows per wave
-  const int rbase = wave * RW;
-  double acc[RW];
+  // The accumulation over the rows below the block is a matrix product, acc(r, c) -= L(k, i0 + r) J(k, c) for k descending -- and the
+  // f64 MFMA is a k-ordered fma chain (tests/test_gpu_arith.py), so it runs on the matrix cores with the bits of the scalar chains:
+  // wave w owns the 16 columns c0 + 16 w .. of the tile and both 16-row halves of the block; lane l holds rows (l >> 4) + 4 r of a
+  // half (r < 4) in column l & 15, feeds A(i = l & 15, k' = l >> 4) = -L and B(k' = l >> 4, j = l & 15) = J, and k' = 0 is the
+  // HIGHEST row of a step of four.  (Rounds 1-3: lane = column with eight scalar chains per lane -- every L entry a broadcast LDS
+  // read, which returns 512 bytes for eight: the kernel was bound by the LDS port, 60 us per block row.)
+  const int mi = lane & 15, mk = lane >> 4;
+  const int cw = c0 + 16 * wave + mi; // the column this lane accumulates
+  double4_t acc2[2];
 #pragma unroll
-  for(int r = 0; r < RW; ++r) acc[r] = (live && c == i0 + rbase + r) ? 1.0 : 0.0;
+  for(int h = 0; h < 2; ++h)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) acc2[h][r] = (cw < n && cw == i0 + 16 * h + mk + 4 * r) ? 1.0 : 0.0;
   for(int e = tid; e < nbk * nbk; e += 256)
   {
     int i = e % nbk, j = e / nbk;
@@ -282,15 +290,21 @@ __global__ __launch_bounds__(256) void jinv_block_kernel(const double * __restri
     }
     lds_barrier();
     if(khi - 64 >= i0 + nbk) request(khi - 64);
-    for(int kk = cnt - 1; kk >= 0; --kk)
+    for(int kt = cnt - 1; kt >= 0; kt -= 4) // rows kt, kt-1, kt-2, kt-3 of the stage: one MFMA step per half (rows past the stage: A = 0)
     {
-      const double jk = live ? Jt[kk * 65 + lane] : 0.0;
-#pragma unroll
-      for(int r = 0; r < RW; ++r) acc[r] = FMA(-Ls[kk * (NB + 1) + rbase + r], jk, acc[r]);
+      const int kk = kt - mk;
+      const bool kin = kk >= 0;
+      const int kc = kin ? kk : 0;
+      const double b = Jt[kc * 65 + 16 * wave + mi];
+      const double a0 = kin ? -Ls[kc * (NB + 1) + mi] : 0.0, a1 = kin ? -Ls[kc * (NB + 1) + 16 + mi] : 0.0;
+      acc2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc2[0], 0, 0, 0);
+      acc2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc2[1], 0, 0, 0);
     }
   }
 #pragma unroll
-  for(int r = 0; r < RW; ++r) As[(rbase + r) * 65 + lane] = acc[r];
+  for(int h = 0; h < 2; ++h)
+#pragma unroll
+    for(int r = 0; r < 4; ++r) As[(16 * h + mk + 4 * r) * 65 + 16 * wave + mi] = acc2[h][r];
   __syncthreads();
   if(wave != 0) return;
   // in-block back substitution (descending i), all columns of this tile at once
