@@ -80,6 +80,13 @@ inline bool wait_tag(const jrlqp::Mailbox * mb, int tag)
   }
 }
 
+// The tag hand-off lets consumer kernels spin on the device while their producers run; that is only safe while the spinning
+// workgroups cannot take the LDS a producer needs.  The workgroups of `jtn` / the scan hold n + 6240 doubles of LDS each and there
+// are n / 16 of them: from n ~ 3700 on they fill every CU, and a solve at n = 3900 was measured to stall (a `jtn` spinning on the tag
+// of a coefficient kernel that found no CU with 62 KB of LDS left; tools/check_max_size.py) until the wait gave up.  Beyond
+// kTagsMaxN unknowns a handle therefore orders its streams by events (n = 3000 and 3500 were measured clean with tags).
+constexpr int kTagsMaxN = 2048;
+
 template<class T>
 hipError_t dmalloc(T *& p, size_t count)
 {
@@ -140,6 +147,8 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
       h->use_events = true;
     else if(mode && std::strcmp(mode, "tags") == 0)
       h->use_events = false;
+    else if(n > kTagsMaxN)
+      h->use_events = true;
     else
     {
       bool side_by_side = true;

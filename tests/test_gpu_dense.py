@@ -176,6 +176,18 @@ def test_dense_n2800(capi, P, oracle):
     assert np.array_equal(np.tril(gpu["L"]), np.tril(ref.L))
 
 
+def test_dense_at_the_size_limit(capi, P, oracle):
+    """n = JRLQP_DENSE_MAX_N: the sweep's LDS at the CU's 160 KiB, 64 blocks in the coefficient scan, `jtn` / the scan with more
+    workgroups than CUs -- and the stream hand-off by events (beyond 2048 unknowns the spinning consumers of the tag hand-off could
+    starve their producers of LDS: tools/check_max_size.py found a solve at n = 3900 stalling until the wait gave up)."""
+    n = 4096
+    pb = P.generate_batch(1, P.benchmark_characteristics(n, 96, 30), first_index=123)
+    ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], max_iter=80)
+    gpu = solve_gpu(capi, pb, 0, False, max_iter=80)
+    check(gpu, ref, "n = 4096")
+    assert ref.term == 0 and ref.iters > 30
+
+
 def test_dense_size_limit(capi):
     with pytest.raises(capi.JrlqpError):
         capi.DenseSolver(capi.DENSE_MAX_N + 1, 1, False)
