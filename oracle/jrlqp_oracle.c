@@ -31,6 +31,35 @@
 
 #define FMA(a, b, c) __builtin_fma((a), (b), (c))
 
+/* LITERAL mode (orc_gi_solve_literal, tests/test_oracle_literal.py).  Rounds 1-3 moved three evaluations away from the most
+ * literal reading of the reference's source: C5 (z.z and n+.z as trees), C6 (which product of a rotation is rounded) and C7 (the
+ * Givens coefficients of an addition from a suffix sum instead of the serial makeGivens recurrence of
+ * GoldfarbIdnaniSolver.cpp:225-232).  Each is one of Eigen's admissible evaluations, but only a test can show that no DECISION
+ * (termination status, iteration count, activation statuses, active order) depends on it.  The flags below switch each change off
+ * per calling thread; the canonical entry points always run with 0.
+ *   ORC_LIT_CHAIN_DOTS   z.z and n+.z as in-order chains (C1), as GoldfarbIdnaniSolver.cpp:174,183-190 read left to right
+ *   ORC_LIT_ROT_C3       rotations as rounds 1-2 had them: x' = fma(c, x, -(s y)), y' = fma(s, x, c y)
+ *   ORC_LIT_SERIAL_GIVENS  makeGivens(d_i, d_{i+1}) for i = n-2 .. q, radius carried in d_i, exactly :225-232
+ *   ORC_LIT_NO_FMA       the dots and rotations above with every product and sum rounded on its own (what a build of Eigen
+ *                        without FMA instructions evaluates, scalar path) */
+static __thread int g_lit = 0;
+
+static double lit_dot(int n, const double * a, const double * b)
+{
+  double acc = 0.0;
+  if(g_lit & ORC_LIT_NO_FMA)
+    for(int k = 0; k < n; ++k) acc = acc + a[k] * b[k];
+  else
+    for(int k = 0; k < n; ++k) acc = FMA(a[k], b[k], acc);
+  return acc;
+}
+
+/* the scalar products of a pass that need z: C5 tree (canonical) or the literal chain */
+static double zdot(int n, const double * a, const double * b)
+{
+  return (g_lit & (ORC_LIT_CHAIN_DOTS | ORC_LIT_NO_FMA)) ? lit_dot(n, a, b) : orc_dot_tree(n, a, b, 0);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* canonical primitives                                                                        */
 /* ------------------------------------------------------------------------------------------- */
@@ -197,6 +226,20 @@ void orc_givens(double p, double q, double * c, double * s, double * r)
 static inline void rot(double c, double s, double * x, double * y)
 {
   double xv = *x, yv = *y;
+  if(__builtin_expect(g_lit & (ORC_LIT_ROT_C3 | ORC_LIT_NO_FMA), 0))
+  {
+    if(g_lit & ORC_LIT_NO_FMA)
+    {
+      *x = c * xv - s * yv;
+      *y = s * xv + c * yv;
+    }
+    else
+    {
+      *x = FMA(c, xv, -(s * yv));
+      *y = FMA(s, xv, c * yv);
+    }
+    return;
+  }
   *x = FMA(-s, yv, c * xv); /* CANON C6: in each output the product of the OTHER operand's partner is rounded first -- c x here, */
   *y = FMA(s, xv, c * yv);  /* c y there -- so that a sweep's carried value (y in a descending sweep, x in an ascending one)
                              * enters one fma per rotation and nothing else */
@@ -310,8 +353,8 @@ static double np_dot(const gi_state * S, int p, int status, const double * v)
   switch(status)
   {
     case ORC_EQUALITY:
-    case ORC_LOWER: return orc_dot_tree(S->n, v, S->C + (long)p * S->ldc, 0);
-    case ORC_UPPER: return -orc_dot_tree(S->n, v, S->C + (long)p * S->ldc, 0);
+    case ORC_LOWER: return zdot(S->n, v, S->C + (long)p * S->ldc);
+    case ORC_UPPER: return -zdot(S->n, v, S->C + (long)p * S->ldc);
     case ORC_FIXED:
     case ORC_LOWER_BOUND: return v[p - S->m];
     case ORC_UPPER_BOUND: return -v[p - S->m];
@@ -394,7 +437,7 @@ int orc_givens_chain(int n, int q, const double * d, double * c, double * s, dou
     if(a > amax) amax = a;
     if(a != 0.0 && a < amin) amin = a;
   }
-  if(!finite || amax > 0x1p500 || amin < 0x1p-500)
+  if(!finite || amax > 0x1p500 || amin < 0x1p-500 || (g_lit & ORC_LIT_SERIAL_GIVENS))
   {
     double r = d[n - 1];
     for(int i = n - 2; i >= q; --i) orc_givens(d[i], r, &c[i], &s[i], &r);
@@ -493,12 +536,12 @@ static void add_initial_constraint(gi_state * S, int p, int status)
   u[q] = 0.0;
   compute_step(S, p, status);
   double t = 0.0;
-  if(sqrt(orc_dot_tree(n, z, z, 0)) > 1e-14)
+  if(sqrt(zdot(n, z, z)) > 1e-14)
   {
     if(status == ORC_EQUALITY)
     {
       const double * cp = S->C + (long)p * S->ldc;
-      t = (S->bl[p] - orc_dot(n, cp, x)) / orc_dot_tree(n, cp, z, 0);
+      t = (S->bl[p] - orc_dot(n, cp, x)) / zdot(n, cp, z);
     }
     else
     {
@@ -923,7 +966,7 @@ main_loop:
         }
       }
       double cz = 0.0;
-      if(sqrt(orc_dot_tree(n, z, z, 0)) > 1e-14) /* CANON C5 */
+      if(sqrt(zdot(n, z, z)) > 1e-14) /* CANON C5 */
       {
         double b, cx;
         if(pstatus == ORC_LOWER || pstatus == ORC_UPPER)
@@ -931,7 +974,7 @@ main_loop:
           const double * cp = C + (long)p * ldc;
           b = (pstatus == ORC_LOWER) ? bl[p] : bu[p];
           cx = orc_dot(n, cp, x);         /* C1: == cxs[p] of the scan when p was selected in this pass */
-          cz = orc_dot_tree(n, cp, z, 0); /* C5 */
+          cz = zdot(n, cp, z); /* C5 */
         }
         else
         {
@@ -1020,6 +1063,47 @@ int orc_gi_solve_warm(int n, int m, int nb, double * G, int ldg, const double * 
 {
   return gi_solve_impl(1, as_in, n, m, nb, G, ldg, a, C, ldc, bl, bu, xl, xu, max_iter, big_bnd, xout, uout, status_out,
                        active_out, nactive_out, iters_out, f_out, trace, trace_cap, work);
+}
+
+/* The cold solve with some of CANON C5 / C6 / C7 switched off for the calling thread (see g_lit above); flags = 0 is orc_gi_solve. */
+int orc_gi_solve_literal(int flags, int n, int m, int nb, double * G, int ldg, const double * a, const double * C, int ldc,
+                         const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
+                         double big_bnd, double * xout, double * uout, int * status_out, int * active_out, int * nactive_out,
+                         int * iters_out, double * f_out, orc_trace_rec * trace, int trace_cap, double * work)
+{
+  g_lit = flags;
+  const int rc = gi_solve_impl(0, NULL, n, m, nb, G, ldg, a, C, ldc, bl, bu, xl, xu, max_iter, big_bnd, xout, uout, status_out,
+                               active_out, nactive_out, iters_out, f_out, trace, trace_cap, work);
+  g_lit = 0;
+  return rc;
+}
+
+/* Packed batch through orc_gi_solve_literal; active: B x n ordered active lists (may be NULL), nactive: B. */
+void orc_gi_solve_batch_literal(int flags, int B, int n, int m, int nb, double * G, const double * a, const double * C,
+                                const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
+                                double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * term,
+                                int * iters, double * f, int nthreads)
+{
+  if(nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    double * work = (double *)malloc(sizeof(double) * (size_t)orc_gi_work_doubles(n, m, nb));
+    int * act = (int *)malloc(sizeof(int) * (size_t)(m + nb + 1));
+#pragma omp for schedule(static)
+    for(int b = 0; b < B; ++b)
+    {
+      int na = 0;
+      term[b] = orc_gi_solve_literal(flags, n, m, nb, G + (long)b * n * n, n, a + (long)b * n, C + (long)b * n * m, n,
+                                     bl + (long)b * m, bu + (long)b * m, nb ? xl + (long)b * nb : NULL,
+                                     nb ? xu + (long)b * nb : NULL, max_iter, big_bnd, x + (long)b * n, u + (long)b * (m + nb),
+                                     status + (long)b * (m + nb), act, &na, iters + b, f + b, NULL, 0, work);
+      if(nactive) nactive[b] = na;
+      if(active)
+        for(int k = 0; k < n; ++k) active[(long)b * n + k] = (k < na) ? act[k] : -1;
+    }
+    free(act);
+    free(work);
+  }
 }
 
 /* experimental::BoxAndSingleConstraintSolver::solve(x0, c, bl, xl, xu) (BoxAndSingleConstraintSolver.cpp:11-44):

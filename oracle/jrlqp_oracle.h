@@ -126,6 +126,27 @@ void orc_gi_solve_batch(int B,
                         double * f,
                         int nthreads);
 
+/* LITERAL evaluation of the three places where the CANON contract (oracle/README.md) departs from the most literal reading of
+ * the reference's source -- C5, C6, C7 -- one flag each, plus "no fma".  Test infrastructure for tests/test_oracle_literal.py:
+ * the DECISIONS of a solve (termination, iterations, activation statuses, order of the active list) must not depend on them. */
+enum
+{
+  ORC_LIT_CHAIN_DOTS = 1,    /* z.z and n+.z as in-order chains (GoldfarbIdnaniSolver.cpp:174,183-190) instead of C5 trees */
+  ORC_LIT_ROT_C3 = 2,        /* rotations x' = fma(c, x, -(s y)), y' = fma(s, x, c y) instead of C6 */
+  ORC_LIT_SERIAL_GIVENS = 4, /* makeGivens(d_i, d_{i+1}), i = n-2 .. q, radius in d_i (GoldfarbIdnaniSolver.cpp:225-232) instead of C7 */
+  ORC_LIT_NO_FMA = 8,        /* those dots and rotations with every product and sum rounded separately */
+  ORC_LIT_ALL = 7
+};
+int orc_gi_solve_literal(int flags, int n, int m, int nb, double * G, int ldg, const double * a, const double * C, int ldc,
+                         const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
+                         double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * iters,
+                         double * f, orc_trace_rec * trace, int trace_cap, double * work);
+/* packed batch; active: B x n (entries beyond nactive[b] are -1), may be NULL */
+void orc_gi_solve_batch_literal(int flags, int B, int n, int m, int nb, double * G, const double * a, const double * C,
+                                const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
+                                double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * term,
+                                int * iters, double * f, int nthreads);
+
 /* Timing loop of bench.py's cpu_baseline leg: the reference's benchmark loop (benchmarks/Solvers.cpp:447-453, :508-520) --
  * per thread one workspace and one G buffer, G restored by memcpy INSIDE the loop before every solve, `rounds` passes over the
  * B problems (static partition), outputs into caller-preallocated arrays.  Returns the wall seconds of the rounds alone

@@ -61,6 +61,9 @@ class Oracle:
         L.orc_gi_solve_batch.restype = None
         L.orc_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
                                          ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_dp, ct.c_int]
+        L.orc_gi_solve_batch_literal.restype = None
+        L.orc_gi_solve_batch_literal.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
+                                                 ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip, c_ip, c_dp, ct.c_int]
         L.orc_gi_bench_rounds.restype = ct.c_double
         L.orc_gi_bench_rounds.argtypes = [ct.c_int] * 5 + [c_dp] * 7 + [ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_dp, ct.c_int]
         L.orc_gi_solve_warm.restype = ct.c_int
@@ -218,6 +221,26 @@ class Oracle:
             self.lib.orc_gi_solve_batch(B, n, m, nb, _dp(Gc), _dp(a), _dp(C), _dp(bl), _dp(bu), _dp(xlc), _dp(xuc), max_iter, big_bnd,
                                         _dp(x), _dp(u), _ip(status), _ip(term), _ip(iters), _dp(f), nthreads)
         return dict(x=x, u=u, status=status, term=term, iters=iters, f=f, L=Gc)
+
+    LIT_CHAIN_DOTS, LIT_ROT_C3, LIT_SERIAL_GIVENS, LIT_NO_FMA, LIT_ALL = 1, 2, 4, 8, 7
+
+    def solve_batch_literal(self, flags, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, nthreads=1):
+        """Cold packed batch with some of CANON C5 / C6 / C7 switched off (orc_gi_solve_batch_literal; flags = 0 is the canonical
+        solve).  Also returns the ordered active lists (B x n, -1 beyond nactive)."""
+        B, n, _ = G.shape
+        m = C.shape[1]
+        nb = 0 if xl is None or xl.shape[1] == 0 else xl.shape[1]
+        Gc = np.ascontiguousarray(G, dtype=np.float64).copy()
+        a, C, bl, bu = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, C, bl, bu))
+        xlc = np.ascontiguousarray(xl) if nb else None
+        xuc = np.ascontiguousarray(xu) if nb else None
+        out = dict(x=np.zeros((B, n)), u=np.zeros((B, m + nb)), status=np.zeros((B, m + nb), dtype=np.int32),
+                   active=np.zeros((B, n), dtype=np.int32), nactive=np.zeros(B, dtype=np.int32), term=np.zeros(B, dtype=np.int32),
+                   iters=np.zeros(B, dtype=np.int32), f=np.zeros(B))
+        self.lib.orc_gi_solve_batch_literal(flags, B, n, m, nb, _dp(Gc), _dp(a), _dp(C), _dp(bl), _dp(bu), _dp(xlc), _dp(xuc), max_iter,
+                                            big_bnd, _dp(out["x"]), _dp(out["u"]), _ip(out["status"]), _ip(out["active"]),
+                                            _ip(out["nactive"]), _ip(out["term"]), _ip(out["iters"]), _dp(out["f"]), nthreads)
+        return out
 
     # ---- primitives ----------------------------------------------------------------------------
     def llt(self, A):
