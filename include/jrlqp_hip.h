@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define JRLQP_ABI_VERSION 2 /* 2: jrlqp_gi_batch_workspace_bytes / jrlqp_gi_solve_batch_ws; no allocation inside any solve */
+#define JRLQP_ABI_VERSION 3 /* 2: jrlqp_gi_batch_workspace_bytes / jrlqp_gi_solve_batch_ws; no allocation inside any solve.  3: hook level
+                             * complete (jrlqp_dense_init_active_set, mirror kept by add / remove), jrlqp_dense_set_trace, multi-device entry */
 
 /* jrl::qp::ActivationStatus, include/jrl-qp/enums.h:15-23 (same numeric values) */
 enum jrlqp_activation
@@ -243,6 +244,42 @@ int jrlqp_box_solve_batch(int n,
                           int trace_cap,
                           void * stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * One process, several devices.  The reference has no counterpart (it is single-threaded CPU code); this is the batched front
+ * end of SURVEY.md section 8(e): QPs are independent, so a batch of B_total problems is cut into ndev CONTIGUOUS shards,
+ *     shard r = [first_r, first_r + count_r),  jrlqp_shard_range(B_total, ndev, r, &first_r, &count_r)
+ * (balanced: the first B_total % ndev shards hold one problem more -- the same arithmetic as the one-process-per-GPU launcher,
+ * jrl-qp_amd/dist.py), shard r lives entirely on device device_ids[r] and is solved there by the batched kernel; there is NO
+ * exchange between devices during the solve and no collective.  shards[r] holds DEVICE pointers into device_ids[r]'s memory for
+ * the count_r problems of the shard, packed exactly as for jrlqp_gi_solve_batch (problem first_r + k of the batch is problem k of
+ * the shard); `stream` is a stream of that device (NULL: its default stream); `dworkspace` / `workspace_bytes` is the shard's
+ * workspace (jrlqp_gi_batch_workspace_bytes_on(device, n, m, nb, count_r); nothing is needed up to n = 64) -- nothing is
+ * allocated inside the call.  Every shard is enqueued before any is waited for, so the devices run side by side while the
+ * calling thread only launches; synchronize != 0 then waits for every shard's stream.  The caller's current device is restored.
+ * jrlqp_gi_gather_x_multi copies the shards' solutions into ONE array of B_total x n doubles on device device_ids[root] (peer
+ * copies over xGMI, each ordered behind its shard's solve on the shard's own stream; the epilogue of SURVEY.md section 5 for a
+ * single consumer: 13 MB for 32768 problems of 50 unknowns) -- the only traffic between devices, and optional.
+ * Errors: JRLQP_ERR_INVALID_ARGUMENT for a device id out of range or used twice; whatever jrlqp_gi_solve_batch_ws returns for a
+ * shard otherwise (shards enqueued before the failing one keep running). */
+typedef struct jrlqp_shard_buffers
+{
+  const double *dG, *da, *dC, *dbl, *dbu, *dxl, *dxu; /* inputs of the shard (dxl / dxu NULL when nb == 0, dC / dbl / dbu when m == 0) */
+  const int * das;                                    /* activation-status guesses of a warm start, or NULL */
+  double *dx, *du;                                    /* outputs of the shard */
+  int *dstatus, *dterm, *diters;
+  double * df;
+  double * dL;                                        /* optional: the Cholesky factors (may alias dG), or NULL */
+  void * dworkspace;
+  long long workspace_bytes;
+  void * stream;
+} jrlqp_shard_buffers;
+void jrlqp_shard_range(int B_total, int nshards, int r, int * first, int * count);
+long long jrlqp_gi_batch_workspace_bytes_on(int device, int n, int m, int nb, int B);
+int jrlqp_gi_solve_batch_multi(int warm, int n, int m, int nb, int B_total, int ndev, const int * device_ids,
+                               const jrlqp_shard_buffers * shards, const jrlqp_options * opts, int synchronize);
+int jrlqp_gi_gather_x_multi(int n, int B_total, int ndev, const int * device_ids, const jrlqp_shard_buffers * shards, int root,
+                            double * dx_all_on_root, int synchronize);
+
 /* LDS bytes one workgroup of the batched kernel uses for (n, m, nb), and where the constraint matrix lives during the
  * solve: *c_placement = 2 one column per thread in registers, 1 staged in LDS, 0 streamed from L2/HBM; returns -1 if
  * unsupported.  Lets a caller reason about occupancy (163840 B of LDS per CU). */
@@ -280,12 +317,27 @@ int jrlqp_dense_bind(jrlqp_dense * h, double * dG, int ldg, const double * da, c
                      const double * dbu, const double * dxl, const double * dxu);
 /* init_ without the equality pre-activation: *llt_info = -1 or the failing column (Eigen llt_inplace), *f0 = a.x0/2 */
 int jrlqp_dense_init(jrlqp_dense * h, int * llt_info, double * f0, void * stream);
-/* selectViolatedConstraint_: *p = -1 and *status = JRLQP_INACTIVE when no constraint is violated */
+/* initActiveSet (GoldfarbIdnaniSolver.cpp:268-287), the second half of the reference's init_ hook (:75-79): activates every data
+ * equality (bl_i == bu_i, status EQUALITY) and then every fixed variable (xl_i == xu_i, FIXED) by increasing index, each through
+ * addInitialConstraint (:295-338).  Call it right behind a successful jrlqp_dense_init.  *term = JRLQP_SUCCESS, or
+ * JRLQP_OVERCONSTRAINED_PROBLEM when there are more of them than unknowns (UB in the reference; nothing is activated then).
+ * Optional outputs for the caller's own ActiveSet: *nactive, active_host[k] / status_host[k] (k < *nactive <= n, in activation
+ * order), *f (the objective value after the full steps).  Synchronises the stream. */
+int jrlqp_dense_init_active_set(jrlqp_dense * h, double big_bnd, int * term, int * nactive, int * active_host, int * status_host,
+                                double * f, void * stream);
+/* selectViolatedConstraint_: *p = -1 and *status = JRLQP_INACTIVE when no constraint is violated.  Also clears u[q] for the
+ * current number q of active constraints (DualSolver.cpp:119-121 does that right behind the selection; u lives on the device). */
 int jrlqp_dense_select(jrlqp_dense * h, int * p, int * status, void * stream);
 /* computeStep_ + computeStepLength_'s reductions + dot_: d, z, r stay on the device; returns t1, l, z.z, n.z, n.x, u[q] */
 int jrlqp_dense_step(jrlqp_dense * h, int p, int status, int q, double big_bnd, double * t1, int * l, double * zz, double * nz,
                      double * nx, double * uq, void * stream);
+/* x += t z (primal != 0), u[0:q] -= t r, u[q] += t  (DualSolver.cpp:136-137, :146-150) */
 int jrlqp_dense_advance(jrlqp_dense * h, double t, int q, int primal, void * stream);
+/* addConstraint (DualSolver.cpp:231-235) + addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237); q = active constraints BEFORE the
+ * addition.  removeConstraint (DualSolver.cpp:237-244, incl. the shift of u) + removeConstraint_ (:239-256); q = active constraints
+ * BEFORE the removal, index = the constraint at position l.  Both also keep the handle's own mirror of the ActiveSet (status per
+ * constraint + ordered list), which jrlqp_dense_results expands the multipliers with: q (and index) must agree with it, otherwise
+ * JRLQP_ERR_INVALID_ARGUMENT and nothing is launched. */
 int jrlqp_dense_add(jrlqp_dense * h, int p, int status, int q, void * stream);
 int jrlqp_dense_remove(jrlqp_dense * h, int l, int q, int index, void * stream);
 int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
@@ -301,8 +353,18 @@ int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, 
 int jrlqp_dense_solve_warm(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
                            const double * dbu, const double * dxl, const double * dxu, const int * as_host, const jrlqp_options * opts,
                            int * term, void * stream);
-/* host outputs: x[n], sign-expanded multipliers u[m+nb], activation status[m+nb], iterations, objective value */
+/* host outputs: x[n], sign-expanded multipliers u[m+nb], activation status[m+nb] -- valid behind jrlqp_dense_solve[_warm] AND
+ * behind a loop of the caller's own over the hooks above --, and the iteration count and objective value of the LIBRARY's loop
+ * (a caller that runs the loop itself owns it_ and f_, as DualSolver does) */
 int jrlqp_dense_results(jrlqp_dense * h, double * x_host, double * u_host, int * status_host, int * iters, double * f, void * stream);
+/* Iteration trace of jrlqp_dense_solve[_warm] -- the counterpart of the reference's per-pass log lines (DualSolver.cpp:105-108, 116,
+ * 128-129, 138, 153, 159): record `it` of trace_host (HOST memory, caller-owned, trace_cap records; NULL / 0 switches it off)
+ * is written by pass `it` of the loop, exactly like dtrace of the batched entry points. */
+int jrlqp_dense_set_trace(jrlqp_dense * h, jrlqp_trace_rec * trace_host, int trace_cap);
+/* How the handle orders the kernels of a pass that run on different streams: 0 = device-side tags, 1 = events.  Decided at
+ * creation (JRLQP_DENSE_SYNC=events|tags overrides) and switched to events for good by a solve whose tag
+ * hand-off starved (the solve is then repeated with events and returns its normal result); *event_reruns counts those. */
+int jrlqp_dense_sync_mode(const jrlqp_dense * h, int * event_reruns);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Structured Cholesky family.  Replaces (include/jrl-qp/decomposition/blockArrowLLT.h:70-110, triBlockDiagLLT.h:41-72):
@@ -401,11 +463,10 @@ int jrlqp_selftest_arith(int n,
 #define JRLQP_PROFILE_GI_BATCH 0
 #define JRLQP_PROFILE_BLOCKGI 1
 int jrlqp_debug_set_profile(int kernel, long long * dprof, int slots_per_problem, int nprob);
-/* Retired diagnostic, kept for ABI stability: rounds 1-3 ran the Givens radius recurrence of an addition
- * (GoldfarbIdnaniSolver.cpp:228-231) from seeds with a verified fallback and this switch selected among the variants.  The
- * coefficients now come from a suffix sum of squares (CANON C7; the serial recurrence only for entries
- * that cannot be squared -- a function of the data, tests/test_gpu_chain_modes.py).  The value is stored and ignored. */
-int jrlqp_debug_set_chain_mode(int mode);
+/* Fault injection for tests/test_gpu_dense.py: in pass `pass` (counted like iterations(); -1 = off) of the next solves of this
+ * handle the first kernel of the step waits for a tag nobody posts, gives up after ~1 s and reports it -- the path a starved
+ * hand-off takes.  The solve must then come back with its normal result through the event-ordered rerun. */
+int jrlqp_debug_dense_inject_sync_fault(jrlqp_dense * h, int pass);
 /* D(16x16) = A(16x4) * B(4x16) + C(16x16), row-major, one MFMA instruction on one wave */
 int jrlqp_selftest_mfma_f64(const double * dA, const double * dB, const double * dC, double * dD, void * stream);
 

@@ -28,6 +28,10 @@ EXPORTED = [
     "jrlqp_gi_batch_workspace_bytes",
     "jrlqp_gi_solve_batch_ws",
     "jrlqp_box_solve_batch",
+    "jrlqp_shard_range",
+    "jrlqp_gi_batch_workspace_bytes_on",
+    "jrlqp_gi_solve_batch_multi",
+    "jrlqp_gi_gather_x_multi",
     "jrlqp_gi_batch_lds_bytes",
     "jrlqp_gi_batch_warm_lds_bytes",
     "jrlqp_dense_create",
@@ -36,6 +40,7 @@ EXPORTED = [
     "jrlqp_dense_last_hip_error",
     "jrlqp_dense_bind",
     "jrlqp_dense_init",
+    "jrlqp_dense_init_active_set",
     "jrlqp_dense_select",
     "jrlqp_dense_step",
     "jrlqp_dense_advance",
@@ -44,6 +49,8 @@ EXPORTED = [
     "jrlqp_dense_solve",
     "jrlqp_dense_solve_warm",
     "jrlqp_dense_results",
+    "jrlqp_dense_set_trace",
+    "jrlqp_dense_sync_mode",
     "jrlqp_blocks_create",
     "jrlqp_blocks_destroy",
     "jrlqp_blocks_bind",
@@ -56,7 +63,7 @@ EXPORTED = [
     "jrlqp_blockgi_bind",
     "jrlqp_blockgi_solve",
     "jrlqp_debug_set_profile",
-    "jrlqp_debug_set_chain_mode",
+    "jrlqp_debug_dense_inject_sync_fault",
     "jrlqp_selftest_arith",
     "jrlqp_selftest_mfma_f64",
 ]
@@ -71,6 +78,13 @@ class Options(ct.Structure):
 
 class TraceRec(ct.Structure):
     _fields_ = [("p", ct.c_int), ("status", ct.c_int), ("l", ct.c_int), ("kind", ct.c_int), ("t1", ct.c_double), ("t2", ct.c_double)]
+
+
+class ShardBuffers(ct.Structure):
+    """struct jrlqp_shard_buffers (include/jrlqp_hip.h): the buffers of one device's shard of a multi-device batch."""
+
+    _fields_ = [(k, ct.c_void_p) for k in ("dG", "da", "dC", "dbl", "dbu", "dxl", "dxu", "das", "dx", "du", "dstatus", "dterm", "diters", "df", "dL",
+                                           "dworkspace")] + [("workspace_bytes", ct.c_longlong), ("stream", ct.c_void_p)]
 
 
 class JrlqpError(RuntimeError):
@@ -167,9 +181,24 @@ def load_library() -> ct.CDLL:
                                        ct.POINTER(ct.c_int), ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_int), c_dp]
     lib.jrlqp_blockgi_solve.restype = ct.c_int
     lib.jrlqp_blockgi_solve.argtypes = [ct.c_void_p] + [c_dp] * 5 + [ct.POINTER(Options)] + [c_dp] * 6 + [c_dp, ct.c_int, c_dp]
+    lib.jrlqp_shard_range.restype = None
+    lib.jrlqp_shard_range.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]
+    lib.jrlqp_gi_batch_workspace_bytes_on.restype = ct.c_longlong
+    lib.jrlqp_gi_batch_workspace_bytes_on.argtypes = [ct.c_int] * 5
+    lib.jrlqp_gi_solve_batch_multi.restype = ct.c_int
+    lib.jrlqp_gi_solve_batch_multi.argtypes = [ct.c_int] * 6 + [ct.POINTER(ct.c_int), ct.POINTER(ShardBuffers), ct.POINTER(Options), ct.c_int]
+    lib.jrlqp_gi_gather_x_multi.restype = ct.c_int
+    lib.jrlqp_gi_gather_x_multi.argtypes = [ct.c_int] * 3 + [ct.POINTER(ct.c_int), ct.POINTER(ShardBuffers), ct.c_int, ct.c_void_p, ct.c_int]
     lib.jrlqp_debug_set_profile.restype = ct.c_int
-    lib.jrlqp_debug_set_chain_mode.restype = ct.c_int
-    lib.jrlqp_debug_set_chain_mode.argtypes = [ct.c_int]
+    lib.jrlqp_debug_dense_inject_sync_fault.restype = ct.c_int
+    lib.jrlqp_debug_dense_inject_sync_fault.argtypes = [ct.c_void_p, ct.c_int]
+    lib.jrlqp_dense_set_trace.restype = ct.c_int
+    lib.jrlqp_dense_set_trace.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int]
+    lib.jrlqp_dense_sync_mode.restype = ct.c_int
+    lib.jrlqp_dense_sync_mode.argtypes = [ct.c_void_p, ct.POINTER(ct.c_int)]
+    lib.jrlqp_dense_init_active_set.restype = ct.c_int
+    lib.jrlqp_dense_init_active_set.argtypes = [ct.c_void_p, ct.c_double, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.c_void_p, ct.c_void_p,
+                                                ct.POINTER(ct.c_double), ct.c_void_p]
     lib.jrlqp_debug_set_profile.argtypes = [ct.c_int, c_dp, ct.c_int, ct.c_int]
     lib.jrlqp_selftest_arith.restype = ct.c_int
     lib.jrlqp_selftest_arith.argtypes = [ct.c_int] + [c_dp] * 9 + [c_dp]
@@ -295,6 +324,66 @@ class BatchSolver:
         return raw.view(dt).reshape(self.B, self.trace_cap)
 
 
+def shard_range(total, nshards, r):
+    """jrlqp_shard_range: (first, count) of shard r of a batch of `total` problems cut into `nshards` contiguous shards."""
+    f, c = ct.c_int(0), ct.c_int(0)
+    load_library().jrlqp_shard_range(total, nshards, r, ct.byref(f), ct.byref(c))
+    return f.value, c.value
+
+
+class MultiDeviceBatchSolver:
+    """jrlqp_gi_solve_batch_multi from one process: the batch is cut into contiguous shards, one per device, each solved on its own
+    device with no exchange in between; outputs stay on their devices, `gather_x` assembles x on one."""
+
+    def __init__(self, n, m, use_bounds, B_total, devices, max_iter=500, big_bnd=1e100):
+        import torch
+
+        self.torch = torch
+        self.lib = load_library()
+        self.n, self.m, self.nb, self.B = n, m, (n if use_bounds else 0), B_total
+        self.devices = [torch.device(d) for d in devices]
+        self.ids = (ct.c_int * len(devices))(*[d.index or 0 for d in self.devices])
+        self.opts = Options(max_iter, big_bnd)
+        self.out = []
+        mt = m + self.nb
+        for r, dev in enumerate(self.devices):
+            _, cnt = shard_range(B_total, len(devices), r)
+            wsb = int(self.lib.jrlqp_gi_batch_workspace_bytes_on(self.ids[r], n, m, self.nb, cnt))
+            if wsb < 0:
+                raise JrlqpError(f"batched path does not support n={n}, m={m}")
+            f64, i32 = torch.float64, torch.int32
+            self.out.append(dict(x=torch.empty((cnt, n), dtype=f64, device=dev), u=torch.empty((cnt, mt), dtype=f64, device=dev),
+                                 status=torch.empty((cnt, mt), dtype=i32, device=dev), term=torch.empty((cnt,), dtype=i32, device=dev),
+                                 iters=torch.empty((cnt,), dtype=i32, device=dev), f=torch.empty((cnt,), dtype=f64, device=dev),
+                                 ws=torch.empty((wsb + 7) // 8, dtype=f64, device=dev) if wsb else None, wsb=wsb))
+
+    def _shards(self, inputs):
+        sh = (ShardBuffers * len(self.devices))()
+        for r, (dev, o) in enumerate(zip(self.devices, self.out)):
+            i = inputs[r]
+            for k in ("G", "a", "C", "bl", "bu", "xl", "xu"):
+                setattr(sh[r], "d" + k, i[k].data_ptr() if i.get(k) is not None and i[k].numel() else None)
+            sh[r].das = None
+            sh[r].dx, sh[r].du, sh[r].dstatus = o["x"].data_ptr(), o["u"].data_ptr() if o["u"].numel() else None, o["status"].data_ptr() if o["status"].numel() else None
+            sh[r].dterm, sh[r].diters, sh[r].df, sh[r].dL = o["term"].data_ptr(), o["iters"].data_ptr(), o["f"].data_ptr(), None
+            sh[r].dworkspace = o["ws"].data_ptr() if o["ws"] is not None else None
+            sh[r].workspace_bytes = o["wsb"]
+            sh[r].stream = self.torch.cuda.current_stream(dev).cuda_stream
+        return sh
+
+    def solve(self, inputs, synchronize=True):
+        """inputs[r]: dict of the shard's tensors on device r (G (cnt, n, n), a, C (cnt, m, n), bl, bu, xl, xu).  Returns self.out."""
+        self._sh = self._shards(inputs)
+        check(self.lib.jrlqp_gi_solve_batch_multi(0, self.n, self.m, self.nb, self.B, len(self.devices), self.ids, self._sh, ct.byref(self.opts),
+                                                  1 if synchronize else 0))
+        return self.out
+
+    def gather_x(self, root=0):
+        x_all = self.torch.empty((self.B, self.n), dtype=self.torch.float64, device=self.devices[root])
+        check(self.lib.jrlqp_gi_gather_x_multi(self.n, self.B, len(self.devices), self.ids, self._sh, root, ct.c_void_p(x_all.data_ptr()), 1))
+        return x_all
+
+
 class DenseSolver:
     """Mode A: one (large) dense QP, state in HBM, host-driven active-set loop (jrlqp_dense_* of the C ABI).
     Mirrors the reference's GoldfarbIdnaniSolver(nbVar, nbCstr, useBounds) + solve(G, a, C, bl, bu, xl, xu)."""
@@ -306,6 +395,23 @@ class DenseSolver:
         h = ct.c_void_p()
         check(self.lib.jrlqp_dense_create(n, m, self.nb, ct.byref(h)))
         self.h = h
+        self._trace = None
+
+    def set_trace(self, cap):
+        """Iteration trace of the next solves (jrlqp_dense_set_trace): `cap` host records, read back with trace_numpy()."""
+        self._trace = (TraceRec * cap)() if cap else None
+        check(self.lib.jrlqp_dense_set_trace(self.h, ct.cast(self._trace, ct.c_void_p) if cap else None, cap))
+
+    def trace_numpy(self, iters):
+        return [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in self._trace[: min(iters, len(self._trace))]]
+
+    def sync_mode(self):
+        """(mode, reruns): mode 0 = device-side tags, 1 = events; reruns = solves repeated with events after a starved hand-off."""
+        r = ct.c_int(0)
+        return self.lib.jrlqp_dense_sync_mode(self.h, ct.byref(r)), r.value
+
+    def inject_sync_fault(self, at_pass):
+        check(self.lib.jrlqp_debug_dense_inject_sync_fault(self.h, at_pass))
 
     def solve(self, G, a, C, bl, bu, xl=None, xu=None, warm=False, guess=None):
         """G (n,n) symmetric float64 CUDA tensor -- OVERWRITTEN by its Cholesky factor (lower triangle of the

@@ -23,10 +23,8 @@ struct ProfBuf
   int stride = 0, nprob = 0;
 };
 ProfBuf g_prof[2];
-std::atomic<int> g_chain_mode{0};
 
-// experiment knob (never part of the ABI): JRLQP_TUNE=<bits> in the environment, read once; travels in the upper bits of
-// BatchArgs::chain_mode (gi_batch_kernel.h, "tune")
+// experiment knob (never part of the ABI): JRLQP_TUNE=<bits> in the environment, read once; travels in BatchArgs::tune
 int env_tune()
 {
   static const int v = [] {
@@ -111,13 +109,12 @@ struct jrlqp_blockgi
   bool bound = false;
 };
 
-namespace jrlqp
-{
-int chain_debug_mode()
-{
-  return g_chain_mode.load();
-}
-} // namespace jrlqp
+#define HIP_TRY(x)                      \
+  do                                    \
+  {                                     \
+    hipError_t e_ = (x);                \
+    if(e_ != hipSuccess) return hip_fail(e_); \
+  } while(0)
 
 extern "C" {
 
@@ -261,7 +258,7 @@ static int gi_batch_common(int warm,
   if(a.prof && B > g_prof[JRLQP_PROFILE_GI_BATCH].nprob) return JRLQP_ERR_INVALID_ARGUMENT;
   a.warm = warm;
   a.as_in = das;
-  a.chain_mode = (g_chain_mode.load() & 255) | (env_tune() << 8);
+  a.tune = env_tune();
   hipStream_t st = static_cast<hipStream_t>(stream);
   if(bign)
   {
@@ -331,6 +328,103 @@ int jrlqp_gi_solve_batch_warm(int n, int m, int nb, int B, const double * dG, co
                          dtrace, trace_cap, nullptr, 0, stream);
 }
 
+// ---- one process, several devices (the batch shards with no exchange during the solve) ---------------------------
+void jrlqp_shard_range(int B_total, int nshards, int r, int * first, int * count)
+{
+  // contiguous and balanced: the first (B_total % nshards) shards hold one problem more (jrl-qp_amd/dist.py shard_range)
+  int f = 0, c = 0;
+  if(B_total >= 0 && nshards > 0 && r >= 0 && r < nshards)
+  {
+    const int base = B_total / nshards, rem = B_total % nshards;
+    f = r * base + (r < rem ? r : rem);
+    c = base + (r < rem ? 1 : 0);
+  }
+  if(first) *first = f;
+  if(count) *count = c;
+}
+
+namespace
+{
+// the caller's current device, restored on every way out
+struct DeviceGuard
+{
+  int prev = -1;
+  DeviceGuard() { if(hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if(prev >= 0) (void)hipSetDevice(prev); }
+};
+} // namespace
+
+long long jrlqp_gi_batch_workspace_bytes_on(int device, int n, int m, int nb, int B)
+{
+  DeviceGuard g;
+  if(hipSetDevice(device) != hipSuccess) return -1;
+  return jrlqp_gi_batch_workspace_bytes(n, m, nb, B);
+}
+
+int jrlqp_gi_solve_batch_multi(int warm, int n, int m, int nb, int B_total, int ndev, const int * device_ids,
+                               const jrlqp_shard_buffers * shards, const jrlqp_options * opts, int synchronize)
+{
+  if(ndev < 1 || !device_ids || !shards || B_total < 0) return JRLQP_ERR_INVALID_ARGUMENT;
+  int visible = 0;
+  if(hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return JRLQP_ERR_NO_DEVICE;
+  for(int r = 0; r < ndev; ++r)
+  {
+    if(device_ids[r] < 0 || device_ids[r] >= visible) return JRLQP_ERR_INVALID_ARGUMENT;
+    for(int k = 0; k < r; ++k)
+      if(device_ids[k] == device_ids[r]) return JRLQP_ERR_INVALID_ARGUMENT; // one shard per device
+  }
+  DeviceGuard guard;
+  // enqueue every shard before waiting for any: the devices run side by side, the host thread only launches
+  for(int r = 0; r < ndev; ++r)
+  {
+    int first = 0, count = 0;
+    jrlqp_shard_range(B_total, ndev, r, &first, &count);
+    if(count == 0) continue;
+    const jrlqp_shard_buffers & b = shards[r];
+    HIP_TRY(hipSetDevice(device_ids[r]));
+    const int rc = gi_batch_common(warm ? 1 : 0, warm ? b.das : nullptr, n, m, nb, count, b.dG, b.da, b.dC, b.dbl, b.dbu, b.dxl, b.dxu, opts,
+                                   b.dx, b.du, b.dstatus, b.dterm, b.diters, b.df, b.dL, nullptr, 0, b.dworkspace, b.workspace_bytes, b.stream);
+    if(rc != JRLQP_OK) return rc;
+  }
+  if(synchronize)
+    for(int r = 0; r < ndev; ++r)
+    {
+      HIP_TRY(hipSetDevice(device_ids[r]));
+      HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(shards[r].stream)));
+    }
+  return JRLQP_OK;
+}
+
+int jrlqp_gi_gather_x_multi(int n, int B_total, int ndev, const int * device_ids, const jrlqp_shard_buffers * shards, int root,
+                            double * dx_all_on_root, int synchronize)
+{
+  if(n < 1 || ndev < 1 || !device_ids || !shards || root < 0 || root >= ndev || !dx_all_on_root) return JRLQP_ERR_INVALID_ARGUMENT;
+  DeviceGuard guard;
+  for(int r = 0; r < ndev; ++r)
+  {
+    int first = 0, count = 0;
+    jrlqp_shard_range(B_total, ndev, r, &first, &count);
+    if(count == 0) continue;
+    // every copy is ordered behind its shard's solve on the shard's OWN stream (a device-to-device copy over xGMI; on the root it
+    // is a plain on-device copy), so nothing waits on the host
+    HIP_TRY(hipSetDevice(device_ids[r]));
+    const size_t bytes = sizeof(double) * (size_t)n * count;
+    double * dst = dx_all_on_root + (size_t)first * n;
+    hipStream_t st = static_cast<hipStream_t>(shards[r].stream);
+    if(r == root)
+      HIP_TRY(hipMemcpyAsync(dst, shards[r].dx, bytes, hipMemcpyDeviceToDevice, st));
+    else
+      HIP_TRY(hipMemcpyPeerAsync(dst, device_ids[root], shards[r].dx, device_ids[r], bytes, st));
+  }
+  if(synchronize)
+    for(int r = 0; r < ndev; ++r)
+    {
+      HIP_TRY(hipSetDevice(device_ids[r]));
+      HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(shards[r].stream)));
+    }
+  return JRLQP_OK;
+}
+
 int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, const double * dbl, const double * dxl,
                           const double * dxu, const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm,
                           int * diters, double * df, jrlqp_trace_rec * dtrace, int trace_cap, void * stream)
@@ -357,17 +451,10 @@ int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, c
   a.trace = dtrace;
   a.prof = nullptr; a.prof_stride = 0;
   a.warm = 0; a.as_in = nullptr;
-  a.chain_mode = (g_chain_mode.load() & 255) | (env_tune() << 8);
+  a.tune = env_tune();
   hipError_t e = jrlqp::launch_gi_batch_box(a, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }
-
-#define HIP_TRY(x)                      \
-  do                                    \
-  {                                     \
-    hipError_t e_ = (x);                \
-    if(e_ != hipSuccess) return hip_fail(e_); \
-  } while(0)
 
 int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, int max_nrhs, jrlqp_blocks ** out)
 {
@@ -488,13 +575,6 @@ int jrlqp_blocks_solve(jrlqp_blocks * p, int transpose, double * dM, int ldm, lo
   else
     e = jrlqp::launch_block_arrow_solve(d, p->nprob, transpose != 0, dM, ldm, nrhs, start, end, p->d_tmp, st);
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
-}
-
-int jrlqp_debug_set_chain_mode(int mode)
-{
-  if(mode < 0 || mode > 2) return JRLQP_ERR_INVALID_ARGUMENT;
-  g_chain_mode.store(mode);
-  return JRLQP_OK;
 }
 
 int jrlqp_debug_set_profile(int kernel, long long * dprof, int slots_per_problem, int nprob)

@@ -277,91 +277,6 @@ __device__ __forceinline__ bool div_safe_num(double v)
 }
 
 
-// ---- the radius recurrence of an addition sweep with its division and square root SEEDED ahead of the chain ---------
-// r_i = givens_r_only(d_i, r_{i+1}) is the only serial part of addConstraint_ (26 dependent ops per step through
-// a/b and sqrt).  Up to rounding noise r_{i+1} is the 2-norm of d(i+1:n), which a parallel suffix sum gives to ~1e-13
-// before the chain starts; from it every lane prepares, for its own step, approximations (1e-10 would do) of
-//   1/hi,  q0 ~ lo/hi = t,  G ~ sqrt(1 + t^2),  h ~ 1/(2G)
-// and the chain keeps, per step, ONE correction of the quotient (e = fma(-hi, q0, lo); t = fma(e, 1/hi, q0)) and ONE of
-// the root (s = fma(fma(-G, G, x), h, G)).  A correction step squares the relative error of its seed (1e-13 -> 1e-26),
-// so t and s are the correctly rounded quotient / root unless the exact value lies within 1e-26 of a rounding boundary
-// (~1e-10 per step).  Bit-exactness does not rest on that: afterwards every lane recomputes ITS step from the chain's
-// r_{i+1} with the plain formula (it has to anyway, for c_i and s_i) and compares the radius.  If all steps agree the
-// chain is the exact chain by induction from r_{n-1}; otherwise the caller reruns the plain recurrence.
-// Zeros at the tail of d (bound constraints against a triangular J) are exact: q0 = 0, G = 1 give r' = r.
-//
-// The step is branch-free and its seeds are per-lane constants, so a wave runs the chain SYSTOLICALLY: lane i owns step
-// i, takes r_{i+1} from lane i+1 by a DPP shift, and every lane executes the same loop-invariant body.  After k sweeps
-// lanes n-2 .. n-1-k hold their final r_i and keep reproducing it (same inputs, same bits); lane n-1 seeded with
-// s_next = 0 reproduces |d_{n-1}|; lanes >= n (d = 0) stay 0: no masks, no loop index, no broadcasts, no memory
-// traffic inside the chain.  Eight dependent ops per step instead of 26 (measured 2.4x, tools/ubench/givens_seeded.hip).
-struct GivensSeed
-{
-  double a;  // |d_i|
-  double Pn; // usual case (r_{i+1} >= |d_i|): q0 = |d_i| / ~r_{i+1}, else 0
-  double Pu; // unusual case: 1 / |d_i|, else 0            (q0 = fma(|r|, Pu, Pn) in both cases)
-  double W;  // ~ 1 / hi
-  double G;  // ~ sqrt(1 + q0^2)
-  double h;  // ~ 1 / (2 G)
-};
-// s_next ~ sum of d_k^2 over k > i (any summation order)
-__device__ __forceinline__ GivensSeed givens_seed(double d_i, double s_next)
-{
-  GivensSeed g;
-  g.a = fabs(d_i);
-  // rt ~ sqrt(s_next) and its reciprocal from one coupled Newton step on rsq
-  const double y = __builtin_amdgcn_rsq(s_next);
-  const double g0 = s_next * y, h0 = 0.5 * y, c0 = FMA(-h0, g0, 0.5);
-  const bool tail0 = !(s_next > 0.0);
-  const double rt = tail0 ? 0.0 : FMA(g0, c0, g0);
-  const double h1 = FMA(h0, c0, h0);
-  const double irt = tail0 ? 0.0 : h1 + h1;
-  double ia = __builtin_amdgcn_rcp(g.a);
-  ia = FMA(ia, FMA(-g.a, ia, 1.0), ia);
-  const bool flg = g.a > rt;
-  const double inv = flg ? ia : irt;
-  const double q0 = (flg ? rt : g.a) * inv;
-  g.Pn = flg ? 0.0 : q0;
-  g.Pu = flg ? inv : 0.0;
-  g.W = inv;
-  const double x = FMA(q0, q0, 1.0);
-  const double y2 = __builtin_amdgcn_rsq(x);
-  const double g2 = x * y2, h2 = 0.5 * y2, c2 = FMA(-h2, g2, 0.5);
-  g.G = FMA(g2, c2, g2);
-  g.h = FMA(h2, c2, h2);
-  return g;
-}
-__device__ __forceinline__ double givens_seeded_step(double r, const GivensSeed & g)
-{
-  const double rb = fabs(r);
-  const double q0 = FMA(rb, g.Pu, g.Pn);
-  double hi, lo; // v_max / v_min spelled out: fmax() would first canonicalise both operands (one more dependent op)
-  asm("v_max_f64 %0, |%1|, %2" : "=v"(hi) : "v"(r), "v"(g.a));
-  asm("v_min_f64 %0, |%1|, %2" : "=v"(lo) : "v"(r), "v"(g.a));
-  const double e = FMA(-hi, q0, lo);
-  const double t = FMA(e, g.W, q0);
-  const double x = FMA(t, t, 1.0);
-  const double e2 = FMA(-g.G, g.G, x);
-  const double s = FMA(e2, g.h, g.G);
-  return hi * s;
-}
-
-// inclusive suffix sum over the lanes of a wave (lane i: sum of v over lanes >= i); summation order unspecified --
-// for estimates only, never for a CANON value
-__device__ __forceinline__ double wave_suffix_sum_approx(double v, int lane)
-{
-  v = v + dpp_shift0_d<0x101>(v); // row_shl:1  (lane i <- lane i+1 inside its row of 16, else 0)
-  v = v + dpp_shift0_d<0x102>(v); // row_shl:2
-  v = v + dpp_shift0_d<0x104>(v); // row_shl:4
-  v = v + dpp_shift0_d<0x108>(v); // row_shl:8
-  const double t1 = bcast_lane(v, 16), t2 = bcast_lane(v, 32), t3 = bcast_lane(v, 48);
-  const int row = lane >> 4;
-  const double s2 = t2 + t3, s1 = t1 + s2;
-  const double add = (row == 0) ? s1 : (row == 1) ? s2 : (row == 2) ? t3 : 0.0;
-  return v + add;
-}
-
-
 // ---- wave-level substitutions on one block (shared by the structured Cholesky family and the structured GI loop) ----
 constexpr int kAhead = 16; // operands of a dependent chain are requested this many steps ahead (one HBM/L2 latency per group)
 

@@ -23,12 +23,8 @@ struct BatchArgs
   int prof_stride;
   int warm;           // 1: warm-started solve (experimental::GoldfarbIdnaniSolver), as_in = activation-status guess
   const int * as_in;  // B x (m+nb) guesses, or nullptr ("no guess"); may alias `status`
-  int chain_mode;     // chain_debug_mode() at launch
+  int tune;           // experiment bits (JRLQP_TUNE in the environment, capi.cpp env_tune; 0 in production)
 };
-
-// debug knob of the seeded Givens chain (jrlqp_debug_set_chain_mode): 0 = seeded (production), 1 = plain recurrence only,
-// 2 = seeded with deliberately spoiled seeds -- every sweep fails its verification and is redone by the fallback
-int chain_debug_mode();
 
 constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
 

@@ -865,7 +865,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     // the MAIN wave (wave 3, which owns no constraint column), x0 on wave 0, and there is NO barrier behind them: the helpers go
     // straight on to fetch their columns and, once wave 0 has posted x0 (fx0), to the first scan -- all of it beside MAIN's J, which
     // is the longest of the three.
-    ovl = WS && uniform(ctl->eq_next) == NONE && !(A.chain_mode & (8 << 8));
+    ovl = WS && uniform(ctl->eq_next) == NONE && !(A.tune & 8);
     if constexpr(BOX)
     {
       q = uniform(ctl->nact); // J, R, x, u, f, the active list: all set by the closed form above
@@ -2166,7 +2166,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
           }
           __syncthreads();
         }
-        const int tune = A.chain_mode >> 8; // experiment bits (JRLQP_TUNE): 1 MAIN priority 3, 2 chain wave priority 2, 4 z wave priority 1
+        const int tune = A.tune; // experiment bits (JRLQP_TUNE): 1 MAIN priority 3, 2 chain wave priority 2, 4 z wave priority 1
         if(wave == MAINW)
         {
           // ------------------------------------------------------------------------------------------ MAIN

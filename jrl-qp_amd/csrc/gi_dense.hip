@@ -1964,9 +1964,12 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   const bool dev_p = (p == kSelOnDevice); // (p, status) are read from s.psel by the kernels
   const double sign = (pstat == UPPER || pstat == UPPER_BOUND) ? -1.0 : 1.0;
   const double * cp = nullptr;
-  const bool chain = spec && q < n;
+  // (a problem without any constraint has no selection, so neither jtn nor jrow runs and nobody would ever publish d_tag: nothing
+  // may be enqueued that waits for it -- the host loop returns before its first pass in that case, this is the second fence)
+  const bool no_producer = dev_p && v.m == 0 && v.nb == 0;
+  const bool chain = spec && q < n && !no_producer;
   const bool events = (ev_d != nullptr);   // event mode (kernels of different streams cannot run side by side: see PassSync): no tags
-  const bool zs = zside && tag && !events; // z = J2 d2 on its own stream, beside the substitution (both only need d)
+  const bool zs = zside && tag && !events && !no_producer; // z = J2 d2 on its own stream, beside the substitution (both only need d)
   const int dpost = (!events && (chain || zs)) ? tag : 0; // d_tag is published for whoever runs beside the main stream
   if(events) wait_sel_tag = wait_chain_tag = 0;
   const int jt_wgs = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;

@@ -45,6 +45,10 @@ struct jrlqp_dense
   bool use_events = false;
   hipEvent_t ev_x = nullptr, ev_sel = nullptr, ev_d = nullptr, ev_chain = nullptr;
   int tag = 0;                         // pass counter: the step kernel echoes it into the mailbox when its scalars are out
+  jrlqp_trace_rec * trace = nullptr;   // jrlqp_dense_set_trace: one record per pass of the library's loop (host memory, caller-owned)
+  int trace_cap = 0;
+  int inject_fault_pass = -1;          // jrlqp_debug_dense_inject_sync_fault: the pass whose first kernel waits for a tag nobody posts
+  int event_reruns = 0;                // solves that were re-run with event edges after a device-side wait gave up
 };
 
 namespace
@@ -230,44 +234,73 @@ int jrlqp_dense_bind(jrlqp_dense * h, double * dG, int ldg, const double * da, c
   return JRLQP_OK;
 }
 
+// init_ (GoldfarbIdnaniSolver.cpp:56-74) in two halves: the factorisation, which consumes G, and everything that can be redone from
+// the factor (J = L^-T, x0, f0, the empty active set) -- a solve that has to be re-run (dense_solve_impl) only repeats the second.
+static int dense_init_llt(jrlqp_dense * h, int * info_out, hipStream_t st)
+{
+  const DenseViews & v = h->v;
+  DenseState & s = h->s;
+  TRY(hipMemsetAsync(s.info, 0xff, sizeof(int), st)); // -1
+  TRY(dense_llt(v.G, v.ldg, v.n, s.info, st));
+  int info = -1;
+  TRY(hipMemcpyAsync(&info, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  TRY(hipStreamSynchronize(st));
+  *info_out = info;
+  return JRLQP_OK;
+}
+static int dense_init_state(jrlqp_dense * h, hipStream_t st)
+{
+  const DenseViews & v = h->v;
+  DenseState & s = h->s;
+  TRY(hipMemsetAsync(s.st, 0, (size_t)v.m + v.nb, st));
+  TRY(hipMemsetAsync(s.u, 0, sizeof(double) * ((size_t)v.m + v.nb + 2), st));
+  TRY(hipMemsetAsync(s.x, 0, sizeof(double) * v.n, st));
+  std::fill(h->status.begin(), h->status.end(), 0);
+  h->active.clear();
+  h->f = 0.0;
+  return JRLQP_OK;
+}
+static int dense_init_point(jrlqp_dense * h, hipStream_t st)
+{
+  const DenseViews & v = h->v;
+  DenseState & s = h->s;
+  TRY(dense_jinv(v.G, v.ldg, s.J, v.n, st));
+  TRY(dense_x0(v.G, v.ldg, v.n, v.a, s.x, &s.mb->f0, st));
+  TRY(hipStreamSynchronize(st));
+  h->f = h->h_mb->f0;
+  return JRLQP_OK;
+}
+
 // init_ (GoldfarbIdnaniSolver.cpp:56-74): LLT, J = L^-T, x0, f0, empty active set.  Synchronises the stream.
 int jrlqp_dense_init(jrlqp_dense * h, int * llt_info, double * f0, void * stream)
 {
   if(!h || !h->bound) return JRLQP_ERR_INVALID_ARGUMENT;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const DenseViews & v = h->v;
-  DenseState & s = h->s;
-  TRY(hipMemsetAsync(s.info, 0xff, sizeof(int), st)); // -1
-  TRY(hipMemsetAsync(s.st, 0, (size_t)v.m + v.nb, st));
-  TRY(hipMemsetAsync(s.u, 0, sizeof(double) * ((size_t)v.m + v.nb + 2), st));
-  TRY(hipMemsetAsync(s.x, 0, sizeof(double) * v.n, st));
-  TRY(dense_llt(v.G, v.ldg, v.n, s.info, st));
+  int rc = dense_init_state(h, st);
+  if(rc != JRLQP_OK) return rc;
   int info = -1;
-  TRY(hipMemcpyAsync(&info, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
-  TRY(hipStreamSynchronize(st));
+  rc = dense_init_llt(h, &info, st);
+  if(rc != JRLQP_OK) return rc;
   if(llt_info) *llt_info = info;
-  std::fill(h->status.begin(), h->status.end(), 0);
-  h->active.clear();
-  h->f = 0.0;
   if(info >= 0)
   {
     if(f0) *f0 = 0.0;
     return JRLQP_OK;
   }
-  TRY(dense_jinv(v.G, v.ldg, s.J, v.n, st));
-  TRY(dense_x0(v.G, v.ldg, v.n, v.a, s.x, &s.mb->f0, st));
-  TRY(hipStreamSynchronize(st));
-  h->f = h->h_mb->f0;
+  rc = dense_init_point(h, st);
+  if(rc != JRLQP_OK) return rc;
   if(f0) *f0 = h->f;
   return JRLQP_OK;
 }
 
-// selectViolatedConstraint_ (GoldfarbIdnaniSolver.cpp:84-134).  p = -1 / status INACTIVE when none is violated.
+// selectViolatedConstraint_ (GoldfarbIdnaniSolver.cpp:84-134).  p = -1 / status INACTIVE when none is violated.  Also u[q] = 0 for
+// the q the handle's active-set mirror holds (DualSolver.cpp:119-121: the loop re-seats u to q + 1 entries and clears the new one
+// right behind the selection; u lives on the device, so the hook does it).
 int jrlqp_dense_select(jrlqp_dense * h, int * p, int * status, void * stream)
 {
   if(!h || !h->bound || !p || !status) return JRLQP_ERR_INVALID_ARGUMENT;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  TRY(dense_select(h->v, h->s, -1, st));
+  TRY(dense_select(h->v, h->s, -1, st, (int)h->active.size()));
   TRY(hipStreamSynchronize(st));
   *p = h->h_mb->p;
   *status = h->h_mb->pstatus;
@@ -304,8 +337,10 @@ int jrlqp_dense_advance(jrlqp_dense * h, double t, int q, int primal, void * str
 // addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237); q = number of active constraints BEFORE the addition
 int jrlqp_dense_add(jrlqp_dense * h, int p, int status, int q, void * stream)
 {
-  if(!h || !h->bound || q >= h->n) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(!h || !h->bound || q >= h->n || q != (int)h->active.size() || p < 0 || p >= h->m + h->nb) return JRLQP_ERR_INVALID_ARGUMENT;
   TRY(dense_add(h->v, h->s, p, status, q, static_cast<hipStream_t>(stream)));
+  h->active.push_back(p); // A_.activate (DualSolver.cpp:231-235; ActiveSet.cpp:87-131): the handle's mirror, read by jrlqp_dense_results
+  h->status[p] = status;
   return JRLQP_OK;
 }
 
@@ -313,8 +348,98 @@ int jrlqp_dense_add(jrlqp_dense * h, int p, int status, int q, void * stream)
 // active constraints BEFORE the removal, `index` = constraint index of the l-th active constraint
 int jrlqp_dense_remove(jrlqp_dense * h, int l, int q, int index, void * stream)
 {
-  if(!h || !h->bound || l < 0 || l >= q || q > JRLQP_DENSE_MAX_N) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(!h || !h->bound || l < 0 || l >= q || q > JRLQP_DENSE_MAX_N || q != (int)h->active.size() || h->active[l] != index)
+    return JRLQP_ERR_INVALID_ARGUMENT;
   TRY(dense_remove(h->v, h->s, l, q, index, static_cast<hipStream_t>(stream)));
+  h->status[index] = 0; // A_.deactivate(l) (DualSolver.cpp:237-244; ActiveSet.cpp:132-168)
+  h->active.erase(h->active.begin() + l);
+  return JRLQP_OK;
+}
+
+// initActiveSet (GoldfarbIdnaniSolver.cpp:268-287) -- the second half of the reference's init_ hook (:75-79): every data equality
+// (bl_i == bu_i), then every fixed variable (xl_i == xu_i), by increasing index, each through addInitialConstraint (:295-338: step
+// direction, full step, no ratio test, addConstraint).  hbl .. hxu: the bounds on the HOST (m, m, nb, nb entries).  *term =
+// JRLQP_SUCCESS, or JRLQP_OVERCONSTRAINED_PROBLEM when there are more of them than unknowns (UB in the reference); *f is updated.
+static int dense_init_active_set(jrlqp_dense * h, const double * hbl, const double * hbu, const double * hxl, const double * hxu,
+                                 double big, int * term, void * stream)
+{
+  enum { EQUALITY = 3, FIXED = 6 };
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int n = h->n, m = h->m, nb = h->nb;
+  int neq = 0;
+  for(int i = 0; i < m; ++i) neq += (hbl[i] == hbu[i]);
+  for(int i = 0; i < nb; ++i) neq += (hxl[i] == hxu[i]);
+  *term = JRLQP_SUCCESS;
+  if(neq > n)
+  {
+    *term = JRLQP_OVERCONSTRAINED_PROBLEM;
+    return JRLQP_OK;
+  }
+  for(int i = 0; i < m + nb; ++i)
+  {
+    const bool eq = (i < m) ? (hbl[i] == hbu[i]) : (hxl[i - m] == hxu[i - m]);
+    if(!eq) continue;
+    const int status = (i < m) ? EQUALITY : FIXED;
+    const int q = (int)h->active.size();
+    TRY(hipMemsetAsync(h->s.u + q, 0, sizeof(double), st)); // u[q] = 0
+    double t1, zz, nz, nx, uq;
+    int l;
+    int rc = jrlqp_dense_step(h, i, status, q, big, &t1, &l, &zz, &nz, &nx, &uq, stream);
+    if(rc != JRLQP_OK) return rc;
+    double t = 0.0;
+    if(std::sqrt(zz) > 1e-14) t = (((i < m) ? hbl[i] : hxl[i - m]) - nx) / nz; // addInitialConstraint :309-322
+    rc = jrlqp_dense_advance(h, t, q, 1, stream);
+    if(rc != JRLQP_OK) return rc;
+    h->f = std::fma(t * nz, 0.5 * t + uq, h->f);
+    rc = jrlqp_dense_add(h, i, status, q, stream);
+    if(rc != JRLQP_OK) return rc;
+  }
+  return JRLQP_OK;
+}
+
+int jrlqp_dense_init_active_set(jrlqp_dense * h, double big_bnd, int * term, int * nactive, int * active_host, int * status_host,
+                                double * f, void * stream)
+{
+  if(!h || !h->bound || !term) return JRLQP_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const DenseViews & v = h->v;
+  if(h->m) TRY(hipMemcpyAsync(h->h_bl.data(), v.bl, sizeof(double) * h->m, hipMemcpyDeviceToHost, st));
+  if(h->m) TRY(hipMemcpyAsync(h->h_bu.data(), v.bu, sizeof(double) * h->m, hipMemcpyDeviceToHost, st));
+  if(h->nb) TRY(hipMemcpyAsync(h->h_xl.data(), v.xl, sizeof(double) * h->nb, hipMemcpyDeviceToHost, st));
+  if(h->nb) TRY(hipMemcpyAsync(h->h_xu.data(), v.xu, sizeof(double) * h->nb, hipMemcpyDeviceToHost, st));
+  TRY(hipStreamSynchronize(st));
+  const int rc = dense_init_active_set(h, h->h_bl.data(), h->h_bu.data(), h->h_xl.data(), h->h_xu.data(), big_bnd, term, stream);
+  if(rc != JRLQP_OK) return rc;
+  const int q = (int)h->active.size();
+  if(nactive) *nactive = q;
+  for(int k = 0; k < q; ++k)
+  {
+    if(active_host) active_host[k] = h->active[k];
+    if(status_host) status_host[k] = h->status[h->active[k]];
+  }
+  if(f) *f = h->f;
+  return JRLQP_OK;
+}
+
+int jrlqp_dense_set_trace(jrlqp_dense * h, jrlqp_trace_rec * trace_host, int trace_cap)
+{
+  if(!h || trace_cap < 0 || (trace_cap > 0 && !trace_host)) return JRLQP_ERR_INVALID_ARGUMENT;
+  h->trace = trace_cap ? trace_host : nullptr;
+  h->trace_cap = trace_cap;
+  return JRLQP_OK;
+}
+
+int jrlqp_dense_sync_mode(const jrlqp_dense * h, int * event_reruns)
+{
+  if(!h) return -1;
+  if(event_reruns) *event_reruns = h->event_reruns;
+  return h->use_events ? 1 : 0;
+}
+
+int jrlqp_debug_dense_inject_sync_fault(jrlqp_dense * h, int pass)
+{
+  if(!h) return JRLQP_ERR_INVALID_ARGUMENT;
+  h->inject_fault_pass = pass;
   return JRLQP_OK;
 }
 
@@ -339,25 +464,42 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
   if(nb) TRY(hipMemcpyAsync(h->h_xl.data(), dxl, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
   if(nb) TRY(hipMemcpyAsync(h->h_xu.data(), dxu, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
 
-  h->it = 0;
-  h->term = JRLQP_UNKNOWN;
-  if(h->chain_pending) // a discarded chain of the previous solve may still be reading d (it ended long ago: this returns at once)
-  {
-    TRY(hipStreamSynchronize(h->spec));
-    h->chain_pending = 0;
-  }
+  // kernels of the previous solve may still be in flight on the side streams (a discarded coefficient chain reading d, the z of a
+  // final pass whose step found nothing to do): they ended long ago -- these calls return at once -- but nothing of this solve may
+  // race with them
+  TRY(hipStreamSynchronize(h->spec));
+  TRY(hipStreamSynchronize(h->side));
+  h->chain_pending = 0;
   h->h_mb->sync_err = 0;
   auto finish = [&](int term) {
     h->term = term;
     if(term_out) *term_out = term;
+    (void)hipStreamSynchronize(h->spec); // nothing this solve enqueued outlives it (the exported hooks and the next solve write the
+    (void)hipStreamSynchronize(h->side); // same buffers from the caller's stream)
     return JRLQP_OK;
   };
+  // A device-side wait between the streams that gave up (PassSync, gi_dense.h: a consumer that did not see its producer within
+  // ~1 s -- CUs held by someone else's kernels, several handles spinning at once) voids the pass, not the problem: the streams
+  // are drained, the handle switches to event edges for good, and the solve is repeated from the factor (G holds L: the
+  // factorisation is the one step that cannot be redone).  JRLQP_ERR_HIP is left for a rerun that fails too.
+  bool rerun = false;
   int info = -1;
+attempt:
+  h->it = 0;
+  h->term = JRLQP_UNKNOWN;
   if(!warm)
   {
-    rc = jrlqp_dense_init(h, &info, nullptr, stream);
+    rc = dense_init_state(h, st);
     if(rc != JRLQP_OK) return rc;
-    if(info >= 0) return finish(JRLQP_NON_POS_HESSIAN);
+    if(!rerun)
+    {
+      rc = dense_init_llt(h, &info, st);
+      if(rc != JRLQP_OK) return rc;
+      if(info >= 0) return finish(JRLQP_NON_POS_HESSIAN);
+    }
+    rc = dense_init_point(h, st);
+    if(rc != JRLQP_OK) return rc;
+    if(m + nb == 0) return finish(JRLQP_SUCCESS); // no constraint: x0 is the solution (and no kernel of a pass has anything to wait for)
   }
 
   auto bound_value = [&](int p, int status) -> double {
@@ -432,10 +574,11 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
       }
     }
     // the factorisation (:66-71)
-    TRY(hipMemsetAsync(s.info, 0xff, sizeof(int), st));
-    TRY(dense_llt(h->v.G, h->v.ldg, n, s.info, st));
-    TRY(hipMemcpyAsync(&info, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
-    TRY(hipStreamSynchronize(st));
+    if(!rerun)
+    {
+      rc = dense_init_llt(h, &info, st);
+      if(rc != JRLQP_OK) return rc;
+    }
     if(info >= 0)
     {
       h->active.clear();
@@ -474,10 +617,8 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
       if(lmin < 0) break;
       ++h->it;
       h->h_bact.erase(h->h_bact.begin() + lmin);
-      rc = jrlqp_dense_remove(h, lmin, q, h->active[lmin], stream); // (its shift of u is harmless: u is recomputed)
+      rc = jrlqp_dense_remove(h, lmin, q, h->active[lmin], stream); // (its shift of u is harmless: u is recomputed; it also updates the mirror)
       if(rc != JRLQP_OK) return rc;
-      h->status[h->active[lmin]] = INACTIVE;
-      h->active.erase(h->active.begin() + lmin);
       --q;
       if(q) TRY(hipMemcpyAsync(s.bact, h->h_bact.data(), sizeof(double) * q, hipMemcpyHostToDevice, st));
     }
@@ -486,30 +627,10 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
   else
   // initActiveSet (GoldfarbIdnaniSolver.cpp:268-287)
   {
-    int neq = 0;
-    for(int i = 0; i < m; ++i) neq += (h->h_bl[i] == h->h_bu[i]);
-    for(int i = 0; i < nb; ++i) neq += (h->h_xl[i] == h->h_xu[i]);
-    if(neq > n) return finish(JRLQP_OVERCONSTRAINED_PROBLEM);
-    for(int i = 0; i < m + nb; ++i)
-    {
-      const bool eq = (i < m) ? (h->h_bl[i] == h->h_bu[i]) : (h->h_xl[i - m] == h->h_xu[i - m]);
-      if(!eq) continue;
-      const int status = (i < m) ? EQUALITY : FIXED;
-      const int q = (int)h->active.size();
-      TRY(hipMemsetAsync(h->s.u + q, 0, sizeof(double), st)); // u[q] = 0
-      double t1, zz, nz, nx, uq;
-      int l;
-      rc = jrlqp_dense_step(h, i, status, q, big, &t1, &l, &zz, &nz, &nx, &uq, stream);
-      if(rc != JRLQP_OK) return rc;
-      double t = 0.0;
-      if(std::sqrt(zz) > 1e-14) t = (bound_value(i, status) - nx) / nz; // addInitialConstraint :309-322
-      rc = jrlqp_dense_advance(h, t, q, 1, stream);
-      if(rc != JRLQP_OK) return rc;
-      h->f = std::fma(t * nz, 0.5 * t + uq, h->f);
-      rc = jrlqp_dense_add(h, i, status, q, stream);
-      if(rc != JRLQP_OK) return rc;
-      activate(i, status);
-    }
+    int t0 = JRLQP_SUCCESS;
+    rc = dense_init_active_set(h, h->h_bl.data(), h->h_bu.data(), h->h_xl.data(), h->h_xu.data(), big, &t0, stream);
+    if(rc != JRLQP_OK) return rc;
+    if(t0 != JRLQP_SUCCESS) return finish(t0);
   }
 
   // optional host-side time line of the loop (JRLQP_DENSE_TIMING=1): where the host spends a pass
@@ -564,7 +685,11 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
         TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, 0, 0, nullptr, h->ev_d, h->ev_chain));
       }
       else
-        TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, h->chain_pending, h->side));
+      {
+        // (fault injection, tests only: this pass's first kernel waits for a chain tag nobody will ever post)
+        const int wait_chain = (h->inject_fault_pass == h->it && !rerun) ? 0x7ffffff0 : h->chain_pending;
+        TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, wait_chain, h->side));
+      }
       h->chain_pending = spec ? tag : 0;
       const double tb = timing ? now() : 0;
       if(!wait_tag(h->h_mb, tag)) TRY(hipStreamSynchronize(st));
@@ -576,10 +701,22 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
         t_mark = tc; // (the rest of the pass is closed at the top of the next one)
       }
       const Mailbox & mb = *h->h_mb;
-      if(mb.sync_err) // a device-side wait between the streams gave up (gi_dense.h, PassSync): nothing of this solve can be trusted
+      if(mb.sync_err) // a device-side wait between the streams gave up (gi_dense.h, PassSync): nothing of this attempt can be trusted
       {
-        h->last_hip = (int)hipErrorLaunchTimeOut;
-        return JRLQP_ERR_HIP;
+        TRY(hipStreamSynchronize(st)); // (every kernel runs on after its wait has given up: the streams drain)
+        TRY(hipStreamSynchronize(h->spec));
+        TRY(hipStreamSynchronize(h->side));
+        h->chain_pending = 0;
+        h->h_mb->sync_err = 0;
+        if(h->use_events || rerun)
+        {
+          h->last_hip = (int)hipErrorLaunchTimeOut;
+          return JRLQP_ERR_HIP;
+        }
+        h->use_events = true; // for good: whatever starved the hand-off may still be there for the next solve
+        ++h->event_reruns;
+        rerun = true;
+        goto attempt;
       }
       if(!skip)
       {
@@ -592,16 +729,16 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
     double t2 = big;
     if(std::sqrt(zz) > 1e-14) t2 = (bound_value(p, pstat) - nx) / nz;
     const double t = (t2 < t1) ? t2 : t1;
+    if(h->trace && h->it < h->trace_cap) // the reference logs every pass (DualSolver.cpp:116,128-129,138,153,159)
+      h->trace[h->it] = jrlqp_trace_rec{p, pstat, l, (t2 >= big) ? 2 : ((t == t2) ? 0 : 1), t1, t2};
     if(t >= big) return finish(JRLQP_INFEASIBLE);
     const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -nz : nz;
     if(t2 >= big)
     {
       rc = jrlqp_dense_advance(h, t, q, 0, stream);
       if(rc != JRLQP_OK) return rc;
-      rc = jrlqp_dense_remove(h, l, q, h->active[l], stream);
+      rc = jrlqp_dense_remove(h, l, q, h->active[l], stream); // (also A_.deactivate on the handle's mirror)
       if(rc != JRLQP_OK) return rc;
-      h->status[h->active[l]] = INACTIVE;
-      h->active.erase(h->active.begin() + l);
       skip = true;
     }
     else
@@ -646,8 +783,6 @@ static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double 
       {
         rc = jrlqp_dense_remove(h, l, q, h->active[l], stream);
         if(rc != JRLQP_OK) return rc;
-        h->status[h->active[l]] = INACTIVE;
-        h->active.erase(h->active.begin() + l);
         skip = true;
       }
     }

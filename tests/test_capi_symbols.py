@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/jrlqp_hip.h but not exported"
     assert sorted(capi.EXPORTED) == decl
-    assert lib.jrlqp_abi_version() == 2
+    assert lib.jrlqp_abi_version() == 3
 
 
 def test_defaults_and_lds_budget(pkg):
@@ -78,6 +78,31 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.jrlqp_gi_solve_batch_ws(0, 4, 1, 0, 1, *ws_args) == -1  # null pointers
     ws_bad = [None] * 8 + [None] + [None] * 8 + [0, None, 64, None]
     assert lib.jrlqp_gi_solve_batch_ws(0, 4, 1, 0, 1, *ws_bad) == -1  # a size without a pointer
+
+
+def test_shard_arithmetic_of_the_multi_device_entry(pkg):
+    """jrlqp_shard_range (the split jrlqp_gi_solve_batch_multi applies) == jrl-qp_amd/dist.py shard_range (the split of the
+    one-process-per-GPU launcher): contiguous, balanced, covering, in order -- BASELINE c4 (32768 over 8) included."""
+    import jrl_qp_amd.capi as capi
+    import jrl_qp_amd.dist as jdist
+
+    for total in (0, 1, 7, 8, 9, 100, 4096, 32768, 32771):
+        for world in (1, 2, 3, 4, 6, 8):
+            nxt = 0
+            for r in range(world):
+                first, count = capi.shard_range(total, world, r)
+                lo, hi = jdist.shard_range(total, r, world)
+                assert (first, first + count) == (lo, hi) and first == nxt
+                assert count in (total // world, total // world + 1)
+                nxt = first + count
+            assert nxt == total
+    assert capi.shard_range(32768, 8, 3) == (3 * 4096, 4096)
+    assert capi.shard_range(10, 4, 7) == (0, 0) and capi.shard_range(-1, 4, 0) == (0, 0)  # out of range: an empty shard
+    lib = capi.load_library()
+    assert lib.jrlqp_gi_solve_batch_multi(0, 4, 1, 0, 8, 0, None, None, None, 1) == -1  # no device list
+    ids = (ct.c_int * 1)(0)
+    assert lib.jrlqp_gi_solve_batch_multi(0, 4, 1, 0, 8, 1, ids, None, None, 1) == -1  # no shard buffers
+    assert lib.jrlqp_gi_gather_x_multi(4, 8, 1, ids, None, 0, None, 1) == -1
 
 
 def test_blockgi_plan_validation_without_gpu(pkg):

@@ -2,6 +2,7 @@
 -- communicator creation, the epilogue all-reduce of counters and the all-gather of the device-resident results of
 jrl-qp_amd/dist.py, on device tensors the kernel has just written.  (The N = 2 partitioning itself is covered on CPU by
 tests/test_dist_gloo.py; N > 1 on GPUs is the driver's scaling run.)"""
+import ctypes as ct
 import os
 import socket
 
@@ -64,3 +65,32 @@ def test_hip_solver_under_rccl_world1(pkg, oracle, nccl_world1):
     out = [torch.empty_like(t)]
     dist.all_gather(out, t)
     assert float(out[0].item()) == 1.5
+
+
+def test_multi_device_entry_with_one_device(pkg, oracle):
+    """jrlqp_gi_solve_batch_multi / jrlqp_gi_gather_x_multi of the C ABI (one process, a list of devices; here the list is [0] -- a
+    box with more GPUs runs the same code with more shards): results bit-identical to the oracle, for a shape without a workspace
+    (n = 50) and one with (n = 100), and to the single-device entry point."""
+    import torch
+
+    import jrl_qp_amd.capi as capi
+    import jrl_qp_amd.problems as P
+
+    for ch, total in ((P.benchmark_characteristics(50, 200), 96), (P.Characteristics(nVar=100, nObj=100, nIneq=120, nStrongActIneq=20), 24)):
+        pb = P.generate_batch(total, ch, first_index=600)
+        dev = capi.to_device(pb, "cuda:0")
+        ms = capi.MultiDeviceBatchSolver(pb.n, pb.m, False, total, ["cuda:0"])
+        out = ms.solve([dev])
+        x_all = ms.gather_x(0)
+        ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=8)
+        for k in ("x", "u", "status", "term", "iters", "f"):
+            assert np.array_equal(out[0][k].cpu().numpy(), ref[k]), k
+        assert np.array_equal(x_all.cpu().numpy(), ref["x"])
+        single = capi.BatchSolver(pb.n, pb.m, False, total, device="cuda:0").solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"])
+        torch.cuda.synchronize()
+        assert torch.equal(single.x, out[0]["x"]) and torch.equal(single.u, out[0]["u"])
+    # a device id the process does not see, and a device listed twice
+    lib = capi.load_library()
+    sh = (capi.ShardBuffers * 2)()
+    assert lib.jrlqp_gi_solve_batch_multi(0, 50, 200, 0, 8, 1, (ct.c_int * 1)(torch.cuda.device_count()), sh, None, 1) == -1
+    assert lib.jrlqp_gi_solve_batch_multi(0, 50, 200, 0, 8, 2, (ct.c_int * 2)(0, 0), sh, None, 1) == -1
