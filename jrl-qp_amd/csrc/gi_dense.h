@@ -55,7 +55,7 @@ struct DenseState
   unsigned char * st; // activation status per constraint / bound
   double * pval;      // select partials
   int *pidx, *pstat;
-  int * info;         // LLT info (device)
+  int * info;         // {LLT info, arrival counter of the panel kernel} (device, two ints)
   int * psel;         // {p, status} of the last selection (device copy of the mailbox entries)
   int * wact;         // warm start: the initial active list (n ints)
   double *bact, *hco, *beta; // warm start: b_act, Householder coefficients, beta = R^-T b_act (n doubles each)
@@ -65,7 +65,7 @@ struct DenseState
 
 constexpr int kSelOnDevice = -2; // dense_step: take (p, status) from DenseState::psel instead of the arguments
 
-hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st);
+hipError_t dense_llt(double * G, int ldg, int n, int * d_info, hipStream_t st); // d_info: two ints, d_info[1] zero (gi_dense.hip llt_panel_fused_kernel)
 hipError_t dense_jinv(const double * L, int ldl, double * J, int n, hipStream_t st);
 hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double * x, double * f0, hipStream_t st);
 // zero_u >= 0: also clears u[zero_u] (the multiplier slot of the constraint this selection is for; saves a memset launch).

@@ -107,7 +107,12 @@ constexpr int NB = 32; // panel width
 // Panel j0, steps 1 and 2 in ONE launch (round 2): every workgroup (one wave) factorises the diagonal block A11 itself, out of
 // registers (lane = row; llt_reg_columns, device_common.h: look-ahead pivot, the finished columns in LDS), and then computes its
 // 64 rows of L21 = A21 L11^-T out of registers as well (trsm_reg_columns: L11 read back from LDS as broadcasts).  The redundant
-// factorisation costs 6 us per workgroup and saves a dependent launch per panel; workgroup 0 writes L11.  Blocks narrower than
+// factorisation costs 6 us per workgroup and saves a dependent launch per panel.  L11 goes back over A11 -- which every
+// workgroup of the launch has to READ first: it is written by the workgroup that was the LAST to have A11 in its registers (an
+// arrival counter behind the loads, info[1]; every workgroup holds the same bits, so any of them can be the writer).  Rounds 2-3
+// let workgroup 0 write it as soon as it had finished, which is only safe while all workgroups of the launch start together: with
+// another tenant's kernels on the CUs a late workgroup read L11 for A11 and reported a non-positive pivot
+// (tests/test_gpu_dense.py::test_dense_with_a_third_party_on_the_cus).  Blocks narrower than
 // NB (the last panel) are padded with the identity, which factorises to itself and contributes exact zeros.  Per element: the
 // terms in ascending k, then one division -- the bits of the two left-looking LDS kernels of round 1 (26 + 23 us per panel;
 // this: 9 us).  A non-positive pivot: *info = its index, nothing at or after that column is written and
@@ -130,6 +135,19 @@ __global__ __launch_bounds__(64) void llt_panel_fused_kernel(double * G, int ldg
       a[c] = (row && c < nb) ? v : ((lane == c) ? 1.0 : 0.0);
     }
   }
+  // A11 is in registers: arrive.  (release: the loads above are complete before the increment is visible; acquire: the writer's
+  // stores below come after every other workgroup's loads)
+  bool writer = true;
+  if(gridDim.x > 1)
+  {
+    int arrived = 0;
+    if(lane == 0)
+    {
+      arrived = __hip_atomic_fetch_add(info + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if(arrived == (int)gridDim.x - 1) __hip_atomic_store(info + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the next panel's launch finds zero)
+    }
+    writer = (__builtin_amdgcn_readfirstlane(arrived) == (int)gridDim.x - 1);
+  }
   int bad = -1;
   {
     const double p0 = bcast_lane(a[0], 0), l0 = __builtin_sqrt(opaque_v(p0));
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(64) void llt_panel_fused_kernel(double * G, int ldg
   }
   // (llt_reg_columns stores lanes >= J of column J for lane < NB: the padded rows too, harmless)
   const int cols = (bad < 0) ? nb : bad; // finished columns
-  if(blockIdx.x == 0)
+  if(writer)
   {
     if(lane < nb)
     {

@@ -127,7 +127,8 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = dmalloc(s.pval, parts);
   if(e == hipSuccess) e = dmalloc(s.pidx, parts);
   if(e == hipSuccess) e = dmalloc(s.pstat, parts);
-  if(e == hipSuccess) e = dmalloc(s.info, 1);
+  if(e == hipSuccess) e = dmalloc(s.info, 2); // {LLT info, arrival counter of llt_panel_fused_kernel (zero between launches)}
+  if(e == hipSuccess) e = hipMemset(s.info, 0, 2 * sizeof(int));
   if(e == hipSuccess) e = dmalloc(s.psel, 2);
   if(e == hipSuccess) e = dmalloc(s.wact, (size_t)n + 1);
   if(e == hipSuccess) e = dmalloc(s.bact, n);

@@ -348,16 +348,18 @@ def test_dense_no_constraint_twice_on_one_handle(capi, P, oracle):
 
 
 @pytest.mark.timeout(600)
-def test_dense_starved_handoff_is_rerun_with_events(capi, P, oracle):
+def test_dense_starved_handoff_is_rerun_with_events(capi, P, oracle, monkeypatch):
     """A device-side wait between the streams that gives up (fault injection: pass 3's first kernel waits for a tag nobody posts,
     ~1 s) must not surface as an error: the handle drains its streams, switches to event edges for good and repeats the solve from
     the factor it already has -- same bits as the oracle, G holds L as always, and the next solve on the handle is clean."""
     ch = P.Characteristics(nVar=140, nObj=140, nIneq=200, nStrongActIneq=30)
     pb = P.generate_batch(2, ch, first_index=5190)
+    # (tags whatever the creation-time probe says: when the handle's two side streams happen to share a hardware queue the probe
+    # -- which enqueues a consumer BEFORE its producer on purpose -- picks events, and there would be nothing to starve)
+    monkeypatch.setenv("JRLQP_DENSE_SYNC", "tags")
     s = capi.DenseSolver(pb.n, pb.m, False)
-    mode0, _ = s.sync_mode()
-    if mode0 != 0:
-        pytest.skip("this environment orders the streams by events from the start (a profiler?): nothing to starve")
+    monkeypatch.delenv("JRLQP_DENSE_SYNC")
+    assert s.sync_mode() == (0, 0)
     s.inject_sync_fault(3)
     ref = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0])
     args = _torch_problem(pb, 0, False)
