@@ -383,6 +383,14 @@ __device__ __forceinline__ double chain_down_neg(const double * __restrict__ a, 
     atomicAdd(&prof_lds[(slot)], (unsigned long long)(now_ - last3_));                  \
     last3_ = clock64();                                                                 \
   }
+// same for the first lane of wave 2 (the helper that also scans the LDS-staged extra columns): slots 16 / 17
+#define STAMP2(slot)                                                                    \
+  if(PROF && tid == 128)                                                                \
+  {                                                                                     \
+    long long now_ = clock64();                                                         \
+    atomicAdd(&prof_lds[(slot)], (unsigned long long)(now_ - last2_));                  \
+    last2_ = clock64();                                                                 \
+  }
 #define PROF_COUNT(slot)                                   \
   if(PROF && tid == 0) atomicAdd(&prof_lds[(slot)], 1ull);
 #define PROF_COUNT3(slot)                                  \
@@ -433,11 +441,12 @@ __device__ __forceinline__ void jinv_reg_rows(double (&acc)[N], int lane, const 
 template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false, bool BOX = false>
 __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : (NT <= 16 ? 5 : (NT <= 32 ? 4 : 3))) : 1) void gi_batch_kernel(const BatchArgs A)
 {
-  long long last_ = 0, wall0_ = 0, last3_ = 0;
+  long long last_ = 0, wall0_ = 0, last3_ = 0, last2_ = 0;
   if(PROF)
   {
     last_ = clock64();
     last3_ = last_;
+    last2_ = last_;
     wall0_ = wall_clock64();
   }
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -486,6 +495,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
   // allocation) and push column entries of the scanning waves into scratch.
   double * gsc = tail;
   if(CMODE == 2) tail = gsc + 6 * 64;
+  // gsc: [0, 2n + 1) the (c, s) pairs of an addition (csb, role-specialised loop); [128, 192) / [192, 256) bl / bu of the LDS-staged
+  // extra columns when there are at most 64 of them (round 4: the wave that scans them fetched both from global memory in EVERY
+  // scan -- two dependent loads, their pointers reloaded from scratch first, on the path every pass that adds waits for)
+  double * ebl = gsc + 128;
+  double * ebu = gsc + 192;
   // WARM: N -> B = L^-1 N -> its QR factors (n x q), b_act, Householder coefficients
   double * Bw = tail;
   double * bact = Bw + (WARM ? n * ld : 0);
@@ -566,6 +580,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
     {
       int k = e % n, i = e / n;
       Ce[(size_t)i * ld + k] = (k < nr) ? Cg[(size_t)(CREG_MAX + i) * nr + k] : 0.0;
+    }
+    if(ne > 0 && ne <= 64 && tid < ne)
+    {
+      ebl[tid] = blg[CREG_MAX + tid];
+      ebu[tid] = bug[CREG_MAX + tid];
     }
   }
 
@@ -2083,7 +2102,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             const int i = CREG_MAX + lane;
             if(e_on && lane < ne && st[i] == INACTIVE && i != excl)
             {
-              const double sl = ex - blg[i], su = bug[i] - ex;
+              const double sl = ex - ebl[lane], su = ebu[lane] - ex; // (bl, bu of the staged columns: in LDS since the prologue)
               if(sl < 0.0)
               {
                 ev = sl;
@@ -2584,9 +2603,11 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
             {
               ++sc;
               STAMP(6)
+              STAMP2(16)
               ws_scan(wp); // wp is treated as active (MAIN writes its status byte meanwhile)
               ws_post(&ctl->fscan[wave], sc);
               STAMP(7)
+              STAMP2(17)
             }
             else if(wave == 0)
               ws_post(&ctl->fack0, sq);
@@ -2803,7 +2824,11 @@ hipError_t launch_prof(const BatchArgs & a, long lds, hipStream_t stream)
   else
   {
     if(a.n != NT || a.warm) return hipErrorInvalidValue;
+#ifdef JRLQP_EXP_NOPROF // (register-pressure experiments: the production instantiation alone, 8 s per build)
+    return launch_one<NT, CMODE, false, false>(a, lds, stream);
+#else
     return a.prof ? launch_one<NT, CMODE, true, false>(a, lds, stream) : launch_one<NT, CMODE, false, false>(a, lds, stream);
+#endif
   }
 #else
   if(NT > 0 && a.n != NT) // a smaller problem, embedded (no phase-profile build of these)

@@ -35,7 +35,7 @@ capi.set_profile(capi.PROFILE_GI_BATCH, None)
 pr = prof.cpu().numpy().astype(np.float64)
 # role-specialised main loop (WS): wave 0 (chain wave) stamps slots 3-7, the MAIN wave (wave 3) slots 23-31
 names = ["load", "llt", "Jinv/x0", "w0: wait for d (idle)", "w0: coefficient chain", "w0: (c,s) + post", "w0: wait for the decision", "w0: scan + publish + post", "", "store",
-         "#adds", "#drops", "realtime(100MHz)", "seeded-chain fallbacks", "", "", "", "", "llt chain", "llt pivot", "", "", "MAIN: sweep of J",
+         "#adds", "#drops", "realtime(100MHz)", "seeded-chain fallbacks", "", "", "w2: everything but its scans", "w2: scan + publish + post", "llt chain", "llt pivot", "", "", "MAIN: sweep of J",
          "MAIN: drop (+ wait chain wave)", "MAIN: init + first selection", "MAIN: d = J^T n+ (+ post)", "MAIN: trsv + ratio", "MAIN: wait z / dots", "MAIN: step length + update",
          "MAIN: wait (c,s)", "MAIN: R column + bookkeeping", "MAIN: wait scans + combine"]
 tot = pr[:, 21:32].sum(axis=1)  # the MAIN wave's time line
