@@ -13,6 +13,7 @@ struct Mailbox
   double uq;            // u[q] before the update (needed by the f update on the host)
   double f0;            // init_
   int llt_info;
+  int dkind;             // the device's own decision for this pass (StepDev::kind), echoed for the host's cross-check; -1: none taken
   volatile int sync_err; // a device-side wait of the pass hand-off (PassSync) gave up: the results of this solve are void
   // pass tags written LAST by the two blocks of the step kernel (after a system-scope fence): the host state machine polls
   // them instead of synchronising the stream -- a stream synchronisation wakes up tens of microseconds after the kernel ends
@@ -33,6 +34,20 @@ struct PassSync
   int sel_tag;        // psel = {p, status} of the NEXT pass (select_final -> jtn)
   int z_cnt, z_tag;   // z = J2 d2 is complete              (z_rows on the side stream -> the scalar products of step_tail)
 };
+
+// Device-side copy of a pass's step scalars and the add / drop decision they imply (round 4).  The two workgroups of the step kernel
+// leave their scalars here as well as in the mailbox; the one that arrives last forms t2, t = min(t1, t2) and the decision with the
+// very operations the host uses (DualSolver.cpp:127-151) and tags it with the pass number.  The sweep of an ADDITION, which also
+// advances x and u (DualSolver.cpp:146-150), is enqueued right behind the step kernel, BEFORE the host has seen the scalars, and
+// runs only if the decision of its pass is "add": the GPU goes from the ratio test to the sweep without the host round trip
+// (8-12 us of an 87 us pass); the host still takes the same decision from the mailbox and drives everything else.
+struct StepDev
+{
+  double t1, zz, cz, cx, uq, t;
+  int l, arrive;
+  int tag, kind; // kind: 0 full step + add, 1 partial step + drop, 2 dual-only step + drop, 3 infeasible (same coding as jrlqp_trace_rec)
+};
+constexpr int kKindAdd = 0, kKindDrop = 1, kKindDual = 2, kKindInfeasible = 3;
 
 // the caller's problem (device pointers; GoldfarbIdnaniSolver::Problem, GoldfarbIdnaniSolver.h:35-58)
 struct DenseViews
@@ -61,6 +76,7 @@ struct DenseState
   double *bact, *hco, *beta; // warm start: b_act, Householder coefficients, beta = R^-T b_act (n doubles each)
   Mailbox * mb;       // device view of the mailbox
   PassSync * sync;    // pass hand-off tags (zeroed at creation; tags only grow)
+  StepDev * sd;       // device copy of the step scalars + the decision (zeroed at creation)
 };
 
 constexpr int kSelOnDevice = -2; // dense_step: take (p, status) from DenseState::psel instead of the arguments
@@ -86,6 +102,9 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
 hipError_t dense_advance(const DenseViews & v, DenseState & s, double t, int q, bool primal, hipStream_t st, int post_x_tag = 0);
 // wait_chain_tag != 0: the chain already ran on the side (dense_step with spec); the sweep waits for its tag and commits
 hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int q, hipStream_t st, int wait_chain_tag = 0);
+// The same sweep enqueued AHEAD of the decision (tags mode, q < n - 1): it runs only if StepDev says pass `tag` adds, takes p / status
+// from psel and t from StepDev, advances x and u itself (no advance kernel) and publishes x_tag = post_x_tag when asked to
+hipError_t dense_add_speculative(const DenseViews & v, DenseState & s, int q, hipStream_t st, int tag, int wait_chain_tag, int post_x_tag);
 hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int gone, hipStream_t st);
 // warm start (experimental::GoldfarbIdnaniSolver.cpp:388-487): with the LLT in G, the active list in s.wact and the status bytes in
 // s.st: N -> B = L^-1 N -> Householder QR (in s.R: R is its upper triangle), J = L^-T Q, b_act -> s.bact

@@ -905,7 +905,9 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
                                                         const double * __restrict__ u, const unsigned char * __restrict__ st, double big,
                                                         const double * __restrict__ z, const double * __restrict__ x, const double * __restrict__ cp,
                                                         int pb, Mailbox * mb, const int * psel = nullptr, const double * cbase = nullptr, int ldc = 0,
-                                                        int m = 0, int tag = 0, const PassSync * zsync = nullptr, int wait_z = 0)
+                                                        int m = 0, int tag = 0, const PassSync * zsync = nullptr, int wait_z = 0,
+                                                        StepDev * sd = nullptr, const double * gbl = nullptr, const double * gbu = nullptr,
+                                                        const double * gxl = nullptr, const double * gxu = nullptr)
 {
   extern __shared__ double rs[]; // block 0: the running right-hand side (q) ; block 1: z | x | n+ (3 n)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -931,6 +933,38 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
     cp = (p < m) ? cbase + (size_t)p * ldc : nullptr;
     pb = p - m;
   }
+  // The decision on the device (StepDev, gi_dense.h): called by the ONE thread of each workgroup that has just written that
+  // workgroup's scalars; the second to arrive has both halves and forms t2, t and the kind of step exactly as the host does
+  // (gi_dense_host.cpp; DualSolver.cpp:127-151; GoldfarbIdnaniSolver.cpp:174-218).
+  auto decide = [&]() {
+    if(!sd || !psel) return;
+    __threadfence();
+    const int old = __hip_atomic_fetch_add(&sd->arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if(old != 1) return;
+    __hip_atomic_store(&sd->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int p = psel[0], ps = psel[1];
+    const volatile StepDev * sv = sd; // (behind the acquire fence: the other workgroup's half, out of L2)
+    const double t1v = sv->t1, zzv = sv->zz, czv = sv->cz, cxv = sv->cx;
+    double b;
+    if(ps == LOWER || ps == EQUALITY)
+      b = gbl[p];
+    else if(ps == UPPER)
+      b = gbu[p];
+    else if(ps == LOWER_BOUND || ps == FIXED)
+      b = gxl[p - m];
+    else
+      b = gxu[p - m];
+    double t2v = big;
+    if(__builtin_sqrt(zzv) > 1e-14) t2v = (b - cxv) / czv;
+    const double tv = (t2v < t1v) ? t2v : t1v;
+    const int kind = (tv >= big) ? kKindInfeasible : ((t2v >= big) ? kKindDual : ((tv == t2v) ? kKindAdd : kKindDrop));
+    sd->t = tv;
+    sd->kind = kind;
+    mb->dkind = kind;
+    __threadfence();
+    __hip_atomic_store(&sd->tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  };
   if(blockIdx.x == 1)
   {
     double * zl = rs;
@@ -967,6 +1001,7 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
       else
         acc = xl[pb];
       mb->cx = acc;
+      if(sd) sd->cx = acc;
     }
     if(zsync && wait_z) flag_wait(&zsync->z_tag, wait_z, mb);
     for(int i = tid; i < n; i += 512) zl[i] = z[i];
@@ -1004,8 +1039,16 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
       double w[16];
 #pragma unroll
       for(int i = 0; i < 16; ++i) w[i] = red[i];
-      mb->zz = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
-      mb->cz = cp ? (((w[8] + w[9]) + (w[10] + w[11])) + ((w[12] + w[13]) + (w[14] + w[15]))) : zl[pb];
+      const double zzv = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      const double czv = cp ? (((w[8] + w[9]) + (w[10] + w[11])) + ((w[12] + w[13]) + (w[14] + w[15]))) : zl[pb];
+      mb->zz = zzv;
+      mb->cz = czv;
+      if(sd)
+      {
+        sd->zz = zzv;
+        sd->cz = czv;
+      }
+      decide();
     }
     post_tag(); // (wave 0 of block 1 wrote the three scalars; thread 0 is one of its lanes)
     return;
@@ -1135,9 +1178,12 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
   wave_argmin(tk, kk, dummy);
   if(lane == 0)
   {
-    mb->t1 = (kk == NONE) ? big : tk;
+    const double t1v = (kk == NONE) ? big : tk;
+    mb->t1 = t1v;
     mb->l = (kk == NONE) ? 0 : kk;
     mb->uq = u[q];
+    if(sd) sd->t1 = t1v;
+    decide();
   }
   post_tag();
 }
@@ -1493,12 +1539,42 @@ struct CommitArgs
   int wait_chain;
   Mailbox * mb;
 };
+// The sweep enqueued AHEAD of the add / drop decision (StepDev, gi_dense.h): it runs only if the device's decision for pass `tag` is
+// "add", takes (p, status) from psel and t from StepDev, and does the primal / dual update itself -- workgroup g advances its 64
+// entries of x, workgroup 0 also u (DualSolver.cpp:146-150) -- before it commits and sweeps.
+struct SpecArgs
+{
+  const StepDev * sd; // nullptr: not speculative (the host has decided; `advance` ran as its own kernel)
+  int tag;
+  const int * psel;
+  const double *z, *r;
+  double *x, *u;
+  PassSync * xsync;
+  int post_x;
+};
 
 __global__ __launch_bounds__(ROT_THREADS) void rot_apply_kernel(double * J, int ld, int n, int i_lo, int i_hi, int descending, const double * __restrict__ cc,
-                                                                const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr})
+                                                                const double * __restrict__ ss, CommitArgs cm = CommitArgs{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr},
+                                                                SpecArgs sp = SpecArgs{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0})
 {
   extern __shared__ double rsm[]; // four chunk slots | two chunk buffers | (c_i, s_i) pairs (T)
   const unsigned long long tk0 = ROTT();
+  if(sp.sd)
+  {
+    // same stream as the step kernel that took the decision: it is complete (and its stores visible) when this kernel starts
+    if(sp.sd->tag != sp.tag || sp.sd->kind != kKindAdd) return; // this pass does not add: nothing was touched
+    cm.p = sp.psel[0];
+    cm.pstat = sp.psel[1];
+    const double t = sp.sd->t;
+    const int i = blockIdx.x * 64 + (int)threadIdx.x;
+    if(threadIdx.x < 64 && i < n) sp.x[i] = FMA(t, sp.z[i], sp.x[i]);
+    if(blockIdx.x == 0)
+    {
+      for(int k = threadIdx.x; k < cm.q; k += ROT_THREADS) sp.u[k] = FMA(-t, sp.r[k], sp.u[k]);
+      if(threadIdx.x == 0) sp.u[cm.q] = sp.u[cm.q] + t;
+    }
+    if(sp.xsync && sp.post_x) flag_post(&sp.xsync->x_cnt, &sp.xsync->x_tag, gridDim.x, sp.post_x);
+  }
   if(cm.sync && cm.wait_chain) flag_wait(&cm.sync->chain_tag, cm.wait_chain, cm.mb);
   const unsigned long long tk1 = ROTT();
   if(cm.d && blockIdx.x == 0)
@@ -2044,7 +2120,7 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   }
   if(dev_p)
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
-                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag, s.sync, zs ? tag : 0);
+                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag, s.sync, zs ? tag : 0, s.sd, v.bl, v.bu, v.xl, v.xu);
   else
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
                        p - v.m, s.mb, nullptr, nullptr, 0, 0, tag, s.sync, zs ? tag : 0);
@@ -2078,6 +2154,18 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
                        CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat, s.sync, wait_chain_tag, s.mb});
   else // q = n - 1: nothing to rotate
     hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat, s.sync, wait_chain_tag, s.mb);
+  return hipGetLastError();
+}
+
+hipError_t dense_add_speculative(const DenseViews & v, DenseState & s, int q, hipStream_t st, int tag, int wait_chain_tag, int post_x_tag)
+{
+  const int n = v.n;
+  if(n - 2 < q) return hipErrorInvalidValue; // (q = n - 1: nothing to rotate -- the caller takes the decided path)
+  hipError_t e = rot_attr(n);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(ROT_THREADS), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
+                     CommitArgs{s.d, s.rfin, s.R, s.st, q, n, -1, 0, s.sync, wait_chain_tag, s.mb},
+                     SpecArgs{s.sd, tag, s.psel, s.z, s.r, s.x, s.u, s.sync, post_x_tag});
   return hipGetLastError();
 }
 

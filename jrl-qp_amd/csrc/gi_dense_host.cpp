@@ -47,6 +47,7 @@ struct jrlqp_dense
   int tag = 0;                         // pass counter: the step kernel echoes it into the mailbox when its scalars are out
   jrlqp_trace_rec * trace = nullptr;   // jrlqp_dense_set_trace: one record per pass of the library's loop (host memory, caller-owned)
   int trace_cap = 0;
+  bool speculate = true;               // enqueue the sweep of an addition ahead of the decision (StepDev; JRLQP_DENSE_SPECULATE=0 switches it off)
   int inject_fault_pass = -1;          // jrlqp_debug_dense_inject_sync_fault: the pass whose first kernel waits for a tag nobody posts
   int event_reruns = 0;                // solves that were re-run with event edges after a device-side wait gave up
 };
@@ -141,12 +142,16 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = hipStreamCreateWithFlags(&h->spec, hipStreamNonBlocking);
   if(e == hipSuccess) e = dmalloc(s.sync, 1);
   if(e == hipSuccess) e = hipMemset(s.sync, 0, sizeof(PassSync));
+  if(e == hipSuccess) e = dmalloc(s.sd, 1);
+  if(e == hipSuccess) e = hipMemset(s.sd, 0, sizeof(StepDev));
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_d, hipEventDisableTiming);
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming);
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming);
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming);
   if(e == hipSuccess)
   {
+    const char * spc = std::getenv("JRLQP_DENSE_SPECULATE");
+    if(spc && std::strcmp(spc, "0") == 0) h->speculate = false;
     const char * mode = std::getenv("JRLQP_DENSE_SYNC");
     if(mode && std::strcmp(mode, "events") == 0)
       h->use_events = true;
@@ -192,6 +197,7 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   if(h->side) (void)hipStreamDestroy(h->side);
   if(h->spec) (void)hipStreamDestroy(h->spec);
   (void)hipFree(s.sync);
+  (void)hipFree(s.sd);
   if(h->ev_d) (void)hipEventDestroy(h->ev_d);
   if(h->ev_chain) (void)hipEventDestroy(h->ev_chain);
   if(h->ev_x) (void)hipEventDestroy(h->ev_x);
@@ -649,6 +655,7 @@ attempt:
     }
   } report{timing, t_launch_step, t_wait, t_rest, h->it};
   bool skip = false;
+  bool speculated = false; // the sweep of this pass's possible addition is already in the stream (dense_add_speculative)
   bool prefetched = false; // the scan of this pass already ran on the side stream, beside the previous pass's sweep
   int p = -1, pstat = INACTIVE;
   for(; h->it < o.max_iter; ++h->it)
@@ -692,6 +699,14 @@ attempt:
         TRY(dense_step(h->v, h->s, kSelOnDevice, 0, q, big, st, spec ? h->spec : nullptr, tag, wait_sel, wait_chain, h->side));
       }
       h->chain_pending = spec ? tag : 0;
+      // The sweep of an addition -- most passes add -- goes into the stream NOW, behind the step kernel and ahead of the decision:
+      // it runs only if the device's own decision for this pass (StepDev) is "add", and then also advances x and u.  The GPU no
+      // longer idles while the scalars travel to the host and the launches travel back.
+      speculated = h->speculate && !h->use_events && spec && q < n - 1;
+      // (Measured and NOT kept: the next pass's constraint scan enqueued ahead of the decision as well, gated on StepDev -- c2 45.4 ms
+      // with the sweep alone ahead, 46.2 ms with both; and the selection it publishes may reach the mailbox before the host has read
+      // this pass's.)
+      if(speculated) TRY(dense_add_speculative(h->v, h->s, q, st, tag, tag, (h->it + 1 < o.max_iter) ? tag : 0));
       const double tb = timing ? now() : 0;
       if(!wait_tag(h->h_mb, tag)) TRY(hipStreamSynchronize(st));
       if(timing)
@@ -732,6 +747,17 @@ attempt:
     const double t = (t2 < t1) ? t2 : t1;
     if(h->trace && h->it < h->trace_cap) // the reference logs every pass (DualSolver.cpp:116,128-129,138,153,159)
       h->trace[h->it] = jrlqp_trace_rec{p, pstat, l, (t2 >= big) ? 2 : ((t == t2) ? 0 : 1), t1, t2};
+    if(speculated)
+    {
+      // the device took the same decision from the same scalars with the same operations; a disagreement would mean that the sweep in
+      // the stream did something the host does not know of
+      const int kind = (t >= big) ? kKindInfeasible : ((t2 >= big) ? kKindDual : ((t == t2) ? kKindAdd : kKindDrop));
+      if(h->h_mb->dkind != kind)
+      {
+        h->last_hip = (int)hipErrorAssert;
+        return JRLQP_ERR_HIP;
+      }
+    }
     if(t >= big) return finish(JRLQP_INFEASIBLE);
     const double dotsc = (pstat == UPPER || pstat == UPPER_BOUND) ? -nz : nz;
     if(t2 >= big)
@@ -746,7 +772,8 @@ attempt:
     {
       const bool more = h->it + 1 < o.max_iter;
       const bool prefetch = (t == t2) && more;
-      TRY(dense_advance(h->v, h->s, t, q, true, st, (prefetch && !h->use_events) ? tag : 0)); // (x_tag: the side stream's scan reads the new x)
+      const bool swept = speculated && (t == t2); // the sweep in the stream is running: it advances x and u itself
+      if(!swept) TRY(dense_advance(h->v, h->s, t, q, true, st, (prefetch && !h->use_events) ? tag : 0)); // (x_tag: the side stream's scan reads the new x)
       h->f = std::fma(t * dotsc, 0.5 * t + uq, h->f);
       if(t == t2)
       {
@@ -761,7 +788,7 @@ attempt:
           if(h->chain_pending) TRY(hipStreamWaitEvent(st, h->ev_chain, 0));
           TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending ? -1 : 0)); // (-1: the chain ran ahead, ordered by the event)
         }
-        else
+        else if(!swept)
           TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending)); // commit: the chain ran ahead (the sweep waits for chain_tag)
         h->chain_pending = 0;
         if(prefetch)
