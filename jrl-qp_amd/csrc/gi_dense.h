@@ -13,6 +13,8 @@ struct Mailbox
   double uq;            // u[q] before the update (needed by the f update on the host)
   double f0;            // init_
   int llt_info;
+  int sp, sps;           // (p, status) of the pass whose step scalars these are, echoed by the step kernel: the NEXT pass's selection may
+                         // already have overwritten p / pstatus above when its scan went into the stream ahead of the decision
   int dkind;             // the device's own decision for this pass (StepDev::kind), echoed for the host's cross-check; -1: none taken
   volatile int sync_err; // a device-side wait of the pass hand-off (PassSync) gave up: the results of this solve are void
   // pass tags written LAST by the two blocks of the step kernel (after a system-scope fence): the host state machine polls
@@ -47,7 +49,7 @@ struct StepDev
   int l, arrive;
   int tag, kind; // kind: 0 full step + add, 1 partial step + drop, 2 dual-only step + drop, 3 infeasible (same coding as jrlqp_trace_rec)
 };
-constexpr int kKindAdd = 0, kKindDrop = 1, kKindDual = 2, kKindInfeasible = 3;
+constexpr int kKindAdd = 0, kKindDrop = 1, kKindDual = 2, kKindInfeasible = 3, kKindNone = 4; // (4: nothing was selected)
 
 // the caller's problem (device pointers; GoldfarbIdnaniSolver::Problem, GoldfarbIdnaniSolver.h:35-58)
 struct DenseViews
@@ -77,6 +79,10 @@ struct DenseState
   Mailbox * mb;       // device view of the mailbox
   PassSync * sync;    // pass hand-off tags (zeroed at creation; tags only grow)
   StepDev * sd;       // device copy of the step scalars + the decision (zeroed at creation)
+  // CANON C8 (more than 256 unknowns): segment sums of the three blocked products and the arrival counters of their column / row groups
+  double *partJ, *partZ, *partC; // [segment][column] with leading dimensions ldpJ (>= n, multiple of 64) and ldpC (>= m)
+  int ldpJ, ldpC;
+  int *cntJ, *cntZ, *cntC;       // zero between launches
 };
 
 constexpr int kSelOnDevice = -2; // dense_step: take (p, status) from DenseState::psel instead of the arguments
@@ -87,7 +93,10 @@ hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double *
 // zero_u >= 0: also clears u[zero_u] (the multiplier slot of the constraint this selection is for; saves a memset launch).
 // wait_x_tag != 0: the scan first waits for PassSync::x_tag == wait_x_tag (it runs on another stream than `advance`);
 // post_sel_tag != 0: the selection publishes PassSync::sel_tag = post_sel_tag behind psel.
-hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u = -1, int wait_x_tag = 0, int post_sel_tag = 0);
+// gate_tag != 0: the scan goes into the stream AHEAD of the decision of pass gate_tag (StepDev): a one-wave gate kernel waits for the
+// decision, the scan kernels behind it run only if that pass adds and exclude the constraint standing in psel (the one being activated)
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u = -1, int wait_x_tag = 0, int post_sel_tag = 0,
+                        int gate_tag = 0);
 // spec != nullptr: the Givens coefficient chain of an ADDITION is launched on `spec` at once and starts as soon as d exists
 // (PassSync::d_tag == tag), beside z / r / the ratio test on `st`; it publishes chain_tag = tag.  dense_add(..., wait_chain_tag = tag)
 // then only commits.  wait_sel_tag / wait_chain_tag != 0: the first kernel waits for the selection made on the side stream / for a

@@ -99,6 +99,42 @@ __device__ __forceinline__ void flag_post(int * cnt, int * flag, int total, int 
   }
 }
 
+// The scan of the pass BEHIND an addition enqueued ahead of the add / drop decision (StepDev, gi_dense.h): a one-wave gate kernel in
+// front of the scan kernels waits for the step kernel's decision tag (the step kernel is in another stream; enqueued earlier, so it is
+// never stuck behind the gate); the kernels behind the gate find the decision there and simply return if the pass does not add.
+// The gate also waits for the x of the sweep's first phase (x_tag): the scan's workgroups must not sit on their LDS waiting for it --
+// 512 of them, two per CU, left no CU with room for a workgroup of the sweep that was to publish it (a 0.4 s stall until the wait
+// gave up, then the event-ordered rerun).  Behind the gate nothing waits.
+__global__ void decision_gate_kernel(const StepDev * sd, int tag, const PassSync * sync, int wait_x, Mailbox * mb)
+{
+  int spins = 0;
+  while(__hip_atomic_load(&sd->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag)
+  {
+    __builtin_amdgcn_s_sleep(4);
+    if(++spins > (1 << 20))
+    {
+      if(mb) mb->sync_err = 1;
+      return;
+    }
+  }
+  if(__hip_atomic_load(&sd->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kKindAdd || !wait_x) return;
+  spins = 0;
+  while(__hip_atomic_load(&sync->x_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait_x)
+  {
+    __builtin_amdgcn_s_sleep(4);
+    if(++spins > (1 << 20))
+    {
+      if(mb) mb->sync_err = 1;
+      return;
+    }
+  }
+}
+__device__ __forceinline__ bool gate_is_add(const StepDev * sd, int tag)
+{
+  return __hip_atomic_load(&sd->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag &&
+         __hip_atomic_load(&sd->kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kKindAdd;
+}
+
 // ============================================================================================================
 // K1  blocked right-looking Cholesky
 // ============================================================================================================
@@ -561,14 +597,17 @@ constexpr int TS_SLOT = (CT / 2) * TS_PAIR;
 constexpr int TILE_THREADS = 128;
 static_assert(8 * (TS_NS - 1) <= 63, "vmcnt");
 
-__device__ __forceinline__ void tile_loader(const double * __restrict__ M, size_t ld, int n, int col0, int ncols, double * slots, int lane)
+// (t0 / t1: the tiles [t0, t1) only -- the blocked kernels of CANON C8 split the rows of a column group over several workgroups)
+__device__ __forceinline__ void tile_loader(const double * __restrict__ M, size_t ld, int n, int col0, int ncols, double * slots, int lane, int t0 = 0,
+                                            int t1 = -1)
 {
-  const int ntiles = (n + KT - 1) / KT;
+  const int ntiles_all = (n + KT - 1) / KT;
+  const int tb = t0, ntiles = (t1 < 0) ? ntiles_all : t1;
   const int kp = lane & 31, half = lane >> 5;
   const int cmax = col0 + ((ncols > 0) ? ncols - 1 : 0);
   auto issue = [&](int t) {
     if(n < 2) return; // (a single row: the odd-n path below fetches it; a 16-byte load could leave the caller's buffer)
-    double * slot = slots + (t % TS_NS) * TS_SLOT;
+    double * slot = slots + ((t - tb) % TS_NS) * TS_SLOT;
     int row = t * KT + 2 * kp;
     if(row + 1 >= n) row = n - 2; // past the end, or the pair that starts at the last row of an odd n (see above)
 #pragma unroll
@@ -578,18 +617,18 @@ __device__ __forceinline__ void tile_loader(const double * __restrict__ M, size_
       __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(slot + i * TS_PAIR), 16, 0, 0);
     }
   };
-  for(int t = 0; t < TS_NS - 1 && t < ntiles; ++t) issue(t);
-  for(int t = 0; t < ntiles; ++t)
+  for(int t = tb; t < tb + TS_NS - 1 && t < ntiles; ++t) issue(t);
+  for(int t = tb; t < ntiles; ++t)
   {
     if(t + TS_NS - 2 < ntiles) // the TS_NS - 2 tiles behind tile t are all requested: tile t has landed once only they are outstanding
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (TS_NS - 2)) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if((n & 1) && t == ntiles - 1 && lane < CT)
+    if((n & 1) && t == ntiles_all - 1 && lane < CT)
     {
       // odd n: element n - 1 of column `lane` (its pair was fetched one row low)
       const double vlast = M[(size_t)min(col0 + lane, cmax) * ld + (n - 1)];
-      slots[(t % TS_NS) * TS_SLOT + (lane >> 1) * TS_PAIR + (lane & 1) * 64 + (n - 1 - t * KT)] = vlast;
+      slots[((t - tb) % TS_NS) * TS_SLOT + (lane >> 1) * TS_PAIR + (lane & 1) * 64 + (n - 1 - t * KT)] = vlast;
     }
     lds_barrier(); // B_t
     if(t + TS_NS - 1 < ntiles) issue(t + TS_NS - 1);
@@ -688,6 +727,223 @@ __global__ __launch_bounds__(TILE_THREADS) void jtn_kernel(const double * __rest
   if(ds.sync && ds.post) flag_post(&ds.sync->d_cnt, &ds.sync->d_tag, ds.total, ds.post);
 }
 
+
+// ---- CANON C8 (oracle orc_dot_blk): the column dots BLOCKED, for more than kBlockN unknowns ---------------------------------------
+// A column's sum is cut into segments of 64 rows -- exactly the tiles of the stream above --, each segment an ascending fma chain from
+// +0, the segment sums combined by the adjacent-first pairwise tree.  The chain of an output is then 64 steps instead of n, and the
+// rows of a column group are split over RS workgroups (grid.y): every CU streams its share of M.  Each workgroup leaves its segment
+// sums in P[tile][column]; a second, small kernel behind it in the stream combines them (lane = output, the oracle's tree over 64
+// slots in registers, the slots beyond the last segment +0).  (First version: the workgroup that arrived last at a per-group counter
+// combined -- one agent-scope release per workgroup, i.e. an L2 write-back on this eight-XCD part, 384 of them beside a sweep that
+// is dirtying 8 MiB of J: select 20 -> 52 us, jtn 20 -> 41 us.  A kernel boundary costs 1.5 us and no fence.)
+constexpr int kBlockN = 256;
+struct BlkArgs
+{
+  double * P; // segment sums: P[t * ldp + column]
+  int ldp;
+  int * cnt;  // one arrival counter per column group (zero between launches)
+  int tps;    // tiles per workgroup
+};
+__device__ __forceinline__ void tile_chain_blk(int n, const double * vs, const double * slots, int lane, int t0, int t1, const BlkArgs & ba, int col0, int nc)
+{
+  const int c = min(lane, CT - 1);
+  const int coff = (c >> 1) * TS_PAIR + (c & 1) * 64;
+  for(int t = t0; t < t1; ++t)
+  {
+    lds_barrier(); // B_t: tile t is in its slot
+    const double * a = slots + ((t - t0) % TS_NS) * TS_SLOT + coff;
+    const int k0 = t * KT, cnt = min(KT, n - k0);
+    const double acc = (cnt == KT) ? chain64<1, true>(0.0, a, vs + k0, cnt) : chain64<1, false>(0.0, a, vs + k0, cnt);
+    if(lane < nc) ba.P[(size_t)t * ba.ldp + col0 + lane] = acc;
+  }
+}
+__global__ __launch_bounds__(TILE_THREADS) void jtn_blk_kernel(const double * __restrict__ M, int ld, int n, int ncols, const double * __restrict__ v, double sign,
+                                                               double * out, const int * psel, const double * vbase, int ldv, int m, DSync ds, BlkArgs ba)
+{
+  extern __shared__ double sh[]; // vector (n) | tile slots
+  double * vs = sh;
+  double * slots = sh + n + (n & 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * CT;
+  const int nc = min(CT, ncols - col0);
+  const int ntiles = (n + KT - 1) / KT;
+  const int t0 = blockIdx.y * ba.tps, t1 = min(ntiles, t0 + ba.tps);
+  if(wave == 1)
+    tile_loader(M, (size_t)ld, n, col0, nc, slots, lane, t0, t1);
+  else
+  {
+    if(ds.sync)
+    {
+      if(ds.wait_sel) flag_wait_wave(&ds.sync->sel_tag, ds.wait_sel, ds.mb, lane);
+      // (a discarded chain that may still be reading d is waited for by the combine kernel: this one only writes segment sums)
+    }
+    bool live = true;
+    if(psel)
+    {
+      const int p = psel[0];
+      live = !(p < 0 || p >= m); // none selected, or a bound (jrow_kernel)
+      if(live) v = vbase + (size_t)p * ldv;
+    }
+    const int r0 = t0 * KT, r1 = min(n, t1 * KT);
+    if(live)
+      for(int i = r0 + lane; i < r1; i += 64) vs[i] = v[i];
+    tile_chain_blk(n, vs, slots, lane, t0, t1, ba, col0, nc); // (not live: chains on whatever LDS holds -- the loader's barriers need their partner)
+  }
+}
+
+// K4 partial, blocked: C^T x in segments (C8), then per CT constraints the first-index arg-min of min(c.x - bl, bu - c.x) below 0
+__global__ __launch_bounds__(TILE_THREADS) void select_blk_kernel(const double * __restrict__ C, int ldc, int n, int m, const double * __restrict__ x,
+                                                                  const double * __restrict__ bl, const double * __restrict__ bu,
+                                                                  const unsigned char * __restrict__ st, int excl, double * pval, int * pidx, int * pstat,
+                                                                  const PassSync * sync, int wait_x, Mailbox * mb, BlkArgs ba, const StepDev * gate = nullptr,
+                                                                  int gate_tag = 0)
+{
+  extern __shared__ double sh[];
+  double * vs = sh;
+  double * slots = sh + n + (n & 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * CT;
+  const int nc = min(CT, m - col0);
+  const int ntiles = (n + KT - 1) / KT;
+  const int t0 = blockIdx.y * ba.tps, t1 = min(ntiles, t0 + ba.tps);
+  if(gate && !gate_is_add(gate, gate_tag)) return; // (behind decision_gate_kernel: the pass does not add -- no scan)
+  if(wave == 1)
+    tile_loader(C, (size_t)ldc, n, col0, nc, slots, lane, t0, t1); // (C is the caller's: its tiles start at once, beside the wait for x)
+  else
+  {
+    if(sync && wait_x) flag_wait_wave(&sync->x_tag, wait_x, mb, lane); // x of this pass comes from `advance` / the sweep on another stream
+    const int r0 = t0 * KT, r1 = min(n, t1 * KT);
+    for(int i = r0 + lane; i < r1; i += 64) vs[i] = x[i];
+    tile_chain_blk(n, vs, slots, lane, t0, t1, ba, col0, nc);
+  }
+}
+
+// The tree over the segment sums of an output (CANON C8), lane = output: P[t * ldp + o], t < nseg <= 64, the slots beyond nseg +0 --
+// so the tree over the first power of two >= nseg slots is the whole tree (x + (+0) = x, and a segment sum is never -0)
+template<int SL>
+__device__ __forceinline__ double blk_tree_n(const double * P, int ldp, int nseg, int o)
+{
+  double p[SL];
+#pragma unroll
+  for(int t = 0; t < SL; ++t) p[t] = P[(size_t)min(t, nseg - 1) * ldp + o]; // (clamped, not predicated: every load in flight at once)
+#pragma unroll
+  for(int t = 0; t < SL; ++t) p[t] = (t < nseg) ? p[t] : 0.0;
+#pragma unroll
+  for(int h = 1; h < SL; h <<= 1)
+#pragma unroll
+    for(int i = 0; i < SL; i += 2 * h) p[i] = p[i] + p[i + h];
+  return p[0];
+}
+__device__ __forceinline__ double blk_tree(const double * P, int ldp, int nseg, int o)
+{
+  if(nseg <= 8) return blk_tree_n<8>(P, ldp, nseg, o);
+  if(nseg <= 16) return blk_tree_n<16>(P, ldp, nseg, o);
+  if(nseg <= 32) return blk_tree_n<32>(P, ldp, nseg, o);
+  return blk_tree_n<64>(P, ldp, nseg, o);
+}
+// d = +-(tree of the segment sums), 64 outputs per workgroup (one wave); psel != nullptr: sign and "is there a general constraint at
+// all" from the selection on the device; publishes d_tag like jtn_kernel.  Also the combine of z (plain: sign 1, no psel).
+__global__ __launch_bounds__(64) void blk_comb_kernel(const double * __restrict__ P, int ldp, int nseg, int nout, double sign, double * out, const int * psel,
+                                                      int m, DSync ds, PassSync * zsync = nullptr, int post_z = 0)
+{
+  const int o = blockIdx.x * 64 + threadIdx.x;
+  if(ds.sync && ds.wait_chain) flag_wait(&ds.sync->chain_tag, ds.wait_chain, ds.mb); // a discarded chain may still be reading d
+  bool live = true;
+  if(psel)
+  {
+    const int p = psel[0];
+    live = !(p < 0 || p >= m);
+    sign = (psel[1] == UPPER) ? -1.0 : 1.0;
+  }
+  if(live && o < nout)
+  {
+    const double r = blk_tree(P, ldp, nseg, o);
+    out[o] = (sign < 0.0) ? -r : r;
+  }
+  if(ds.sync && ds.post) flag_post(&ds.sync->d_cnt, &ds.sync->d_tag, ds.total, ds.post);
+  if(zsync && post_z) flag_post(&zsync->z_cnt, &zsync->z_tag, gridDim.x, post_z);
+}
+// K4 partial behind select_blk_kernel: c.x of CT constraints per workgroup (the tree), then the first-index arg-min of
+// min(c.x - bl, bu - c.x) below 0 -- what select_partial_kernel leaves for select_final_kernel.  (Folded into select_final_kernel it
+// was one launch less and 29 us instead of 3 + 6: 2048 trees on one workgroup.)
+__global__ __launch_bounds__(64) void select_comb_kernel(const double * __restrict__ P, int ldp, int nseg, int m, const double * __restrict__ bl,
+                                                         const double * __restrict__ bu, const unsigned char * __restrict__ st, int excl, double * pval,
+                                                         int * pidx, int * pstat, const StepDev * gate = nullptr, int gate_tag = 0, const int * psel = nullptr)
+{
+  if(gate)
+  {
+    if(!gate_is_add(gate, gate_tag)) return;
+    excl = psel[0]; // the constraint being activated (its status byte is written by the sweep, concurrently)
+  }
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * CT + lane;
+  const bool on = lane < CT && i < m;
+  const double cx = blk_tree(P, ldp, nseg, on ? i : 0);
+  double bval = 0.0;
+  int bidx = NONE, bstat = INACTIVE;
+  if(on && st[i] == INACTIVE && i != excl) // `excl`: a constraint being activated concurrently (its status byte may not be set yet)
+  {
+    double sl = cx - bl[i];
+    if(sl < 0.0)
+    {
+      bval = sl;
+      bidx = i;
+      bstat = LOWER;
+    }
+    else
+    {
+      double su = bu[i] - cx;
+      if(su < 0.0)
+      {
+        bval = su;
+        bidx = i;
+        bstat = UPPER;
+      }
+    }
+  }
+  wave_argmin(bval, bidx, bstat);
+  if(lane == 0)
+  {
+    pval[blockIdx.x] = bval;
+    pidx[blockIdx.x] = bidx;
+    pstat[blockIdx.x] = bstat;
+  }
+}
+
+// K6 blocked (C8): z_i = sum over the columns q .. n-1 in segments of 64 by ABSOLUTE column index.  One wave per (64 rows, segment):
+// lane = row (a column's 64 rows are 512 contiguous bytes), the segment's 64 entries of the row in registers -- all loads in flight at
+// once --, d2 through LDS with the entries outside [q, n) replaced by +0 (a term fma(J_ij, +0, acc) leaves acc as it is).  The wave of
+// a row group that arrives last adds the segment sums of its 64 rows (lane = row: the tree in registers).
+__global__ __launch_bounds__(64) void z_blk_kernel(const double * __restrict__ J, int ld, int n, int q, const double * __restrict__ d, double * z,
+                                                   PassSync * sync, int wait_d, int post_z, Mailbox * mb, BlkArgs ba)
+{
+  __shared__ double dsm[64];
+  if(sync && wait_d) flag_wait(&sync->d_tag, wait_d, mb); // on its own stream, beside the substitution: d (and with it J) of this pass
+  const int lane = threadIdx.x;
+  const int row = min((int)blockIdx.x * 64 + lane, n - 1);
+  const int s = blockIdx.y, j0 = s * 64;
+  double acc = 0.0;
+  if(j0 + 64 > q) // (a segment entirely below q has no term: +0)
+  {
+    double a[64];
+#pragma unroll
+    for(int t = 0; t < 64; ++t) a[t] = AT(J, ld, row, min(j0 + t, n - 1));
+    const int j = j0 + lane;
+    dsm[lane] = (j >= q && j < n) ? d[j] : 0.0;
+    wave_sync();
+#pragma unroll
+    for(int t0 = 0; t0 < 64; t0 += 8)
+    {
+      double dv[8];
+#pragma unroll
+      for(int t = 0; t < 8; ++t) dv[t] = dsm[t0 + t];
+#pragma unroll
+      for(int t = 0; t < 8; ++t) acc = FMA(a[t0 + t], dv[t], acc);
+    }
+  }
+  ba.P[(size_t)s * ba.ldp + blockIdx.x * 64 + lane] = acc; // (ldp >= 64 * gridDim.x); blk_comb_kernel adds the segment sums and publishes z_tag
+}
+
 // bound constraint: d = +-row pb of J
 __global__ void jrow_kernel(const double * __restrict__ J, int ld, int n, int pb, double sign, double * out, const int * psel = nullptr, int m = 0,
                             DSync ds = DSync{nullptr, nullptr, 0, 0, 0, 0})
@@ -770,8 +1026,14 @@ __global__ __launch_bounds__(TILE_THREADS) void select_partial_kernel(const doub
 __global__ __launch_bounds__(256) void select_final_kernel(int nparts, const double * pval, const int * pidx, const int * pstat, int m, int nb,
                                                           const double * __restrict__ x, const double * __restrict__ xl,
                                                           const double * __restrict__ xu, const unsigned char * __restrict__ st, int excl, Mailbox * mb,
-                                                          int * psel, double * uq = nullptr, PassSync * sync = nullptr, int wait_x = 0, int post_sel = 0)
+                                                          int * psel, double * uq = nullptr, PassSync * sync = nullptr, int wait_x = 0, int post_sel = 0,
+                                                          const StepDev * gate = nullptr, int gate_tag = 0)
 {
+  if(gate)
+  {
+    if(!gate_is_add(gate, gate_tag)) return;
+    excl = psel[0];
+  }
   if(sync && wait_x) flag_wait(&sync->x_tag, wait_x, mb); // (m == 0: no partial kernel ran ahead of this one)
   if(uq && threadIdx.x == 0) *uq = 0.0; // u[q] = 0 for the constraint about to be selected (DualSolver.cpp:121)
   __shared__ double sv[4];
@@ -907,7 +1169,8 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
                                                         int pb, Mailbox * mb, const int * psel = nullptr, const double * cbase = nullptr, int ldc = 0,
                                                         int m = 0, int tag = 0, const PassSync * zsync = nullptr, int wait_z = 0,
                                                         StepDev * sd = nullptr, const double * gbl = nullptr, const double * gbu = nullptr,
-                                                        const double * gxl = nullptr, const double * gxu = nullptr)
+                                                        const double * gxl = nullptr, const double * gxu = nullptr, const double * Pz = nullptr,
+                                                        int ldpz = 0, int nsegz = 0, double * zout = nullptr)
 {
   extern __shared__ double rs[]; // block 0: the running right-hand side (q) ; block 1: z | x | n+ (3 n)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -925,8 +1188,19 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
   if(psel)
   {
     const int p = psel[0];
+    if(blockIdx.x == 0 && tid == 0)
+    {
+      mb->sp = p;
+      mb->sps = psel[1];
+    }
     if(p < 0) // nothing violated: the host terminates on the p it reads with this pass's scalars
     {
+      if(sd && blockIdx.x == 0 && tid == 0) // (a scan waiting at its gate learns that there is no decision to act on)
+      {
+        sd->kind = kKindNone;
+        __threadfence();
+        __hip_atomic_store(&sd->tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
       post_tag();
       return;
     }
@@ -967,18 +1241,56 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
   };
   if(blockIdx.x == 1)
   {
+    // (x and n+ staged with one pad entry per 64: lane s of the blocked n+.x below walks segment s, a stride of 64 doubles would put
+    // the 64 lanes of a step on one LDS bank)
+    const int npad = n + (n >> 6) + 1;
+    auto pd = [](int i) { return i + (i >> 6); };
     double * zl = rs;
     double * xl = rs + n;
-    double * cl = rs + 2 * n;
+    double * cl = xl + npad;
     for(int i = tid; i < n; i += 512)
     {
-      xl[i] = x[i];
-      cl[i] = cp ? cp[i] : 0.0;
+      xl[pd(i)] = x[i];
+      cl[pd(i)] = cp ? cp[i] : 0.0;
     }
     __syncthreads();
-    // n+.x: the C1 chain (bit for bit the scan's value for the constraint), one lane of wave 1 -- it needs neither z nor r, and runs
-    // while z is still being computed (zsync: z_rows runs on another stream, beside the substitution of block 0)
-    if(tid == 64)
+    // n+.x (bit for bit the scan's value for the constraint) on wave 1 -- it needs neither z nor r, and runs while z is still being
+    // computed (zsync: z_rows runs on another stream, beside the substitution of block 0).  Up to kBlockN unknowns the C1 chain in one
+    // lane; beyond, CANON C8: lane s runs the chain of segment s (64 terms), then the tree over the lanes.
+    if(wave == 1 && n > kBlockN)
+    {
+      double acc = 0.0;
+      if(cp)
+      {
+        const int k0 = lane * 64, cnt = min(64, n - k0); // (n <= 4096: at most 64 segments)
+        if(cnt > 0)
+        {
+          const double *ca = cl + pd(k0), *xa = xl + pd(k0);
+          for(int k = 0; k + 8 <= cnt; k += 8)
+          {
+            double av[8], bv[8];
+#pragma unroll
+            for(int t = 0; t < 8; ++t)
+            {
+              av[t] = ca[k + t];
+              bv[t] = xa[k + t];
+            }
+#pragma unroll
+            for(int t = 0; t < 8; ++t) acc = FMA(av[t], bv[t], acc);
+          }
+          for(int k = cnt & ~7; k < cnt; ++k) acc = FMA(ca[k], xa[k], acc);
+        }
+        acc = wave_sum_tree(acc);
+      }
+      else
+        acc = xl[pd(pb)];
+      if(lane == 0)
+      {
+        mb->cx = acc;
+        if(sd) sd->cx = acc;
+      }
+    }
+    else if(tid == 64 && n <= kBlockN)
     {
       double acc = 0.0;
       if(cp)
@@ -990,21 +1302,32 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
 #pragma unroll
           for(int t = 0; t < 16; ++t)
           {
-            av[t] = cl[k + t];
-            bv[t] = xl[k + t];
+            av[t] = cl[pd(k + t)];
+            bv[t] = xl[pd(k + t)];
           }
 #pragma unroll
           for(int t = 0; t < 16; ++t) acc = FMA(av[t], bv[t], acc);
         }
-        for(; k < n; ++k) acc = FMA(cl[k], xl[k], acc);
+        for(; k < n; ++k) acc = FMA(cl[pd(k)], xl[pd(k)], acc);
       }
       else
-        acc = xl[pb];
+        acc = xl[pd(pb)];
       mb->cx = acc;
       if(sd) sd->cx = acc;
     }
     if(zsync && wait_z) flag_wait(&zsync->z_tag, wait_z, mb);
-    for(int i = tid; i < n; i += 512) zl[i] = z[i];
+    if(Pz)
+    {
+      // CANON C8: z_blk_kernel (ahead of this kernel in the stream) left the segment sums of z: the tree here, z itself for the update
+      for(int i = tid; i < n; i += 512)
+      {
+        const double zi = blk_tree(Pz, ldpz, nsegz, i);
+        zl[i] = zi;
+        zout[i] = zi;
+      }
+    }
+    else
+      for(int i = tid; i < n; i += 512) zl[i] = z[i];
     __syncthreads();
     // z.z and n+.z: C4 trees (CANON C5, oracle orc_dot_tree): element e joins chain e mod 1024, thread t owns chains 2t and
     // 2t + 1 (ascending e), then the adjacent-first pairwise tree -- the two chains of a thread, the lanes of a wave
@@ -1017,17 +1340,17 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
       {
         const double zv = zl[e0];
         pz0 = FMA(zv, zv, pz0);
-        pc0 = FMA(cl[e0], zv, pc0);
+        pc0 = FMA(cl[pd(e0)], zv, pc0);
       }
       if(e1 < n)
       {
         const double zv = zl[e1];
         pz1 = FMA(zv, zv, pz1);
-        pc1 = FMA(cl[e1], zv, pc1);
+        pc1 = FMA(cl[pd(e1)], zv, pc1);
       }
     }
     const double sz = wave_sum_tree(pz0 + pz1), sc = wave_sum_tree(pc0 + pc1);
-    double * red = rs + 3 * n; // (inside the dynamic allocation: tail_lds; a static array on top of a raised dynamic limit does not fit)
+    double * red = cl + npad; // (inside the dynamic allocation: tail_lds; a static array on top of a raised dynamic limit does not fit)
     if(lane == 0)
     {
       red[wave] = sz;
@@ -1946,7 +2269,8 @@ static size_t tile_lds(int n)
 }
 static size_t tail_lds(int n, int q)
 {
-  return sizeof(double) * (size_t)((3 * n + 16 > q + 2) ? 3 * n + 16 : q + 2); // (+16: the per-wave partial sums of the two C4 trees)
+  const int b1 = 3 * n + 2 * ((n >> 6) + 1) + 16; // block 1: z | x | n+ (the two padded, one entry per 64) | the per-wave partial sums of the two C4 trees
+  return sizeof(double) * (size_t)((b1 > q + 2) ? b1 : q + 2);
 }
 // Dynamic LDS beyond the default 64 KiB (step_tail: three n-vectors, n > 2730; rot_apply: the (c, s) pairs of a sweep,
 // more than ~1900 rotations; add_chain: the third vector of the seeded recurrence): the limit is raised once, to the
@@ -2036,18 +2360,59 @@ hipError_t dense_x0(const double * L, int ldl, int n, const double * a, double *
   return hipGetLastError();
 }
 
-hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u, int wait_x_tag, int post_sel_tag)
+#ifndef JRLQP_BLK_TARGET
+#define JRLQP_BLK_TARGET 512
+#endif
+// CANON C8 launch geometry: the 64-row tiles of a column group are split over `splits` workgroups of `tps` tiles each, so that about
+// kBlkTarget workgroups stream the matrix (256 CUs; a workgroup of two waves)
+constexpr int kBlkTarget = JRLQP_BLK_TARGET;
+static void blk_split(int n, int groups, int & tps, int & splits)
+{
+  const int ntiles = (n + KT - 1) / KT;
+  int want = (groups > 0) ? (kBlkTarget + groups - 1) / groups : 1;
+  if(want < 1) want = 1;
+  if(want > ntiles) want = ntiles;
+  tps = (ntiles + want - 1) / want;
+  splits = (ntiles + tps - 1) / tps;
+}
+static hipError_t tile_attr_blk(int n)
+{
+  static LdsRaised done_j, done_s;
+  hipError_t e = raise_lds(&jtn_blk_kernel, done_j, tile_lds(n));
+  return e == hipSuccess ? raise_lds(&select_blk_kernel, done_s, tile_lds(n)) : e;
+}
+
+hipError_t dense_select(const DenseViews & v, DenseState & s, int excl, hipStream_t st, int zero_u, int wait_x_tag, int post_sel_tag, int gate_tag)
 {
   const int parts = (v.m + CT - 1) / CT;
+  const StepDev * gate = nullptr;
+  if(gate_tag)
+  {
+    if(!(v.n > kBlockN && parts > 0)) return hipErrorInvalidValue; // (only the blocked scan is ever enqueued ahead)
+    gate = s.sd;
+    hipLaunchKernelGGL(decision_gate_kernel, dim3(1), dim3(1), 0, st, s.sd, gate_tag, s.sync, wait_x_tag, s.mb);
+    wait_x_tag = 0; // (the gate has waited for x: the scan's workgroups do not)
+  }
   {
     hipError_t e = tile_attr(v.n);
     if(e != hipSuccess) return e;
   }
-  if(parts > 0)
+  if(parts > 0 && v.n > kBlockN)
+  {
+    hipError_t e = tile_attr_blk(v.n);
+    if(e != hipSuccess) return e;
+    int tps, splits;
+    blk_split(v.n, parts, tps, splits);
+    hipLaunchKernelGGL(select_blk_kernel, dim3(parts, splits), dim3(TILE_THREADS), tile_lds(v.n), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st, excl,
+                       s.pval, s.pidx, s.pstat, s.sync, wait_x_tag, s.mb, BlkArgs{s.partC, s.ldpC, s.cntC, tps}, gate, gate_tag);
+    hipLaunchKernelGGL(select_comb_kernel, dim3(parts), dim3(64), 0, st, s.partC, s.ldpC, (v.n + KT - 1) / KT, v.m, v.bl, v.bu, s.st, excl, s.pval, s.pidx,
+                       s.pstat, gate, gate_tag, s.psel);
+  }
+  else if(parts > 0)
     hipLaunchKernelGGL(select_partial_kernel, dim3(parts), dim3(TILE_THREADS), tile_lds(v.n), st, v.C, v.ldc, v.n, v.m, s.x, v.bl, v.bu, s.st,
                        excl, s.pval, s.pidx, s.pstat, s.sync, wait_x_tag, s.mb);
   hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(256), 0, st, parts, s.pval, s.pidx, s.pstat, v.m, v.nb, s.x, v.xl, v.xu, s.st, excl, s.mb, s.psel,
-                     zero_u >= 0 ? s.u + zero_u : nullptr, s.sync, parts > 0 ? 0 : wait_x_tag, post_sel_tag);
+                     zero_u >= 0 ? s.u + zero_u : nullptr, s.sync, parts > 0 ? 0 : wait_x_tag, post_sel_tag, gate, gate_tag);
   return hipGetLastError();
 }
 
@@ -2063,14 +2428,21 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   const bool no_producer = dev_p && v.m == 0 && v.nb == 0;
   const bool chain = spec && q < n && !no_producer;
   const bool events = (ev_d != nullptr);   // event mode (kernels of different streams cannot run side by side: see PassSync): no tags
-  const bool zs = zside && tag && !events && !no_producer; // z = J2 d2 on its own stream, beside the substitution (both only need d)
+  const bool zs = zside && tag && !events && !no_producer && !(v.n > kBlockN); // z = J2 d2 on its own stream, beside the substitution (both only need d)
   const int dpost = (!events && (chain || zs)) ? tag : 0; // d_tag is published for whoever runs beside the main stream
   if(events) wait_sel_tag = wait_chain_tag = 0;
-  const int jt_wgs = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;
+  const int jt_groups = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;
+  const bool blk = n > kBlockN; // CANON C8: the streaming products blocked (64-row segments + tree), their rows split over workgroups
+  int jt_tps = 0, jt_splits = 1;
+  if(blk) blk_split(n, jt_groups, jt_tps, jt_splits);
+  const int nseg = (n + KT - 1) / KT, comb_wgs = (n + 63) / 64;
+  const int jt_wgs = blk ? comb_wgs : jt_groups; // the workgroups that arrive at the d counter
   {
     hipError_t e = tile_attr(n);
+    if(e == hipSuccess && blk) e = tile_attr_blk(n);
     if(e != hipSuccess) return e;
   }
+  const BlkArgs bj{s.partJ, s.ldpJ, s.cntJ, jt_tps};
   if(dev_p)
   {
     // (with general constraints AND bounds both kernels run -- each returns at once unless the selection is of its kind -- and both
@@ -2078,7 +2450,14 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     DSync ds{s.sync, s.mb, wait_sel_tag, wait_chain_tag, dpost, (v.m > 0 ? jt_wgs : 0) + (v.nb > 0 ? jr_wgs : 0)};
     if(v.m > 0)
     {
-      hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc, v.m, ds);
+      if(blk)
+      {
+        hipLaunchKernelGGL(jtn_blk_kernel, dim3(jt_groups, jt_splits), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc,
+                           v.m, ds, bj);
+        hipLaunchKernelGGL(blk_comb_kernel, dim3(comb_wgs), dim3(64), 0, st, s.partJ, s.ldpJ, nseg, n, 1.0, s.d, s.psel, v.m, ds);
+      }
+      else
+        hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc, v.m, ds);
       ds.wait_sel = ds.wait_chain = 0;
     }
     if(v.nb > 0) hipLaunchKernelGGL(jrow_kernel, dim3(jr_wgs), dim3(256), 0, st, s.J, n, n, 0, 1.0, s.d, s.psel, v.m, ds);
@@ -2086,8 +2465,16 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   else if(p < v.m)
   {
     cp = v.C + (size_t)p * v.ldc;
-    hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
-                       DSync{s.sync, s.mb, 0, wait_chain_tag, dpost, jt_wgs});
+    if(blk)
+    {
+      const DSync ds{s.sync, s.mb, 0, wait_chain_tag, dpost, jt_wgs};
+      hipLaunchKernelGGL(jtn_blk_kernel, dim3(jt_groups, jt_splits), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
+                         ds, bj);
+      hipLaunchKernelGGL(blk_comb_kernel, dim3(comb_wgs), dim3(64), 0, st, s.partJ, s.ldpJ, nseg, n, sign, s.d, nullptr, 0, ds);
+    }
+    else
+      hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
+                         DSync{s.sync, s.mb, 0, wait_chain_tag, dpost, jt_wgs});
   }
   else
     hipLaunchKernelGGL(jrow_kernel, dim3(jr_wgs), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d, nullptr, 0,
@@ -2110,7 +2497,15 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
       if(e != hipSuccess) return e;
     }
   }
-  if(zs)
+  if(blk)
+  {
+    // z in the main stream, behind d and ahead of the step kernel, whose dot-product workgroup adds the segment sums itself: two
+    // launches less than "z on the side stream + its own combine kernel" for a host that had become the bottleneck of a pass (ten
+    // launches of ~4 us), at the price of z (a few us now that every CU streams J) no longer running beside the substitution
+    const dim3 zg((n + 63) / 64, (n + 63) / 64);
+    hipLaunchKernelGGL(z_blk_kernel, zg, dim3(64), 0, st, s.J, n, n, q, s.d, s.z, nullptr, 0, 0, nullptr, BlkArgs{s.partZ, s.ldpJ, s.cntZ, 1});
+  }
+  else if(zs)
     hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, zside, s.J, n, n, q, s.d, s.z, s.sync, tag, tag, s.mb);
   else
     hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, st, s.J, n, n, q, s.d, s.z);
@@ -2120,10 +2515,12 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   }
   if(dev_p)
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
-                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag, s.sync, zs ? tag : 0, s.sd, v.bl, v.bu, v.xl, v.xu);
+                       nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag, s.sync, zs ? tag : 0, s.sd, v.bl, v.bu, v.xl, v.xu, blk ? s.partZ : nullptr, s.ldpJ, nseg,
+                       s.z);
   else
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
-                       p - v.m, s.mb, nullptr, nullptr, 0, 0, tag, s.sync, zs ? tag : 0);
+                       p - v.m, s.mb, nullptr, nullptr, 0, 0, tag, s.sync, zs ? tag : 0, nullptr, nullptr, nullptr, nullptr, nullptr, blk ? s.partZ : nullptr,
+                       s.ldpJ, nseg, s.z);
   return hipGetLastError();
 }
 
@@ -2270,7 +2667,20 @@ hipError_t dense_warm_point(const DenseViews & v, DenseState & s, int q, hipStre
     hipError_t e = tile_attr(n);
     if(e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, v.a, 1.0, s.d, nullptr, nullptr, 0, 0);
+  if(n > kBlockN) // alpha = J^T a: the same product as d = J^T n+ (CANON C8 beyond kBlockN unknowns; oracle multi_dot)
+  {
+    hipError_t e = tile_attr_blk(n);
+    if(e != hipSuccess) return e;
+    const int groups = (n + CT - 1) / CT;
+    int tps, splits;
+    blk_split(n, groups, tps, splits);
+    const DSync none{nullptr, nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(jtn_blk_kernel, dim3(groups, splits), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, v.a, 1.0, s.d, nullptr, nullptr, 0, 0, none,
+                       BlkArgs{s.partJ, s.ldpJ, s.cntJ, tps});
+    hipLaunchKernelGGL(blk_comb_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.partJ, s.ldpJ, (n + KT - 1) / KT, n, 1.0, s.d, nullptr, 0, none);
+  }
+  else
+    hipLaunchKernelGGL(jtn_kernel, dim3((n + CT - 1) / CT), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, v.a, 1.0, s.d, nullptr, nullptr, 0, 0);
   if(q > 0) hipLaunchKernelGGL(warm_tri_kernel<true>, dim3(1), dim3(1024), sizeof(double) * 2 * q, st, s.R, n, q, s.bact, s.bact, s.beta);
   hipLaunchKernelGGL(warm_x_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, q, s.beta, s.d, s.x);
   if(q > 0) hipLaunchKernelGGL(warm_tri_kernel<false>, dim3(1), dim3(1024), sizeof(double) * 2 * q, st, s.R, n, q, s.d, s.beta, s.u);

@@ -47,6 +47,7 @@ struct jrlqp_dense
   int tag = 0;                         // pass counter: the step kernel echoes it into the mailbox when its scalars are out
   jrlqp_trace_rec * trace = nullptr;   // jrlqp_dense_set_trace: one record per pass of the library's loop (host memory, caller-owned)
   int trace_cap = 0;
+  bool speculate_scan = true;          // ... and the next pass's constraint scan with it (blocked scan only)
   bool speculate = true;               // enqueue the sweep of an addition ahead of the decision (StepDev; JRLQP_DENSE_SPECULATE=0 switches it off)
   int inject_fault_pass = -1;          // jrlqp_debug_dense_inject_sync_fault: the pass whose first kernel waits for a tag nobody posts
   int event_reruns = 0;                // solves that were re-run with event edges after a device-side wait gave up
@@ -144,6 +145,22 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   if(e == hipSuccess) e = hipMemset(s.sync, 0, sizeof(PassSync));
   if(e == hipSuccess) e = dmalloc(s.sd, 1);
   if(e == hipSuccess) e = hipMemset(s.sd, 0, sizeof(StepDev));
+  {
+    // CANON C8: segment sums of the blocked products (64 rows per segment) and the arrival counters of their groups
+    const size_t nseg = ((size_t)n + 63) / 64;
+    s.ldpJ = (int)(nseg * 64);
+    s.ldpC = m > 0 ? m : 1;
+    const size_t gj = (size_t)n / 16 + 2, gz = nseg + 1, gc = (size_t)m / 16 + 2;
+    if(e == hipSuccess) e = dmalloc(s.partJ, nseg * s.ldpJ);
+    if(e == hipSuccess) e = dmalloc(s.partZ, nseg * s.ldpJ);
+    if(e == hipSuccess) e = dmalloc(s.partC, nseg * s.ldpC);
+    if(e == hipSuccess) e = dmalloc(s.cntJ, gj);
+    if(e == hipSuccess) e = dmalloc(s.cntZ, gz);
+    if(e == hipSuccess) e = dmalloc(s.cntC, gc);
+    if(e == hipSuccess) e = hipMemset(s.cntJ, 0, sizeof(int) * gj);
+    if(e == hipSuccess) e = hipMemset(s.cntZ, 0, sizeof(int) * gz);
+    if(e == hipSuccess) e = hipMemset(s.cntC, 0, sizeof(int) * gc);
+  }
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_d, hipEventDisableTiming);
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming);
   if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_x, hipEventDisableTiming);
@@ -152,6 +169,7 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   {
     const char * spc = std::getenv("JRLQP_DENSE_SPECULATE");
     if(spc && std::strcmp(spc, "0") == 0) h->speculate = false;
+    if(spc && std::strcmp(spc, "sweep") == 0) h->speculate_scan = false; // (A/B: the sweep ahead of the decision, the scan behind it)
     const char * mode = std::getenv("JRLQP_DENSE_SYNC");
     if(mode && std::strcmp(mode, "events") == 0)
       h->use_events = true;
@@ -198,6 +216,7 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   if(h->spec) (void)hipStreamDestroy(h->spec);
   (void)hipFree(s.sync);
   (void)hipFree(s.sd);
+  (void)hipFree(s.partJ); (void)hipFree(s.partZ); (void)hipFree(s.partC); (void)hipFree(s.cntJ); (void)hipFree(s.cntZ); (void)hipFree(s.cntC);
   if(h->ev_d) (void)hipEventDestroy(h->ev_d);
   if(h->ev_chain) (void)hipEventDestroy(h->ev_chain);
   if(h->ev_x) (void)hipEventDestroy(h->ev_x);
@@ -655,6 +674,7 @@ attempt:
     }
   } report{timing, t_launch_step, t_wait, t_rest, h->it};
   bool skip = false;
+  bool scan_ahead = false; // ... and so is the next pass's constraint scan
   bool speculated = false; // the sweep of this pass's possible addition is already in the stream (dense_add_speculative)
   bool prefetched = false; // the scan of this pass already ran on the side stream, beside the previous pass's sweep
   int p = -1, pstat = INACTIVE;
@@ -703,10 +723,16 @@ attempt:
       // it runs only if the device's own decision for this pass (StepDev) is "add", and then also advances x and u.  The GPU no
       // longer idles while the scalars travel to the host and the launches travel back.
       speculated = h->speculate && !h->use_events && spec && q < n - 1;
-      // (Measured and NOT kept: the next pass's constraint scan enqueued ahead of the decision as well, gated on StepDev -- c2 45.4 ms
-      // with the sweep alone ahead, 46.2 ms with both; and the selection it publishes may reach the mailbox before the host has read
-      // this pass's.)
-      if(speculated) TRY(dense_add_speculative(h->v, h->s, q, st, tag, tag, (h->it + 1 < o.max_iter) ? tag : 0));
+      if(speculated)
+      {
+        const bool more = h->it + 1 < o.max_iter;
+        TRY(dense_add_speculative(h->v, h->s, q, st, tag, tag, more ? tag : 0));
+        // ... and, with the blocked scan (more than 256 unknowns), the next pass's constraint scan on the side stream behind a one-wave
+        // gate that waits for the decision: the scan no longer starts a host round trip after the step (it is what the next d waits
+        // for).  (First version, round 4: every workgroup of the scan polling the decision itself -- 0.8 ms slower than no scan ahead.)
+        scan_ahead = more && h->speculate_scan && n > 256 && m > 0;
+        if(scan_ahead) TRY(dense_select(h->v, h->s, -1, h->side, q + 1, tag, tag + 1, tag));
+      }
       const double tb = timing ? now() : 0;
       if(!wait_tag(h->h_mb, tag)) TRY(hipStreamSynchronize(st));
       if(timing)
@@ -736,8 +762,8 @@ attempt:
       }
       if(!skip)
       {
-        p = mb.p;
-        pstat = mb.pstatus;
+        p = mb.sp; // (the step kernel's echo of the selection it worked on: mb.p may already hold the NEXT pass's, see Mailbox)
+        pstat = mb.sps;
         if(p < 0 || pstat == INACTIVE) return finish(JRLQP_SUCCESS);
       }
       t1 = mb.t1; l = mb.l; zz = mb.zz; nz = mb.cz; nx = mb.cx; uq = mb.uq;
@@ -791,7 +817,9 @@ attempt:
         else if(!swept)
           TRY(dense_add(h->v, h->s, p, pstat, q, st, h->chain_pending)); // commit: the chain ran ahead (the sweep waits for chain_tag)
         h->chain_pending = 0;
-        if(prefetch)
+        if(prefetch && swept && scan_ahead)
+          prefetched = true; // (the scan went into the side stream with the sweep, ahead of the decision)
+        else if(prefetch)
         {
           // (also u[q+1] = 0 for the next pass: a slot this pass does not touch)
           if(h->use_events)

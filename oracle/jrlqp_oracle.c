@@ -20,6 +20,15 @@
  *       single chain of C1 was -- and it is the shape a wavefront evaluates in log2(64) exchanges instead of n dependent fmas
  *       on the critical path of every pass.  n+.x stays the C1 chain: it is bit for bit the value C.col(p).dot(x) the constraint
  *       scan has just computed for the selected constraint (:97), and the kernels reuse it.
+ *   C8  (round 4) beyond ORC_BLOCK_N = 256 unknowns -- i.e. for the host-driven solver of ONE large problem only; the batched kernels
+ *       stop at 256 -- the three streaming products of a pass, d = J^T n+ (ConstraintNormal::preMultiplyByMt, ConstraintNormal.h:81-102),
+ *       the scan's C.col(i).dot(x) (GoldfarbIdnaniSolver.cpp:97, and n+.x of :183-190, the same expression) and z = J2 d2 (:145), are
+ *       BLOCKED: the index range of a sum is cut into segments of 64 consecutive indices (segment s = [64 s, 64 s + 63]), inside a
+ *       segment the terms form one ascending fma chain from +0 (C1), and the at most 64 segment sums are combined by the adjacent-first
+ *       pairwise tree of C4 / C5 (orc_dot_blk).  Eigen's own GEMV is blocked and vectorised too (its packet width and blocking are
+ *       unspecified), so this is as faithful as the single chain was; on a GPU a 1024-term chain per output is ~4 us of dependent
+ *       fmas whatever the bandwidth, a 64-term chain lets every CU stream J and C.  z sums over the columns q .. n-1: segments by
+ *       ABSOLUTE column index, a segment's chain starting at max(64 s, q).
  */
 #include "jrlqp_oracle.h"
 
@@ -72,12 +81,85 @@ double orc_dot(int n, const double * a, const double * b)
   return acc;
 }
 
+/* CANON C8: the blocked product for vectors of more than ORC_BLOCK_N entries (shorter ones: the C1 chain).  Terms lo .. n-1. */
+#define ORC_BLOCK_N 256
+double orc_dot_blk(int n, const double * a, const double * b, int lo)
+{
+  if(n <= ORC_BLOCK_N || (g_lit & ORC_LIT_CHAIN_GEMV))
+  {
+    double acc = 0.0;
+    for(int k = lo; k < n; ++k) acc = FMA(a[k], b[k], acc);
+    return acc;
+  }
+  double p[64];
+  const int S = (n + 63) >> 6;
+  for(int s = 0; s < 64; ++s)
+  {
+    double acc = 0.0;
+    if(s < S)
+    {
+      const int k0 = (64 * s > lo) ? 64 * s : lo, k1 = (64 * s + 64 < n) ? 64 * s + 64 : n;
+      for(int k = k0; k < k1; ++k) acc = FMA(a[k], b[k], acc);
+    }
+    p[s] = acc;
+  }
+  for(int h = 1; h < 64; h <<= 1)
+    for(int i = 0; i < 64; i += 2 * h) p[i] = p[i] + p[i + h];
+  return p[0];
+}
+
+/* out[j] = orc_dot_blk(n, M + j*ldm, v, 0) for j < ncols, eight segment chains of a column in flight (a lone 64-term chain is bound
+ * by the latency of its fmas) */
+static void multi_dot_blk(int n, const double * M, long ldm, int ncols, const double * v, double * out)
+{
+  const int S = (n + 63) >> 6;
+  for(int j = 0; j < ncols; ++j)
+  {
+    const double * c = M + (long)j * ldm;
+    double p[64];
+    int s = 0;
+    for(; s + 8 <= S && 64 * (s + 8) <= n; s += 8) /* eight FULL segments */
+    {
+      const double *c0 = c + 64 * s, *v0 = v + 64 * s;
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+      for(int k = 0; k < 64; ++k)
+      {
+        a0 = FMA(c0[k], v0[k], a0);
+        a1 = FMA(c0[k + 64], v0[k + 64], a1);
+        a2 = FMA(c0[k + 128], v0[k + 128], a2);
+        a3 = FMA(c0[k + 192], v0[k + 192], a3);
+        a4 = FMA(c0[k + 256], v0[k + 256], a4);
+        a5 = FMA(c0[k + 320], v0[k + 320], a5);
+        a6 = FMA(c0[k + 384], v0[k + 384], a6);
+        a7 = FMA(c0[k + 448], v0[k + 448], a7);
+      }
+      p[s] = a0; p[s + 1] = a1; p[s + 2] = a2; p[s + 3] = a3; p[s + 4] = a4; p[s + 5] = a5; p[s + 6] = a6; p[s + 7] = a7;
+    }
+    for(; s < S; ++s)
+    {
+      const int k1 = (64 * s + 64 < n) ? 64 * s + 64 : n;
+      double acc = 0.0;
+      for(int k = 64 * s; k < k1; ++k) acc = FMA(c[k], v[k], acc);
+      p[s] = acc;
+    }
+    for(; s < 64; ++s) p[s] = 0.0;
+    for(int h = 1; h < 64; h <<= 1)
+      for(int i = 0; i < 64; i += 2 * h) p[i] = p[i] + p[i + h];
+    out[j] = p[0];
+  }
+}
+
 /* out[j] = orc_dot(n, M + j*ldm, v) for j < ncols: same per-output chain as orc_dot (bit-identical), eight
  * independent chains in flight so that the CPU baseline is not bound by fma latency.  When the column stride is a multiple
  * of 4 KiB (n = 1024: BASELINE c2) eight column streams plus v land in one set of an 8-way L1 and evict each other -- the
  * baseline would run 4x slower than at n = 1000 for no algorithmic reason -- so that case walks six columns at a time. */
 static void multi_dot(int n, const double * M, long ldm, int ncols, const double * v, double * out)
 {
+  if(n > ORC_BLOCK_N && !(g_lit & ORC_LIT_CHAIN_GEMV)) /* CANON C8 */
+  {
+    multi_dot_blk(n, M, ldm, ncols, v, out);
+    return;
+  }
   int j = 0;
   if((ldm * (long)sizeof(double)) % 4096 == 0)
   {
@@ -388,12 +470,44 @@ static void compute_step(gi_state * S, int p, int status)
     default: break;
   }
   /* z = J2 d2 (:145) */
+  if(n > ORC_BLOCK_N && !(g_lit & ORC_LIT_CHAIN_GEMV))
+  {
+    /* CANON C8: per row the columns in segments of 64 by absolute index (a segment's chain from max(64 s, q)), then the tree */
+    const int S = (n + 63) >> 6;
+    int P2 = 1;
+    while(P2 < S) P2 <<= 1;
+    double * P = (double *)malloc(sizeof(double) * (size_t)P2 * n);
+    for(int s = 0; s < P2; ++s)
+    {
+      double * ps = P + (long)s * n;
+      for(int i = 0; i < n; ++i) ps[i] = 0.0;
+      if(s >= S) continue;
+      const int j0 = (64 * s > q) ? 64 * s : q, j1 = (64 * s + 64 < n) ? 64 * s + 64 : n;
+      for(int j = j0; j < j1; ++j)
+      {
+        const double * cj = J + (long)j * n;
+        const double dj = d[j];
+        for(int i = 0; i < n; ++i) ps[i] = FMA(cj[i], dj, ps[i]);
+      }
+    }
+    for(int h = 1; h < P2; h <<= 1)
+      for(int s = 0; s < P2; s += 2 * h)
+      {
+        double *pa = P + (long)s * n, *pb = P + (long)(s + h) * n;
+        for(int i = 0; i < n; ++i) pa[i] = pa[i] + pb[i];
+      }
+    for(int i = 0; i < n; ++i) z[i] = P[i];
+    free(P);
+  }
+  else
+  {
   for(int i = 0; i < n; ++i) z[i] = 0.0;
   for(int j = q; j < n; ++j) /* per element: the same chain over increasing j; loop order only helps the compiler */
   {
     const double * cj = J + (long)j * n;
     const double dj = d[j];
     for(int i = 0; i < n; ++i) z[i] = FMA(cj[i], dj, z[i]);
+  }
   }
   /* r = R^-1 d1 (:146), upper triangular back substitution */
   for(int k = 0; k < q; ++k) r[k] = d[k];
@@ -541,7 +655,7 @@ static void add_initial_constraint(gi_state * S, int p, int status)
     if(status == ORC_EQUALITY)
     {
       const double * cp = S->C + (long)p * S->ldc;
-      t = (S->bl[p] - orc_dot(n, cp, x)) / zdot(n, cp, z);
+      t = (S->bl[p] - orc_dot_blk(n, cp, x, 0)) / zdot(n, cp, z);
     }
     else
     {
@@ -973,7 +1087,7 @@ main_loop:
         {
           const double * cp = C + (long)p * ldc;
           b = (pstatus == ORC_LOWER) ? bl[p] : bu[p];
-          cx = orc_dot(n, cp, x);         /* C1: == cxs[p] of the scan when p was selected in this pass */
+          cx = orc_dot_blk(n, cp, x, 0);  /* C1 / C8: == cxs[p] of the scan when p was selected in this pass */
           cz = zdot(n, cp, z); /* C5 */
         }
         else

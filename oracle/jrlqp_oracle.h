@@ -135,7 +135,8 @@ enum
   ORC_LIT_ROT_C3 = 2,        /* rotations x' = fma(c, x, -(s y)), y' = fma(s, x, c y) instead of C6 */
   ORC_LIT_SERIAL_GIVENS = 4, /* makeGivens(d_i, d_{i+1}), i = n-2 .. q, radius in d_i (GoldfarbIdnaniSolver.cpp:225-232) instead of C7 */
   ORC_LIT_NO_FMA = 8,        /* those dots and rotations with every product and sum rounded separately */
-  ORC_LIT_ALL = 7
+  ORC_LIT_CHAIN_GEMV = 16,   /* d = J^T n+, C^T x, n+.x and z = J2 d2 as in-order chains at every size instead of C8 (blocked beyond 256 unknowns) */
+  ORC_LIT_ALL = 23
 };
 int orc_gi_solve_literal(int flags, int n, int m, int nb, double * G, int ldg, const double * a, const double * C, int ldc,
                          const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,
@@ -188,6 +189,8 @@ void orc_givens(double p, double q, double * c, double * s, double * r);
 /* CANON C7: the coefficients (c_i, s_i), i = n-2 .. q, of an addition's sweep and the final radius, from d[q .. n-1] (jrlqp_oracle.c) */
 int orc_givens_chain(int n, int q, const double * d, double * c, double * s, double * rfin);
 double orc_dot(int n, const double * a, const double * b);
+/* CANON C8: sum of a[k] b[k], k = lo .. n-1: the C1 chain up to 256 entries, beyond: 64-term segments (by absolute index) + the C4 tree */
+double orc_dot_blk(int n, const double * a, const double * b, int lo);
 
 /* ActiveSet restatement (ActiveSet.cpp:45-168) driven through a flat API for the integer-sequence test. */
 typedef struct orc_active_set orc_active_set;

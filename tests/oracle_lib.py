@@ -83,6 +83,8 @@ class Oracle:
         L.orc_givens.argtypes = [ct.c_double, ct.c_double, c_dp, c_dp, c_dp]
         L.orc_dot.restype = ct.c_double
         L.orc_dot.argtypes = [ct.c_int, c_dp, c_dp]
+        L.orc_dot_blk.restype = ct.c_double
+        L.orc_dot_blk.argtypes = [ct.c_int, c_dp, c_dp, ct.c_int]
         L.orc_as_new.restype = ct.c_void_p
         L.orc_as_new.argtypes = [ct.c_int, ct.c_int]
         for nm in ("orc_as_free", "orc_as_reset"):
@@ -222,7 +224,7 @@ class Oracle:
                                         _dp(x), _dp(u), _ip(status), _ip(term), _ip(iters), _dp(f), nthreads)
         return dict(x=x, u=u, status=status, term=term, iters=iters, f=f, L=Gc)
 
-    LIT_CHAIN_DOTS, LIT_ROT_C3, LIT_SERIAL_GIVENS, LIT_NO_FMA, LIT_ALL = 1, 2, 4, 8, 7
+    LIT_CHAIN_DOTS, LIT_ROT_C3, LIT_SERIAL_GIVENS, LIT_NO_FMA, LIT_CHAIN_GEMV, LIT_ALL = 1, 2, 4, 8, 16, 23
 
     def solve_batch_literal(self, flags, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, nthreads=1):
         """Cold packed batch with some of CANON C5 / C6 / C7 switched off (orc_gi_solve_batch_literal; flags = 0 is the canonical
@@ -264,6 +266,12 @@ class Oracle:
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = np.ascontiguousarray(b, dtype=np.float64)
         return self.lib.orc_dot(len(a), _dp(a), _dp(b))
+
+    def dot_blk(self, a, b, lo=0):
+        """CANON C8: the C1 chain up to 256 entries, 64-term segments + the C4 tree beyond."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        return self.lib.orc_dot_blk(len(a), _dp(a), _dp(b), lo)
 
     # ---- structured ----------------------------------------------------------------------------
     @staticmethod

@@ -4,7 +4,9 @@ Rounds 1-3 moved three evaluations away from the most literal reading of the ref
   C5  z.z and n+.z as pairwise trees instead of in-order chains (GoldfarbIdnaniSolver.cpp:174, 183-190; DualSolver.cpp:147),
   C6  which product of a plane rotation is rounded on its own (GoldfarbIdnaniSolver.cpp:231, 251-252),
   C7  the Givens coefficients of an addition from a suffix sum of squares instead of the serial makeGivens recurrence
-      (GoldfarbIdnaniSolver.cpp:225-232).
+      (GoldfarbIdnaniSolver.cpp:225-232),
+  C8  (round 4, beyond 256 unknowns) d = J^T n+, the scan's C.col(i).dot(x) and z = J2 d2 in 64-term segments combined by a pairwise
+      tree instead of one chain per output (ConstraintNormal.h:81-102; GoldfarbIdnaniSolver.cpp:97, :145).
 Each is one of the evaluations Eigen itself may choose, but the reference's decisions carry no tolerance (threshold 0, strict <,
 t == t2), so only a test can show that none of them changes a decision.  The oracle therefore has a LITERAL mode
 (orc_gi_solve_literal) that switches each change off; this test runs the canonical and the literal evaluation on every dense
@@ -84,6 +86,10 @@ def workloads(P):
     for k, (name, label, chd) in enumerate(_families()):
         ch = P.Characteristics(**chd)
         yield f"{name} {label}", P.generate_batch(100, ch, first_index=50000 + 1000 * k), ch.bounds
+    # beyond 256 unknowns: the blocked products of C8 (the sizes of the host-driven solver, BASELINE c2's recipe at a third of its size)
+    yield "n=300, m=400, 90 active", P.generate_batch(12, P.benchmark_characteristics(300, 400), first_index=91000), False
+    ch = P.Characteristics(nVar=330, nObj=330, nEq=20, nIneq=300, nStrongActIneq=60, bounds=True, nStrongActBounds=30, doubleSidedIneq=True)
+    yield "n=330 mixed (eq + double-sided + bounds)", P.generate_batch(6, ch, first_index=92000), True
 
 
 @pytest.fixture(scope="module")
@@ -93,12 +99,12 @@ def P(pkg):
     return problems
 
 
-@pytest.mark.parametrize("flags,name", [(7, "literal (C5, C6, C7 off)"), (1, "C5 off"), (2, "C6 off"), (4, "C7 off"), (15, "literal, no fma")])
+@pytest.mark.parametrize("flags,name", [(23, "literal (C5, C6, C7, C8 off)"), (1, "C5 off"), (2, "C6 off"), (4, "C7 off"), (16, "C8 off"), (31, "literal, no fma")])
 def test_decisions_do_not_depend_on_the_rounding_contract(P, oracle, flags, name, capsys):
     report = []
     total = differing = 0
     for label, pb, hb in workloads(P):
-        if flags not in (7, 15) and pb.B > 1000:
+        if flags not in (23, 31) and pb.B > 1000:
             pb_args = [v[:512] for v in (pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl, pb.xu)]  # the single-flag runs: a sample
         else:
             pb_args = [pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl, pb.xu]
@@ -120,7 +126,7 @@ def test_decisions_do_not_depend_on_the_rounding_contract(P, oracle, flags, name
     assert differing == 0, [r for r in report if r[2]]
 
 
-@pytest.mark.parametrize("flags", [7, 15])
+@pytest.mark.parametrize("flags", [23, 31])
 def test_multiik_fixtures_literal(oracle, flags):
     """Both fixtures of the reference's tests/MultiIK.zip (BlockGISolverTest.in.cpp:172-188, :273-307) through the dense solver."""
     for rd, hb in ((read_tri_block_diag, False), (read_arrow, True)):

@@ -70,3 +70,37 @@ def test_dot_is_sequential_fma_chain(oracle):
     for k in range(37):
         acc = fma(a[k], b[k], acc)
     assert oracle.dot(a, b) == acc
+
+
+def test_dot_blk_is_segments_of_64_and_a_pairwise_tree(oracle):
+    """CANON C8 (oracle/jrlqp_oracle.c orc_dot_blk): up to 256 entries the C1 chain; beyond, per segment [64 s, 64 s + 63] an ascending
+    fma chain from +0 over the entries >= lo, the segment sums combined by the adjacent-first pairwise tree."""
+    from fractions import Fraction
+
+    def fma(x, y, z):
+        return float(Fraction(x) * Fraction(y) + Fraction(z))  # exact rational, rounded once
+
+    rng = np.random.default_rng(8)
+    for n, lo in ((200, 0), (256, 7), (257, 0), (300, 0), (1000, 0), (1000, 130), (1024, 64), (1500, 1499), (4096, 0)):
+        a = rng.standard_normal(n) * np.exp(rng.uniform(-8, 8, n))
+        b = rng.standard_normal(n)
+        if n <= 256:
+            acc = 0.0
+            for k in range(lo, n):
+                acc = fma(a[k], b[k], acc)
+            want = acc
+        else:
+            p = [0.0] * 64
+            for s in range((n + 63) // 64):
+                acc = 0.0
+                for k in range(max(64 * s, lo), min(64 * s + 64, n)):
+                    acc = fma(a[k], b[k], acc)
+                p[s] = acc
+            h = 1
+            while h < 64:
+                for i in range(0, 64, 2 * h):
+                    p[i] = p[i] + p[i + h]
+                h *= 2
+            want = p[0]
+        assert oracle.dot_blk(a, b, lo) == want, (n, lo)
+    assert oracle.dot_blk(np.ones(10), np.ones(10)) == oracle.dot(np.ones(10), np.ones(10)) == 10.0
