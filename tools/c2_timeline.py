@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 count = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-NAMES = ['add_chain', 'rot_apply', 'jtn', 'select_partial', 'select_final', 'step_tail', 'z_rows', 'remove_r', 'advance', 'jinv', 'x0', 'llt_panel',
+NAMES = ['add_chain', 'rot_apply', 'jtn', 'select_partial', 'select_final', 'select_blk', 'select_comb', 'decision_gate', 'blk_comb', 'z_blk', 'step_tail', 'z_rows', 'remove_r', 'advance', 'jinv', 'x0', 'llt_panel',
          'llt_update', 'copyBuffer', 'fillBuffer', 'jrow', 'add_commit']
 def nm(r):
     for s in NAMES:
