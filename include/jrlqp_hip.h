@@ -224,8 +224,11 @@ int jrlqp_gi_solve_batch_ws(int warm,
  * (multiplier |x0_i - bound_i|, J a permutation, R = diag(+-1)), no factorisation; then the unchanged GI loop.
  *   dx0, dc, dxl, dxu [B][n]; dbl [B].  Outputs: dx [B][n]; du, dstatus [B][1+n] (the general constraint first, then the
  *   bounds); dterm, diters, df [B]; df is 1/2 ||x - x0||^2 itself (the reference's objectiveValue(), constant included).
- * Requires n <= JRLQP_BATCH_WAVE_N (the closed-form start is one wavefront, lane = variable); larger n returns
- * JRLQP_ERR_UNSUPPORTED_SIZE.  One launch, no allocation, no host synchronisation. */
+ * n <= JRLQP_BATCH_MAX_N (256).  Up to JRLQP_BATCH_WAVE_N variables the closed-form start is one wavefront (lane = variable); beyond
+ * (round 4) the large-n batched kernel runs it with thread = variable.  jrlqp_box_solve_batch needs no workspace up to n = 104;
+ * past that the packed R (and past n = 128 the factor J) of the large-n kernel live in a caller-owned workspace of
+ * jrlqp_gi_batch_workspace_bytes(n, 1, n, B) bytes, passed to jrlqp_box_solve_batch_ws (JRLQP_ERR_WORKSPACE without it).
+ * One launch, no allocation, no host synchronisation. */
 int jrlqp_box_solve_batch(int n,
                           int B,
                           const double * dx0,
@@ -242,6 +245,25 @@ int jrlqp_box_solve_batch(int n,
                           double * df,
                           jrlqp_trace_rec * dtrace,
                           int trace_cap,
+                          void * stream);
+int jrlqp_box_solve_batch_ws(int n,
+                          int B,
+                          const double * dx0,
+                          const double * dc,
+                          const double * dbl,
+                          const double * dxl,
+                          const double * dxu,
+                          const jrlqp_options * opts,
+                          double * dx,
+                          double * du,
+                          int * dstatus,
+                          int * dterm,
+                          int * diters,
+                          double * df,
+                          jrlqp_trace_rec * dtrace,
+                          int trace_cap,
+                          void * dworkspace,
+                          long long workspace_bytes,
                           void * stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -28,6 +28,7 @@ EXPORTED = [
     "jrlqp_gi_batch_workspace_bytes",
     "jrlqp_gi_solve_batch_ws",
     "jrlqp_box_solve_batch",
+    "jrlqp_box_solve_batch_ws",
     "jrlqp_shard_range",
     "jrlqp_gi_batch_workspace_bytes_on",
     "jrlqp_gi_solve_batch_multi",
@@ -140,6 +141,8 @@ def load_library() -> ct.CDLL:
                                             + [ct.c_int, c_dp, ct.c_longlong, c_dp])
     lib.jrlqp_box_solve_batch.restype = ct.c_int
     lib.jrlqp_box_solve_batch.argtypes = [ct.c_int, ct.c_int] + [c_dp] * 5 + [ct.POINTER(Options)] + [c_dp] * 6 + [c_dp, ct.c_int, c_dp]
+    lib.jrlqp_box_solve_batch_ws.restype = ct.c_int
+    lib.jrlqp_box_solve_batch_ws.argtypes = [ct.c_int, ct.c_int] + [c_dp] * 5 + [ct.POINTER(Options)] + [c_dp] * 6 + [c_dp, ct.c_int, c_dp, ct.c_longlong, c_dp]
     lib.jrlqp_gi_solve_batch.restype = ct.c_int
     lib.jrlqp_gi_solve_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int] + [c_dp] * 7 + [ct.POINTER(Options)] + [c_dp] * 8 + [ct.c_int, c_dp]
     lib.jrlqp_dense_create.restype = ct.c_int
@@ -660,6 +663,15 @@ class BoxAndSingleConstraintSolver:
         self.term = torch.empty((B,), dtype=i32, device=self.device)
         self.iters = torch.empty((B,), dtype=i32, device=self.device)
         self.f = torch.empty((B,), dtype=f64, device=self.device)
+        # beyond 104 variables the large-n kernel keeps R (and past 128 J) in a workspace: allocated HERE, never inside solve()
+        wsb = 0
+        if n > 64:
+            with torch.cuda.device(self.device):
+                wsb = int(self.lib.jrlqp_gi_batch_workspace_bytes(n, 1, n, B))
+            if wsb < 0:
+                raise JrlqpError(f"box solver: n = {n} is not supported", ERR_UNSUPPORTED_SIZE)
+        self.workspace_bytes = wsb
+        self.workspace = torch.empty((wsb + 7) // 8, dtype=f64, device=self.device) if wsb else None
 
     def solve(self, x0, c, bl, xl, xu, stream=None):
         """x0, c, xl, xu: (B, n) float64 CUDA tensors; bl: (B,) or (B, 1)."""
@@ -671,9 +683,9 @@ class BoxAndSingleConstraintSolver:
             assert t.is_cuda and t.dtype == torch.float64 and t.shape == (self.B, self.n)
         assert bl.is_cuda and bl.dtype == torch.float64
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        check(self.lib.jrlqp_box_solve_batch(self.n, self.B, _ptr(x0), _ptr(c), _ptr(bl), _ptr(xl), _ptr(xu), ct.byref(self.opts),
-                                             _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term), _ptr(self.iters),
-                                             _ptr(self.f), None, 0, ct.c_void_p(s.cuda_stream)))
+        check(self.lib.jrlqp_box_solve_batch_ws(self.n, self.B, _ptr(x0), _ptr(c), _ptr(bl), _ptr(xl), _ptr(xu), ct.byref(self.opts),
+                                                _ptr(self.x), _ptr(self.u), _ptr(self.status), _ptr(self.term), _ptr(self.iters),
+                                                _ptr(self.f), None, 0, _ptr(self.workspace), self.workspace_bytes, ct.c_void_p(s.cuda_stream)))
         return BatchResult(self.x, self.u, self.status, self.term, self.iters, self.f, None)
 
 

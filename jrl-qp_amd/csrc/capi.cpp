@@ -257,6 +257,7 @@ static int gi_batch_common(int warm,
   a.prof_stride = g_prof[JRLQP_PROFILE_GI_BATCH].stride;
   if(a.prof && B > g_prof[JRLQP_PROFILE_GI_BATCH].nprob) return JRLQP_ERR_INVALID_ARGUMENT;
   a.warm = warm;
+  a.box = 0;
   a.as_in = das;
   a.tune = env_tune();
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -425,16 +426,15 @@ int jrlqp_gi_gather_x_multi(int n, int B_total, int ndev, const int * device_ids
   return JRLQP_OK;
 }
 
-int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, const double * dbl, const double * dxl,
-                          const double * dxu, const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm,
-                          int * diters, double * df, jrlqp_trace_rec * dtrace, int trace_cap, void * stream)
+static int box_common(int n, int B, const double * dx0, const double * dc, const double * dbl, const double * dxl, const double * dxu,
+                      const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm, int * diters, double * df,
+                      jrlqp_trace_rec * dtrace, int trace_cap, void * dws, long long ws_bytes, void * stream)
 {
   if(n < 1 || B < 0) return JRLQP_ERR_INVALID_ARGUMENT;
   if(B == 0) return JRLQP_OK;
   if(!dx0 || !dc || !dbl || !dxl || !dxu || !dx || !du || !dstatus || !dterm || !diters || !df) return JRLQP_ERR_INVALID_ARGUMENT;
   if(dtrace && trace_cap <= 0) return JRLQP_ERR_INVALID_ARGUMENT;
-  // the closed-form prologue is lane = variable on ONE wavefront (gi_batch_kernel.h, BOX): n <= 64 only
-  if(n > JRLQP_BATCH_WAVE_N || jrlqp::batch_lds_bytes(n, 1, n, 1, 0) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
   jrlqp_options o;
   jrlqp_default_options(&o);
   if(opts) o = *opts;
@@ -451,9 +451,49 @@ int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, c
   a.trace = dtrace;
   a.prof = nullptr; a.prof_stride = 0;
   a.warm = 0; a.as_in = nullptr;
+  a.box = 1;
   a.tune = env_tune();
-  hipError_t e = jrlqp::launch_gi_batch_box(a, static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if(n <= JRLQP_BATCH_WAVE_N)
+  {
+    // the closed-form prologue as lane = variable on ONE wavefront (gi_batch_kernel.h, BOX)
+    if(jrlqp::batch_lds_bytes(n, 1, n, 1, 0) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
+    hipError_t e = jrlqp::launch_gi_batch_box(a, st);
+    return e == hipSuccess ? JRLQP_OK : hip_fail(e);
+  }
+  // beyond one wavefront of variables (round 4): the large-n batched kernel with the same closed form, thread = variable
+  // (gi_batch_big.hip, BOX); R (past n = 104) and J (past n = 128) live in the caller's workspace like a cold dense solve's
+  int r_in_lds = 0;
+  if(jrlqp::batch_big_lds_bytes(n, 1, n, &r_in_lds) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  const int nwg = big_grid(n, 1, n, B);
+  if(nwg < 1) return JRLQP_ERR_NO_DEVICE;
+  double * ws = nullptr;
+  const long per_wg = jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, 0);
+  if(per_wg > 0)
+  {
+    const long long need = (long long)sizeof(double) * nwg * per_wg;
+    if(!dws || ws_bytes < need || (reinterpret_cast<size_t>(dws) & 15)) return JRLQP_ERR_WORKSPACE;
+    ws = static_cast<double *>(dws);
+  }
+  hipError_t e = jrlqp::launch_gi_batch_big(a, nwg, ws, st);
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
+}
+
+int jrlqp_box_solve_batch(int n, int B, const double * dx0, const double * dc, const double * dbl, const double * dxl,
+                          const double * dxu, const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm,
+                          int * diters, double * df, jrlqp_trace_rec * dtrace, int trace_cap, void * stream)
+{
+  return box_common(n, B, dx0, dc, dbl, dxl, dxu, opts, dx, du, dstatus, dterm, diters, df, dtrace, trace_cap, nullptr, 0, stream);
+}
+
+int jrlqp_box_solve_batch_ws(int n, int B, const double * dx0, const double * dc, const double * dbl, const double * dxl,
+                             const double * dxu, const jrlqp_options * opts, double * dx, double * du, int * dstatus, int * dterm,
+                             int * diters, double * df, jrlqp_trace_rec * dtrace, int trace_cap, void * dworkspace,
+                             long long workspace_bytes, void * stream)
+{
+  if(workspace_bytes < 0 || (workspace_bytes > 0 && !dworkspace)) return JRLQP_ERR_INVALID_ARGUMENT;
+  return box_common(n, B, dx0, dc, dbl, dxl, dxu, opts, dx, du, dstatus, dterm, diters, df, dtrace, trace_cap, dworkspace, workspace_bytes,
+                    stream);
 }
 
 int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, int max_nrhs, jrlqp_blocks ** out)

@@ -23,6 +23,7 @@ struct BatchArgs
   int prof_stride;
   int warm;           // 1: warm-started solve (experimental::GoldfarbIdnaniSolver), as_in = activation-status guess
   const int * as_in;  // B x (m+nb) guesses, or nullptr ("no guess"); may alias `status`
+  int box;            // 1: experimental::BoxAndSingleConstraintSolver (G = I implicit, a = x0, m == 1, nb == n, bu = +inf); n > 64: gi_batch_big.hip
   int tune;           // experiment bits (JRLQP_TUNE in the environment, capi.cpp env_tune; 0 in production)
 };
 

@@ -189,9 +189,14 @@ __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho,
 // WIDE: 128 < n <= 256: L / J (up to 526 KB) no longer fit in LDS at all -- they live in the workgroup's slice of the
 // global workspace, behind R (L2 / Infinity-Cache resident: a slice is re-read every pass), LDS keeps the vectors; the wave-level
 // substitutions carry four entries per lane instead of two.  Same code otherwise: every output element still owns its chain.
-template<bool RLDS, bool WARM, bool WIDE = false, bool PROFB = false, int OCC = 1>
+// BOX: experimental::BoxAndSingleConstraintSolver beyond one wavefront of variables (round 4; src/experimental/
+// BoxAndSingleConstraintSolver.cpp:46-94, oracle gi_solve_impl warm == 2): G = I implicit, A.a holds x0, m == 1, nb == n, bu = +inf; the
+// closed-form init_ (start point x0 clamped to the box, the clamped variables' bounds active, J a permutation, R = diag(+-1)) replaces
+// the factorisation, J = L^-T, x0 and initActiveSet; then the same loop.
+template<bool RLDS, bool WARM, bool WIDE = false, bool PROFB = false, int OCC = 1, bool BOX = false>
 __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const BatchArgs A, double * ws, long ws_stride)
 {
+  static_assert(!(BOX && WARM), "the box solver starts cold");
   // (launch bounds: OCC = 2 -- two workgroups per CU while their LDS allows it, n <= 88: at most 256 VGPRs, a few spills; OCC = 1
   // beyond, where one workgroup fills the CU's LDS anyway and the spills would only cost; the wide variant keeps its factors in
   // memory and lives on occupancy: three waves per SIMD, 168 VGPRs)
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
 
   for(int b = blockIdx.x; b < A.B; b += gridDim.x)
   {
-    const double * Gg = A.G + (size_t)b * n * n;
+    const double * Gg = BOX ? nullptr : A.G + (size_t)b * n * n;
     const double * ag = A.a + (size_t)b * n;
     const double * Cg = A.C + (size_t)b * n * m;
     const double * blg = A.bl + (size_t)b * m;
@@ -277,6 +282,13 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     };
 
     // ---------------------------------------------------------------- load G (lower triangle), reset
+    if constexpr(BOX)
+    {
+      // J.setZero() (BoxAndSingleConstraintSolver.cpp:61); R.col(q).head(q).setZero() for whatever q comes out (:69, :80)
+      for(int e = tid; e < n * ld; e += WGB) M[e] = 0.0;
+      for(long e = tid; e < rlen; e += WGB) (RLDS ? Rl : Rg)[e] = 0.0;
+    }
+    else
     for(int e = tid; e < n * n; e += WGB)
     {
       const int i = e % n, j = e / n;
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     }
     // ---------------------------------------------------------------- LLT, left-looking column by column (orc_llt)
     int info = -1;
-    for(int j = 0; j < n && !over; ++j)
+    for(int j = 0; j < n && !over && !BOX; ++j)
     {
       // rows i = j .. n-1 over the threads (two rounds when n - j > 256 never happens: n <= 128)
       const int i = j + tid;
@@ -505,6 +517,51 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           __syncthreads();
         }
       }
+      else if constexpr(BOX)
+      {
+        // ---- BoxAndSingleConstraintSolver::init_ (:46-94), thread = variable (n <= 256): the start point is x0 clamped to the box,
+        // every clamped variable's bound is active (in index order) with multiplier |x0_i - bound_i|, J is the permutation that puts the
+        // clamped coordinates first (free coordinate number k goes to column n-1-k) and R = diag(+1 lower / -1 upper)
+        const bool in = tid < n;
+        const double x0 = in ? ag[tid] : 0.0, lo = in ? xlg[tid] : 0.0, hi = in ? xug[tid] : 0.0;
+        const bool blo = in && x0 < lo;
+        const bool bup = in && !blo && x0 > hi;
+        const unsigned long long mk = __ballot(blo || bup);
+        unsigned long long * wm = reinterpret_cast<unsigned long long *>(ssq); // (scratch of the coefficient chain: free here)
+        if(lane == 0) wm[wave] = mk;
+        __syncthreads();
+        int pos = __popcll(mk & ((1ull << lane) - 1ull)), total = 0;
+        for(int w = 0; w < WGB / 64; ++w)
+        {
+          const int c = __popcll(wm[w]);
+          if(w < wave) pos += c;
+          total += c;
+        }
+        const double xv = blo ? lo : (bup ? hi : x0);
+        const double uv = blo ? (xv - x0) : (x0 - xv);
+        if(in)
+        {
+          xs[tid] = xv;
+          const int col = (blo || bup) ? pos : (n - 1 - (tid - pos));
+          M[tid + (long)col * ld] = 1.0;
+          if(blo || bup)
+          {
+            RP(pos, pos) = blo ? 1.0 : -1.0;
+            us[pos] = uv;
+            act[pos] = m + tid; // (:72 "i + 1": one general constraint in front of the bounds)
+            st[m + tid] = (unsigned char)(blo ? B_LOWER_BOUND : B_UPPER_BOUND);
+          }
+        }
+        q = total;
+        __syncthreads();
+        if(tid == 0)
+        {
+          double f = 0.0; // f_ += 0.5 * u[q] * u[q], in activation order: one chain
+          for(int k = 0; k < total; ++k) f = FMA(0.5 * us[k], us[k], f);
+          ctl->f = f;
+        }
+        __syncthreads();
+      }
       else
       // ---------------------------------------------------------------- x0 = -L^-T L^-1 a, f0 (GoldfarbIdnaniSolver.cpp:68-74)
       // thread i owns x_i; one barrier per substitution step (the pivot travels through LDS)
@@ -539,6 +596,8 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         __syncthreads();
         if(tid == 0) ctl->f = 0.5 * chain_asc<false>(ag, 1, xs, 1, 0, n, 0.0);
       }
+      if constexpr(!BOX)
+      {
       // ---------------------------------------------------------------- J = L^-T in place (orc_inv_lt), row by row from the bottom:
       // J(i,c) = (delta_ic - sum_{k = c .. i+1, descending} L(k,i) J(k,c)) / L(i,i): column i of L is last read by row i of
       // J, which only writes the upper triangle -- the two share the array, L's diagonal is in dgl
@@ -557,6 +616,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       {
         const int i = e % n, j = e / n;
         if(i > j) M[i + (long)j * ld] = 0.0;
+      }
       }
       __syncthreads();
       if constexpr(WARM)
@@ -597,7 +657,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     auto bound_of = [&](int pp, int ps) -> double {
       const bool lower = (ps == B_LOWER || ps == B_EQUALITY || ps == B_LOWER_BOUND || ps == B_FIXED);
       if(pp >= m) return lower ? xlg[pp - m] : xug[pp - m];
-      return lower ? blg[pp] : bug[pp];
+      return lower ? blg[pp] : (BOX ? __builtin_inf() : bug[pp]); // (box solver: bu_[0] = +inf, BoxAndSingleConstraintSolver.cpp:33)
     };
     // computeStep_ + the scalar products of computeStepLength_ (barriers inside: called by every thread)
     // fresh: pp was selected by a scan of the current x -- n+.x is then the scan's own chain value (ctl->cx, written by the thread
@@ -913,7 +973,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       if(tid == 0) us[q] = 0.0;
       __syncthreads();
     }
-    else if(term == BT_SUCCESS)
+    else if(term == BT_SUCCESS && !BOX) // (the box solver's init_ replaces initActiveSet as well: no pre-activation of xl == xu)
     {
       // ---------------------------------------------------------------- initActiveSet (GoldfarbIdnaniSolver.cpp:268-287)
       {
@@ -977,7 +1037,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             }
             else
             {
-              const double su = bug[i] - cx;
+              const double su = (BOX ? __builtin_inf() : bug[i]) - cx;
               if(su < bval)
               {
                 bval = su;
@@ -1165,6 +1225,11 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(WGB), (size_t)lds, stream, a, ws, stride);
     return hipGetLastError();
   };
+  if(a.box) // experimental::BoxAndSingleConstraintSolver beyond 64 variables (cold start only)
+  {
+    if(a.n > 128) return go(&gi_batch_big_kernel<false, false, true, false, 1, true>);
+    return r_in_lds ? go(&gi_batch_big_kernel<true, false, false, false, 1, true>) : go(&gi_batch_big_kernel<false, false, false, false, 1, true>);
+  }
   if(a.n > 128) return a.warm ? go(&gi_batch_big_kernel<false, true, true>) : go(&gi_batch_big_kernel<false, false, true>);
   if(a.prof && !a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, false, false, true>) : go(&gi_batch_big_kernel<false, false, false, true>);
   if(2 * lds <= kLdsPerCU && r_in_lds) // two workgroups per CU: the instantiations held to 256 VGPRs

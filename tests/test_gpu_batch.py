@@ -1,6 +1,8 @@
 """GPU parity tests proper: the batched HIP path (through the C ABI) against the CPU oracle on the same seeded
 inputs -- BIT-exact on termination status, iteration count, active-set vector AND on x, u, f (the CANON rounding
 contract makes the floating-point results identical, so the stated fp64 tolerance is 0 ulp)."""
+import ctypes as ct
+
 import numpy as np
 import pytest
 
@@ -283,7 +285,9 @@ def test_box_and_single_constraint_solver(pkg, oracle):
     import jrl_qp_amd.problems as P
 
     dev = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
-    for n, reps, seed in ((10, 11, 20201), (1, 4, 5), (7, 6, 6), (33, 6, 7), (64, 5, 8)):
+    # (beyond 64 variables -- round 4 -- the closed form runs in the large-n kernel, thread = variable: R in LDS up to 104, in the
+    # workspace beyond, J in the workspace past 128)
+    for n, reps, seed in ((10, 11, 20201), (1, 4, 5), (7, 6, 6), (33, 6, 7), (64, 5, 8), (65, 4, 9), (100, 5, 10), (120, 3, 11), (200, 3, 12), (256, 2, 13)):
         rng = np.random.default_rng(seed)
         pbs = [P.box_and_single_constraint_problem(n, act, rng) for act in (False, True) for _ in range(reps)]
         B = len(pbs)
@@ -306,13 +310,20 @@ def test_box_and_single_constraint_solver(pkg, oracle):
             assert abs(f[b] - (gi.f + 0.5 * x0[b] @ x0[b])) <= 1e-9 * (1 + abs(f[b]))
             nact += int(status[b, 0] != 0)
         assert nact <= reps and (n < 7 or nact == reps)  # the "active" half ends with the general constraint active
-    # beyond one wavefront of variables the closed-form start does not exist: refused, never a silent wrong answer
-    for n in (65, 96, 128):
-        s = capi.BoxAndSingleConstraintSolver(n, 2)
-        z = torch.zeros((2, n), dtype=torch.float64, device="cuda")
-        with pytest.raises(capi.JrlqpError) as ei:
-            s.solve(z, z + 1.0, torch.zeros(2, dtype=torch.float64, device="cuda"), z - 1.0, z + 1.0)
-        assert ei.value.status == capi.ERR_UNSUPPORTED_SIZE
+    # beyond the batched kernels' 256 unknowns: refused, never a silent wrong answer; and the plain entry point past n = 104 asks for
+    # the workspace instead of allocating one
+    with pytest.raises(capi.JrlqpError) as ei:
+        capi.BoxAndSingleConstraintSolver(257, 2)
+    assert ei.value.status == capi.ERR_UNSUPPORTED_SIZE
+    lib = capi.load_library()
+    z = torch.zeros((2, 120), dtype=torch.float64, device="cuda")
+    o3 = [torch.zeros((2, 121), dtype=torch.float64, device="cuda"), torch.zeros((2, 121), dtype=torch.int32, device="cuda")]
+    i1 = [torch.zeros(2, dtype=torch.int32, device="cuda") for _ in range(2)]
+    f1 = torch.zeros(2, dtype=torch.float64, device="cuda")
+    P_ = lambda t: ct.c_void_p(t.data_ptr())
+    rc = lib.jrlqp_box_solve_batch(120, 2, P_(z), P_(z), P_(f1), P_(z), P_(z), None, P_(z.clone()), P_(o3[0]), P_(o3[1]), P_(i1[0]), P_(i1[1]), P_(f1.clone()),
+                                   None, 0, None)
+    assert rc == capi.ERR_WORKSPACE
     # termination statuses other than SUCCESS come out of the same loop: infeasible constraint, iteration limit
     n = 5
     x0 = np.array([[0.5, -2.0, 3.0, 0.1, -0.7]] * 2)
