@@ -62,3 +62,29 @@ def test_scopes_do_not_leak_between_functions():
     two = ("0000000000001000 <first>:\n\tv_readlane_b32 s1, v205, 31\n\ts_endpgm\n"
            "0000000000002000 <second>:\n\tglobal_load_dwordx2 v[2:3], v1, s[0:1]\n")
     assert rules(two) == []
+
+
+def test_wait_states_are_counted_along_branch_edges():
+    """A consumer at a branch target is not credited with the instructions the taken branch skipped (round 3's advisor): the producer
+    sits right in front of an s_cbranch, eight fall-through instructions follow, the consumer is the first instruction behind the label."""
+    skipped = ["v_mov_b32_e32 v20, 0"] * 8
+    # hipcc -S form of a label
+    s_form = "kernel_under_test:\n" + "\n".join("\t" + l for l in ["v_readfirstlane_b32 s6, v3", "s_cbranch_scc1 .LBB0_2"] + skipped) + \
+             "\n.LBB0_2:\n\tv_readlane_b32 s8, v10, s6\n\ts_endpgm\n"
+    out = []
+    lint.lint_listing(s_form, 5, "unit", out)
+    padded = "\n".join(out)
+    assert "isa_lint R1" in padded  # one wait state (the branch) on the taken edge: four more inserted in front of the consumer
+    assert "s_nop 3 ; isa_lint R1" in padded
+    # llvm-objdump --symbolize-operands form
+    d_form = listing(["v_readfirstlane_b32 s6, v3", "s_cbranch_scc1 L2"] + skipped) + "0000000000001100 <L2>:\n\tv_readlane_b32 s8, v10, s6\n\ts_endpgm\n"
+    assert rules(d_form) == ["R1"]
+    # a memory instruction at a loop head whose base pair is reloaded at the loop's end (backward branch): R3 along the back edge
+    loop = "kernel_under_test:\n.LBB0_1:\n\tglobal_load_dwordx2 v[2:3], v1, s[0:1]\n" + "\n".join("\t" + l for l in skipped) + \
+           "\n\tv_readlane_b32 s0, v205, 30\n\tv_readlane_b32 s1, v205, 31\n\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n"
+    out = []
+    lint.lint_listing(loop, 5, "unit", out)
+    assert "isa_lint R3" in "\n".join(out)
+    # enough wait states in front of the branch: clean either way
+    ok = listing(["v_readfirstlane_b32 s6, v3", "s_nop 4", "s_cbranch_scc1 L2"] + skipped) + "0000000000001100 <L2>:\n\tv_readlane_b32 s8, v10, s6\n\ts_endpgm\n"
+    assert rules(ok) == []

@@ -18,8 +18,11 @@
       s[0:1]` five wait states behind `v_readlane_b32 s1, v205, 31`, at addresses made of whatever s[0:1] held BEFORE the reload
       (rocgdb, precise memory mode: tools/gdb_fault.sh).
 
-All are checked on the DISASSEMBLY of the built objects (every instruction, compiler-emitted and inline assembly alike), in
-straight-line order inside each function: a taken branch only adds time between producer and consumer.
+All are checked on the DISASSEMBLY of the built objects (every instruction, compiler-emitted and inline assembly alike).  Wait states
+are counted along the listing AND along every branch edge: a first pass records, at each s_branch / s_cbranch, how many wait states
+each pending VALU-written SGPR has behind it (the branch itself included); at the target label the youngest of "fall-through" and
+"every branch that lands here" counts -- a consumer at a branch target is not credited with the instructions the taken branch skipped
+(round 3 counted in listing order only).
 
 usage: isa_lint.py [--min-states 5] [--objdir jrl-qp_amd/csrc] [--list] [objects...]      exit status 1 on any finding
        isa_lint.py --fix in.s out.s        the SAME rules applied to a `hipcc -S --offload-device-only` listing: every finding
@@ -66,12 +69,22 @@ def disassemble(obj, workdir):
     subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, base + ".fat"])
     subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                            f"--input={base}.fat", f"--output={base}.co", "--unbundle"])
-    return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", base + ".co"], check=True, capture_output=True,
+    return subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--symbolize-operands", "--mcpu=gfx950", base + ".co"], check=True, capture_output=True,
                           text=True).stdout
+
+
+LABEL = re.compile(r"^(?:<(L\d+)>|(\.L[\w$.]+)):")  # llvm-objdump --symbolize-operands / hipcc -S
 
 
 def lint_listing(text, min_states, name, fix_out=None):
     """fix_out: a list that receives the lines of the listing with the missing wait states inserted (then nothing is a finding)."""
+    # pass 1: the age of every pending VALU-written SGPR at each branch, per target label; pass 2: the lint proper
+    ages = {}
+    _lint_pass(text, min_states, name, None, ages, None, fix_out is not None)
+    return _lint_pass(text, min_states, name, fix_out, None, ages, fix_out is not None)
+
+
+def _lint_pass(text, min_states, name, fix_out, collect, label_ages, s_listing):
     findings = []
     stats = dict(functions=0, instructions=0, lane_selects=0, valu_sgpr_selects=0, readlanes=0)
     func = "?"
@@ -84,15 +97,29 @@ def lint_listing(text, min_states, name, fix_out=None):
         if fix_out is not None:
             fix_out.append(line)
         fm = FUNC.match(line)
-        if fm is None and fix_out is not None:
+        if fm is None and s_listing:
             lm = re.match(r"^([A-Za-z_$.][\w$.]*):", line)  # -S listing: a label; function symbols start a new scope
             if lm and not lm.group(1).startswith(".L"):
                 fm = lm
+        if fm and re.fullmatch(r"L\d+", fm.group(1)):
+            line = "<" + fm.group(1) + ">:"  # llvm-objdump --symbolize-operands prints a branch target like a symbol: a label, not a function
+            fm = None
         if fm:
             func = fm.group(1)
             stats["functions"] += 1
             clock = 0
             sgpr_valu_write = {}
+            prev_vgpr_writes = set()
+            continue
+        lb = LABEL.match(line.strip())
+        if lb:
+            # a branch target: for every SGPR some branch arrives with, the youngest write counts
+            key = (func, lb.group(1) or lb.group(2))
+            if label_ages is not None:
+                for sreg, (age, txt) in label_ages.get(key, {}).items():
+                    w = clock - age
+                    if sreg not in sgpr_valu_write or sgpr_valu_write[sreg][0] < w:
+                        sgpr_valu_write[sreg] = (w, txt + " (via a branch)")
             prev_vgpr_writes = set()
             continue
         m = INSN.match(line)
@@ -149,6 +176,12 @@ def lint_listing(text, min_states, name, fix_out=None):
                     stats["fixed"] = stats.get("fixed", 0) + 1
                 else:
                     findings.append((name, func, "R3", f"{worst[0]} wait states between '{worst[1]}' and '{line.strip().split('//')[0].strip()}'"))
+        if collect is not None and mn.startswith(("s_cbranch", "s_branch")) and ops:
+            tgt = collect.setdefault((func, ops[0].strip()), {})
+            for sreg, (w, txt) in sgpr_valu_write.items():
+                age = clock + 1 - w  # (the branch itself is a wait state)
+                if age < max(min_states, MEM_STATES) and (sreg not in tgt or age < tgt[sreg][0]):
+                    tgt[sreg] = (age, txt)
         # ---- producers
         written_s = set()
         if is_valu and ops:
