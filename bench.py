@@ -114,9 +114,10 @@ def cpu_baseline(pb, budget_s=12.0):
         cores = os.cpu_count() or 1
     sample = pb.B
     run, _ = o.bench_rounds_fn(pb.G[:sample], pb.a[:sample], pb.C[:sample], pb.bl[:sample], pb.bu[:sample])
-    probe_run, _ = o.bench_rounds_fn(pb.G[:256], pb.a[:256], pb.C[:256], pb.bl[:256], pb.bu[:256])
+    np_ = min(256, pb.B)
+    probe_run, _ = o.bench_rounds_fn(pb.G[:np_], pb.a[:np_], pb.C[:np_], pb.bl[:np_], pb.bu[:np_])
     probe_run(1, 1)
-    per = min(probe_run(1, 1) for _ in range(3)) / 256  # single-thread seconds per solve (same loop, same restore)
+    per = min(probe_run(1, 1) for _ in range(3)) / np_  # single-thread seconds per solve (same loop, same restore)
     # The affinity mask can overstate what the container may really use: a cgroup CPU quota throttles a pool that is wider than
     # the quota, but only once the quota of a scheduling period (100 ms) is spent -- a probe of a few milliseconds runs at the
     # full width of the host and says nothing about a sustained run.  So every width is probed for >= 0.6 s (several periods),
