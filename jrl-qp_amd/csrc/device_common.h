@@ -118,6 +118,54 @@ __device__ __forceinline__ double dpp_shift0_d(double v)
   return __hiloint2double(hi, lo);
 }
 
+// minimum over the 64 lanes, every lane gets it: four DPP exchanges inside each row of 16, then the four row
+// minima through readlane -- no LDS crossbar (ds_bpermute) round trips
+template<int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+  double o;
+  o = dpp_move<0xB1>(v); // quad_perm [1,0,3,2]
+  v = (o < v) ? o : v;
+  o = dpp_move<0x4E>(v); // quad_perm [2,3,0,1]
+  v = (o < v) ? o : v;
+  o = dpp_move<0x141>(v); // row_half_mirror
+  v = (o < v) ? o : v;
+  o = dpp_move<0x140>(v); // row_mirror
+  v = (o < v) ? o : v;
+  double r0 = bcast_lane(v, 0), r1 = bcast_lane(v, 16), r2 = bcast_lane(v, 32), r3 = bcast_lane(v, 48);
+  double m01 = (r1 < r0) ? r1 : r0;
+  double m23 = (r3 < r2) ? r3 : r2;
+  return (m23 < m01) ? m23 : m01;
+}
+
+// the same for ints
+template<int CTRL>
+__device__ __forceinline__ int dpp_move_i(int v)
+{
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+  int o;
+  o = dpp_move_i<0xB1>(v);
+  v = (o < v) ? o : v;
+  o = dpp_move_i<0x4E>(v);
+  v = (o < v) ? o : v;
+  o = dpp_move_i<0x141>(v);
+  v = (o < v) ? o : v;
+  o = dpp_move_i<0x140>(v);
+  v = (o < v) ? o : v;
+  const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  const int m01 = (r1 < r0) ? r1 : r0, m23 = (r3 < r2) ? r3 : r2;
+  return (m23 < m01) ? m23 : m01;
+}
+
 // Sum over the 64 lanes as an ADJACENT-FIRST pairwise tree (lane 2i with 2i+1, then pairs of pairs, ...): rule C4 of
 // the oracle (oracle/blockgi_oracle.c orc_dot_tree).  Every lane returns the same bits: each level adds the totals of
 // two sibling groups, and a + b == b + a.  quad_perm / row_half_mirror / row_mirror inside a row of 16, then the four

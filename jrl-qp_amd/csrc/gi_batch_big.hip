@@ -64,10 +64,14 @@ struct CtlB
   int red_idx[4];
   int red_stat[4];
   int l, info, pad0, pad1;
+  long long wt[4]; // (phase profile build: when each wave left its branch of computeStep_)
 };
 
-// acc <- chain over k = k0 .. k1-1 (ascending) of fma(+-a[k*sa], b[k*sb], acc); operands a chunk ahead (flat pointers:
-// LDS or global)
+// acc <- chain over k = k0 .. k1-1 (ascending) of fma(+-a[k*sa], b[k*sb], acc); operands a group of CH ahead (flat pointers: LDS or
+// global).  The left-over terms are ONE more group with clamped (in-footprint) addresses and a select per term, not a scalar loop
+// (round 4: at n = 100 the four left-over terms were four exposed round trips per chain).  Requesting group g + 1 before group g
+// is accumulated (two register buffers, a branch-free steady loop) was built and measured: no gain -- tools/ubench/chain_lat.hip:
+// a wave moves one (LDS operand pair, fma) per ~33 cycles whatever the lookahead and however many lanes are active.
 template<bool NEG, int CH = 8>
 __device__ __forceinline__ double chain_asc(const double * a, long sa, const double * b, long sb, int k0, int k1, double acc)
 {
@@ -84,7 +88,23 @@ __device__ __forceinline__ double chain_asc(const double * a, long sa, const dou
 #pragma unroll
     for(int u = 0; u < CH; ++u) acc = NEG ? FMA(-av[u], bv[u], acc) : FMA(av[u], bv[u], acc);
   }
-  for(; k < k1; ++k) acc = NEG ? FMA(-a[k * sa], b[k * sb], acc) : FMA(a[k * sa], b[k * sb], acc);
+  if(k < k1)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      const int w = min(k + u, k1 - 1);
+      av[u] = a[w * sa];
+      bv[u] = b[w * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      const double t = NEG ? FMA(-av[u], bv[u], acc) : FMA(av[u], bv[u], acc);
+      acc = (k + u < k1) ? t : acc;
+    }
+  }
   return acc;
 }
 // descending: k = k1-1 .. k0, first operand negated
@@ -104,26 +124,44 @@ __device__ __forceinline__ double chain_desc_neg(const double * a, long sa, cons
 #pragma unroll
     for(int u = 0; u < CH; ++u) acc = FMA(-av[u], bv[u], acc);
   }
-  for(; k >= k0; --k) acc = FMA(-a[k * sa], b[k * sb], acc);
+  if(k >= k0) // the left-over terms as one clamped group (see chain_asc)
+  {
+    double av[CH], bv[CH];
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      const int w = max(k - u, k0);
+      av[u] = a[w * sa];
+      bv[u] = b[w * sb];
+    }
+#pragma unroll
+    for(int u = 0; u < CH; ++u)
+    {
+      const double t = FMA(-av[u], bv[u], acc);
+      acc = (k - u >= k0) ? t : acc;
+    }
+  }
   return acc;
 }
 
+// Lexicographic (value, index) minimum over the candidates of a wave (idx != NONE_B), every lane gets the winner and its aux word.
+// DPP exchanges and readlanes only: the value's minimum, then the smallest index among the lanes that hold it, then one ballot for the
+// lane (round 3 ran a butterfly of ds_bpermute round trips: 24 LDS crossbar trips per reduction, twice per pass).
 __device__ __forceinline__ void argmin3(double & val, int & idx, int & aux)
 {
-#pragma unroll
-  for(int off = 32; off >= 1; off >>= 1)
+  const bool cand = idx != NONE_B;
+  const double mn = wave_min_d(cand ? val : __builtin_inf());
+  const int ci = (cand && val == mn) ? idx : NONE_B;
+  const int mi = wave_min_i(ci);
+  if(mi == NONE_B) // (uniform) no candidate, or only NaNs
   {
-    const double ov = shfl_xor_d(val, off);
-    const int oi = __shfl_xor(idx, off);
-    const int oa = __shfl_xor(aux, off);
-    const bool take = (oi != NONE_B) && (idx == NONE_B || ov < val || (ov == val && oi < idx));
-    if(take)
-    {
-      val = ov;
-      idx = oi;
-      aux = oa;
-    }
+    idx = NONE_B;
+    return;
   }
+  const int src = __builtin_ctzll(__ballot(ci == mi));
+  val = mn;
+  idx = mi;
+  aux = __builtin_amdgcn_readlane(aux, src);
 }
 
 // The Givens coefficients of an addition on ONE wave, n up to 256 (GoldfarbIdnaniSolver.cpp:228-231), CANON C7 (oracle
@@ -268,9 +306,10 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     __syncthreads(); // (the previous problem's results are out)
     // diagnostic phase profile (jrlqp_debug_set_profile, JRLQP_PROFILE_GI_BATCH): thread 0 accumulates shader-clock cycles per phase
     // -- slots: 0 load, 1 LLT, 2 x0 / J (/ warm factorisation), 3 scan + selection, 4 d = J^T n+, 5 z || R^-1 d || coefficient chain,
-    // 6 scalar products, 7 step, 8 addition (sweep of J), 9 removal, 10 #additions, 11 #removals -- into prof[b * stride + slot]
+    // 6 scalar products, 7 step, 8 addition (sweep of J), 9 removal, 10 #additions, 11 #removals, 12-15 what waves 0-3 each needed of slot 5
+    // (0: R^-1 d and the ratio test, 1: the coefficient chain, 2-3: z) -- into prof[b * stride + slot]
     const bool profb = PROFB && A.prof != nullptr && tid == 0; // (PROFB: a build of its own -- the accumulators cost the production kernel 5 %)
-    long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long plast = profb ? clock64() : 0;
     auto stamp = [&](int slot) {
       if(profb)
@@ -669,6 +708,9 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         if(ps == B_UPPER || ps == B_UPPER_BOUND) dj = -dj;
         ds[tid] = dj;
       }
+      // n+.x when the scan has not just left it (an initial constraint; the pass behind a removal): the C1 chain, on the last lane of
+      // the workgroup BESIDE d (x does not move before the step is taken) -- round 3 ran it behind the trees, one chain on its own
+      if(tid == WGB - 1 && !(fresh && pp < m)) ctl->cx = (pp < m) ? chain_asc<false>(nps, 1, xs, 1, 0, n, 0.0) : xs[pp - m];
       __syncthreads();
       stamp(4);
       if(tid >= 128)
@@ -690,24 +732,89 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       {
         // r = R^-1 d1 on wave 0, EPL entries per lane (rows lane, lane + 64, ...), columns k = q-1 .. 0: the quotient of the
         // pivot row is formed in every lane (same operands, same bits)
-        double rv[EPL];
-#pragma unroll
-        for(int h = 0; h < EPL; ++h) rv[h] = (lane + 64 * h < q) ? ds[lane + 64 * h] : 0.0;
+        double rv[EPL], dg[EPL], rinv[EPL];
         const int qs = __builtin_amdgcn_readfirstlane(q); // (a scalar loop counter: see bcast_lane in device_common.h)
-        for(int k = qs - 1; k >= 0; --k)
+#pragma unroll
+        for(int h = 0; h < EPL; ++h)
         {
-          double num = 0.0;
+          const int e = lane + 64 * h;
+          rv[h] = (e < qs) ? ds[e] : 0.0;
+          dg[h] = (e < qs) ? RP(e, e) : 1.0;
+          rinv[h] = recip_refined(dg[h]); // every pivot's reciprocal at once (device_common.h, div_pre)
+        }
+        // The lean step of wave_bwd (device_common.h) with EPL entries per lane: the quotient of the pivot row is formed by every lane
+        // on its own entry (three dependent operations, no broadcast of pivot or reciprocal), one v_readlane, one fma and one select
+        // per entry block; the column's entries are requested a group of TG steps ahead (clamped into the column: in-footprint), no
+        // branch inside a group.  Row e's chain is untouched: fma(-R(e, k), r_k, .) for k = q-1 .. e+1, then the quotient.  (Round 3
+        // divided in every step and branched per step: 150-250 cycles per step, the longest phase of a pass at n = 100.)
+        constexpr int TG = 8;
 #pragma unroll
-          for(int h = 0; h < EPL; ++h)
-            if((k >> 6) == h) num = bcast_lane(rv[h], k & 63); // (k is scalar: a uniform branch)
-          const double v = num / RP(k, k);
-          const double * col = &RP(0, k);
+        for(int hb = EPL - 1; hb >= 0; --hb)
+        {
+          // pivots of entry block hb: k = min(qs, 64 hb + 64) - 1 .. 64 hb, in groups of TG from the top (steps past the block's
+          // lower end are clamped to its first pivot and update no lane)
+          const int ktop = min(qs, 64 * hb + 64) - 1, kbot = 64 * hb;
+          if(ktop < kbot) continue;
+          double cn[EPL][TG], cv[EPL][TG];
+          auto fetch = [&](int kg) __attribute__((always_inline)) {
 #pragma unroll
-          for(int h = 0; h < EPL; ++h)
+            for(int j = 0; j < TG; ++j)
+            {
+              const int k = max(kg - j, kbot);
+#pragma unroll
+              for(int h = 0; h <= hb; ++h) cn[h][j] = RP(min(lane + 64 * h, k), k);
+            }
+          };
+          fetch(ktop);
+          for(int kg = ktop; kg >= kbot; kg -= TG)
           {
-            const int e = lane + 64 * h;
-            if(e < k) rv[h] = FMA(-col[e], v, rv[h]);
-            if(e == k) rv[h] = v;
+#pragma unroll
+            for(int j = 0; j < TG; ++j)
+#pragma unroll
+              for(int h = 0; h <= hb; ++h) cv[h][j] = cn[h][j];
+            fetch(kg - TG); // (unconditional: past the block's lower end the addresses are clamped, and a branch here would make the steps wait for it)
+#pragma unroll
+            for(int j = 0; j < TG; ++j)
+            {
+              const int k = kg - j; // (k < kbot, past the block's lower end: the select below matches no lane)
+              const double v = bcast_lane_s(div_pre(rv[hb], dg[hb], rinv[hb]), max(k, kbot) & 63);
+#pragma unroll
+              for(int h = 0; h <= hb; ++h)
+              {
+                const double upd = FMA(-cv[h][j], v, rv[h]);
+                rv[h] = (k >= kbot && lane + 64 * h < k) ? upd : rv[h];
+              }
+            }
+          }
+        }
+        bool safe = true;
+#pragma unroll
+        for(int h = 0; h < EPL; ++h)
+        {
+          const double pre = rv[h]; // the numerators
+          safe = safe && (lane + 64 * h >= qs || (div_safe_den(dg[h]) && div_safe_num(pre)));
+          rv[h] = div_pre(pre, dg[h], rinv[h]);
+        }
+        if(!__all(safe))
+        {
+          // an operand left the range in which the hoisted reciprocal is provably the compiler's own quotient: redo with a / b
+#pragma unroll
+          for(int h = 0; h < EPL; ++h) rv[h] = (lane + 64 * h < qs) ? ds[lane + 64 * h] : 0.0;
+          for(int k = qs - 1; k >= 0; --k)
+          {
+            double num = 0.0;
+#pragma unroll
+            for(int h = 0; h < EPL; ++h)
+              if((k >> 6) == h) num = bcast_lane(rv[h], k & 63); // (k is scalar: a uniform branch)
+            const double v = num / RP(k, k);
+            const double * col = &RP(0, k);
+#pragma unroll
+            for(int h = 0; h < EPL; ++h)
+            {
+              const int e = lane + 64 * h;
+              if(e < k) rv[h] = FMA(-col[e], v, rv[h]);
+              if(e == k) rv[h] = v;
+            }
           }
         }
 #pragma unroll
@@ -740,11 +847,14 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           ctl->l = (kk == NONE_B) ? 0 : kk;
         }
       }
+      if(PROFB && A.prof != nullptr && lane == 0) ctl->wt[wave] = clock64();
       __syncthreads();
+      if(profb)
+        for(int w = 0; w < 4; ++w) pacc[12 + w] += ctl->wt[w] - plast;
       stamp(5);
       // z.z and n+.z: C4 trees (CANON C5) -- one product per element, element e on thread e: each wave's adjacent-first tree over
-      // its 64 elements, then the waves pairwise ((w0 + w1) + (w2 + w3); up to n = 128 the second pair is exactly +0).  n+.x:
-      // the C1 chain (the scan's value for that constraint), the last lane of wave 3 behind its share of the trees
+      // its 64 elements, then the waves pairwise ((w0 + w1) + (w2 + w3); up to n = 128 the second pair is exactly +0).  (n+.x:
+      // the C1 chain -- the scan's value for that constraint, or the chain beside d above)
       {
         const bool in = tid < n;
         const double zi = in ? zs[tid] : 0.0;
@@ -756,7 +866,6 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           ctl->dotp[2 * wave] = pz;
           ctl->dotp[2 * wave + 1] = pc;
         }
-        if(tid == WGB - 1 && !(fresh && pp < m)) ctl->cx = (pp < m) ? chain_asc<false>(nps, 1, xs, 1, 0, n, 0.0) : xs[pp - m];
       }
       __syncthreads();
       if(tid == 0)
@@ -977,25 +1086,48 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     {
       // ---------------------------------------------------------------- initActiveSet (GoldfarbIdnaniSolver.cpp:268-287)
       {
-        int cnt = 0;
-        for(int i = tid; i < mt; i += WGB) cnt += ((i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m])) ? 1 : 0;
+        // the equalities / fixed variables in index order, compacted into act[] (the very entries addConstraint_ writes again as it
+        // activates them; q == 0 here): each thread tests its own constraints once, a ballot per wave and the waves' counts order them.
+        // (Round 3 walked all m + nb constraints in every thread, two dependent global loads per constraint.)
         if(tid == 0) ctl->l = 0;
         __syncthreads();
-        if(cnt) atomicAdd(&ctl->l, cnt);
-        __syncthreads();
+        for(int base = 0; base < mt; base += WGB)
+        {
+          const int i = base + tid;
+          const bool eq = (i < mt) && ((i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]));
+          const unsigned long long mask = __ballot(eq);
+          if(lane == 0) ctl->red_idx[wave] = __popcll(mask);
+          __syncthreads();
+          int off = ctl->l;
+          for(int w = 0; w < wave; ++w) off += ctl->red_idx[w];
+          off += __popcll(mask & ((1ull << lane) - 1ull));
+          if(eq && off < n) act[off] = i;
+          __syncthreads();
+          if(tid == 0) ctl->l += ctl->red_idx[0] + ctl->red_idx[1] + ctl->red_idx[2] + ctl->red_idx[3];
+          __syncthreads();
+        }
         const int neq = ctl->l;
         __syncthreads();
         if(neq > n)
           term = BT_OVERCONSTRAINED; // UB in the reference; reported (as the oracle does)
         else if(neq > 0)
         {
-          for(int i = 0; i < mt; ++i)
+          // n+ of the NEXT initial constraint is requested before the current one's step (a column of C is a global round trip)
+          double npn = 0.0;
           {
-            const bool eq = (i < m) ? (blg[i] == bug[i]) : (xlg[i - m] == xug[i - m]);
-            if(!eq) continue; // (uniform: every thread reads the same data)
-            p = i;
-            pstat = (i < m) ? B_EQUALITY : B_FIXED;
-            load_np(p);
+            const int p0 = act[0];
+            if(p0 < m && tid < n) npn = Cg[(size_t)p0 * n + tid];
+          }
+          for(int k = 0; k < neq; ++k)
+          {
+            p = act[k];
+            pstat = (p < m) ? B_EQUALITY : B_FIXED;
+            if(p < m && tid < n) nps[tid] = npn;
+            if(k + 1 < neq)
+            {
+              const int pn = act[k + 1];
+              if(pn < m && tid < n) npn = Cg[(size_t)pn * n + tid];
+            }
             if(tid == 0) us[q] = 0.0;
             __syncthreads();
             compute_step(p, pstat, false);
@@ -1175,7 +1307,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       A.f[b] = ctl->f;
     }
     if(profb)
-      for(int k = 0; k < 12; ++k) A.prof[(size_t)b * A.prof_stride + k] = pacc[k];
+      for(int k = 0; k < 16; ++k) A.prof[(size_t)b * A.prof_stride + k] = pacc[k];
   }
 }
 

@@ -115,8 +115,6 @@ __device__ __forceinline__ double uniform_d(double v)
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_min_d(double v);
-
 // Lexicographic (value, index) minimum over the wave when the candidate index is monotone in the lane id
 // (idx == NONE marks "no candidate" and must come with val == +big).  Butterfly min on the value, then one
 // ballot picks the first lane holding it.  Every lane gets the winner.
@@ -197,32 +195,6 @@ __device__ __forceinline__ void givens_cs(const GivensHalf & h, double & c, doub
     c = (h.p < 0.0) ? -1.0 : 1.0;
     s = 0.0;
   }
-}
-
-// minimum over the 64 lanes, every lane gets it: four DPP exchanges inside each row of 16, then the four row
-// minima through readlane -- no LDS crossbar (ds_bpermute) round trips
-template<int CTRL>
-__device__ __forceinline__ double dpp_move(double v)
-{
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_min_d(double v)
-{
-  double o;
-  o = dpp_move<0xB1>(v); // quad_perm [1,0,3,2]
-  v = (o < v) ? o : v;
-  o = dpp_move<0x4E>(v); // quad_perm [2,3,0,1]
-  v = (o < v) ? o : v;
-  o = dpp_move<0x141>(v); // row_half_mirror
-  v = (o < v) ? o : v;
-  o = dpp_move<0x140>(v); // row_mirror
-  v = (o < v) ? o : v;
-  double r0 = bcast_lane(v, 0), r1 = bcast_lane(v, 16), r2 = bcast_lane(v, 32), r3 = bcast_lane(v, 48);
-  double m01 = (r1 < r0) ? r1 : r0;
-  double m23 = (r3 < r2) ? r3 : r2;
-  return (m23 < m01) ? m23 : m01;
 }
 
 // the same with v_min_f64 spelled out (three instructions per exchange instead of five); for operands that are numbers
