@@ -58,7 +58,7 @@ enum : int
 struct CtlB
 {
   double red_val[4];
-  double zz, cz, cx, t1, f, rho;
+  double bnd, cx, t1, f, rho; // bnd: the bound of the selected constraint, left by the thread that scanned it
   double dotp[8]; // per wave: its share of the C4 trees of z.z and n+.z
   double gc, gs, gr; // rotation of the removal step in flight
   int red_idx[4];
@@ -701,6 +701,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     // computeStep_ + the scalar products of computeStepLength_ (barriers inside: called by every thread)
     // fresh: pp was selected by a scan of the current x -- n+.x is then the scan's own chain value (ctl->cx, written by the thread
     // that owns the constraint: GoldfarbIdnaniSolver.cpp:97 and :183-190 are one expression) and is not recomputed
+    double step_zz = 0.0, step_cz = 0.0; // z.z and n+.z of the step in flight (every thread holds them)
     auto compute_step = [&](int pp, int ps, bool fresh) {
       if(tid < n)
       {
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             {
               const int k = max(kg - j, kbot);
 #pragma unroll
-              for(int h = 0; h <= hb; ++h) cn[h][j] = RP(min(lane + 64 * h, k), k);
+              for(int h = 0; h <= hb; ++h) cn[h][j] = RP(RLDS ? lane + 64 * h : min(lane + 64 * h, k), k); // (LDS: an entry past the column's end is read and not used)
             }
           };
           fetch(ktop);
@@ -776,13 +777,14 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
 #pragma unroll
             for(int j = 0; j < TG; ++j)
             {
-              const int k = kg - j; // (k < kbot, past the block's lower end: the select below matches no lane)
+              const int k = kg - j;
+              const int kk = (k >= kbot) ? k : -1; // (scalar; past the block's lower end the compare below matches no lane)
               const double v = bcast_lane_s(div_pre(rv[hb], dg[hb], rinv[hb]), max(k, kbot) & 63);
 #pragma unroll
               for(int h = 0; h <= hb; ++h)
               {
                 const double upd = FMA(-cv[h][j], v, rv[h]);
-                rv[h] = (k >= kbot && lane + 64 * h < k) ? upd : rv[h];
+                rv[h] = (lane + 64 * h < kk) ? upd : rv[h];
               }
             }
           }
@@ -868,12 +870,9 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         }
       }
       __syncthreads();
-      if(tid == 0)
-      {
-        ctl->zz = (ctl->dotp[0] + ctl->dotp[2]) + (ctl->dotp[4] + ctl->dotp[6]);
-        ctl->cz = (pp < m) ? ((ctl->dotp[1] + ctl->dotp[3]) + (ctl->dotp[5] + ctl->dotp[7])) : zs[pp - m];
-      }
-      __syncthreads();
+      // (the waves' shares combined by every thread for itself -- the same four additions on the same operands: no second barrier)
+      step_zz = (ctl->dotp[0] + ctl->dotp[2]) + (ctl->dotp[4] + ctl->dotp[6]);
+      step_cz = (pp < m) ? ((ctl->dotp[1] + ctl->dotp[3]) + (ctl->dotp[5] + ctl->dotp[7])) : zs[pp - m];
       stamp(6);
     };
     // x += t z (if primal), f, u -= t r, u[q] += t   (DualSolver.cpp:136-150)
@@ -881,17 +880,18 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       if(!dual_only)
       {
         if(tid < n) xs[tid] = FMA(t, zs[tid], xs[tid]);
-        if(tid == 0) ctl->f = FMA(t * dotsc, 0.5 * t + us[q], ctl->f); // uses u[q] BEFORE its update
+        if(tid == 0) ctl->f = FMA(t * dotsc, 0.5 * t + us[q], ctl->f); // uses u[q] BEFORE its update (the same thread, below)
       }
-      __syncthreads();
       if(tid < q) us[tid] = FMA(-t, rs[tid], us[tid]);
       if(tid == 0) us[q] = us[q] + t;
       __syncthreads();
     };
     // addConstraint_ (GoldfarbIdnaniSolver.cpp:221-237): the coefficients come from compute_step (wave 1, speculative); sweep of
     // J one row per thread, new column of R
-    auto add_constraint = [&](int pp, int ps) {
+    auto add_constraint = [&](int pp, int ps, auto && beside) {
       // ((c_i, s_i) and rho: computed beside the step by wave 1, compute_step)
+      // beside(): what waves 2-3 do meanwhile when they have no row of J (n <= 128; the main loop: the NEXT pass's constraint scan)
+      const bool split = !WIDE && n <= 128;
       if(tid < n)
       {
         double carry = J[tid + (long)(n - 1) * ld];
@@ -922,9 +922,10 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         }
         if(n - 2 >= q) J[tid + (long)q * ld] = carry;
       }
+      if(!split || tid < 128)
       {
-        // R.col(q).head(q + 1) = d.head(q) | rho; the active set (threads from the top: up to n = 128 they have no row of J)
-        const int k = WGB - 1 - tid;
+        // R.col(q).head(q + 1) = d.head(q) | rho; the active set (beyond n = 128: threads from the top, whose rows come last)
+        const int k = split ? tid : WGB - 1 - tid;
         if(k < q)
           RP(k, q) = ds[k];
         else if(k == q)
@@ -935,6 +936,8 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           st[pp] = (unsigned char)ps;
         }
       }
+      else
+        beside();
       __syncthreads();
     };
     // removeConstraint (DualSolver.cpp:237-244) + removeConstraint_ (GoldfarbIdnaniSolver.cpp:239-256), orc remove_constraint
@@ -1113,30 +1116,33 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         else if(neq > 0)
         {
           // n+ of the NEXT initial constraint is requested before the current one's step (a column of C is a global round trip)
-          double npn = 0.0;
+          double npn = 0.0, bndn = 0.0;
           {
             const int p0 = act[0];
             if(p0 < m && tid < n) npn = Cg[(size_t)p0 * n + tid];
+            bndn = bound_of(p0, (p0 < m) ? B_EQUALITY : B_FIXED);
           }
           for(int k = 0; k < neq; ++k)
           {
             p = act[k];
             pstat = (p < m) ? B_EQUALITY : B_FIXED;
             if(p < m && tid < n) nps[tid] = npn;
+            const double bnd = bndn;
             if(k + 1 < neq)
             {
               const int pn = act[k + 1];
               if(pn < m && tid < n) npn = Cg[(size_t)pn * n + tid];
+              bndn = bound_of(pn, (pn < m) ? B_EQUALITY : B_FIXED);
             }
             if(tid == 0) us[q] = 0.0;
             __syncthreads();
             compute_step(p, pstat, false);
             // addInitialConstraint (:295-338): full step, no ratio test
-            const double cz = ctl->cz;
+            const double cz = step_cz;
             double t = 0.0;
-            if(__builtin_sqrt(ctl->zz) > 1e-14) t = (bound_of(p, pstat) - ctl->cx) / cz;
+            if(__builtin_sqrt(step_zz) > 1e-14) t = (bnd - ctl->cx) / cz;
             apply_step(t, cz, false);
-            add_constraint(p, pstat);
+            add_constraint(p, pstat, [] {});
             ++q;
           }
         }
@@ -1147,61 +1153,93 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     if(term == BT_SUCCESS)
     {
       bool skip = false;
+      // a thread's share of the constraint scan: constraints t, t + stride, ... (general ones, then the bounds), `excl` left out (the
+      // constraint an addition is activating meanwhile: its status byte is being written)
+      auto scan_part = [&](int t, int stride, int excl, double & bval, int & bidx, int & bstat, double & mycx, int & mybidx, double & mybnd) {
+        // (the limits of this thread's first bound are requested before the chains of its general constraints: one global round trip less
+        // behind them)
+        const double pxl = (t < nb) ? xlg[t] : 0.0, pxu = (t < nb) ? xug[t] : 0.0;
+        for(int i = t; i < m; i += stride)
+        {
+          if(i == excl || st[i] != B_INACTIVE) continue;
+          const double cx = chain_asc<false, 32>(Cg + (size_t)i * n, 1, xs, 1, 0, n, 0.0); // (32 loads in flight: C comes from L2 / HBM)
+          const double lo = blg[i];
+          const double sl = cx - lo;
+          if(sl < bval)
+          {
+            bval = sl;
+            bidx = i;
+            bstat = B_LOWER;
+            mycx = cx;
+            mybnd = lo;
+          }
+          else
+          {
+            const double up = BOX ? __builtin_inf() : bug[i];
+            const double su = up - cx;
+            if(su < bval)
+            {
+              bval = su;
+              bidx = i;
+              bstat = B_UPPER;
+              mycx = cx;
+              mybnd = up;
+            }
+          }
+        }
+        for(int i = t; i < nb; i += stride)
+        {
+          if(m + i == excl || st[m + i] != B_INACTIVE) continue;
+          const double xi = xs[i];
+          const double lo = (i == t) ? pxl : xlg[i];
+          const double sl = xi - lo;
+          if(sl < bval)
+          {
+            bval = sl;
+            bidx = m + i;
+            bstat = B_LOWER_BOUND;
+            mybnd = lo;
+          }
+          else
+          {
+            const double up = (i == t) ? pxu : xug[i];
+            const double su = up - xi;
+            if(su < bval)
+            {
+              bval = su;
+              bidx = m + i;
+              bstat = B_UPPER_BOUND;
+              mybnd = up;
+            }
+          }
+        }
+        mybidx = bidx; // this thread's own best constraint (before the reduction): it is the only thread that scanned it
+      };
+      // the scan of the pass BEHIND an addition runs beside that addition's sweep, on the waves that have no row of J (n <= 128): x is
+      // final before the sweep, the scan does not read J, and the constraint being activated is left out explicitly
+      bool prescanned = false;
+      double pre_val = 0.0, pre_cx = 0.0, pre_bnd = 0.0;
+      int pre_idx = NONE_B, pre_stat = B_INACTIVE, pre_my = NONE_B;
       term = BT_MAX_ITER;
       for(; it < A.max_iter; ++it)
       {
         if(!skip)
         {
           // selectViolatedConstraint_ (:84-134): most negative slack, general constraints first, lower before upper, first index
-          double bval = 0.0, mycx = 0.0;
-          int bidx = NONE_B, bstat = B_INACTIVE;
-          for(int i = tid; i < m; i += WGB)
+          double bval = 0.0, mycx = 0.0, mybnd = 0.0;
+          int bidx = NONE_B, bstat = B_INACTIVE, mybidx = NONE_B;
+          if(!prescanned)
+            scan_part(tid, WGB, -1, bval, bidx, bstat, mycx, mybidx, mybnd);
+          else if(tid >= 128) // (waves 2-3 scanned everything beside the sweep of the addition before)
           {
-            if(st[i] != B_INACTIVE) continue;
-            const double cx = chain_asc<false, 32>(Cg + (size_t)i * n, 1, xs, 1, 0, n, 0.0); // (32 loads in flight: C comes from L2 / HBM)
-            const double sl = cx - blg[i];
-            if(sl < bval)
-            {
-              bval = sl;
-              bidx = i;
-              bstat = B_LOWER;
-              mycx = cx;
-            }
-            else
-            {
-              const double su = (BOX ? __builtin_inf() : bug[i]) - cx;
-              if(su < bval)
-              {
-                bval = su;
-                bidx = i;
-                bstat = B_UPPER;
-                mycx = cx;
-              }
-            }
+            bval = pre_val;
+            bidx = pre_idx;
+            bstat = pre_stat;
+            mycx = pre_cx;
+            mybidx = pre_my;
+            mybnd = pre_bnd;
           }
-          const int mybidx = (bidx < m) ? bidx : NONE_B; // this thread's own best general constraint (before the reduction below)
-          for(int i = tid; i < nb; i += WGB)
-          {
-            if(st[m + i] != B_INACTIVE) continue;
-            const double xi = xs[i];
-            const double sl = xi - xlg[i];
-            if(sl < bval)
-            {
-              bval = sl;
-              bidx = m + i;
-              bstat = B_LOWER_BOUND;
-            }
-            else
-            {
-              const double su = xug[i] - xi;
-              if(su < bval)
-              {
-                bval = su;
-                bidx = m + i;
-                bstat = B_UPPER_BOUND;
-              }
-            }
-          }
+          prescanned = false;
           argmin3(bval, bidx, bstat);
           if(lane == 0)
           {
@@ -1232,19 +1270,23 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           p = ix;
           pstat = sx;
           load_np(p);
-          if(p < m && mybidx == p) ctl->cx = mycx; // (exactly one thread: the owner of constraint p)
+          if(mybidx == p) // (exactly one thread: the one that scanned constraint p; its candidate carries the selected status)
+          {
+            if(p < m) ctl->cx = mycx;
+            ctl->bnd = mybnd; // (the limit the slack was formed with: bound_of(p, pstat) without another global round trip)
+          }
           if(tid == 0) us[q] = 0.0; // DualSolver.cpp:121
           __syncthreads();
         }
         stamp(3);
         compute_step(p, pstat, !skip);
         // computeStepLength_ (:150-219)
-        const double cz = ctl->cz;
+        const double cz = step_cz;
         const double dotsc = (pstat == B_UPPER || pstat == B_UPPER_BOUND) ? -cz : cz; // ConstraintNormal::dot
         const double t1 = ctl->t1;
         const int l = ctl->l;
         double t2 = big;
-        if(__builtin_sqrt(ctl->zz) > 1e-14) t2 = (bound_of(p, pstat) - ctl->cx) / cz;
+        if(__builtin_sqrt(step_zz) > 1e-14) t2 = (ctl->bnd - ctl->cx) / cz; // (ctl->bnd == bound_of(p, pstat); it stays behind a removal: same p, same status)
         const double t = (t2 < t1) ? t2 : t1;
         if(A.trace && tid == 0 && it < A.trace_cap)
         {
@@ -1266,7 +1308,15 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         stamp(7);
         if(!dual_only && t == t2)
         {
-          add_constraint(p, pstat);
+          add_constraint(p, pstat, [&] {
+            pre_val = 0.0;
+            pre_cx = 0.0;
+            pre_idx = NONE_B;
+            pre_stat = B_INACTIVE;
+            pre_my = NONE_B;
+            scan_part(tid - 128, 128, p, pre_val, pre_idx, pre_stat, pre_cx, pre_my, pre_bnd);
+          });
+          prescanned = !WIDE && n <= 128;
           ++q;
           skip = false;
           stamp(8);
