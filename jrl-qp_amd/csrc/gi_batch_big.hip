@@ -218,6 +218,81 @@ __device__ double wave_add_chain(int n, int q, const double * dsm, double * rho,
   return r;
 }
 
+// A triangular solve on ONE wave with EPL entries per lane (rows lane, lane + 64, ...), nn <= 64 EPL unknowns: the lean step of
+// wave_fwd / wave_bwd (device_common.h) -- the quotient of the pivot row formed by every lane on its own entry with the pivots'
+// reciprocals hoisted (div_pre), one v_readlane pair, one fma and one select per entry block, the pivot column's coefficients
+// requested a group of steps ahead, no branch inside a group.  FWD: pivots k = 0 .. nn-1, rows e > k receive fma(-coef(e, k), x_k, .);
+// !FWD: pivots k = nn-1 .. 0, rows e < k.  coef(e, k) must be readable for every e < 64 EPL (the caller clamps), diag(e) for e < nn.
+// Row e's chain is the sequential one.  Returns false if an operand left the range in which the hoisted reciprocal is provably the
+// compiler's own quotient (the caller then redoes the solve with plain divisions); rv is then unspecified.
+template<int EPL, bool FWD, class COEF, class DIAG>
+__device__ __forceinline__ bool wave_tri_lean(double (&rv)[EPL], int nn, int lane, COEF coef, DIAG diag)
+{
+  nn = __builtin_amdgcn_readfirstlane(nn);
+  double dg[EPL], rinv[EPL];
+#pragma unroll
+  for(int h = 0; h < EPL; ++h)
+  {
+    const int e = lane + 64 * h;
+    dg[h] = (e < nn) ? diag(e) : 1.0;
+    rinv[h] = recip_refined(dg[h]);
+  }
+  constexpr int TG = 8;
+#pragma unroll
+  for(int hq = 0; hq < EPL; ++hq)
+  {
+    const int hb = FWD ? hq : EPL - 1 - hq;
+    const int klo = 64 * hb, khi = min(nn, 64 * hb + 64) - 1; // the pivots of entry block hb
+    if(khi < klo) continue;
+    double cn[EPL][TG], cv[EPL][TG];
+    // group starting at pivot kg (FWD: kg, kg + 1, ...; else kg, kg - 1, ...), pivots past the block's end clamped to its last one
+    auto fetch = [&](int kg) __attribute__((always_inline)) {
+#pragma unroll
+      for(int j = 0; j < TG; ++j)
+      {
+        const int k = FWD ? min(kg + j, khi) : max(kg - j, klo);
+#pragma unroll
+        for(int h = 0; h < EPL; ++h)
+          if(FWD ? (h >= hb) : (h <= hb)) cn[h][j] = coef(lane + 64 * h, k);
+      }
+    };
+    fetch(FWD ? klo : khi);
+    for(int kg = FWD ? klo : khi; FWD ? (kg <= khi) : (kg >= klo); kg += FWD ? TG : -TG)
+    {
+#pragma unroll
+      for(int j = 0; j < TG; ++j)
+#pragma unroll
+        for(int h = 0; h < EPL; ++h)
+          if(FWD ? (h >= hb) : (h <= hb)) cv[h][j] = cn[h][j];
+      fetch(FWD ? kg + TG : kg - TG); // (unconditional: clamped addresses; a branch here would make the steps wait for it)
+#pragma unroll
+      for(int j = 0; j < TG; ++j)
+      {
+        const int k = FWD ? kg + j : kg - j;
+        const bool in = FWD ? (k <= khi) : (k >= klo);
+        const int kk = in ? k : (FWD ? (1 << 30) : -1); // (scalar; past the block's end the compare below matches no lane)
+        const double v = bcast_lane_s(div_pre(rv[hb], dg[hb], rinv[hb]), (FWD ? min(k, khi) : max(k, klo)) & 63);
+#pragma unroll
+        for(int h = 0; h < EPL; ++h)
+          if(FWD ? (h >= hb) : (h <= hb))
+          {
+            const double upd = FMA(-cv[h][j], v, rv[h]);
+            rv[h] = (FWD ? (lane + 64 * h > kk) : (lane + 64 * h < kk)) ? upd : rv[h];
+          }
+      }
+    }
+  }
+  bool safe = true;
+#pragma unroll
+  for(int h = 0; h < EPL; ++h)
+  {
+    const double pre = rv[h]; // the numerators
+    safe = safe && (lane + 64 * h >= nn || (div_safe_den(dg[h]) && div_safe_num(pre)));
+    rv[h] = div_pre(pre, dg[h], rinv[h]);
+  }
+  return __all(safe);
+}
+
 // RLDS: R lives in LDS (compile-time, so that its accesses are ds_ instructions: with a run-time choice between LDS and the
 // global scratch every access to R is a FLAT load, and the substitution -- two dependent loads per step -- pays ~500 cycles each)
 // WARM: warm-started solve (experimental::GoldfarbIdnaniSolver, src/experimental/GoldfarbIdnaniSolver.cpp:20-112, :306-487; oracle
@@ -603,8 +678,9 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       }
       else
       // ---------------------------------------------------------------- x0 = -L^-T L^-1 a, f0 (GoldfarbIdnaniSolver.cpp:68-74)
-      // thread i owns x_i; one barrier per substitution step (the pivot travels through LDS)
+      if constexpr(WIDE)
       {
+        // thread i owns x_i; one barrier per substitution step (the pivot travels through LDS)
         double xi = (tid < n) ? ag[tid] : 0.0;
         for(int k = 0; k < n; ++k) // x = L.solve(a)
         {
@@ -635,19 +711,88 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         __syncthreads();
         if(tid == 0) ctl->f = 0.5 * chain_asc<false>(ag, 1, xs, 1, 0, n, 0.0);
       }
+      else
+      {
+        if(tid < n) dgl[tid] = M[tid + (long)tid * ld];
+        __syncthreads();
+      }
       if constexpr(!BOX)
       {
-      // ---------------------------------------------------------------- J = L^-T in place (orc_inv_lt), row by row from the bottom:
-      // J(i,c) = (delta_ic - sum_{k = c .. i+1, descending} L(k,i) J(k,c)) / L(i,i): column i of L is last read by row i of
-      // J, which only writes the upper triangle -- the two share the array, L's diagonal is in dgl
-      for(int i = n - 1; i >= 0; --i)
+      // ---------------------------------------------------------------- J = L^-T in place (orc_inv_lt):
+      // J(i,c) = (delta_ic - sum_{k = c .. i+1, descending} L(k,i) J(k,c)) / L(i,i).  L (strictly lower) and J (upper) share the
+      // array, L's diagonal is in dgl.
+      if constexpr(WIDE)
       {
-        const int c = i + tid;
-        if(c < n)
+        // row by row from the bottom over all threads (column i of L is last read by row i of J)
+        for(int i = n - 1; i >= 0; --i)
         {
-          double acc = (c == i) ? 1.0 : 0.0;
-          acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
-          M[i + (long)c * ld] = acc / dgl[i];
+          const int c = i + tid;
+          if(c < n)
+          {
+            double acc = (c == i) ? 1.0 : 0.0;
+            acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
+            M[i + (long)c * ld] = acc / dgl[i];
+          }
+          __syncthreads();
+        }
+      }
+      else
+      {
+        // n <= 128 (round 4): a column of J is a back substitution of its own -- thread c runs column c from its diagonal up and meets
+        // nobody else's entries, so there is no barrier between the rows (round 3 dealt the columns of a row to the lowest threads and
+        // paid a barrier per row); waves 0-1 hold the columns.  Beside them wave 2 computes x0 with the lean wave-level substitutions
+        // (two entries per lane, no barrier either: round 3 spent 2 n barrier steps with a division each on it).
+        if(tid < n)
+        {
+          const int c = tid;
+          for(int i = c; i >= 0; --i)
+          {
+            double acc = (c == i) ? 1.0 : 0.0;
+            acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
+            M[i + (long)c * ld] = acc / dgl[i];
+          }
+        }
+        else if(!WARM && wave == 2) // (a warm start computes its own point later)
+        {
+          double xv[EPL];
+#pragma unroll
+          for(int h = 0; h < EPL; ++h) xv[h] = (lane + 64 * h < n) ? ag[lane + 64 * h] : 0.0;
+          const int nl = n - 1;
+          bool ok = wave_tri_lean<EPL, true>(xv, n, lane, [&](int e, int k) { return M[min(e, nl) + (long)k * ld]; }, [&](int e) { return dgl[e]; });
+          if(ok) ok = wave_tri_lean<EPL, false>(xv, n, lane, [&](int e, int k) { return M[k + (long)min(e, nl) * ld]; }, [&](int e) { return dgl[e]; });
+          if(!ok)
+          {
+            // plain divisions, step by step (an operand outside the safe range of the hoisted reciprocals)
+#pragma unroll
+            for(int h = 0; h < EPL; ++h) xv[h] = (lane + 64 * h < n) ? ag[lane + 64 * h] : 0.0;
+            for(int k = 0; k < n; ++k)
+            {
+              const double v = vec_bcast(xv, k) / dgl[k];
+#pragma unroll
+              for(int h = 0; h < EPL; ++h)
+              {
+                const int e = lane + 64 * h;
+                if(e == k) xv[h] = v;
+                if(e > k && e < n) xv[h] = FMA(-M[e + (long)k * ld], v, xv[h]);
+              }
+            }
+            for(int k = n - 1; k >= 0; --k)
+            {
+              const double v = vec_bcast(xv, k) / dgl[k];
+#pragma unroll
+              for(int h = 0; h < EPL; ++h)
+              {
+                const int e = lane + 64 * h;
+                if(e == k) xv[h] = v;
+                if(e < k) xv[h] = FMA(-M[k + (long)e * ld], v, xv[h]);
+              }
+            }
+          }
+#pragma unroll
+          for(int h = 0; h < EPL; ++h)
+            if(lane + 64 * h < n) xs[lane + 64 * h] = -xv[h];
+          wave_sync();
+          if(lane == 0) ctl->f = 0.5 * chain_asc<false>(ag, 1, xs, 1, 0, n, 0.0);
         }
         __syncthreads();
       }
