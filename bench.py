@@ -504,7 +504,15 @@ def bench_structured(args, rank, world, device, jdist, emit=True):
                                                   "what": "compulsory bytes + the reflector rows both Q applications of every iteration re-read "
                                                           "(sum over iterations of 2 k n 8 bytes): traffic of this data structure, not of the problem"},
                          "note": "frac is against the COMPULSORY bytes of SURVEY 8(d); the kernel is bandwidth-relevant only through its own re-reads "
-                                 "(implementation_model), and a single CU per problem is instruction-issue/barrier bound (DESIGN.md 7.3)"},
+                                 "(implementation_model), and a single CU per problem is instruction-issue/barrier bound (DESIGN.md 7.3)",
+                         "floor_argument": "the re-read rows ARE the reference's data structure: StructuredQR keeps Q as an OrthonormalSequence of "
+                                           "Householder elements applied one after another (src/internal/OrthonormalSequence.cpp:189-226), an iteration applies "
+                                           "every element made so far twice (Q^T d, then Q z, which depends on d), and one problem's elements (iterations x n x 8 "
+                                           "bytes = 14 MB at c5) exceed LDS + registers, a batch's exceed L2 + Infinity Cache: implementation_model is the "
+                                           "floor of this data structure, and against it the kernel runs at implementation_model.frac of the HBM peak (measured "
+                                           "traffic: traffic_over_implementation_model x that; the excess is the zero padding of the rows outside their "
+                                           "support).  Headroom without changing the data structure (and with it the rounding contract): support-only rows "
+                                           "(-17 % bytes) and 0.85 of peak instead of 0.70 => at most 1.45x (DESIGN.md 7.3)"},
         }
         out["ms_per_step_min"], out["ms_per_step_median"] = float(np.min(kern_ms)), float(np.median(kern_ms))
         if traffic is not None:

@@ -94,7 +94,7 @@ __device__ __forceinline__ double chain_rl(const double * a, long sa, double b0,
 }
 // b through SGPRs: the broadcast operand read once per group by lane 0 ... (here: every lane reads, then readfirstlane)
 template<int MODE>
-__global__ __launch_bounds__(256) void k(int n, int reps, int active, long long * out, double * sink)
+__global__ __launch_bounds__(256) void k(int n, int reps, int active, long long * out, double * sink, const double * __restrict__ gv)
 {
   extern __shared__ double sm[];
   const int ld = n | 1, tid = threadIdx.x;
@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void k(int n, int reps, int active, long long 
       if(MODE == 5) dj = chain_simple<4>(J + (long)tid * ld, 1, v, 1, 0, n, acc * 1e-300);
       if(MODE == 6) dj = chain_rl<8>(J + (long)tid * ld, 1, v[threadIdx.x & 63], v[(threadIdx.x & 63) + 36], 0, n, acc * 1e-300);
       if(MODE == 7) dj = chain_rl<8>(J + tid, ld, v[threadIdx.x & 63], v[(threadIdx.x & 63) + 36], 0, n, acc * 1e-300);
+      if(MODE == 8) dj = chain_simple<8>(J + (long)tid * ld, 1, gv + (r & 7) * n, 1, 0, n, acc * 1e-300); // b: a wave-uniform vector in GLOBAL memory (const __restrict__)
+      if(MODE == 9) dj = chain_simple<16>(J + (long)tid * ld, 1, gv + (r & 7) * n, 1, 0, n, acc * 1e-300);
       d[tid] = dj;
       acc += dj;
     }
@@ -129,26 +131,28 @@ __global__ __launch_bounds__(256) void k(int n, int reps, int active, long long 
 int main()
 {
   long long * out; double * sink;
-  hipMalloc(&out, 8); hipMalloc(&sink, 8 * 256);
+  double * gv; (void)hipMalloc(&out, 8); (void)hipMalloc(&sink, 8 * 256); (void)hipMalloc(&gv, 8 * 1024); (void)hipMemset(gv, 0, 8 * 1024);
   const int n = 100, reps = 2000;
   size_t lds = sizeof(double) * ((size_t)n * (n | 1) + 2 * n);
-  const char * names[] = {"simple<8> column (d)", "pipelined<8> column (d)", "simple<8> row (z)", "pipelined<8> row (z)", "simple<16> column", "simple<4> column", "readlane<8> column (d)", "readlane<8> row (z)"};
+  const char * names[] = {"simple<8> column (d)", "pipelined<8> column (d)", "simple<8> row (z)", "pipelined<8> row (z)", "simple<16> column", "simple<4> column", "readlane<8> column (d)", "readlane<8> row (z)", "b from global memory <8>", "b from global memory <16>"};
   for(int active : {100, 64})
-    for(int mode = 0; mode < 8; ++mode)
+    for(int mode = 0; mode < 10; ++mode)
     {
       long long h = 0;
       for(int rep = 0; rep < 2; ++rep)
       {
         switch(mode)
         {
-          case 0: hipLaunchKernelGGL(k<0>, 1, 256, lds, 0, n, reps, active, out, sink); break;
-          case 1: hipLaunchKernelGGL(k<1>, 1, 256, lds, 0, n, reps, active, out, sink); break;
-          case 2: hipLaunchKernelGGL(k<2>, 1, 256, lds, 0, n, reps, active, out, sink); break;
-          case 3: hipLaunchKernelGGL(k<3>, 1, 256, lds, 0, n, reps, active, out, sink); break;
-          case 4: hipLaunchKernelGGL(k<4>, 1, 256, lds, 0, n, reps, active, out, sink); break;
-          case 5: hipLaunchKernelGGL(k<5>, 1, 256, lds, 0, n, reps, active, out, sink); break;
-          case 6: hipLaunchKernelGGL(k<6>, 1, 256, lds, 0, n, reps, active, out, sink); break;
-          case 7: hipLaunchKernelGGL(k<7>, 1, 256, lds, 0, n, reps, active, out, sink); break;
+          case 0: hipLaunchKernelGGL(k<0>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 1: hipLaunchKernelGGL(k<1>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 2: hipLaunchKernelGGL(k<2>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 3: hipLaunchKernelGGL(k<3>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 4: hipLaunchKernelGGL(k<4>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 5: hipLaunchKernelGGL(k<5>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 6: hipLaunchKernelGGL(k<6>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 7: hipLaunchKernelGGL(k<7>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 8: hipLaunchKernelGGL(k<8>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
+          case 9: hipLaunchKernelGGL(k<9>, 1, 256, lds, 0, n, reps, active, out, sink, gv); break;
         }
         hipDeviceSynchronize();
         hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
