@@ -399,10 +399,13 @@ int jrlqp_dense_sync_mode(const jrlqp_dense * h, int * event_reruns);
  * problems), so that the compute calls allocate nothing.  Blocks stay in caller-owned device memory and are factored
  * in place exactly like the reference does (diag[i] lower triangle <- L_i, side[i] <- B_i or B_i^T).
  *   kind: 0 = block arrow pointing down (up = false), 1 = block arrow pointing up (up = true), 2 = block tridiagonal
- *   block_sizes[nblk] (host); every block <= JRLQP_BLOCK_MAX rows (one wavefront, row per lane).
+ *   block_sizes[nblk] (host); every block <= JRLQP_BLOCK_MAX rows (up to 64 rows: one wavefront, row per lane, everything of a
+ *   block in LDS at once; 65 .. 128 rows (round 4): two rows per lane, side blocks pass through LDS in panels -- same results per
+ *   element, slower kernels).
  *   side block i: kind 0: n_last x n_i; kind 1: n_{i+1} x n_0; kind 2: n_{i+1} x n_i.
  */
-#define JRLQP_BLOCK_MAX 64
+#define JRLQP_BLOCK_MAX 128
+#define JRLQP_BLOCKGI_BLOCK_MAX 64 /* the structured GI loop (jrlqp_blockgi_*) */
 typedef struct jrlqp_blocks jrlqp_blocks;
 int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, int max_nrhs, jrlqp_blocks ** out);
 void jrlqp_blocks_destroy(jrlqp_blocks * plan);
@@ -438,7 +441,8 @@ int jrlqp_blocks_solve(jrlqp_blocks * plan, int transpose, double * dM, int ldm,
  *                                        column); sum cvar = nbVar; + jrlqp_blockgi_bind(dcblk, ldc)
  * The whole active-set loop runs on the device (one workgroup per problem, one launch per batch); the orthonormal
  * sequence grows by one element per iteration, so the plan's workspace is sized by `max_iter` at creation and
- * options.max_iter must not exceed it.  n <= 3072 unknowns per problem (the vectors of unknowns live in LDS).
+ * options.max_iter must not exceed it.  n <= 3072 unknowns per problem (the vectors of unknowns live in LDS); blocks of at most
+ * JRLQP_BLOCKGI_BLOCK_MAX rows.
  * As in the reference, only the cold start without data equalities / fixed variables is functional (the reference
  * asserts in initializePrimalDualPoints, BlockGISolver.cpp:475): such inputs return INCONSISTENT_INPUT per problem.
  * Outputs as jrlqp_gi_solve_batch: x [nprob*n], sign-expanded multipliers u and activation status [nprob*(m+nb)],

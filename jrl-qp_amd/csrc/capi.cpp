@@ -582,6 +582,7 @@ static jrlqp::BlockDesc make_desc(const jrlqp_blocks * p, long mstride)
   d.bs = p->d_bs; d.ldd = p->d_ldd; d.lds = p->d_lds;
   d.diag = p->d_diag; d.side = p->d_side; d.fail = p->d_fail;
   d.h_bs = p->h_bs.data();
+  d.xs_cap = 0; // (set by the factorisation launch helpers)
   return d;
 }
 
@@ -661,6 +662,7 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   for(int i = 0; i < nblk; ++i)
   {
     if(block_sizes[i] < 1) return JRLQP_ERR_INVALID_ARGUMENT;
+    if(block_sizes[i] > JRLQP_BLOCKGI_BLOCK_MAX) return JRLQP_ERR_UNSUPPORTED_SIZE;
     n += block_sizes[i];
   }
   for(int i = 0; i < ncb; ++i)

@@ -484,6 +484,42 @@ __device__ __forceinline__ double chain_neg8(int k0, int step, int cnt, double a
   return acc;
 }
 
+// ---- blocks of 65 .. 128 rows (round 4): two entries per lane (rows lane and lane + 64), two 64-row stages ------------------------
+// x = (a, b) <- L^-1 x, n <= 128.  Stage 1 is wave_fwd on the leading 64 x 64 block; then rows 64 .. n-1 receive their terms of the
+// first 64 unknowns -- k ascending, the unknowns handed out by v_readlane, the coefficients fetched ahead --; stage 2 is wave_fwd on
+// the trailing block.  Row e's chain is the sequential one (terms k = 0 .. e-1 in order), so the bits are those of a single
+// substitution over all n rows.  n <= 64: exactly wave_fwd (b is not touched).
+__device__ __forceinline__ void wave_fwd2(const double * L, int ldl, int n, double & a, double & b, int lane)
+{
+  n = __builtin_amdgcn_readfirstlane(n);
+  if(n <= 64)
+  {
+    a = wave_fwd(L, ldl, n, a, lane);
+    return;
+  }
+  a = wave_fwd(L, ldl, 64, a, lane);
+  const int n1 = n - 64, rl = 64 + min(lane, n1 - 1);
+  const double a0 = a;
+  b = chain_neg8(0, 1, 64, b, [&](int k) { return AT(L, ldl, rl, k); }, [&](int k) { return bcast_lane(a0, k); });
+  b = wave_fwd(L + 64 + (size_t)64 * ldl, ldl, n1, b, lane);
+}
+// x = (a, b) <- L^-T x, n <= 128: the trailing block first, then rows 0 .. 63 receive their terms of the unknowns 64 .. n-1 (k
+// descending), then the leading block
+__device__ __forceinline__ void wave_bwd2(const double * L, int ldl, int n, double & a, double & b, int lane)
+{
+  n = __builtin_amdgcn_readfirstlane(n);
+  if(n <= 64)
+  {
+    a = wave_bwd(L, ldl, n, a, lane);
+    return;
+  }
+  const int n1 = n - 64;
+  b = wave_bwd(L + 64 + (size_t)64 * ldl, ldl, n1, b, lane);
+  const double b0 = b;
+  a = chain_neg8(n - 1, -1, n1, a, [&](int k) { return AT(L, ldl, k, lane); }, [&](int k) { return bcast_lane(b0, k - 64); });
+  a = wave_bwd(L, ldl, 64, a, lane);
+}
+
 // same with BOTH operand streams fetched ahead (operands in LDS: a dependent loop that reads, waits and fmas one term at
 // a time pays one LDS round trip per term; eight terms in flight hide it)
 template<class FA, class FB>

@@ -16,6 +16,7 @@ struct BlockDesc
   double ** side;  // [nprob*(nblk-1)] device pointers
   int * fail;      // [nprob] set to 1 when a factorisation fails
   const int * h_bs; // host copy of bs (launch helpers only)
+  int xs_cap;      // doubles of LDS the factorisation kernels may use for a panel of a side block (set by the launch helpers)
 };
 
 hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st);

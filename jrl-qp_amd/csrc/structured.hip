@@ -173,14 +173,15 @@ __global__ __launch_bounds__(kTriThreads) void arrow_block_kernel(const BlockDes
   const int ldd = D.ldd[id], ldsg = D.lds[i];
   const int ldl = ni | 1;
   double * Ls = sm;
-  double * Xs = Ls + (size_t)ni * ldl;
-  const int ldx = D.up ? (ni | 1) : (nbk | 1);
-  double * diagL = Xs + (size_t)(D.up ? nbk : ni) * ldx;
+  double * diagL = Ls + (size_t)ni * ldl;
+  double * Xs = diagL + ((ni + 1) & ~1);
+  // The side block goes through LDS in PANELS that fit behind L (round 4: blocks of up to 128 rows -- L alone is 132 KB then): rows of
+  // side[i] for the down arrow (X <- X L^-T: a row meets only itself), columns for the up arrow (X <- L^-1 X: so does a column).  Up
+  // to 64 rows everything is one panel, as before.
+  const int prow = D.up ? ni : min(nbk, max(1, D.xs_cap / ni - 1));               // rows of a panel
+  const int pcol = D.up ? min(nbk, max(1, D.xs_cap / (ni | 1))) : ni;             // columns of a panel
+  const int ldx = prow | 1;
   load_block(Ls, ldl, Dg, ldd, ni, ni, tid, kTriThreads);
-  if(!D.up)
-    load_block(Xs, ldx, Sg, ldsg, nbk, ni, tid, kTriThreads); // side[i]: nbk x ni
-  else
-    load_block(Xs, ldx, Sg, ldsg, ni, nbk, tid, kTriThreads); // side[i]: ni x nbk
   __syncthreads();
   const int ret = block_llt(Ls, ldl, ni, diagL, tid);
   __syncthreads();
@@ -197,13 +198,27 @@ __global__ __launch_bounds__(kTriThreads) void arrow_block_kernel(const BlockDes
   if(ret > 0) return;
   if(!D.up)
   {
-    block_trsm_right_lt(Ls, ldl, diagL, ni, Xs, ldx, nbk, tid); // side[i] <- side[i] L_i^-T   (:71-72)
-    for(int e = tid; e < nbk * ni; e += kTriThreads) AT(Sg, ldsg, e % nbk, e / nbk) = AT(Xs, ldx, e % nbk, e / nbk);
+    for(int r0 = 0; r0 < nbk; r0 += prow) // side[i] <- side[i] L_i^-T   (:71-72), side[i]: nbk x ni
+    {
+      const int rows = min(prow, nbk - r0);
+      __syncthreads();
+      load_block(Xs, ldx, Sg + r0, ldsg, rows, ni, tid, kTriThreads);
+      __syncthreads();
+      block_trsm_right_lt(Ls, ldl, diagL, ni, Xs, ldx, rows, tid);
+      for(int e = tid; e < rows * ni; e += kTriThreads) AT(Sg, ldsg, r0 + e % rows, e / rows) = AT(Xs, ldx, e % rows, e / rows);
+    }
   }
   else
   {
-    block_trsm_left(Ls, ldl, diagL, ni, Xs, ldx, nbk, tid); // side[i] <- L_i^-1 side[i]; it then stores B_i^T   (:68-70)
-    for(int e = tid; e < ni * nbk; e += kTriThreads) AT(Sg, ldsg, e % ni, e / ni) = AT(Xs, ldx, e % ni, e / ni);
+    for(int c0 = 0; c0 < nbk; c0 += pcol) // side[i] <- L_i^-1 side[i]; it then stores B_i^T   (:68-70), side[i]: ni x nbk
+    {
+      const int cols = min(pcol, nbk - c0);
+      __syncthreads();
+      load_block(Xs, ldx, Sg + (size_t)c0 * ldsg, ldsg, ni, cols, tid, kTriThreads);
+      __syncthreads();
+      block_trsm_left(Ls, ldl, diagL, ni, Xs, ldx, cols, tid);
+      for(int e = tid; e < ni * cols; e += kTriThreads) AT(Sg, ldsg, e % ni, c0 + e / ni) = AT(Xs, ldx, e % ni, e / ni);
+    }
   }
 }
 
@@ -300,6 +315,80 @@ __global__ __launch_bounds__(256) void arrow_head_kernel(const BlockDesc D)
   }
 }
 
+// The head block when a block has more than 64 rows (round 4; up to 128): 64 lower-triangle elements per thread, ONE LDS region of
+// maxb x (maxb | 1) doubles that holds the current side block while the products are accumulated and the head block afterwards
+// (block_llt, 256 threads, right-looking -- per element the same chain as wave_llt's column-by-column order).  On a failure at column
+// j the finished columns are written back and the columns from j on keep their rank-updated values, as the reference's in-place LLT
+// leaves them.
+__global__ __launch_bounds__(256) void arrow_head_big_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x;
+  const int pb = blockIdx.x;
+  const int ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int nbk = D.bs[ib];
+  double * Dg = D.diag[(size_t)pb * D.nblk + ib];
+  const int ldd = D.ldd[ib];
+  const int ldl = nbk | 1;
+  if(D.fail[pb]) return; // a block already failed: the reference returns false before touching D_b further
+  constexpr int SL = 64;
+  double acc[SL];
+#pragma unroll
+  for(int s = 0; s < SL; ++s)
+  {
+    const int e = tid + 256 * s;
+    const int r = e % nbk, c = e / nbk;
+    acc[s] = (e < nbk * nbk && r >= c) ? AT(Dg, ldd, r, c) : 0.0;
+  }
+  for(int i = 0; i < D.nblk - 1; ++i)
+  {
+    const int id = dsel(D.nblk, D.up, i);
+    const int ni = D.bs[id];
+    const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+    const int ldsg = D.lds[i];
+    const int rows = D.up ? ni : nbk, cols = D.up ? nbk : ni; // stored shape of side[i]
+    const int ldb = rows | 1;
+    __syncthreads();
+    load_block(sm, ldb, Sg, ldsg, rows, cols, tid, 256);
+    __syncthreads();
+#pragma unroll
+    for(int s = 0; s < SL; ++s)
+    {
+      const int e = tid + 256 * s;
+      const int r = e % nbk, c = e / nbk;
+      if(e < nbk * nbk && r >= c)
+      {
+        if(!D.up) // B_i(r,k) B_i(c,k)
+          acc[s] = chain2_neg(0, 1, ni, acc[s], [&](int k) { return sm[r + k * ldb]; }, [&](int k) { return sm[c + k * ldb]; });
+        else // side stores B_i^T
+          acc[s] = chain2_neg(0, 1, ni, acc[s], [&](int k) { return sm[k + r * ldb]; }, [&](int k) { return sm[k + c * ldb]; });
+      }
+    }
+  }
+  __syncthreads();
+  double * Ls = sm;
+  double * diagL = sm + (size_t)nbk * ldl;
+#pragma unroll
+  for(int s = 0; s < SL; ++s)
+  {
+    const int e = tid + 256 * s;
+    const int r = e % nbk, c = e / nbk;
+    if(e < nbk * nbk && r >= c) AT(Ls, ldl, r, c) = acc[s];
+  }
+  __syncthreads();
+  const int ret = block_llt(Ls, ldl, nbk, diagL, tid);
+  __syncthreads();
+  if(ret > 0 && tid == 0) atomicExch(&D.fail[pb], 1); // (:80) ret <= 0 is success
+  const int done = (ret < 0) ? nbk : ret;
+#pragma unroll
+  for(int s = 0; s < SL; ++s)
+  {
+    const int e = tid + 256 * s;
+    const int r = e % nbk, c = e / nbk;
+    if(e < nbk * nbk && r >= c) AT(Dg, ldd, r, c) = (c >= done) ? acc[s] : ((r == c) ? diagL[c] : AT(Ls, ldl, r, c));
+  }
+}
+
 // =========================================================================================================
 // block arrow solves.  M is N x nrhs column-major (already permuted for the up variant).
 // =========================================================================================================
@@ -320,9 +409,11 @@ __global__ __launch_bounds__(64) void arrow_lsolve_blocks_kernel(const BlockDesc
   for(int c = 0; c < nrhs; ++c)
   {
     double * Mi = Mp + n0 + s + (size_t)c * ldm;
-    double xi = (lane < ni - s) ? Mi[lane] : 0.0;
-    xi = wave_fwd(Lsub, ldd, ni - s, xi, lane);
-    if(lane < ni - s) Mi[lane] = xi;
+    const int nr = ni - s;
+    double xa = (lane < nr) ? Mi[lane] : 0.0, xb = (lane + 64 < nr) ? Mi[lane + 64] : 0.0; // (rows lane, lane + 64: blocks of up to 128 rows)
+    wave_fwd2(Lsub, ldd, nr, xa, xb, lane);
+    if(lane < nr) Mi[lane] = xa;
+    if(lane + 64 < nr) Mi[lane + 64] = xb;
   }
 }
 
@@ -339,28 +430,38 @@ __global__ __launch_bounds__(64) void arrow_lsolve_head_kernel(const BlockDesc D
   for(int c = 0; c < nrhs; ++c)
   {
     double * Mb = Mp + (ntot - nbk) + (size_t)c * ldm;
-    double acc = (lane < nbk) ? Mb[lane] : 0.0;
+    double acc[2]; // rows lane, lane + 64 of the head block
+#pragma unroll
+    for(int h = 0; h < 2; ++h) acc[h] = (lane + 64 * h < nbk) ? Mb[lane + 64 * h] : 0.0;
     int n0 = 0;
     for(int i = 0; i < D.nblk - 1; ++i)
     {
       const int id = dsel(D.nblk, D.up, i);
       const int ni = D.bs[id];
       int s = max(start - n0, 0);
-      if(!(ni < s || end <= n0) && lane < nbk)
+      if(!(ni < s || end <= n0))
       {
         const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
         const int ldsg = D.lds[i];
         const double * Xi = Mp + n0 + (size_t)c * ldm;
-        for(int k = s; k < ni; ++k)
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
         {
-          double bv = D.up ? AT(Sg, ldsg, k, lane) : AT(Sg, ldsg, lane, k);
-          acc = FMA(-bv, Xi[k], acc);
+          const int r = lane + 64 * h;
+          if(r < nbk)
+            for(int k = s; k < ni; ++k)
+            {
+              double bv = D.up ? AT(Sg, ldsg, k, r) : AT(Sg, ldsg, r, k);
+              acc[h] = FMA(-bv, Xi[k], acc[h]);
+            }
         }
       }
       n0 += ni;
     }
-    acc = wave_fwd(Lb, D.ldd[ib], nbk, acc, lane);
-    if(lane < nbk) Mb[lane] = acc;
+    wave_fwd2(Lb, D.ldd[ib], nbk, acc[0], acc[1], lane);
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+      if(lane + 64 * h < nbk) Mb[lane + 64 * h] = acc[h];
   }
 }
 
@@ -379,9 +480,10 @@ __global__ __launch_bounds__(64) void arrow_ltsolve_head_kernel(const BlockDesc 
   for(int c = 0; c < nrhs; ++c)
   {
     double * Mb = Mp + (ntot - nbk) + (size_t)c * ldm;
-    double xi = (lane < r) ? Mb[lane] : 0.0;
-    xi = wave_bwd(Lb, D.ldd[ib], r, xi, lane);
-    if(lane < r) Mb[lane] = xi;
+    double xa = (lane < r) ? Mb[lane] : 0.0, xb = (lane + 64 < r) ? Mb[lane + 64] : 0.0;
+    wave_bwd2(Lb, D.ldd[ib], r, xa, xb, lane);
+    if(lane < r) Mb[lane] = xa;
+    if(lane + 64 < r) Mb[lane + 64] = xb;
   }
 }
 
@@ -408,20 +510,30 @@ __global__ __launch_bounds__(64) void arrow_ltsolve_blocks_kernel(const BlockDes
   {
     double * Mi = Mp + n0 + (size_t)c * ldm;
     const double * Xb = Mp + (ntot - nbk) + (size_t)c * ldm;
-    double acc = (lane < ni) ? Mi[lane] : 0.0;
-    if(!zero && lane < ni)
-      for(int k = nbk - 1; k >= 0; --k)
-      {
-        double bv = D.up ? AT(Sg, ldsg, lane, k) : AT(Sg, ldsg, k, lane);
-        acc = FMA(-bv, Xb[k], acc);
-      }
+    double acc[2]; // rows lane, lane + 64 of block i
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+    {
+      const int r = lane + 64 * h;
+      acc[h] = (r < ni) ? Mi[r] : 0.0;
+      if(!zero && r < ni)
+        for(int k = nbk - 1; k >= 0; --k)
+        {
+          double bv = D.up ? AT(Sg, ldsg, r, k) : AT(Sg, ldsg, k, r);
+          acc[h] = FMA(-bv, Xb[k], acc[h]);
+        }
+    }
     if(end >= n0)
     {
       const int r = (end >= n0 + ni) ? ni : (end - n0);
-      double solved = wave_bwd(Li, ldd, r, acc, lane);
-      acc = (lane < r) ? solved : acc;
+      double sa = acc[0], sb = acc[1];
+      wave_bwd2(Li, ldd, r, sa, sb, lane);
+      acc[0] = (lane < r) ? sa : acc[0];
+      acc[1] = (lane + 64 < r) ? sb : acc[1];
     }
-    if(lane < ni) Mi[lane] = acc;
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+      if(lane + 64 * h < ni) Mi[lane + 64 * h] = acc[h];
   }
 }
 
@@ -520,6 +632,78 @@ __device__ void tri_llt_from(const BlockDesc & D, int i0, double * sm)
     double * t = Ls; // the updated next block becomes the current one
     Ls = Ns;
     Ns = t;
+  }
+}
+
+// The same chain when a block has more than 64 rows (round 4; up to 128): three blocks no longer fit in LDS, so there is ONE block
+// region -- the diagonal block while it is factorised, then the finished sub-diagonal block while D_{i+1} receives its rank update --
+// and a panel region through which S_i <- S_i L_i^-T passes in row panels (as in arrow_block_kernel).  D_{i+1} is updated in memory
+// (read, chain out of LDS, written) and fetched again as the next diagonal block.  Per element the chains are tri_llt_from's.
+__global__ __launch_bounds__(kTriThreads) void tri_llt_big_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, pb = blockIdx.x;
+  int maxb = 0;
+  for(int k = 0; k < D.nblk; ++k) maxb = max(maxb, D.bs[k]);
+  double * Ls = sm;
+  double * diagL = Ls + (size_t)maxb * (maxb | 1);
+  double * Xs = diagL + ((maxb + 1) & ~1);
+  for(int i = 0; i < D.nblk; ++i)
+  {
+    const int ni = D.bs[i];
+    const int ldl = ni | 1;
+    double * Dg = D.diag[(size_t)pb * D.nblk + i];
+    const int ldd = D.ldd[i];
+    const bool last = (i == D.nblk - 1);
+    __syncthreads();
+    load_block(Ls, ldl, Dg, ldd, ni, ni, tid, kTriThreads);
+    __syncthreads();
+    const int ret = block_llt(Ls, ldl, ni, diagL, tid);
+    __syncthreads();
+    const int cols = (ret < 0) ? ni : ret; // the factor goes back: all of the lower triangle on success, the finished columns on failure
+    for(int e = tid; e < ni * cols; e += kTriThreads)
+    {
+      const int r = e % ni, c = e / ni;
+      if(r > c)
+        AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+      else if(r == c)
+        AT(Dg, ldd, r, c) = diagL[c];
+    }
+    if(ret > 0) // triBlockDiagLLT.cpp:19,32 (a failure at column 0 goes undetected there, and here)
+    {
+      if(tid == 0) D.fail[pb] = 1;
+      return;
+    }
+    if(last) break;
+    const int n1 = D.bs[i + 1];
+    double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+    const int ldsg = D.lds[i];
+    const int prow = min(n1, max(1, D.xs_cap / ni - 1)), ldx = prow | 1;
+    for(int r0 = 0; r0 < n1; r0 += prow) // S_i <- S_i L_i^-T, S_i: n1 x ni
+    {
+      const int rows = min(prow, n1 - r0);
+      __syncthreads();
+      load_block(Xs, ldx, Sg + r0, ldsg, rows, ni, tid, kTriThreads);
+      __syncthreads();
+      block_trsm_right_lt(Ls, ldl, diagL, ni, Xs, ldx, rows, tid);
+      for(int e = tid; e < rows * ni; e += kTriThreads) AT(Sg, ldsg, r0 + e % rows, e / rows) = AT(Xs, ldx, e % rows, e / rows);
+    }
+    // D_{i+1} -= S_i S_i^T (lower): the finished S_i comes back into the block region (this workgroup's own stores: visible behind
+    // the fence and the barrier), one element per thread and round, terms in ascending k
+    __threadfence_block();
+    __syncthreads();
+    const int lds1 = n1 | 1;
+    load_block(Ls, lds1, Sg, ldsg, n1, ni, tid, kTriThreads);
+    __syncthreads();
+    double * Dn = D.diag[(size_t)pb * D.nblk + i + 1];
+    const int ldn = D.ldd[i + 1];
+    for(int c = (tid >> 4); c < n1; c += 16)
+      for(int r = (tid & 15); r < n1; r += 16)
+      {
+        if(r < c) continue;
+        AT(Dn, ldn, r, c) = chain2_neg(0, 1, ni, AT(Dn, ldn, r, c), [&](int k) { return AT(Ls, lds1, r, k); }, [&](int k) { return AT(Ls, lds1, c, k); });
+      }
+    __threadfence_block();
   }
 }
 
@@ -910,20 +1094,29 @@ __global__ __launch_bounds__(64) void tri_lsolve_kernel(const BlockDesc D, doubl
         if(zero)
         {
           const int r = n + ni - start, off = ni - r;
-          double xi = (lane < r) ? Mc[start + lane] : 0.0;
-          xi = wave_fwd(Li + off + (size_t)off * ldd, ldd, r, xi, lane);
-          if(lane < r) Mc[start + lane] = xi;
+          double xa = (lane < r) ? Mc[start + lane] : 0.0, xb = (lane + 64 < r) ? Mc[start + lane + 64] : 0.0;
+          wave_fwd2(Li + off + (size_t)off * ldd, ldd, r, xa, xb, lane);
+          if(lane < r) Mc[start + lane] = xa;
+          if(lane + 64 < r) Mc[start + lane + 64] = xb;
           zero = false;
         }
         else
         {
           const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i - 1];
           const int ldsg = D.lds[i - 1];
-          double acc = (lane < ni) ? Mc[n + lane] : 0.0;
-          if(lane < ni)
-            for(int k = 0; k < li; ++k) acc = FMA(-AT(Sg, ldsg, lane, k), Mc[l + k], acc);
-          acc = wave_fwd(Li, ldd, ni, acc, lane);
-          if(lane < ni) Mc[n + lane] = acc;
+          double acc[2]; // rows lane, lane + 64 of block i
+#pragma unroll
+          for(int h = 0; h < 2; ++h)
+          {
+            const int r = lane + 64 * h;
+            acc[h] = (r < ni) ? Mc[n + r] : 0.0;
+            if(r < ni)
+              for(int k = 0; k < li; ++k) acc[h] = FMA(-AT(Sg, ldsg, r, k), Mc[l + k], acc[h]);
+          }
+          wave_fwd2(Li, ldd, ni, acc[0], acc[1], lane);
+#pragma unroll
+          for(int h = 0; h < 2; ++h)
+            if(lane + 64 * h < ni) Mc[n + lane + 64 * h] = acc[h];
         }
         __threadfence_block();
         wave_sync();
@@ -958,20 +1151,29 @@ __global__ __launch_bounds__(64) void tri_ltsolve_kernel(const BlockDesc D, doub
         if(zero)
         {
           const int r = end - n + ni;
-          double xi = (lane < r) ? Mc[n - ni + lane] : 0.0;
-          xi = wave_bwd(Li, ldd, r, xi, lane);
-          if(lane < r) Mc[n - ni + lane] = xi;
+          double xa = (lane < r) ? Mc[n - ni + lane] : 0.0, xb = (lane + 64 < r) ? Mc[n - ni + lane + 64] : 0.0;
+          wave_bwd2(Li, ldd, r, xa, xb, lane);
+          if(lane < r) Mc[n - ni + lane] = xa;
+          if(lane + 64 < r) Mc[n - ni + lane + 64] = xb;
           zero = false;
         }
         else
         {
           const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
           const int ldsg = D.lds[i];
-          double acc = (lane < ni) ? Mc[n - ni + lane] : 0.0;
-          if(lane < ni)
-            for(int k = li - 1; k >= 0; --k) acc = FMA(-AT(Sg, ldsg, k, lane), Mc[(l - li) + k], acc);
-          acc = wave_bwd(Li, ldd, ni, acc, lane);
-          if(lane < ni) Mc[n - ni + lane] = acc;
+          double acc[2]; // rows lane, lane + 64 of block i
+#pragma unroll
+          for(int h = 0; h < 2; ++h)
+          {
+            const int r = lane + 64 * h;
+            acc[h] = (r < ni) ? Mc[n - ni + r] : 0.0;
+            if(r < ni)
+              for(int k = li - 1; k >= 0; --k) acc[h] = FMA(-AT(Sg, ldsg, k, r), Mc[(l - li) + k], acc[h]);
+          }
+          wave_bwd2(Li, ldd, ni, acc[0], acc[1], lane);
+#pragma unroll
+          for(int h = 0; h < 2; ++h)
+            if(lane + 64 * h < ni) Mc[n - ni + lane + 64 * h] = acc[h];
         }
         __threadfence_block();
         wave_sync();
@@ -987,19 +1189,42 @@ inline size_t lds_arrow_block(int maxb)
 {
   return sizeof(double) * 2 * (size_t)maxb * (maxb | 1);
 }
+// LDS of a kernel that keeps one maxb x (maxb | 1) block, its diagonal and a PANEL of a side block: the panel is a whole block up
+// to 64 rows (everything at once, as before round 4) and whatever the CU's 160 KB leave beyond -- returns the panel's doubles
+inline int panel_doubles(int maxb, size_t & lds_bytes)
+{
+  const size_t blk = (size_t)maxb * (maxb | 1), fixed = blk + (size_t)((maxb + 1) & ~1) + 8;
+  const size_t room = (160 * 1024) / sizeof(double) - fixed;
+  const size_t panel = blk + maxb < room ? blk + maxb : room;
+  lds_bytes = sizeof(double) * (fixed + panel);
+  return (int)panel;
+}
 } // namespace
 
 hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st)
 {
   hipError_t e = hipMemsetAsync(d.fail, 0, sizeof(int) * nprob, st);
   if(e != hipSuccess) return e;
-  const size_t lds_blk = lds_arrow_block(maxb) + sizeof(double) * 64;
-  const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + 64 * 65);
+  BlockDesc dd = d;
+  size_t lds_blk = 0;
+  dd.xs_cap = panel_doubles(maxb, lds_blk);
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk);
-  if(e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
   if(e != hipSuccess) return e;
-  if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(kTriThreads), lds_blk, st, d);
-  hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), lds_head, st, d);
+  if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(kTriThreads), lds_blk, st, dd);
+  if(maxb <= 64)
+  {
+    const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + 64 * 65);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), lds_head, st, dd);
+  }
+  else
+  {
+    const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + maxb + 2);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(arrow_head_big_kernel, dim3(nprob), dim3(256), lds_head, st, dd);
+  }
   return hipGetLastError();
 }
 
@@ -1051,6 +1276,16 @@ hipError_t launch_tri_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t 
       hipLaunchKernelGGL(tri_llt_fast_kernel<32>, dim3(nprob), dim3(kTriThreads), lfast, st, d);
     else
       hipLaunchKernelGGL(tri_llt_fast_kernel<48>, dim3(nprob), dim3(kTriThreads), lfast, st, d);
+    return hipGetLastError();
+  }
+  if(maxb > 64) // (three blocks of more than 64 rows do not fit in LDS)
+  {
+    BlockDesc dd = d;
+    size_t lbig = 0;
+    dd.xs_cap = panel_doubles(maxb, lbig);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_llt_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lbig);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(tri_llt_big_kernel, dim3(nprob), dim3(kTriThreads), lbig, st, dd);
     return hipGetLastError();
   }
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_llt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -166,7 +166,7 @@ def test_failure_flags(capi, oracle):
         assert plan.llt() == [ok_ref, True] and not ok_ref
 
 
-def random_structured_cases(capi, o, ncases, seed, verbose=False):
+def random_structured_cases(capi, o, ncases, seed, verbose=False, tops=(8, 32, 48, 64), max_blocks=8):
     """Random block counts and sizes (1..64: register kernel up to 48 rows, barrier kernel beyond), batches, indefinite blocks at
     random positions (column 0 of a block -- the failure the reference does not notice -- and later columns), and, after a
     successful factorisation, L and L^T solves of random right-hand sides with random zero windows; returns the number of
@@ -177,8 +177,8 @@ def random_structured_cases(capi, o, ncases, seed, verbose=False):
     bad = 0
     for case in range(ncases):
         kind = ["tridiag", "tridiag", "arrow_down", "arrow_up"][case % 4]
-        nblk = int(rng.integers(1, 9))
-        top = int(rng.choice([8, 32, 48, 64]))
+        nblk = int(rng.integers(1, max_blocks + 1))
+        top = int(rng.choice(list(tops)))
         bs = [int(rng.integers(1, top + 1)) for _ in range(nblk)]
         nprob = int(rng.choice([1, 2, 5]))
         Hs = []
@@ -224,3 +224,46 @@ def random_structured_cases(capi, o, ncases, seed, verbose=False):
 
 def test_random_shapes_and_failures(capi, oracle):
     assert random_structured_cases(capi, oracle, 48, 2024) == 0
+
+
+def test_random_shapes_and_failures_blocks_up_to_128_rows(capi, oracle):
+    """Round 4: blocks of 65 .. 128 rows (two rows per lane in the solves, side blocks through LDS in panels, one block region
+    in the tridiagonal chain) -- same generator, block sizes up to 96 / 128, failures included."""
+    assert random_structured_cases(capi, oracle, 24, 4096, tops=(96, 128), max_blocks=5) == 0
+
+
+@pytest.mark.parametrize("kind", ["arrow_down", "arrow_up", "tridiag"])
+def test_big_blocks_unaligned_windows(capi, oracle, kind):
+    """Block sizes 70 / 128 / 65 / 96: the factor bit for bit, then L and L^T solves with zero windows that start and end INSIDE
+    blocks (on both sides of row 64 of a block), three right-hand sides."""
+    import torch
+
+    bs = [70, 128, 65, 96]
+    off = np.concatenate([[0], np.cumsum(bs)]).astype(int)
+    n = int(off[-1])
+    rng = np.random.default_rng({"arrow_down": 11, "arrow_up": 12, "tridiag": 13}[kind])
+    H = spd(rng, bs, kind)
+    ok_ref, Href = oracle_factor(oracle, H, bs, kind)
+    T = to_dev([H])
+    plan = capi.StructuredBlocks(kind, bs, T, max_nrhs=3)
+    ok = plan.llt()
+    torch.cuda.synchronize()
+    assert ok == [ok_ref] and ok_ref
+    assert np.array_equal(from_dev(T)[0], Href)
+    Dr, Sr = views(Href, bs, kind)
+    wins = [(0, n), (3, 60), (10, 75), (66, 130), (71, 199), (140, 198), (135, 270), (200, 264), (263, 359), (300, 340), (330, n), (69, 71)]
+    for st, en in wins:
+        B = np.zeros((n, 3), order="F")
+        B[st:en] = rng.uniform(-1, 1, (en - st, 3))
+        for transpose in (False, True):
+            for windowed in (False, True):
+                a, b = (st, en) if windowed else (0, -1)
+                ref = B.copy(order="F")
+                if kind == "tridiag":
+                    oracle.tri_block_diag_solve(Dr, Sr, ref, start=a, end=b, transpose=transpose)
+                else:
+                    oracle.block_arrow_solve(Dr, Sr, kind == "arrow_up", ref, a, b, transpose=transpose)
+                M = rhs_dev([B])
+                plan.solve(M, transpose=transpose, start=a, end=b)
+                got = M.cpu().numpy()[0].T
+                assert np.array_equal(got, ref), (kind, st, en, transpose, windowed)
