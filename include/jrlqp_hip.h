@@ -405,7 +405,7 @@ int jrlqp_dense_sync_mode(const jrlqp_dense * h, int * event_reruns);
  *   side block i: kind 0: n_last x n_i; kind 1: n_{i+1} x n_0; kind 2: n_{i+1} x n_i.
  */
 #define JRLQP_BLOCK_MAX 128
-#define JRLQP_BLOCKGI_BLOCK_MAX 64 /* the structured GI loop (jrlqp_blockgi_*) */
+#define JRLQP_BLOCKGI_BLOCK_MAX 128 /* the structured GI loop (jrlqp_blockgi_*) */
 typedef struct jrlqp_blocks jrlqp_blocks;
 int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, int max_nrhs, jrlqp_blocks ** out);
 void jrlqp_blocks_destroy(jrlqp_blocks * plan);

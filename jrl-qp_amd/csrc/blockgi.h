@@ -20,6 +20,7 @@ struct BgiArgs
   // StructuredG (shared shape; per-problem block pointers)
   int kind;            // jrlqp_blocks numbering: 0 block arrow down, 1 block arrow up, 2 block tridiagonal
   int nblk, n;
+  int maxb;            // largest block (rows): beyond 64 the block solves carry two rows per lane
   const int * bs;      // [nblk] block sizes
   const int * boff;    // [nblk] first row of block b in the vector of unknowns
   const int * ldd;     // [nblk]

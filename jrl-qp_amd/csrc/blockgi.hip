@@ -284,6 +284,225 @@ __device__ __forceinline__ void tri_ltsolve(Ctx & K, double * v)
   __syncthreads();
 }
 
+// ---- the same four solves for blocks of 65 .. 128 rows (round 4): two rows per lane (wave_fwd2 / wave_bwd2, device_common.h); chosen
+// per launch by BgiArgs::maxb so that problems with small blocks keep the single-entry code above and its register count
+// (StructuredG::solveL / solveInPlaceLTranspose --------------------------------------------
+// Block arrow, L v <- v with the non-zero window [start, end) of v (blockArrowLLT.cpp:92-176).  The up variant's row
+// permutation (:163-170) is a change of offsets only: logical block i sits at physical rows boff[dsel(i)].
+template<int NT>
+__device__ __forceinline__ void arrow_lsolve_big(Ctx & K, double * v, int start, int end)
+{
+  const BgiArgs & A = *K.A;
+  constexpr int NW = NT / 64;
+  const int up = A.kind == 1, nblk = A.nblk, lane = K.lane;
+  const int ib = dsel(nblk, up, nblk - 1), nbk = K.bm[ib].bs;
+  const int shift = up ? K.bm[0].bs : 0; // permuted row = physical row - shift for the off-head blocks
+  if(up)
+  {
+    start = max(0, start - shift);
+    end = max(0, end - shift);
+  }
+  for(int i = K.wave; i < nblk - 1; i += NW)
+  {
+    const int id = dsel(nblk, up, i), ni = K.bm[id].bs, n0 = K.bm[id].boff - shift;
+    const int s = max(start - n0, 0);
+    if(ni < s || end <= n0) continue; // (:121-127)
+    const double * Dg = K.bm[id].diag;
+    const int ldd = K.bm[id].ldd;
+    double * vi = v + K.bm[id].boff + s;
+    const int nr = ni - s;
+    double xa = (lane < nr) ? vi[lane] : 0.0, xb = (lane + 64 < nr) ? vi[lane + 64] : 0.0; // (rows lane, lane + 64: blocks of up to 128 rows)
+    wave_fwd2(Dg + s + (size_t)s * ldd, ldd, nr, xa, xb, lane);
+    if(lane < nr) vi[lane] = xa;
+    if(lane + 64 < nr) vi[lane + 64] = xb;
+  }
+  __syncthreads();
+  if(K.wave == 0)
+  {
+    double * vb = v + K.bm[ib].boff;
+    double acc[2]; // rows lane, lane + 64 of the head block
+#pragma unroll
+    for(int h = 0; h < 2; ++h) acc[h] = (lane + 64 * h < nbk) ? vb[lane + 64 * h] : 0.0;
+    for(int i = 0; i < nblk - 1; ++i)
+    {
+      const int id = dsel(nblk, up, i), ni = K.bm[id].bs, n0 = K.bm[id].boff - shift;
+      const int s = max(start - n0, 0);
+      if(ni < s || end <= n0) continue;
+      const double * Sg = K.bm[i].side;
+      const int ldsg = K.bm[i].lds;
+      const double * Xi = v + K.bm[id].boff;
+#pragma unroll
+      for(int h = 0; h < 2; ++h)
+      {
+        const int r = lane + 64 * h;
+        if(r < nbk)
+          acc[h] = chain_neg8(s, 1, ni - s, acc[h], [&](int k) { return up ? AT(Sg, ldsg, k, r) : AT(Sg, ldsg, r, k); },
+                              [&](int k) { return Xi[k]; });
+      }
+    }
+    wave_fwd2(K.bm[ib].diag, K.bm[ib].ldd, nbk, acc[0], acc[1], lane);
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+      if(lane + 64 * h < nbk) vb[lane + 64 * h] = acc[h];
+  }
+  __syncthreads();
+}
+
+// L^T v <- v, full vector (blockArrowLLT.cpp:179-277 with start = 0, end = n)
+template<int NT>
+__device__ __forceinline__ void arrow_ltsolve_big(Ctx & K, double * v)
+{
+  const BgiArgs & A = *K.A;
+  constexpr int NW = NT / 64;
+  const int up = A.kind == 1, nblk = A.nblk, lane = K.lane;
+  const int ib = dsel(nblk, up, nblk - 1), nbk = K.bm[ib].bs;
+  double * vb = v + K.bm[ib].boff;
+  if(K.wave == 0)
+  {
+    double xa = (lane < nbk) ? vb[lane] : 0.0, xb = (lane + 64 < nbk) ? vb[lane + 64] : 0.0;
+    wave_bwd2(K.bm[ib].diag, K.bm[ib].ldd, nbk, xa, xb, lane);
+    if(lane < nbk) vb[lane] = xa;
+    if(lane + 64 < nbk) vb[lane + 64] = xb;
+  }
+  __syncthreads();
+  for(int i = K.wave; i < nblk - 1; i += NW)
+  {
+    const int id = dsel(nblk, up, i), ni = K.bm[id].bs;
+    const double * Sg = K.bm[i].side;
+    const int ldsg = K.bm[i].lds;
+    double * vi = v + K.bm[id].boff;
+    double acc[2]; // rows lane, lane + 64 of block i
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+    {
+      const int r = lane + 64 * h;
+      acc[h] = (r < ni) ? vi[r] : 0.0;
+      if(h == 0 || ni > 64) // (uniform)
+      {
+        const int rl = (r < ni) ? r : 0; // idle lanes run the same (discarded) chain: no divergent loads
+        const double t = chain_neg8(nbk - 1, -1, nbk, acc[h], [&](int k) { return up ? AT(Sg, ldsg, rl, k) : AT(Sg, ldsg, k, rl); },
+                                    [&](int k) { return vb[k]; });
+        acc[h] = (r < ni) ? t : acc[h];
+      }
+    }
+    wave_bwd2(K.bm[id].diag, K.bm[id].ldd, ni, acc[0], acc[1], lane);
+#pragma unroll
+    for(int h = 0; h < 2; ++h)
+      if(lane + 64 * h < ni) vi[lane + 64 * h] = acc[h];
+  }
+  __syncthreads();
+}
+
+// Block tridiagonal (triBlockDiagLLT.cpp:37-96): serial over the blocks, one wave
+__device__ __forceinline__ void tri_lsolve_big(Ctx & K, double * v, int start)
+{
+  const BgiArgs & A = *K.A;
+  const int lane = K.lane;
+  if(K.wave == 0)
+  {
+    int n = 0, l = 0, li = 0;
+    bool zero = true;
+    for(int i = 0; i < A.nblk; ++i)
+    {
+      const int ni = K.bm[i].bs;
+      const double * Li = K.bm[i].diag;
+      const int ldd = K.bm[i].ldd;
+      if(n + ni >= start)
+      {
+        if(zero)
+        {
+          const int rr = n + ni - start, off = ni - rr;
+          double xa = (lane < rr) ? v[start + lane] : 0.0, xb = (lane + 64 < rr) ? v[start + lane + 64] : 0.0;
+          wave_fwd2(Li + off + (size_t)off * ldd, ldd, rr, xa, xb, lane);
+          if(lane < rr) v[start + lane] = xa;
+          if(lane + 64 < rr) v[start + lane + 64] = xb;
+          zero = false;
+        }
+        else
+        {
+          const double * Sg = K.bm[i - 1].side;
+          const int ldsg = K.bm[i - 1].lds;
+          double acc[2]; // rows lane, lane + 64 of block i
+#pragma unroll
+          for(int h = 0; h < 2; ++h)
+          {
+            const int r = lane + 64 * h;
+            acc[h] = (r < ni) ? v[n + r] : 0.0;
+            if(h == 0 || ni > 64) // (uniform)
+            {
+              const int rl = (r < ni) ? r : 0;
+              const double t = chain_neg8(0, 1, li, acc[h], [&](int k) { return AT(Sg, ldsg, rl, k); }, [&](int k) { return v[l + k]; });
+              acc[h] = (r < ni) ? t : acc[h];
+            }
+          }
+          wave_fwd2(Li, ldd, ni, acc[0], acc[1], lane);
+#pragma unroll
+          for(int h = 0; h < 2; ++h)
+            if(lane + 64 * h < ni) v[n + lane + 64 * h] = acc[h];
+        }
+        wave_sync();
+      }
+      l = n;
+      li = ni;
+      n += ni;
+    }
+  }
+  __syncthreads();
+}
+
+// triBlockDiagLTransposeSolve (triBlockDiagLLT.cpp:98-158), full vector
+__device__ __forceinline__ void tri_ltsolve_big(Ctx & K, double * v)
+{
+  const BgiArgs & A = *K.A;
+  const int lane = K.lane;
+  if(K.wave == 0)
+  {
+    int n = A.n, l = 0, li = 0;
+    bool zero = true;
+    for(int i = A.nblk - 1; i >= 0; --i)
+    {
+      const int ni = K.bm[i].bs;
+      const double * Li = K.bm[i].diag;
+      const int ldd = K.bm[i].ldd;
+      if(zero)
+      {
+        double xa = (lane < ni) ? v[n - ni + lane] : 0.0, xb = (lane + 64 < ni) ? v[n - ni + lane + 64] : 0.0;
+        wave_bwd2(Li, ldd, ni, xa, xb, lane);
+        if(lane < ni) v[n - ni + lane] = xa;
+        if(lane + 64 < ni) v[n - ni + lane + 64] = xb;
+        zero = false;
+      }
+      else
+      {
+        const double * Sg = K.bm[i].side;
+        const int ldsg = K.bm[i].lds;
+        double acc[2]; // rows lane, lane + 64 of block i
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+        {
+          const int r = lane + 64 * h;
+          acc[h] = (r < ni) ? v[n - ni + r] : 0.0;
+          if(h == 0 || ni > 64) // (uniform)
+          {
+            const int rl = (r < ni) ? r : 0;
+            const double t = chain_neg8(li - 1, -1, li, acc[h], [&](int k) { return AT(Sg, ldsg, k, rl); }, [&](int k) { return v[(l - li) + k]; });
+            acc[h] = (r < ni) ? t : acc[h];
+          }
+        }
+        wave_bwd2(Li, ldd, ni, acc[0], acc[1], lane);
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+          if(lane + 64 * h < ni) v[n - ni + lane + 64 * h] = acc[h];
+      }
+      wave_sync();
+      l = n;
+      li = ni;
+      n -= ni;
+    }
+  }
+  __syncthreads();
+}
+
 // The up arrow's row permutation (blockArrowLLT.cpp:163-170, :266-271): blockArrowLSolve returns its result in the
 // PERMUTED order (first block moved last) and blockArrowLTransposeSolve expects its argument in that order -- d, and
 // with it the orthonormal sequence, live in permuted coordinates.  forward: v <- [v(n0:), v(:n0)]; backward: the inverse.
@@ -316,27 +535,46 @@ __device__ __forceinline__ void permute_up(Ctx & K, double * v, bool forward)
 
 // StructuredG::solveL (StructuredG.cpp:67-113); permuted = false keeps the result in the original row order (only
 // valid when the matching sg_ltsolve call is told the same: the two permutations of the reference cancel)
-template<int NT>
+template<int NT, bool BIG>
 __device__ __forceinline__ void sg_lsolve(Ctx & K, double * v, int start, int end, bool permuted = true)
 {
+  constexpr bool big = BIG; // (a kernel of its own for blocks of 65 .. 128 rows: the two-rows-per-lane variants cost the small-block kernel
+                            // 5 % when they merely shared its code -- registers and instruction cache)
   if(K.A->kind == 2)
-    tri_lsolve(K, v, start);
+  {
+    if(big)
+      tri_lsolve_big(K, v, start);
+    else
+      tri_lsolve(K, v, start);
+  }
   else
   {
-    arrow_lsolve<NT>(K, v, start, end);
+    if(big)
+      arrow_lsolve_big<NT>(K, v, start, end);
+    else
+      arrow_lsolve<NT>(K, v, start, end);
     if(K.A->kind == 1 && permuted) permute_up<NT>(K, v, true);
   }
 }
 // StructuredG::solveInPlaceLTranspose (StructuredG.cpp:45-65)
-template<int NT>
+template<int NT, bool BIG>
 __device__ __forceinline__ void sg_ltsolve(Ctx & K, double * v, bool permuted = true)
 {
+  constexpr bool big = BIG;
   if(K.A->kind == 2)
-    tri_ltsolve(K, v);
+  {
+    if(big)
+      tri_ltsolve_big(K, v);
+    else
+      tri_ltsolve(K, v);
+  }
   else
   {
     if(K.A->kind == 1 && permuted) permute_up<NT>(K, v, false);
-    arrow_ltsolve<NT>(K, v);
+    if(big)
+      arrow_ltsolve_big<NT>(K, v);
+    else
+      arrow_ltsolve<NT>(K, v);
   }
 }
 
@@ -739,7 +977,7 @@ __device__ __forceinline__ double cstr_dot(const Ctx & K, int p, const double * 
 // =========================================================================================================
 // the kernel
 // =========================================================================================================
-template<int NT, int NCH>
+template<int NT, int NCH, bool BIG>
 __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 : 0) void blockgi_kernel(const BgiArgs A)
 {
   extern __shared__ double sm[];
@@ -837,8 +1075,8 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
   // initializePrimalDualPoints (:476-481): x = -G^-1 a, f = a.x / 2
   for(int i = tid; i < n; i += NT) x[i] = a[i];
   __syncthreads();
-  sg_lsolve<NT>(K, x, 0, n, false);
-  sg_ltsolve<NT>(K, x, false);
+  sg_lsolve<NT, BIG>(K, x, 0, n, false);
+  sg_ltsolve<NT, BIG>(K, x, false);
   for(int i = tid; i < n; i += NT) x[i] = -x[i];
   __syncthreads();
   f = 0.5 * dot_tree<NT>(K, 0, n, [&](int e) { return a[e]; }, [&](int e) { return x[e]; });
@@ -935,7 +1173,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
         if(tid == 0) d[wst] = (pst == JRLQP_UPPER_BOUND) ? -1.0 : 1.0;
       }
       __syncthreads();
-      sg_lsolve<NT>(K, d, wst, wen);
+      sg_lsolve<NT, BIG>(K, d, wst, wen);
       if(pst == JRLQP_UPPER)
       {
         for(int i = tid; i < n; i += NT) d[i] = -d[i];
@@ -949,7 +1187,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
       __syncthreads();
       q_apply<NT, NCH, false>(K, z, nseq, (A.prof && tid == 0) ? pacc + 11 : nullptr);
       stamp(4);
-      sg_ltsolve<NT>(K, z);
+      sg_ltsolve<NT, BIG>(K, z);
       stamp(5);
       r_solve<NT>(K, q);
       stamp(6);
@@ -1195,14 +1433,19 @@ done:
   }
 }
 
+template<int NT, int NCH, bool BIG>
+hipError_t launch_one_b(const BgiArgs & a, int nprob, size_t lds, hipStream_t st)
+{
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blockgi_kernel<NT, NCH, BIG>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if(e != hipSuccess) return e;
+  hipLaunchKernelGGL((blockgi_kernel<NT, NCH, BIG>), dim3(nprob), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
 template<int NT, int NCH>
 hipError_t launch_one(const BgiArgs & a, int nprob, size_t lds, hipStream_t st)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blockgi_kernel<NT, NCH>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if(e != hipSuccess) return e;
-  hipLaunchKernelGGL((blockgi_kernel<NT, NCH>), dim3(nprob), dim3(NT), lds, st, a);
-  return hipGetLastError();
+  return (a.maxb > 64) ? launch_one_b<NT, NCH, true>(a, nprob, lds, st) : launch_one_b<NT, NCH, false>(a, nprob, lds, st);
 }
 } // namespace
 

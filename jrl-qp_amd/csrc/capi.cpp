@@ -813,6 +813,7 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.cblk = h->d_cblk;
   a.a = da; a.bl = dbl; a.bu = dbu; a.xl = dxl; a.xu = dxu;
   a.max_iter = o.max_iter; a.big_bnd = o.big_bnd;
+  a.maxb = h->blocks->maxb;
   a.n_pad = h->n_pad; a.qcap = h->qcap; a.row_len = h->row_len;
   a.pool = h->d_pool; a.Rp = h->d_Rp; a.rlen = h->rlen; a.desc = h->d_desc; a.active = h->d_active;
   a.xu_ws = h->d_xu; a.xu_global = h->xu_global;

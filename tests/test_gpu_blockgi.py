@@ -205,3 +205,15 @@ def test_fuzz_shapes_bit_exact(oracle, SP, capi):
         g = check_batch(oracle, SP, capi, qps)
         tot_iters += int(g["iters"].sum())
     assert tot_iters > 200
+
+
+@pytest.mark.parametrize("kind,bs,mc", [("tri", [70, 128, 65, 96], [20, 30, 10, 25]), ("arrow_up", [96, 70, 128, 33], [15, 25, 30, 5]),
+                                        ("arrow_down", [128, 40, 97, 65], [30, 10, 25, 12])])
+def test_blocks_of_up_to_128_rows_bit_exact(oracle, SP, capi, kind, bs, mc):
+    """Round 4: Hessian blocks of 65 .. 128 rows (two rows per lane in the block solves of L^-1 and L^-T, the factorisation through the
+    panelled kernels) -- status, iterations, active set, x, u, f bit for bit; one batch also with C on its own partition and a box."""
+    qps = [SP.random_structured_qp(kind, bs, mc, 900 + seed, ridge=0.05) for seed in range(4)]
+    check_batch(oracle, SP, capi, qps, min_iters=40)
+    n = sum(bs)
+    qps = [SP.random_structured_qp(kind, bs, [40, 35, 20], 950 + seed, ridge=0.05, cbs=[100, n - 230, 130], box=1.0) for seed in range(3)]
+    check_batch(oracle, SP, capi, qps, min_iters=20)
