@@ -441,7 +441,8 @@ int jrlqp_blocks_solve(jrlqp_blocks * plan, int transpose, double * dM, int ldm,
  *                                        column); sum cvar = nbVar; + jrlqp_blockgi_bind(dcblk, ldc)
  * The whole active-set loop runs on the device (one workgroup per problem, one launch per batch); the orthonormal
  * sequence grows by one element per iteration, so the plan's workspace is sized by `max_iter` at creation and
- * options.max_iter must not exceed it.  n <= 3072 unknowns per problem (the vectors of unknowns live in LDS); blocks of at most
+ * options.max_iter must not exceed it.  n <= 4096 unknowns per problem (the vectors of unknowns live in LDS: a shape whose vectors -- 3 n + 2 min(n, m + nb) doubles -- do not
+ * fit is refused with JRLQP_ERR_UNSUPPORTED_SIZE; 3072 until round 4); blocks of at most
  * JRLQP_BLOCKGI_BLOCK_MAX rows.
  * As in the reference, only the cold start without data equalities / fixed variables is functional (the reference
  * asserts in initializePrimalDualPoints, BlockGISolver.cpp:475): such inputs return INCONSISTENT_INPUT per problem.

@@ -60,7 +60,7 @@ struct BgiArgs
   int prof_stride;
 };
 
-constexpr int kBgiMaxN = 3072; // unknowns per structured QP (vectors live in LDS)
+constexpr int kBgiMaxN = 4096; // unknowns per structured QP (vectors live in LDS; four chunks of 1024 chains: 3072 until round 4)
 
 // xu_global = 1 (throughput layout for large problems in large batches): x and u are kept in the HBM workspace, which
 // brings a 3000-unknown problem under half a CU's LDS

@@ -1466,8 +1466,10 @@ hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t st)
   // Throughput layout (xu_global, chosen by the caller for large batches of large problems): four waves and half the
   // LDS, so that two problems share a CU and twice as many reflector rows are in flight per CU.
   if(a.n <= 1024) return launch_one<256, 1>(a, nprob, lds, st);
-  if(a.xu_global) return (a.n <= 2048) ? launch_one<256, 2>(a, nprob, lds, st) : launch_one<256, 3>(a, nprob, lds, st);
+  if(a.xu_global)
+    return (a.n <= 2048) ? launch_one<256, 2>(a, nprob, lds, st) : (a.n <= 3072) ? launch_one<256, 3>(a, nprob, lds, st) : launch_one<256, 4>(a, nprob, lds, st);
   if(a.n <= 2048) return launch_one<512, 2>(a, nprob, lds, st);
-  return launch_one<512, 3>(a, nprob, lds, st);
+  if(a.n <= 3072) return launch_one<512, 3>(a, nprob, lds, st);
+  return launch_one<512, 4>(a, nprob, lds, st); // (round 4: n <= 4096, a fourth chunk of 1024 chains per thread)
 }
 } // namespace jrlqp

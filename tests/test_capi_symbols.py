@@ -117,8 +117,8 @@ def test_blockgi_plan_validation_without_gpu(pkg):
     assert lib.jrlqp_blockgi_create(5, 2, I(3, 4), 2, I(3, 4), I(2, 2), 0, 1, 100, ct.byref(h)) == -1  # kind
     assert lib.jrlqp_blockgi_create(2, 2, I(3, 4), 2, I(3, 4), I(2, 2), 0, 0, 100, ct.byref(h)) == -1  # nprob
     assert lib.jrlqp_blockgi_create(2, 2, I(3, 4), 2, I(3, 4), I(2, 2), 0, 1, 0, ct.byref(h)) == -1  # max_iter
-    assert lib.jrlqp_blockgi_create(2, 2, I(3, 70), 2, I(3, 70), I(2, 2), 0, 1, 10, ct.byref(h)) in (-2, -3, -4)  # block > 64 rows
-    assert lib.jrlqp_blockgi_create(2, 64, I(*([60] * 64)), 1, I(3840), I(1), 0, 1, 10, ct.byref(h)) == -2  # n > 3072
+    assert lib.jrlqp_blockgi_create(2, 2, I(3, 130), 2, I(3, 130), I(2, 2), 0, 1, 10, ct.byref(h)) == -2  # block > 128 rows
+    assert lib.jrlqp_blockgi_create(2, 70, I(*([60] * 70)), 1, I(4200), I(1), 0, 1, 10, ct.byref(h)) == -2  # n > 4096
     assert lib.jrlqp_blockgi_workspace_bytes(None) == -1
     assert lib.jrlqp_blockgi_solve(None, *([None] * 12), None, 0, None) == -1
 

@@ -217,3 +217,11 @@ def test_blocks_of_up_to_128_rows_bit_exact(oracle, SP, capi, kind, bs, mc):
     n = sum(bs)
     qps = [SP.random_structured_qp(kind, bs, [40, 35, 20], 950 + seed, ridge=0.05, cbs=[100, n - 230, 130], box=1.0) for seed in range(3)]
     check_batch(oracle, SP, capi, qps, min_iters=20)
+
+
+def test_beyond_3072_unknowns(oracle, SP, capi):
+    """Round 4: n <= 4096 (a fourth chunk of 1024 chains per thread).  An arrow of 130 stages x 30 + head: n = 3930, m = 650."""
+    qp = SP.mpc_arrow_qp(nstage=130, nx=30, mc=5, seed=3, scale_a=1.0)
+    assert sum(qp.bs) == 3930
+    g = check_batch(oracle, SP, capi, [qp], max_iter=1000, min_iters=100)
+    assert g["term"][0] == 0
