@@ -325,6 +325,37 @@ __device__ __forceinline__ bool div_safe_num(double v)
 }
 
 
+// make_givens with the same operations per result and fewer instructions on the way (round 4: the rotations of a REMOVAL are a serial
+// recurrence, one Givens generator per step): the square root's argument 1 + t^2 lies in [1, 2] (sqrt_1to2: the compiler's sequence
+// without its range scaling), 1 / u has |u| in [1, sqrt 2] and the quotient t = q / p (or p / q) of operands inside the safe range is
+// div_pre's (the compiler's own division with the scaling and fix-up steps that are identities there).  Operands outside the safe
+// range take the plain generator.  Bit-identical to make_givens (tests/test_gpu_arith.py drives both over random and edge operands).
+__device__ __forceinline__ void make_givens_lean(double p, double q, double & c, double & s, double & r)
+{
+  if(q == 0.0 || p == 0.0 || !div_safe_den(p) || !div_safe_den(q))
+  {
+    make_givens(p, q, c, s, r);
+    return;
+  }
+  const bool pbig = fabs(p) > fabs(q);
+  const double num = pbig ? q : p, den = pbig ? p : q;
+  const double t = div_pre(num, den, recip_refined(den));
+  double u = sqrt_1to2(FMA(t, t, 1.0));
+  if(den < 0.0) u = -u;
+  const double iu = div_pre(1.0, u, recip_refined(u));
+  if(pbig)
+  {
+    c = iu;
+    s = -t * c;
+  }
+  else
+  {
+    s = -iu;
+    c = -t * s;
+  }
+  r = den * u;
+}
+
 // ---- wave-level substitutions on one block (shared by the structured Cholesky family and the structured GI loop) ----
 constexpr int kAhead = 16; // operands of a dependent chain are requested this many steps ahead (one HBM/L2 latency per group)
 

@@ -914,34 +914,62 @@ __global__ __launch_bounds__(64) void select_comb_kernel(const double * __restri
 // lane = row (a column's 64 rows are 512 contiguous bytes), the segment's 64 entries of the row in registers -- all loads in flight at
 // once --, d2 through LDS with the entries outside [q, n) replaced by +0 (a term fma(J_ij, +0, acc) leaves acc as it is).  The wave of
 // a row group that arrives last adds the segment sums of its 64 rows (lane = row: the tree in registers).
-__global__ __launch_bounds__(64) void z_blk_kernel(const double * __restrict__ J, int ld, int n, int q, const double * __restrict__ d, double * z,
-                                                   PassSync * sync, int wait_d, int post_z, Mailbox * mb, BlkArgs ba)
+__global__ __launch_bounds__(64) void z_blk_kernel(const double * __restrict__ J, int ld, int n, int q, const double * d, double * z,
+                                                   PassSync * sync, int wait_d, int post_z, Mailbox * mb, BlkArgs ba, const double * __restrict__ Pd = nullptr,
+                                                   int ldpd = 0, int nsegd = 0, const int * psel = nullptr, int m = 0, double sign = 1.0, double * dout = nullptr,
+                                                   const PassSync * csync = nullptr, int wait_chain = 0, Mailbox * cmb = nullptr)
 {
   __shared__ double dsm[64];
+  // (the workgroups that store d: a coefficient chain of the pass before, discarded by a removal, may still be reading it)
+  if(Pd && blockIdx.x == 0 && csync && wait_chain) flag_wait(&csync->chain_tag, wait_chain, cmb);
   if(sync && wait_d) flag_wait(&sync->d_tag, wait_d, mb); // on its own stream, beside the substitution: d (and with it J) of this pass
   const int lane = threadIdx.x;
   const int row = min((int)blockIdx.x * 64 + lane, n - 1);
   const int s = blockIdx.y, j0 = s * 64;
+  const int j = j0 + lane;
+  // Pd != nullptr (round 4): d has not been combined yet -- jtn_blk_kernel left the segment sums of d = J^T n+ in Pd, and this kernel
+  // applies the C4 tree to the 64 entries of its segment itself (what blk_comb_kernel did in a launch of its own, on the critical path
+  // of every pass); the workgroups of row group 0 also store d for the kernels behind (substitution, commit, coefficient chain).  With
+  // the selection on the device (psel) the sign comes from there, and a BOUND has no segment sums: jrow_kernel wrote d itself.
+  bool gen = Pd != nullptr;
+  if(gen && psel)
+  {
+    const int p = psel[0];
+    gen = !(p < 0 || p >= m);
+    sign = (psel[1] == UPPER) ? -1.0 : 1.0;
+  }
+  const bool keeper = gen && blockIdx.x == 0; // (this workgroup stores its segment of d)
+  double dv = 0.0;
+  if((j0 + 64 > q || keeper) && j < n)
+  {
+    if(gen)
+    {
+      const double t = blk_tree(Pd, ldpd, nsegd, j);
+      dv = (sign < 0.0) ? -t : t;
+    }
+    else
+      dv = d[j];
+  }
+  if(keeper && j < n) dout[j] = dv;
   double acc = 0.0;
   if(j0 + 64 > q) // (a segment entirely below q has no term: +0)
   {
     double a[64];
 #pragma unroll
     for(int t = 0; t < 64; ++t) a[t] = AT(J, ld, row, min(j0 + t, n - 1));
-    const int j = j0 + lane;
-    dsm[lane] = (j >= q && j < n) ? d[j] : 0.0;
+    dsm[lane] = (j >= q && j < n) ? dv : 0.0;
     wave_sync();
 #pragma unroll
     for(int t0 = 0; t0 < 64; t0 += 8)
     {
-      double dv[8];
+      double dvv[8];
 #pragma unroll
-      for(int t = 0; t < 8; ++t) dv[t] = dsm[t0 + t];
+      for(int t = 0; t < 8; ++t) dvv[t] = dsm[t0 + t];
 #pragma unroll
-      for(int t = 0; t < 8; ++t) acc = FMA(a[t0 + t], dv[t], acc);
+      for(int t = 0; t < 8; ++t) acc = FMA(a[t0 + t], dvv[t], acc);
     }
   }
-  ba.P[(size_t)s * ba.ldp + blockIdx.x * 64 + lane] = acc; // (ldp >= 64 * gridDim.x); blk_comb_kernel adds the segment sums and publishes z_tag
+  ba.P[(size_t)s * ba.ldp + blockIdx.x * 64 + lane] = acc; // (ldp >= 64 * gridDim.x); the step kernel adds the segment sums
 }
 
 // bound constraint: d = +-row pb of J
@@ -1170,10 +1198,13 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
                                                         int m = 0, int tag = 0, const PassSync * zsync = nullptr, int wait_z = 0,
                                                         StepDev * sd = nullptr, const double * gbl = nullptr, const double * gbu = nullptr,
                                                         const double * gxl = nullptr, const double * gxu = nullptr, const double * Pz = nullptr,
-                                                        int ldpz = 0, int nsegz = 0, double * zout = nullptr)
+                                                        int ldpz = 0, int nsegz = 0, double * zout = nullptr, PassSync * dsync = nullptr, int post_d = 0)
 {
   extern __shared__ double rs[]; // block 0: the running right-hand side (q) ; block 1: z | x | n+ (3 n)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (round 4, blocked d: d was completed by the kernel in front of this one in the stream -- z_blk_kernel -- so the kernel boundary has
+  // ordered it; whoever runs beside the main stream on d, the coefficient chain, is told here)
+  if(dsync && post_d && blockIdx.x == 0 && tid == 0) __hip_atomic_store(&dsync->d_tag, post_d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   // the pass tag goes out last, behind a system-scope fence: the host polls it (gi_dense_host.cpp)
   auto post_tag = [&]() {
     __threadfence_system();
@@ -1936,7 +1967,8 @@ __global__ __launch_bounds__(ROT_THREADS) void rot_apply_kernel(double * J, int 
 template<int NC>
 __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int q, int l, double * cc, double * ss, double * u, unsigned char * st, int gone)
 {
-  __shared__ double gc, gs;
+  __shared__ double gcs[2][2]; // (c, s) of the rotation in flight, two slots taking turns: ONE barrier per rotation -- rotation i + 1
+                               // writes the other slot, and nobody can be two rotations ahead of a thread that has not read yet
   const int tid = threadIdx.x;
   const int nt = blockDim.x;
   const int qn = q - 1;
@@ -2014,16 +2046,16 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
           if(k == i)
           {
             double c, s, rho;
-            make_givens(carry[w], y[w], c, s, rho);
-            gc = c;
-            gs = s;
+            make_givens_lean(carry[w], y[w], c, s, rho);
+            gcs[i & 1][0] = c;
+            gcs[i & 1][1] = s;
             cc[i] = c;
             ss[i] = s;
             AT(R, ld, i, i) = rho;
           }
         }
         lds_barrier();
-        const double c = gc, s = gs;
+        const double c = gcs[i & 1][0], s = gcs[i & 1][1];
 #pragma unroll
         for(int w = 0; w < NC; ++w)
         {
@@ -2034,7 +2066,6 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
             carry[w] = FMA(s, carry[w], c * y[w]);
           }
         }
-        lds_barrier();
       }
     }
   }
@@ -2429,7 +2460,10 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   const bool chain = spec && q < n && !no_producer;
   const bool events = (ev_d != nullptr);   // event mode (kernels of different streams cannot run side by side: see PassSync): no tags
   const bool zs = zside && tag && !events && !no_producer && !(v.n > kBlockN); // z = J2 d2 on its own stream, beside the substitution (both only need d)
-  const int dpost = (!events && (chain || zs)) ? tag : 0; // d_tag is published for whoever runs beside the main stream
+  const bool blk_early = v.n > kBlockN;
+  // d_tag is published for whoever runs beside the main stream; blocked d (n > 256): by the step kernel, once z_blk_kernel has combined d
+  const int dpost_any = (!events && (chain || zs)) ? tag : 0;
+  const int dpost = blk_early ? 0 : dpost_any;
   if(events) wait_sel_tag = wait_chain_tag = 0;
   const int jt_groups = (n + CT - 1) / CT, jr_wgs = (n + 255) / 256;
   const bool blk = n > kBlockN; // CANON C8: the streaming products blocked (64-row segments + tree), their rows split over workgroups
@@ -2453,8 +2487,7 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
       if(blk)
       {
         hipLaunchKernelGGL(jtn_blk_kernel, dim3(jt_groups, jt_splits), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc,
-                           v.m, ds, bj);
-        hipLaunchKernelGGL(blk_comb_kernel, dim3(comb_wgs), dim3(64), 0, st, s.partJ, s.ldpJ, nseg, n, 1.0, s.d, s.psel, v.m, ds);
+                           v.m, ds, bj); // (the segment sums only: z_blk_kernel applies the tree)
       }
       else
         hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, nullptr, 1.0, s.d, s.psel, v.C, v.ldc, v.m, ds);
@@ -2470,7 +2503,6 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
       const DSync ds{s.sync, s.mb, 0, wait_chain_tag, dpost, jt_wgs};
       hipLaunchKernelGGL(jtn_blk_kernel, dim3(jt_groups, jt_splits), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
                          ds, bj);
-      hipLaunchKernelGGL(blk_comb_kernel, dim3(comb_wgs), dim3(64), 0, st, s.partJ, s.ldpJ, nseg, n, sign, s.d, nullptr, 0, ds);
     }
     else
       hipLaunchKernelGGL(jtn_kernel, dim3(jt_wgs), dim3(TILE_THREADS), tile_lds(n), st, s.J, n, n, n, cp, sign, s.d, nullptr, nullptr, 0, 0,
@@ -2479,6 +2511,18 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   else
     hipLaunchKernelGGL(jrow_kernel, dim3(jr_wgs), dim3(256), 0, st, s.J, n, n, p - v.m, sign, s.d, nullptr, 0,
                        DSync{s.sync, s.mb, 0, wait_chain_tag, dpost, jr_wgs});
+  const bool gen_host = !dev_p && p < v.m; // (a general constraint selected by the host: the hook level)
+  if(blk)
+  {
+    // z in the main stream, behind d and ahead of the step kernel, whose dot-product workgroup adds the segment sums itself: two
+    // launches less than "z on the side stream + its own combine kernel" for a host that had become the bottleneck of a pass (ten
+    // launches of ~4 us), at the price of z (a few us now that every CU streams J) no longer running beside the substitution.
+    // Round 4: it also combines d (see the kernel) -- one more launch off the critical path of a pass.
+    const dim3 zg((n + 63) / 64, (n + 63) / 64);
+    const bool have_sums = (dev_p && v.m > 0) || gen_host;
+    hipLaunchKernelGGL(z_blk_kernel, zg, dim3(64), 0, st, s.J, n, n, q, s.d, s.z, nullptr, 0, 0, nullptr, BlkArgs{s.partZ, s.ldpJ, s.cntZ, 1},
+                       have_sums ? s.partJ : nullptr, s.ldpJ, nseg, dev_p ? s.psel : nullptr, v.m, sign, s.d, s.sync, events ? 0 : wait_chain_tag, s.mb);
+  }
   if(chain)
   {
     // d is all the coefficient recurrence needs: it is enqueued now, on its own stream, and starts when d_tag says d is complete
@@ -2498,13 +2542,7 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
     }
   }
   if(blk)
-  {
-    // z in the main stream, behind d and ahead of the step kernel, whose dot-product workgroup adds the segment sums itself: two
-    // launches less than "z on the side stream + its own combine kernel" for a host that had become the bottleneck of a pass (ten
-    // launches of ~4 us), at the price of z (a few us now that every CU streams J) no longer running beside the substitution
-    const dim3 zg((n + 63) / 64, (n + 63) / 64);
-    hipLaunchKernelGGL(z_blk_kernel, zg, dim3(64), 0, st, s.J, n, n, q, s.d, s.z, nullptr, 0, 0, nullptr, BlkArgs{s.partZ, s.ldpJ, s.cntZ, 1});
-  }
+    ; // (launched above, in front of the coefficient chain)
   else if(zs)
     hipLaunchKernelGGL(z_rows_kernel, dim3((n + 15) / 16), dim3(64), 0, zside, s.J, n, n, q, s.d, s.z, s.sync, tag, tag, s.mb);
   else
@@ -2516,11 +2554,11 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   if(dev_p)
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
                        nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag, s.sync, zs ? tag : 0, s.sd, v.bl, v.bu, v.xl, v.xu, blk ? s.partZ : nullptr, s.ldpJ, nseg,
-                       s.z);
+                       s.z, blk ? s.sync : nullptr, blk ? dpost_any : 0);
   else
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
                        p - v.m, s.mb, nullptr, nullptr, 0, 0, tag, s.sync, zs ? tag : 0, nullptr, nullptr, nullptr, nullptr, nullptr, blk ? s.partZ : nullptr,
-                       s.ldpJ, nseg, s.z);
+                       s.ldpJ, nseg, s.z, blk ? s.sync : nullptr, blk ? dpost_any : 0);
   return hipGetLastError();
 }
 
