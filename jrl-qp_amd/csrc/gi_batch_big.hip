@@ -1300,11 +1300,14 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       bool skip = false;
       // a thread's share of the constraint scan: constraints t, t + stride, ... (general ones, then the bounds), `excl` left out (the
       // constraint an addition is activating meanwhile: its status byte is being written)
-      auto scan_part = [&](int t, int stride, int excl, double & bval, int & bidx, int & bstat, double & mycx, int & mybidx, double & mybnd) {
+      // general constraints g0 + t, g0 + t + stride, ... below g1, then (with_bounds) the bounds t, t + stride, ...; the accumulators may
+      // arrive holding a candidate of LOWER index (the part scanned beside a sweep): strict < keeps it on a tie
+      auto scan_part = [&](int t, int stride, int excl, double & bval, int & bidx, int & bstat, double & mycx, int & mybidx, double & mybnd, int g0, int g1,
+                           bool with_bounds) {
         // (the limits of this thread's first bound are requested before the chains of its general constraints: one global round trip less
         // behind them)
-        const double pxl = (t < nb) ? xlg[t] : 0.0, pxu = (t < nb) ? xug[t] : 0.0;
-        for(int i = t; i < m; i += stride)
+        const double pxl = (with_bounds && t < nb) ? xlg[t] : 0.0, pxu = (with_bounds && t < nb) ? xug[t] : 0.0;
+        for(int i = g0 + t; i < g1; i += stride)
         {
           if(i == excl || st[i] != B_INACTIVE) continue;
           const double cx = chain_asc<false, 32>(Cg + (size_t)i * n, 1, xs, 1, 0, n, 0.0); // (32 loads in flight: C comes from L2 / HBM)
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             }
           }
         }
-        for(int i = t; i < nb; i += stride)
+        for(int i = t; with_bounds && i < nb; i += stride)
         {
           if(m + i == excl || st[m + i] != B_INACTIVE) continue;
           const double xi = xs[i];
@@ -1360,8 +1363,10 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         }
         mybidx = bidx; // this thread's own best constraint (before the reduction): it is the only thread that scanned it
       };
-      // the scan of the pass BEHIND an addition runs beside that addition's sweep, on the waves that have no row of J (n <= 128): x is
-      // final before the sweep, the scan does not read J, and the constraint being activated is left out explicitly
+      // the scan of the pass BEHIND an addition starts beside that addition's sweep, on the waves that have no row of J (n <= 128): x is
+      // final before the sweep, the scan does not read J, and the constraint being activated is left out explicitly.  One round of 128
+      // general constraints (plus the bounds when there are no more general ones) -- the sweep is shorter than that; all four waves scan
+      // the rest afterwards
       bool prescanned = false;
       double pre_val = 0.0, pre_cx = 0.0, pre_bnd = 0.0;
       int pre_idx = NONE_B, pre_stat = B_INACTIVE, pre_my = NONE_B;
@@ -1374,15 +1379,20 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           double bval = 0.0, mycx = 0.0, mybnd = 0.0;
           int bidx = NONE_B, bstat = B_INACTIVE, mybidx = NONE_B;
           if(!prescanned)
-            scan_part(tid, WGB, -1, bval, bidx, bstat, mycx, mybidx, mybnd);
-          else if(tid >= 128) // (waves 2-3 scanned everything beside the sweep of the addition before)
+            scan_part(tid, WGB, -1, bval, bidx, bstat, mycx, mybidx, mybnd, 0, m, true);
+          else
           {
-            bval = pre_val;
-            bidx = pre_idx;
-            bstat = pre_stat;
-            mycx = pre_cx;
-            mybidx = pre_my;
-            mybnd = pre_bnd;
+            if(tid >= 128) // (waves 2-3 scanned the first constraints beside the sweep of the addition before)
+            {
+              bval = pre_val;
+              bidx = pre_idx;
+              bstat = pre_stat;
+              mycx = pre_cx;
+              mybidx = pre_my;
+              mybnd = pre_bnd;
+            }
+            // the rest -- general constraints from 128 on and, if there were more than 128 of those, the bounds -- on all four waves
+            if(m > 128) scan_part(tid, WGB, -1, bval, bidx, bstat, mycx, mybidx, mybnd, 128, m, true);
           }
           prescanned = false;
           argmin3(bval, bidx, bstat);
@@ -1459,7 +1469,8 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             pre_idx = NONE_B;
             pre_stat = B_INACTIVE;
             pre_my = NONE_B;
-            scan_part(tid - 128, 128, p, pre_val, pre_idx, pre_stat, pre_cx, pre_my, pre_bnd);
+            // one round of general constraints (the sweep beside it takes less than that); the bounds too if that was all of them
+            scan_part(tid - 128, 128, p, pre_val, pre_idx, pre_stat, pre_cx, pre_my, pre_bnd, 0, min(m, 128), m <= 128);
           });
           prescanned = !WIDE && n <= 128;
           ++q;
