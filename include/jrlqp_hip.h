@@ -111,7 +111,7 @@ void jrlqp_default_options(jrlqp_options * opts);
  *        dL == dG reproduces the reference's in-place contract (G's lower triangle <- L, upper part untouched).
  *   dtrace optional [B][trace_cap] records.
  * No allocation, no host synchronisation: the call enqueues one kernel on `stream` (a hipStream_t, may be NULL).
- * Requires 1 <= n <= JRLQP_BATCH_MAX_N.  Shapes that need a workspace (cold: n > 104, the
+ * Requires 1 <= n <= JRLQP_BATCH_MAX_N.  Shapes that need a workspace (cold: from n = 105 .. 113 on, depending on m + nb, the
  * packed R factor -- and past n = 128 J itself -- no longer fit in LDS; warm: every n > 64) take the caller-owned workspace of
  * jrlqp_gi_solve_batch_ws below; this entry point then returns JRLQP_ERR_WORKSPACE instead of allocating.
  */
@@ -180,8 +180,8 @@ int jrlqp_gi_solve_batch_warm(int n,
  *   jrlqp_gi_batch_workspace_bytes: device bytes a batch of B problems of shape (n, m, nb) needs beside its inputs and outputs
  *     on the CURRENT device, cold or warm-started: 0 for every shape whose state fits in LDS and registers (all n <= 64); beyond,
  *     per resident workgroup of the persistent grid (sized by the machine, not by B), the n x n array B = L^-1 N of a warm
- *     start, past n = 104 the packed R factor, and past n = 128 the factors L / J themselves.  A cold solve needs
- *     only the R / J part (nothing up to n = 104) and accepts a smaller workspace accordingly; -1 if the shape is unsupported.
+ *     start, past n = 104 .. 112 (it depends on m + nb too) the packed R factor, and past n = 128 the factors L / J themselves.  A cold solve needs
+ *     only the R / J part (nothing while R fits in LDS) and accepts a smaller workspace accordingly; -1 if the shape is unsupported.
  *   jrlqp_gi_solve_batch_ws: jrlqp_gi_solve_batch (warm == 0, das ignored) or jrlqp_gi_solve_batch_warm (warm != 0) with that
  *     workspace: dworkspace is a 16-byte aligned device pointer to at least workspace_bytes >= the figure above (NULL / 0 when
  *     that figure is 0).  The workspace is scratch: nothing survives the call, and one workspace must not be shared by solves
@@ -225,7 +225,7 @@ int jrlqp_gi_solve_batch_ws(int warm,
  *   dx0, dc, dxl, dxu [B][n]; dbl [B].  Outputs: dx [B][n]; du, dstatus [B][1+n] (the general constraint first, then the
  *   bounds); dterm, diters, df [B]; df is 1/2 ||x - x0||^2 itself (the reference's objectiveValue(), constant included).
  * n <= JRLQP_BATCH_MAX_N (256).  Up to JRLQP_BATCH_WAVE_N variables the closed-form start is one wavefront (lane = variable); beyond
- * (round 4) the large-n batched kernel runs it with thread = variable.  jrlqp_box_solve_batch needs no workspace up to n = 104;
+ * (round 4) the large-n batched kernel runs it with thread = variable.  jrlqp_box_solve_batch needs no workspace while R fits in LDS (n <= 104 at least);
  * past that the packed R (and past n = 128 the factor J) of the large-n kernel live in a caller-owned workspace of
  * jrlqp_gi_batch_workspace_bytes(n, 1, n, B) bytes, passed to jrlqp_box_solve_batch_ws (JRLQP_ERR_WORKSPACE without it).
  * One launch, no allocation, no host synchronisation. */
