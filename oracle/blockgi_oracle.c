@@ -528,6 +528,429 @@ done:
   return rc;
 }
 
+/* =========================================================================================== */
+/* Contract C9 ("thin Q", round 5): the same solver with Q kept as its leading q columns        */
+/* =========================================================================================== */
+/*
+ * The reference keeps Q as an OrthonormalSequence -- one Householder element per added constraint, one Givens sequence
+ * per removed one (src/structured/StructuredQR.cpp:70-102) -- and applies EVERY element twice per iteration
+ * (src/structured/StructuredJ.cpp:32-57, src/internal/OrthonormalSequence.cpp:189-207).  What an iteration needs of Q is
+ *     d1 = Q1^T b          (b = L^-1 n+; the first q entries of Q^T b: the right-hand side of R r = d1 and the new column of R)
+ *     y  = Q2 Q2^T b       (Q [0; d2]: the part of b orthogonal to the active normals; z = L^-T y)
+ * and Q2 Q2^T b = b - Q1 d1.  C9 therefore stores Q1 (n x q, the orthonormal factor of the thin QR  L^-1 N = Q1 R) explicitly:
+ *   add     new column of R = [d1; |y|], new column of Q1 = y / |y|                  (Gram-Schmidt step of the QR update)
+ *   remove  column l of R deleted, the Givens rotations that restore the triangle (StructuredQR.cpp:88-99, unchanged) are
+ *           applied ONCE to columns l .. q of Q1 (as GoldfarbIdnaniSolver.cpp:247-252 does to J), the last column dropped
+ *   one iteration reads Q1 once (y) plus the rows under b's non-zero window (d1) instead of every element twice.
+ * Orthogonality is kept by the Daniel-Gragg-Kaufman-Stewart rule: if |y|^2 < |b|^2 / 2 the projection is repeated once
+ * (e = Q1^T y, y -= Q1 e, d1 += e).  R, r, u, t1, t2, x, f follow the same formulas as above, so the iterates agree with the
+ * sequence form up to rounding (tests/test_oracle_blockgi_literal.py: identical decisions; x, u, f to 1e-10); the sign of a
+ * diagonal entry of R is + here where makeHouseholder gives -sign(d_q) (r = R^-1 d1 is unaffected: row q of R and d1_q flip together).
+ *
+ * Rounding rules (everything a cluster of workgroups can evaluate without caring how the rows are dealt out):
+ *   - b, L^-1, L^-T, C^T x, the R solve, Givens rotations, n+.x, n+.z: as in the sequence form (C1-C3);
+ *   - BLOCK ORDER: off-head blocks in logical order then the head block for the arrows (the order of blockArrowLSolve's permuted
+ *     result, blockArrowLLT.cpp:163-170), natural order for the tridiagonal shape;
+ *   - a reduction over a whole vector of unknowns (|b|^2, |y|^2, |z|^2, a.x): per block the products summed by the adjacent-first
+ *     pairwise tree (orc_dot_tree, phase 0), the block sums combined by the adjacent-first pairwise tree over the block order;
+ *   - d1_j = sum_i Q1(i,j) b_i (and e_j): per block one fma chain over the block's rows ascending from +0, the block values combined
+ *     by the adjacent-first pairwise tree over the block order (blocks in which b is zero contribute +0 and may be skipped);
+ *   - the row products Q1(i,:) . d1: segments of 64 columns (absolute column index), inside a segment an fma chain ascending
+ *     from +0, the segments combined by the adjacent-first pairwise tree; y_i = b_i - that;
+ *   - q == n: y = 0 (Q2 is empty: StructuredJ.cpp:36 multiplies an empty tail).
+ */
+typedef struct
+{
+  int nblk;
+  int off_perm[4097], off_phys[4097], len[4097]; /* block order: offset in permuted / original coordinates, rows */
+} blkorder;
+
+static void blkorder_init(const bgi * S, blkorder * B)
+{
+  const int nblk = S->nblk;
+  B->nblk = nblk;
+  int phys[4097];
+  for(int i = 0, o = 0; i < nblk; ++i) { phys[i] = o; o += S->bs[i]; }
+  int op = 0;
+  for(int k = 0; k < nblk; ++k)
+  {
+    const int b = (S->type == 1) ? (k + 1) % nblk : k; /* dsel: logical block k of the up arrow is physical block k + 1, head = 0 */
+    B->off_perm[k] = op;
+    B->off_phys[k] = phys[b];
+    B->len[k] = S->bs[b];
+    op += S->bs[b];
+  }
+}
+
+static double tree_sum(int n, double * p) /* adjacent-first pairwise tree, p has room for the next power of two */
+{
+  int size = 1;
+  while(size < n) size <<= 1;
+  for(int i = n; i < size; ++i) p[i] = 0.0;
+  for(int h = 1; h < size; h <<= 1)
+    for(int i = 0; i < size; i += 2 * h) p[i] = p[i] + p[i + h];
+  return n > 0 ? p[0] : 0.0;
+}
+
+/* C9 reduction of a.b over the block order; permuted: the vectors are in permuted coordinates (b, y) or original ones (x, z, a) */
+static double blk_reduce(const blkorder * B, const double * a, const double * b, int permuted)
+{
+  double p[8192];
+  for(int k = 0; k < B->nblk; ++k)
+  {
+    const int o = permuted ? B->off_perm[k] : B->off_phys[k];
+    p[k] = orc_dot_tree(B->len[k], a + o, b + o, 0);
+  }
+  return tree_sum(B->nblk, p);
+}
+
+/* row products of C9: out_i = in_i - sum_j Q1(i,j) v_j, j < q, for every row (column sweeps: each (row, segment) chain takes its
+ * terms in ascending j, so the sweep order over the rows is free); W: n * 64 doubles of scratch */
+static void thin_rows(int n, int q, const double * Q1, long ld, const double * v, const double * in, double * out, double * W)
+{
+  const int S = (q + 63) >> 6;
+  int size = 1;
+  while(size < S) size <<= 1;
+  for(int s = 0; s < S; ++s)
+  {
+    double * acc = W + (long)s * n;
+    for(int i = 0; i < n; ++i) acc[i] = 0.0;
+    const int j1 = (64 * s + 64 < q) ? 64 * s + 64 : q;
+    for(int j = 64 * s; j < j1; ++j)
+    {
+      const double * col = Q1 + (long)j * ld;
+      const double vj = v[j];
+      for(int i = 0; i < n; ++i) acc[i] = FMA(col[i], vj, acc[i]);
+    }
+  }
+  for(int s = S; s < size; ++s)
+  {
+    double * acc = W + (long)s * n;
+    for(int i = 0; i < n; ++i) acc[i] = 0.0;
+  }
+  for(int h = 1; h < size; h <<= 1)
+    for(int s = 0; s < size; s += 2 * h)
+    {
+      double *pa = W + (long)s * n, *pb = W + (long)(s + h) * n;
+      for(int i = 0; i < n; ++i) pa[i] = pa[i] + pb[i];
+    }
+  if(S == 0)
+    for(int i = 0; i < n; ++i) out[i] = in[i] - 0.0;
+  else
+    for(int i = 0; i < n; ++i) out[i] = in[i] - W[i];
+}
+
+static int g_thin_reorth = 0;
+static double g_thin_eta2 = 0.5; /* experiment knob */
+void orc_blockgi_thin_set_eta2(double v) { g_thin_eta2 = v; }
+int orc_blockgi_thin_reorth_count(void) { return g_thin_reorth; }
+
+/* out_j = tree over the block order of (chain over the block's rows of Q1(i,j) v_i), j < q.  A block in which v is all zero
+ * contributes +0 (a chain from +0 is never -0, so neither is a sum of such values: adding +0 changes no bit) -- such blocks are left
+ * out of the sweep and their slot of the tree is +0.  W: nblk_pow2 * q doubles of scratch. */
+static void thin_qt_v(const blkorder * B, int q, const double * Q1, long ld, const double * v, double * out, double * W)
+{
+  int size = 1;
+  while(size < B->nblk) size <<= 1;
+  /* slots that hold a value; an empty slot is +0 and x + 0 = x: a node with one empty child is its other child */
+  unsigned char live[8192];
+  for(int k = 0; k < size; ++k) live[k] = 0;
+  for(int k = 0; k < B->nblk; ++k)
+  {
+    const int o = B->off_perm[k], len = B->len[k];
+    int nz = 0;
+    for(int i = 0; i < len && !nz; ++i) nz = (v[o + i] != 0.0);
+    if(!nz) continue;
+    live[k] = 1;
+    double * w = W + (long)k * q;
+    for(int j = 0; j < q; ++j)
+    {
+      const double * col = Q1 + (long)j * ld + o;
+      double acc = 0.0;
+      for(int i = 0; i < len; ++i) acc = FMA(col[i], v[o + i], acc);
+      w[j] = acc;
+    }
+  }
+  for(int h = 1; h < size; h <<= 1)
+    for(int k = 0; k < size; k += 2 * h)
+    {
+      double *pa = W + (long)k * q, *pb = W + (long)(k + h) * q;
+      if(live[k] && live[k + h])
+        for(int j = 0; j < q; ++j) pa[j] = pa[j] + pb[j];
+      else if(live[k + h])
+      {
+        for(int j = 0; j < q; ++j) pa[j] = pb[j];
+        live[k] = 1;
+      }
+    }
+  if(live[0])
+    for(int j = 0; j < q; ++j) out[j] = W[j];
+  else
+    for(int j = 0; j < q; ++j) out[j] = 0.0;
+}
+
+int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, const int * ldd, double ** off, const int * ldo,
+                           const double * a, int ncb, const int * cvar, const int * ccstr, const double ** cblk, const int * cld,
+                           const double * bl, const double * bu, const double * xl, const double * xu, int nb, int max_iter,
+                           double big_bnd, double * xout, double * uout, int * status_out, int * active_out, int * nactive_out,
+                           int * iters_out, double * f_out, orc_trace_rec * trace, int trace_cap)
+{
+  bgi S;
+  memset(&S, 0, sizeof S);
+  S.type = type; S.nblk = nblk; S.bs = bs; S.diag = diag; S.ldd = ldd; S.off = off; S.ldo = ldo;
+  S.ncb = ncb; S.cvar = cvar; S.ccstr = ccstr; S.cblk = cblk; S.cld = cld;
+  S.bl = bl; S.bu = bu; S.xl = xl; S.xu = xu; S.nb = nb;
+  int n = 0, m = 0, nvc = 0;
+  for(int i = 0; i < nblk; ++i) n += bs[i];
+  for(int i = 0; i < ncb; ++i) { m += ccstr[i]; nvc += cvar[i]; }
+  S.n = n; S.m = m;
+  int rc = ORC_UNKNOWN, it = 0;
+  g_thin_reorth = 0;
+  if(nvc != n || (nb != 0 && nb != n) || nblk > 4096) { rc = ORC_INCONSISTENT_INPUT; n = 0; }
+
+  S.to_block = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+  S.cum_var = (int *)malloc(sizeof(int) * (size_t)(ncb + 1));
+  S.cum_cstr = (int *)malloc(sizeof(int) * (size_t)(ncb + 1));
+  {
+    int cv = 0, cc = 0;
+    for(int i = 0; i < ncb; ++i)
+    {
+      S.cum_var[i] = cv; S.cum_cstr[i] = cc;
+      for(int k = 0; k < ccstr[i]; ++k) S.to_block[cc + k] = i;
+      cv += cvar[i]; cc += ccstr[i];
+    }
+    S.cum_var[ncb] = cv; S.cum_cstr[ncb] = cc;
+  }
+  const int qmax = (S.n < m + nb ? S.n : m + nb) + 1;
+  S.d = (double *)calloc((size_t)(3 * S.n + 2 * (m + nb + 2) + m + 1), sizeof(double));
+  S.z = S.d + S.n; S.x = S.z + S.n; S.u = S.x + S.n; S.r = S.u + (m + nb + 2); S.cx = S.r + (m + nb + 2);
+  S.Rp = (double *)calloc((size_t)((long)qmax * (qmax + 1) / 2 + 1), sizeof(double));
+  S.A = orc_as_new(m, nb);
+  const long ld = S.n > 0 ? S.n : 1;
+  double * Q1 = (double *)calloc((size_t)(ld * qmax), sizeof(double));
+  double * d1 = (double *)calloc((size_t)(2 * qmax + 2), sizeof(double)), *e1 = d1 + qmax + 1;
+  double * W = (double *)malloc(sizeof(double) * (size_t)(S.n > 0 ? S.n : 1) * 64);
+  int np2 = 1;
+  while(np2 < nblk) np2 <<= 1;
+  double * W2 = (double *)malloc(sizeof(double) * (size_t)np2 * (size_t)qmax);
+  double *x = S.x, *z = S.z, *u = S.u, *r = S.r, *b = S.d;
+  blkorder * B = (blkorder *)malloc(sizeof(blkorder));
+  if(rc == ORC_INCONSISTENT_INPUT) goto done;
+  blkorder_init(&S, B);
+
+  /* ---- init_ (BlockGISolver.cpp:62-107), as in orc_blockgi_solve ---- */
+  for(int i = 0; i < nb; ++i)
+    if(xl[i] == xu[i]) { rc = ORC_INCONSISTENT_INPUT; goto done; }
+  for(int i = 0; i < m; ++i)
+    if(bl[i] == bu[i]) { rc = ORC_INCONSISTENT_INPUT; goto done; }
+  {
+    int ok = (type == 0) ? orc_tri_block_diag_llt(nblk, bs, diag, ldd, off, ldo)
+                         : orc_block_arrow_llt(nblk, bs, diag, ldd, off, ldo, type == 1);
+    if(!ok) { rc = ORC_NON_POS_HESSIAN; goto done; }
+  }
+  for(int i = 0; i < n; ++i) x[i] = a[i];
+  sg_solve_l(&S, x, 0, n);
+  sg_solve_lt(&S, x);
+  for(int i = 0; i < n; ++i) x[i] = -x[i];
+  S.f = 0.5 * blk_reduce(B, a, x, 0);
+
+  /* ---- DualSolver::solve loop (DualSolver.cpp:96-167) ---- */
+  {
+    int skip_step1 = 0, p = -1, pstatus = ORC_INACTIVE;
+    rc = ORC_MAX_ITER_REACHED;
+    for(; it < max_iter; ++it)
+    {
+      const int q = S.q;
+      if(!skip_step1)
+      {
+        for(int bb = 0; bb < ncb; ++bb)
+          for(int k = 0; k < ccstr[bb]; ++k)
+            S.cx[S.cum_cstr[bb] + k] = orc_dot(cvar[bb], cblk[bb] + (long)k * cld[bb], x + S.cum_var[bb]);
+        double smin = 0.0;
+        p = -1;
+        pstatus = ORC_INACTIVE;
+        for(int i = 0; i < m; ++i)
+        {
+          if(orc_as_status(S.A, i) != ORC_INACTIVE) continue;
+          const double sl = S.cx[i] - bl[i];
+          if(sl < smin) { smin = sl; p = i; pstatus = ORC_LOWER; }
+          else
+          {
+            const double su = bu[i] - S.cx[i];
+            if(su < smin) { smin = su; p = i; pstatus = ORC_UPPER; }
+          }
+        }
+        for(int i = 0; i < nb; ++i)
+        {
+          if(orc_as_status(S.A, m + i) != ORC_INACTIVE) continue;
+          const double sl = x[i] - xl[i];
+          if(sl < smin) { smin = sl; p = m + i; pstatus = ORC_LOWER_BOUND; }
+          else
+          {
+            const double su = xu[i] - x[i];
+            if(su < smin) { smin = su; p = m + i; pstatus = ORC_UPPER_BOUND; }
+          }
+        }
+        if(pstatus == ORC_INACTIVE) { rc = ORC_SUCCESS; break; }
+        u[q] = 0.0;
+      }
+
+      /* ---- computeStep_ under C9 ---- */
+      /* b = L^-1 n+ (StructuredJ.cpp:43-57, unchanged; permuted coordinates for the up arrow) */
+      for(int i = 0; i < n; ++i) b[i] = 0.0;
+      if(pstatus <= ORC_EQUALITY)
+      {
+        int st, len;
+        const double * c = c_col(&S, p, &st, &len);
+        for(int i = 0; i < len; ++i) b[st + i] = c[i];
+        sg_solve_l(&S, b, st, st + len);
+        if(pstatus == ORC_UPPER)
+          for(int i = 0; i < n; ++i) b[i] = -b[i];
+      }
+      else
+      {
+        const int pb = p - S.m;
+        b[pb] = (pstatus == ORC_UPPER_BOUND) ? -1.0 : 1.0;
+        sg_solve_l(&S, b, pb, pb + 1);
+      }
+      double nrm2 = 0.0;
+      thin_qt_v(B, q, Q1, ld, b, d1, W2);
+      if(q == n)
+        for(int i = 0; i < n; ++i) z[i] = 0.0;
+      else
+      {
+        const double bb = blk_reduce(B, b, b, 1);
+        thin_rows(n, q, Q1, ld, d1, b, z, W);
+        nrm2 = blk_reduce(B, z, z, 1);
+        if(q > 0 && nrm2 < g_thin_eta2 * bb)
+        {
+          ++g_thin_reorth;
+          thin_qt_v(B, q, Q1, ld, z, e1, W2);
+          thin_rows(n, q, Q1, ld, e1, z, z, W);
+          for(int j = 0; j < q; ++j) d1[j] = d1[j] + e1[j];
+          nrm2 = blk_reduce(B, z, z, 1);
+        }
+      }
+      /* y (in z) is kept for the new column of Q1; z = L^-T y */
+      for(int i = 0; i < n; ++i) b[i] = z[i]; /* b now holds y (permuted coordinates) */
+      sg_solve_lt(&S, z);
+      /* StructuredQR::RSolve (StructuredQR.cpp:64-68) */
+      for(int k = 0; k < q; ++k) r[k] = d1[k];
+      for(int k = q - 1; k >= 0; --k)
+      {
+        double v = r[k] / RP(&S, k, k);
+        r[k] = v;
+        for(int i = 0; i < k; ++i) r[i] = FMA(-RP(&S, i, k), v, r[i]);
+      }
+
+      /* computeStepLength_ (BlockGISolver.cpp:174-242) */
+      double t1 = big_bnd, t2 = big_bnd;
+      int l = 0;
+      for(int k = 0; k < q; ++k)
+      {
+        const int sk = orc_as_status(S.A, k);
+        if(sk != ORC_EQUALITY && sk != ORC_FIXED && r[k] > 0.0)
+        {
+          const double tk = u[k] / r[k];
+          if(tk < t1) { t1 = tk; l = k; }
+        }
+      }
+      double cz = 0.0;
+      if(sqrt(blk_reduce(B, z, z, 0)) > 1e-14)
+      {
+        const double bnd = (pstatus == ORC_LOWER) ? bl[p] : (pstatus == ORC_UPPER) ? bu[p]
+                           : (pstatus == ORC_LOWER_BOUND) ? xl[p - m] : xu[p - m];
+        const double cxp = cstr_dot(&S, p, x);
+        cz = cstr_dot(&S, p, z);
+        t2 = (bnd - cxp) / cz;
+      }
+      const double t = (t2 < t1) ? t2 : t1;
+
+      if(trace && it < trace_cap)
+      {
+        trace[it].p = p; trace[it].status = pstatus; trace[it].l = l; trace[it].t1 = t1; trace[it].t2 = t2;
+        trace[it].kind = (t2 >= big_bnd) ? 2 : ((t == t2) ? 0 : 1);
+      }
+
+      if(t >= big_bnd) { rc = ORC_INFEASIBLE; break; }
+
+      int drop;
+      if(t2 >= big_bnd)
+      {
+        for(int k = 0; k < q; ++k) u[k] = FMA(-t, r[k], u[k]);
+        u[q] += t;
+        drop = 1;
+      }
+      else
+      {
+        for(int i = 0; i < n; ++i) x[i] = FMA(t, z[i], x[i]);
+        const double nz = (pstatus == ORC_UPPER || pstatus == ORC_UPPER_BOUND) ? -cz : cz;
+        S.f = FMA(t * nz, 0.5 * t + u[q], S.f);
+        for(int k = 0; k < q; ++k) u[k] = FMA(-t, r[k], u[k]);
+        u[q] += t;
+        drop = !(t == t2);
+      }
+      if(!drop)
+      {
+        /* add: R gets the column [d1; |y|], Q1 the column y / |y| */
+        const double nrm = sqrt(nrm2);
+        orc_as_activate(S.A, p, pstatus);
+        for(int k = 0; k < q; ++k) RP(&S, k, q) = d1[k];
+        RP(&S, q, q) = nrm;
+        double * col = Q1 + (long)q * ld;
+        for(int i = 0; i < n; ++i) col[i] = b[i] / nrm;
+        S.q = q + 1;
+        skip_step1 = 0;
+      }
+      else
+      {
+        /* remove (DualSolver.cpp:237-244, StructuredQR.cpp:86-102): R as in qr_remove; the rotations go to columns l .. q-1 of Q1 */
+        for(int k = l; k < q; ++k) u[k] = u[k + 1];
+        orc_as_deactivate(S.A, l);
+        const int q1 = q - 1;
+        for(int i = l; i < q1; ++i)
+        {
+          double c, s;
+          for(int k = 0; k < i; ++k) RP(&S, k, i) = RP(&S, k, i + 1);
+          orc_givens(RP(&S, i, i + 1), RP(&S, i + 1, i + 1), &c, &s, &RP(&S, i, i));
+          for(int k = i + 2; k <= q1; ++k) rot(c, s, &RP(&S, i, k), &RP(&S, i + 1, k));
+          double *ci = Q1 + (long)i * ld, *cj = ci + ld;
+          for(int rr = 0; rr < n; ++rr) rot(c, s, &ci[rr], &cj[rr]);
+        }
+        S.q = q1;
+        skip_step1 = 1;
+      }
+    }
+  }
+
+done:
+  for(int i = 0; i < S.n; ++i) xout[i] = x[i];
+  {
+    int cnt[8];
+    orc_as_counters(S.A, cnt);
+    const int nact = cnt[0];
+    if(uout)
+    {
+      for(int i = 0; i < m + nb; ++i) uout[i] = 0.0;
+      for(int k = 0; k < nact; ++k)
+      {
+        const int i = orc_as_at(S.A, k);
+        const int st = orc_as_status(S.A, i);
+        uout[i] = (st == ORC_UPPER || st == ORC_UPPER_BOUND) ? u[k] : -u[k];
+      }
+    }
+    if(status_out) for(int i = 0; i < m + nb; ++i) status_out[i] = orc_as_status(S.A, i);
+    if(active_out) for(int k = 0; k < nact; ++k) active_out[k] = orc_as_at(S.A, k);
+    if(nactive_out) *nactive_out = nact;
+  }
+  if(iters_out) *iters_out = it;
+  if(f_out) *f_out = S.f;
+  orc_as_free(S.A);
+  free(S.to_block); free(S.cum_var); free(S.cum_cstr);
+  free(S.d); free(S.Rp); free(Q1); free(d1); free(B); free(W); free(W2);
+  return rc;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* stand-alone orthonormal-sequence object, for the identities of the reference's InternalTest  */
 /* (tests/InternalTest.cpp:35-323): build a sequence, apply it / its transpose to vectors.      */
