@@ -529,34 +529,42 @@ done:
 }
 
 /* =========================================================================================== */
-/* Contract C9 ("thin Q", round 5): the same solver with Q kept as its leading q columns        */
+/* Contract C9 (round 5): the same solver without an orthonormal sequence                       */
 /* =========================================================================================== */
 /*
- * The reference keeps Q as an OrthonormalSequence -- one Householder element per added constraint, one Givens sequence
- * per removed one (src/structured/StructuredQR.cpp:70-102) -- and applies EVERY element twice per iteration
- * (src/structured/StructuredJ.cpp:32-57, src/internal/OrthonormalSequence.cpp:189-207).  What an iteration needs of Q is
- *     d1 = Q1^T b          (b = L^-1 n+; the first q entries of Q^T b: the right-hand side of R r = d1 and the new column of R)
- *     y  = Q2 Q2^T b       (Q [0; d2]: the part of b orthogonal to the active normals; z = L^-T y)
- * and Q2 Q2^T b = b - Q1 d1.  C9 therefore stores Q1 (n x q, the orthonormal factor of the thin QR  L^-1 N = Q1 R) explicitly:
- *   add     new column of R = [d1; |y|], new column of Q1 = y / |y|                  (Gram-Schmidt step of the QR update)
- *   remove  column l of R deleted, the Givens rotations that restore the triangle (StructuredQR.cpp:88-99, unchanged) are
- *           applied ONCE to columns l .. q of Q1 (as GoldfarbIdnaniSolver.cpp:247-252 does to J), the last column dropped
- *   one iteration reads Q1 once (y) plus the rows under b's non-zero window (d1) instead of every element twice.
- * Orthogonality is kept by the Daniel-Gragg-Kaufman-Stewart rule: if |y|^2 < |b|^2 / 2 the projection is repeated once
- * (e = Q1^T y, y -= Q1 e, d1 += e).  R, r, u, t1, t2, x, f follow the same formulas as above, so the iterates agree with the
- * sequence form up to rounding (tests/test_oracle_blockgi_literal.py: identical decisions; x, u, f to 1e-10); the sign of a
- * diagonal entry of R is + here where makeHouseholder gives -sign(d_q) (r = R^-1 d1 is unaffected: row q of R and d1_q flip together).
+ * The reference keeps Q of the QR factorisation  L^-1 N = Q [R; 0]  as an OrthonormalSequence -- one Householder element per added
+ * constraint, one Givens sequence per removed one (src/structured/StructuredQR.cpp:70-102) -- and applies EVERY element twice per
+ * iteration (src/structured/StructuredJ.cpp:32-57, src/internal/OrthonormalSequence.cpp:189-207): O(n k) work and memory traffic per
+ * iteration, k = elements made so far.  What an iteration needs of Q and R is
+ *     r  = R^-1 Q1^T b            (b = L^-1 n+; the multipliers' direction, StructuredQR.cpp:64-68)
+ *     y  = Q2 Q2^T b = b - Q1 Q1^T b = b - B r      (B = L^-1 N = Q1 R;  z = L^-T y)
+ * i.e. the least-squares problem  min |b - B r|.  B is SPARSE -- column k is L^-1 n_k, non-zero only in the Hessian blocks under the
+ * constraint's window and in the head block (arrows) -- so C9 keeps
+ *     B   the columns L^-1 n_k of the active constraints (they are the b's of the iterations that added them), and
+ *     S   = R^-1, upper triangular q x q (the inverse Cholesky factor of  B^T B = N^T G^-1 N),
+ * and solves the least-squares problem by the corrected semi-normal equations (Bjorck 1987): r = S S^T B^T b, y = b - B r, then ONE
+ * refinement step on the residual: r += S S^T B^T y, y -= B (S S^T B^T y).  No n x q object is ever touched: one iteration is O(q^2)
+ * (four triangular matrix-vector products) plus O(q) sparse columns.
+ *   add     S gets the column [-r / rho; 1 / rho], rho = |y| (the bordered inverse of [R d1; 0 rho]); B gets the column b
+ *   remove  row l and column l leave: the rotations that fold S(l, l..q-1) into the last column -- orc_givens_chain (CANON C7) on that
+ *           row reversed -- are applied to columns l .. q-1 of S, row by row (rows are independent); row l and the last column go
+ * The iterates agree with the sequence form up to rounding (tests/test_oracle_blockgi_literal.py: identical decisions).
  *
- * Rounding rules (everything a cluster of workgroups can evaluate without caring how the rows are dealt out):
- *   - b, L^-1, L^-T, C^T x, the R solve, Givens rotations, n+.x, n+.z: as in the sequence form (C1-C3);
+ * Rounding rules:
+ *   - b, L^-1, L^-T, C^T x, n+.x, n+.z, u, f: as in the sequence form (C1-C3);
  *   - BLOCK ORDER: off-head blocks in logical order then the head block for the arrows (the order of blockArrowLSolve's permuted
  *     result, blockArrowLLT.cpp:163-170), natural order for the tridiagonal shape;
- *   - a reduction over a whole vector of unknowns (|b|^2, |y|^2, |z|^2, a.x): per block the products summed by the adjacent-first
- *     pairwise tree (orc_dot_tree, phase 0), the block sums combined by the adjacent-first pairwise tree over the block order;
- *   - d1_j = sum_i Q1(i,j) b_i (and e_j): per block one fma chain over the block's rows ascending from +0, the block values combined
- *     by the adjacent-first pairwise tree over the block order (blocks in which b is zero contribute +0 and may be skipped);
- *   - the row products Q1(i,:) . d1: segments of 64 columns (absolute column index), inside a segment an fma chain ascending
- *     from +0, the segments combined by the adjacent-first pairwise tree; y_i = b_i - that;
+ *   - a reduction over a whole vector of unknowns (|y|^2, |z|^2, a.x): per block the products summed by the adjacent-first pairwise
+ *     tree (orc_dot_tree, phase 0), the block sums combined by the adjacent-first pairwise tree over the block order;
+ *   - GROUPS: an active constraint belongs to the group of its block of C (general constraints, group = block index) or of the Hessian
+ *     block that holds its variable (bounds, group = ncb + block-order index); reach(group) = the Hessian blocks in which its b can be
+ *     non-zero: the off-head blocks under the window plus the head (arrows), every block from the first one under the window (tri);
+ *   - g_k = B_k . v (v = b or y): per common block of reach(k) and reach(p) [v = y: reach(k)] one fma chain over the block's rows
+ *     ascending from +0, the block values added up in block order (a chain of additions starting from the first block's value);
+ *   - d1 = S^T g: per column an fma chain over the rows ascending from +0;  r = S d1: per row an fma chain over the columns DESCENDING
+ *     from +0 (the order of a back substitution);
+ *   - B r on block kappa: per group that reaches kappa (static list, group order) an fma chain over the group's active constraints in
+ *     active-set order from +0, the group values combined by the adjacent-first pairwise tree over that list; y = v - that;
  *   - q == n: y = 0 (Q2 is empty: StructuredJ.cpp:36 multiplies an empty tail).
  */
 typedef struct
@@ -604,96 +612,36 @@ static double blk_reduce(const blkorder * B, const double * a, const double * b,
   return tree_sum(B->nblk, p);
 }
 
-/* row products of C9: out_i = in_i - sum_j Q1(i,j) v_j, j < q, for every row (column sweeps: each (row, segment) chain takes its
- * terms in ascending j, so the sweep order over the rows is free); W: n * 64 doubles of scratch */
-static void thin_rows(int n, int q, const double * Q1, long ld, const double * v, const double * in, double * out, double * W)
+typedef struct
 {
-  const int S = (q + 63) >> 6;
-  int size = 1;
-  while(size < S) size <<= 1;
-  for(int s = 0; s < S; ++s)
-  {
-    double * acc = W + (long)s * n;
-    for(int i = 0; i < n; ++i) acc[i] = 0.0;
-    const int j1 = (64 * s + 64 < q) ? 64 * s + 64 : q;
-    for(int j = 64 * s; j < j1; ++j)
+  int klo, khi; /* off-head blocks (block-order index) under the window; klo > khi: none.  tri: khi = nblk - 1 */
+} reach_t;
+
+/* reach of a constraint whose normal is non-zero on the ORIGINAL rows [wst, wen) */
+static reach_t reach_of(const bgi * S, const blkorder * B, int wst, int wen)
+{
+  reach_t r = {B->nblk, -1};
+  const int last = (S->type == 0) ? B->nblk : B->nblk - 1; /* arrows: the head is not an off-head block */
+  for(int k = 0; k < last; ++k)
+    if(B->off_phys[k] < wen && wst < B->off_phys[k] + B->len[k])
     {
-      const double * col = Q1 + (long)j * ld;
-      const double vj = v[j];
-      for(int i = 0; i < n; ++i) acc[i] = FMA(col[i], vj, acc[i]);
+      if(k < r.klo) r.klo = k;
+      r.khi = k;
     }
-  }
-  for(int s = S; s < size; ++s)
-  {
-    double * acc = W + (long)s * n;
-    for(int i = 0; i < n; ++i) acc[i] = 0.0;
-  }
-  for(int h = 1; h < size; h <<= 1)
-    for(int s = 0; s < size; s += 2 * h)
-    {
-      double *pa = W + (long)s * n, *pb = W + (long)(s + h) * n;
-      for(int i = 0; i < n; ++i) pa[i] = pa[i] + pb[i];
-    }
-  if(S == 0)
-    for(int i = 0; i < n; ++i) out[i] = in[i] - 0.0;
-  else
-    for(int i = 0; i < n; ++i) out[i] = in[i] - W[i];
+  if(S->type == 0 && r.klo <= r.khi) r.khi = B->nblk - 1;
+  return r;
+}
+static int reaches(const bgi * S, const blkorder * B, reach_t r, int k)
+{
+  if(S->type != 0 && k == B->nblk - 1) return 1; /* the head of an arrow */
+  return r.klo <= k && k <= r.khi;
 }
 
-static int g_thin_reorth = 0;
-static double g_thin_eta2 = 0.5; /* experiment knob */
-void orc_blockgi_thin_set_eta2(double v) { g_thin_eta2 = v; }
-int orc_blockgi_thin_reorth_count(void) { return g_thin_reorth; }
-
-/* out_j = tree over the block order of (chain over the block's rows of Q1(i,j) v_i), j < q.  A block in which v is all zero
- * contributes +0 (a chain from +0 is never -0, so neither is a sum of such values: adding +0 changes no bit) -- such blocks are left
- * out of the sweep and their slot of the tree is +0.  W: nblk_pow2 * q doubles of scratch. */
-static void thin_qt_v(const blkorder * B, int q, const double * Q1, long ld, const double * v, double * out, double * W)
-{
-  int size = 1;
-  while(size < B->nblk) size <<= 1;
-  /* slots that hold a value; an empty slot is +0 and x + 0 = x: a node with one empty child is its other child */
-  unsigned char live[8192];
-  for(int k = 0; k < size; ++k) live[k] = 0;
-  for(int k = 0; k < B->nblk; ++k)
-  {
-    const int o = B->off_perm[k], len = B->len[k];
-    int nz = 0;
-    for(int i = 0; i < len && !nz; ++i) nz = (v[o + i] != 0.0);
-    if(!nz) continue;
-    live[k] = 1;
-    double * w = W + (long)k * q;
-    for(int j = 0; j < q; ++j)
-    {
-      const double * col = Q1 + (long)j * ld + o;
-      double acc = 0.0;
-      for(int i = 0; i < len; ++i) acc = FMA(col[i], v[o + i], acc);
-      w[j] = acc;
-    }
-  }
-  for(int h = 1; h < size; h <<= 1)
-    for(int k = 0; k < size; k += 2 * h)
-    {
-      double *pa = W + (long)k * q, *pb = W + (long)(k + h) * q;
-      if(live[k] && live[k + h])
-        for(int j = 0; j < q; ++j) pa[j] = pa[j] + pb[j];
-      else if(live[k + h])
-      {
-        for(int j = 0; j < q; ++j) pa[j] = pb[j];
-        live[k] = 1;
-      }
-    }
-  if(live[0])
-    for(int j = 0; j < q; ++j) out[j] = W[j];
-  else
-    for(int j = 0; j < q; ++j) out[j] = 0.0;
-}
-
-int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, const int * ldd, double ** off, const int * ldo,
-                           const double * a, int ncb, const int * cvar, const int * ccstr, const double ** cblk, const int * cld,
-                           const double * bl, const double * bu, const double * xl, const double * xu, int nb, int max_iter,
-                           double big_bnd, double * xout, double * uout, int * status_out, int * active_out, int * nactive_out,
-                           int * iters_out, double * f_out, orc_trace_rec * trace, int trace_cap)
+int orc_blockgi_solve_c9(int type, int nblk, const int * bs, double ** diag, const int * ldd, double ** off, const int * ldo,
+                         const double * a, int ncb, const int * cvar, const int * ccstr, const double ** cblk, const int * cld,
+                         const double * bl, const double * bu, const double * xl, const double * xu, int nb, int max_iter,
+                         double big_bnd, double * xout, double * uout, int * status_out, int * active_out, int * nactive_out,
+                         int * iters_out, double * f_out, orc_trace_rec * trace, int trace_cap)
 {
   bgi S;
   memset(&S, 0, sizeof S);
@@ -705,7 +653,6 @@ int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, c
   for(int i = 0; i < ncb; ++i) { m += ccstr[i]; nvc += cvar[i]; }
   S.n = n; S.m = m;
   int rc = ORC_UNKNOWN, it = 0;
-  g_thin_reorth = 0;
   if(nvc != n || (nb != 0 && nb != n) || nblk > 4096) { rc = ORC_INCONSISTENT_INPUT; n = 0; }
 
   S.to_block = (int *)malloc(sizeof(int) * (size_t)(m + 1));
@@ -724,19 +671,29 @@ int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, c
   const int qmax = (S.n < m + nb ? S.n : m + nb) + 1;
   S.d = (double *)calloc((size_t)(3 * S.n + 2 * (m + nb + 2) + m + 1), sizeof(double));
   S.z = S.d + S.n; S.x = S.z + S.n; S.u = S.x + S.n; S.r = S.u + (m + nb + 2); S.cx = S.r + (m + nb + 2);
-  S.Rp = (double *)calloc((size_t)((long)qmax * (qmax + 1) / 2 + 1), sizeof(double));
   S.A = orc_as_new(m, nb);
   const long ld = S.n > 0 ? S.n : 1;
-  double * Q1 = (double *)calloc((size_t)(ld * qmax), sizeof(double));
-  double * d1 = (double *)calloc((size_t)(2 * qmax + 2), sizeof(double)), *e1 = d1 + qmax + 1;
-  double * W = (double *)malloc(sizeof(double) * (size_t)(S.n > 0 ? S.n : 1) * 64);
-  int np2 = 1;
-  while(np2 < nblk) np2 <<= 1;
-  double * W2 = (double *)malloc(sizeof(double) * (size_t)np2 * (size_t)qmax);
+  const int ngrp = ncb + (nb ? nblk : 0);
+  double * Bc = (double *)calloc((size_t)(ld * qmax), sizeof(double));       /* column storage by SLOT, permuted coordinates */
+  double * Sm = (double *)calloc((size_t)qmax * (size_t)qmax, sizeof(double)); /* S(i,j) at i + j qmax, by position */
+  double * wq = (double *)calloc((size_t)(6 * qmax + 8), sizeof(double));
+  double *g = wq, *d1 = g + qmax, *dl = d1 + qmax, *gc = dl + qmax, *gs = gc + qmax, *grev = gs + qmax;
+  int * slot = (int *)calloc((size_t)(4 * qmax + 4), sizeof(int)); /* position -> column slot */
+  int *freeslot = slot + qmax, *grp = freeslot + qmax, *lpos = grp + qmax; /* free slots (stack), position -> group, scratch */
+  reach_t * rch = (reach_t *)calloc((size_t)qmax + 1, sizeof(reach_t));    /* position -> reach */
+  int nfree = 0;
+  for(int k = qmax - 1; k >= 0; --k) freeslot[nfree++] = k;
   double *x = S.x, *z = S.z, *u = S.u, *r = S.r, *b = S.d;
+  double * y = (double *)calloc((size_t)ld + 1, sizeof(double));
   blkorder * B = (blkorder *)malloc(sizeof(blkorder));
+  reach_t * greach = (reach_t *)calloc((size_t)ngrp + 1, sizeof(reach_t));
+  int * gstart = (int *)calloc((size_t)(ngrp + 2), sizeof(int)); /* per-iteration: positions of group g are lpos[gstart[g] .. gstart[g+1]) */
+  double * slots = (double *)calloc((size_t)2 * (size_t)(ngrp + 2) + 2, sizeof(double));
   if(rc == ORC_INCONSISTENT_INPUT) goto done;
   blkorder_init(&S, B);
+  for(int gI = 0; gI < ncb; ++gI) greach[gI] = reach_of(&S, B, S.cum_var[gI], S.cum_var[gI] + cvar[gI]);
+  if(nb)
+    for(int k = 0; k < nblk; ++k) greach[ncb + k] = reach_of(&S, B, B->off_phys[k], B->off_phys[k] + B->len[k]);
 
   /* ---- init_ (BlockGISolver.cpp:62-107), as in orc_blockgi_solve ---- */
   for(int i = 0; i < nb; ++i)
@@ -797,6 +754,8 @@ int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, c
 
       /* ---- computeStep_ under C9 ---- */
       /* b = L^-1 n+ (StructuredJ.cpp:43-57, unchanged; permuted coordinates for the up arrow) */
+      int pgrp;
+      reach_t preach;
       for(int i = 0; i < n; ++i) b[i] = 0.0;
       if(pstatus <= ORC_EQUALITY)
       {
@@ -806,42 +765,99 @@ int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, c
         sg_solve_l(&S, b, st, st + len);
         if(pstatus == ORC_UPPER)
           for(int i = 0; i < n; ++i) b[i] = -b[i];
+        pgrp = S.to_block[p];
+        preach = greach[pgrp];
       }
       else
       {
         const int pb = p - S.m;
         b[pb] = (pstatus == ORC_UPPER_BOUND) ? -1.0 : 1.0;
         sg_solve_l(&S, b, pb, pb + 1);
+        preach = reach_of(&S, B, pb, pb + 1);
+        pgrp = ncb + ((S.type != 0 && preach.klo > preach.khi) ? nblk - 1 : preach.klo);
       }
       double nrm2 = 0.0;
-      thin_qt_v(B, q, Q1, ld, b, d1, W2);
-      if(q == n)
-        for(int i = 0; i < n; ++i) z[i] = 0.0;
-      else
+      /* positions of every group, in active-set order */
+      for(int gI = 0; gI <= ngrp; ++gI) gstart[gI] = 0;
+      for(int k = 0; k < q; ++k) ++gstart[grp[k] + 1];
+      for(int gI = 0; gI < ngrp; ++gI) gstart[gI + 1] += gstart[gI];
       {
-        const double bb = blk_reduce(B, b, b, 1);
-        thin_rows(n, q, Q1, ld, d1, b, z, W);
-        nrm2 = blk_reduce(B, z, z, 1);
-        if(q > 0 && nrm2 < g_thin_eta2 * bb)
+        int * fill = (int *)slots; /* scratch: next free entry per group (ngrp ints fit in the doubles) */
+        for(int gI = 0; gI < ngrp; ++gI) fill[gI] = gstart[gI];
+        for(int k = 0; k < q; ++k) lpos[fill[grp[k]]++] = k;
+      }
+      for(int k = 0; k < q; ++k) r[k] = 0.0;
+      for(int i = 0; i < n; ++i) y[i] = b[i];
+      for(int pass = 0; pass < 2 && q > 0; ++pass)
+      {
+        /* g = B^T y  (pass 0: y = b) */
+        for(int k = 0; k < q; ++k)
         {
-          ++g_thin_reorth;
-          thin_qt_v(B, q, Q1, ld, z, e1, W2);
-          thin_rows(n, q, Q1, ld, e1, z, z, W);
-          for(int j = 0; j < q; ++j) d1[j] = d1[j] + e1[j];
-          nrm2 = blk_reduce(B, z, z, 1);
+          const double * col = Bc + (long)slot[k] * ld;
+          double acc = 0.0;
+          int first = 1;
+          for(int kap = 0; kap < nblk; ++kap)
+          {
+            if(!reaches(&S, B, rch[k], kap)) continue;
+            if(pass == 0 && !reaches(&S, B, preach, kap)) continue; /* b is zero there */
+            const int o = B->off_perm[kap];
+            double v = 0.0;
+            for(int i = 0; i < B->len[kap]; ++i) v = FMA(col[o + i], y[o + i], v);
+            acc = first ? v : acc + v;
+            first = 0;
+          }
+          g[k] = acc;
+        }
+        /* d1 = S^T g, dl = S d1 */
+        for(int j = 0; j < q; ++j)
+        {
+          double acc = 0.0;
+          for(int i = 0; i <= j; ++i) acc = FMA(Sm[i + (long)j * qmax], g[i], acc);
+          d1[j] = acc;
+        }
+        for(int i = 0; i < q; ++i)
+        {
+          double acc = 0.0;
+          for(int j = q - 1; j >= i; --j) acc = FMA(Sm[i + (long)j * qmax], d1[j], acc);
+          dl[i] = acc;
+        }
+        for(int k = 0; k < q; ++k) r[k] = (pass == 0) ? dl[k] : r[k] + dl[k];
+        if(q == n) /* y = 0 by rule: nothing to refine against */
+        {
+          for(int i = 0; i < n; ++i) y[i] = 0.0;
+          break;
+        }
+        /* y -= B dl */
+        for(int kap = 0; kap < nblk; ++kap)
+        {
+          /* groups that reach this block, in group order */
+          int nT = 0, any = 0;
+          const int o = B->off_perm[kap], len = B->len[kap];
+          for(int gI = 0; gI < ngrp; ++gI)
+            if(reaches(&S, B, greach[gI], kap)) { ++nT; any |= (gstart[gI + 1] > gstart[gI]); }
+          if(!any) continue;
+          for(int i = 0; i < len; ++i)
+          {
+            int t = 0;
+            for(int gI = 0; gI < ngrp; ++gI)
+            {
+              if(!reaches(&S, B, greach[gI], kap)) continue;
+              double acc = 0.0;
+              for(int e = gstart[gI]; e < gstart[gI + 1]; ++e)
+              {
+                const int k = lpos[e];
+                acc = FMA(dl[k], Bc[(long)slot[k] * ld + o + i], acc);
+              }
+              slots[t++] = acc;
+            }
+            y[o + i] = y[o + i] - tree_sum(nT, slots);
+          }
         }
       }
-      /* y (in z) is kept for the new column of Q1; z = L^-T y */
-      for(int i = 0; i < n; ++i) b[i] = z[i]; /* b now holds y (permuted coordinates) */
+      if(q != n) nrm2 = blk_reduce(B, y, y, 1);
+      /* z = L^-T y */
+      for(int i = 0; i < n; ++i) z[i] = y[i];
       sg_solve_lt(&S, z);
-      /* StructuredQR::RSolve (StructuredQR.cpp:64-68) */
-      for(int k = 0; k < q; ++k) r[k] = d1[k];
-      for(int k = q - 1; k >= 0; --k)
-      {
-        double v = r[k] / RP(&S, k, k);
-        r[k] = v;
-        for(int i = 0; i < k; ++i) r[i] = FMA(-RP(&S, i, k), v, r[i]);
-      }
 
       /* computeStepLength_ (BlockGISolver.cpp:174-242) */
       double t1 = big_bnd, t2 = big_bnd;
@@ -892,32 +908,60 @@ int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, c
       }
       if(!drop)
       {
-        /* add: R gets the column [d1; |y|], Q1 the column y / |y| */
-        const double nrm = sqrt(nrm2);
+        /* add: S gets the column [-r / rho; 1 / rho], B the column b */
+        const double rho = sqrt(nrm2);
         orc_as_activate(S.A, p, pstatus);
-        for(int k = 0; k < q; ++k) RP(&S, k, q) = d1[k];
-        RP(&S, q, q) = nrm;
-        double * col = Q1 + (long)q * ld;
-        for(int i = 0; i < n; ++i) col[i] = b[i] / nrm;
+        for(int k = 0; k < q; ++k) Sm[k + (long)q * qmax] = -(r[k] / rho);
+        Sm[q + (long)q * qmax] = 1.0 / rho;
+        const int sl = freeslot[--nfree];
+        slot[q] = sl;
+        grp[q] = pgrp;
+        rch[q] = preach;
+        double * col = Bc + (long)sl * ld;
+        for(int i = 0; i < n; ++i) col[i] = b[i];
         S.q = q + 1;
         skip_step1 = 0;
       }
       else
       {
-        /* remove (DualSolver.cpp:237-244, StructuredQR.cpp:86-102): R as in qr_remove; the rotations go to columns l .. q-1 of Q1 */
+        /* remove (DualSolver.cpp:237-244): u, the active set, then S: fold row l into the last column (C7 on the row reversed) */
         for(int k = l; k < q; ++k) u[k] = u[k + 1];
         orc_as_deactivate(S.A, l);
-        const int q1 = q - 1;
-        for(int i = l; i < q1; ++i)
+        const int len = q - l;
+        if(len > 1)
         {
-          double c, s;
-          for(int k = 0; k < i; ++k) RP(&S, k, i) = RP(&S, k, i + 1);
-          orc_givens(RP(&S, i, i + 1), RP(&S, i + 1, i + 1), &c, &s, &RP(&S, i, i));
-          for(int k = i + 2; k <= q1; ++k) rot(c, s, &RP(&S, i, k), &RP(&S, i + 1, k));
-          double *ci = Q1 + (long)i * ld, *cj = ci + ld;
-          for(int rr = 0; rr < n; ++rr) rot(c, s, &ci[rr], &cj[rr]);
+          double rfin;
+          for(int k = 0; k < len; ++k) grev[k] = Sm[l + (long)(q - 1 - k) * qmax];
+          orc_givens_chain(len, 0, grev, gc, gs, &rfin);
         }
-        S.q = q1;
+        for(int i = 0; i < q; ++i)
+        {
+          if(i == l) continue;
+          const int i2 = (i > l) ? i - 1 : i; /* new position of the row */
+          int t0 = 0;
+          double carry;
+          if(i < l)
+            carry = Sm[i + (long)l * qmax];
+          else
+          {
+            t0 = i - l - 1; /* the row's first non-zero is S(i, i) = the "next" operand of step t0 */
+            carry = 0.0;
+          }
+          for(int tt = t0; tt < len - 1; ++tt)
+          {
+            /* rotation tt: (x, y) = (column l+tt+1, column l+tt) <- (c x - s y, s x + c y)  (rule C3 / C6) */
+            const double c = gc[len - 2 - tt], sn = gs[len - 2 - tt];
+            double xv = Sm[i + (long)(l + tt + 1) * qmax], yv = carry;
+            rot(c, sn, &xv, &yv);
+            Sm[i2 + (long)(l + tt) * qmax] = yv;
+            carry = xv;
+          }
+          if(i2 != i)
+            for(int j = 0; j < l + t0 && j < q - 1; ++j) Sm[i2 + (long)j * qmax] = 0.0; /* (below the diagonal: never read) */
+        }
+        freeslot[nfree++] = slot[l];
+        for(int k = l; k < q - 1; ++k) { slot[k] = slot[k + 1]; grp[k] = grp[k + 1]; rch[k] = rch[k + 1]; }
+        S.q = q - 1;
         skip_step1 = 1;
       }
     }
@@ -947,7 +991,7 @@ done:
   if(f_out) *f_out = S.f;
   orc_as_free(S.A);
   free(S.to_block); free(S.cum_var); free(S.cum_cstr);
-  free(S.d); free(S.Rp); free(Q1); free(d1); free(B); free(W); free(W2);
+  free(S.d); free(Bc); free(Sm); free(wq); free(slot); free(rch); free(y); free(B); free(greach); free(gstart); free(slots);
   return rc;
 }
 

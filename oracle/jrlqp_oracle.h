@@ -273,16 +273,15 @@ int orc_blockgi_solve(int type, int nblk, const int * bs, double ** diag, const 
                       double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * iters,
                       double * f, orc_trace_rec * trace, int trace_cap);
 
-/* The same solver under contract C9 ("thin Q", round 5; blockgi_oracle.c): Q kept as its leading q columns Q1 (thin QR  L^-1 N = Q1 R
- * updated by a Gram-Schmidt step with one conditional re-orthogonalisation on add, by the Givens rotations of StructuredQR::remove
- * applied to Q1's columns on remove) instead of the reference's OrthonormalSequence; reductions over whole vectors by structural block.
+/* The same solver under contract C9 (round 5; blockgi_oracle.c): no orthonormal sequence -- the sparse columns B = L^-1 N of the active
+ * constraints and S = R^-1 (inverse Cholesky factor of N^T G^-1 N), r and y = b - B r by the corrected semi-normal equations, S updated
+ * by a bordered-inverse column on add and by C7 rotations of its columns on remove; reductions over whole vectors by structural block.
  * Same arguments and results as orc_blockgi_solve; decisions identical on every tested problem (tests/test_oracle_blockgi_literal.py). */
-int orc_blockgi_solve_thin(int type, int nblk, const int * bs, double ** diag, const int * ldd, double ** off, const int * ldo,
-                           const double * a, int ncb, const int * cvar, const int * ccstr, const double ** cblk, const int * cld,
-                           const double * bl, const double * bu, const double * xl, const double * xu, int nb, int max_iter,
-                           double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * iters, double * f,
-                           orc_trace_rec * trace, int trace_cap);
-int orc_blockgi_thin_reorth_count(void); /* re-orthogonalisations of the last orc_blockgi_solve_thin call */
+int orc_blockgi_solve_c9(int type, int nblk, const int * bs, double ** diag, const int * ldd, double ** off, const int * ldo,
+                         const double * a, int ncb, const int * cvar, const int * ccstr, const double ** cblk, const int * cld,
+                         const double * bl, const double * bu, const double * xl, const double * xu, int nb, int max_iter,
+                         double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * iters, double * f,
+                         orc_trace_rec * trace, int trace_cap);
 
 /* rule C4 (blockgi_oracle.c): sum a[i] b[i] as 1024 strided fma chains (element i has absolute index phase + i)
  * combined by an adjacent-first pairwise tree */

@@ -116,10 +116,8 @@ class Oracle:
         L.orc_blockgi_solve.argtypes = [ct.c_int] + blk + [c_dp, ct.c_int, c_ip, c_ip, pp, c_ip, c_dp, c_dp, c_dp, c_dp, ct.c_int,
                                                            ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp,
                                                            ct.POINTER(TraceRec), ct.c_int]
-        L.orc_blockgi_solve_thin.restype = ct.c_int
-        L.orc_blockgi_solve_thin.argtypes = L.orc_blockgi_solve.argtypes
-        L.orc_blockgi_thin_reorth_count.restype = ct.c_int
-        L.orc_blockgi_thin_reorth_count.argtypes = []
+        L.orc_blockgi_solve_c9.restype = ct.c_int
+        L.orc_blockgi_solve_c9.argtypes = L.orc_blockgi_solve.argtypes
         L.orc_dot_tree.restype = ct.c_double
         L.orc_dot_tree.argtypes = [ct.c_int, c_dp, c_dp, ct.c_int]
         L.orc_oseq_new.restype = ct.c_void_p
@@ -325,8 +323,8 @@ class Oracle:
 
 
     # ---- structured GI loop (blockgi_oracle.c) ---------------------------------------------------
-    def blockgi_solve(self, kind, diag, off, a, Cblocks, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, trace_cap=0, thin=False):
-        """experimental::BlockGISolver::solve; thin=True: contract C9 (Q kept as its leading q columns, orc_blockgi_solve_thin).  kind: "tri" | "arrow_up" | "arrow_down"; diag/off: col-major views
+    def blockgi_solve(self, kind, diag, off, a, Cblocks, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, trace_cap=0, c9=False):
+        """experimental::BlockGISolver::solve; c9=True: contract C9 (no orthonormal sequence: sparse B = L^-1 N and S = R^-1, orc_blockgi_solve_c9).  kind: "tri" | "arrow_up" | "arrow_down"; diag/off: col-major views
         (factorised IN PLACE); Cblocks: list of n_i x m_i col-major blocks of the block-diagonal C."""
         typ = {"tri": 0, "arrow_up": 1, "arrow_down": 2}[kind]
         bs = np.array([d.shape[0] for d in diag], dtype=np.int32)
@@ -350,7 +348,7 @@ class Oracle:
         active = np.zeros(m + nb + 1, dtype=np.int32)
         nact, iters, f = ct.c_int(0), ct.c_int(0), ct.c_double(0.0)
         tr = (TraceRec * max(trace_cap, 1))()
-        fn = self.lib.orc_blockgi_solve_thin if thin else self.lib.orc_blockgi_solve
+        fn = self.lib.orc_blockgi_solve_c9 if c9 else self.lib.orc_blockgi_solve
         term = fn(typ, len(diag), _ip(bs), dp, _ip(dl), op, _ip(ol), _dp(a), len(Cb), _ip(cv), _ip(cc), cp,
                                           _ip(cl), _dp(bl), _dp(bu), _dp(xl), _dp(xu), nb, max_iter, big_bnd, _dp(x), _dp(u),
                                           _ip(status), _ip(active), ct.byref(nact), ct.byref(iters), ct.byref(f), tr, trace_cap)
