@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JRLQP_ABI_VERSION 3 /* 2: jrlqp_gi_batch_workspace_bytes / jrlqp_gi_solve_batch_ws; no allocation inside any solve.  3: hook level
+#define JRLQP_ABI_VERSION 4 /* 4: jrlqp_blockgi_create_form / jrlqp_blockgi_form (contract C9 of the structured GI loop).  2: jrlqp_gi_batch_workspace_bytes / jrlqp_gi_solve_batch_ws; no allocation inside any solve.  3: hook level
                              * complete (jrlqp_dense_init_active_set, mirror kept by add / remove), jrlqp_dense_set_trace, multi-device entry */
 
 /* jrl::qp::ActivationStatus, include/jrl-qp/enums.h:15-23 (same numeric values) */
@@ -452,6 +452,22 @@ int jrlqp_blocks_solve(jrlqp_blocks * plan, int transpose, double * dM, int ldm,
 typedef struct jrlqp_blockgi jrlqp_blockgi;
 int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, const int * cvar, const int * ccstr, int use_bounds,
                          int nprob, int max_iter, jrlqp_blockgi ** out);
+/* ABI 4 (round 5): which FORM of the QR factors of L^-1 N the loop keeps.
+ *   SEQUENCE  the reference's: Q as an internal::OrthonormalSequence applied element by element (StructuredQR.cpp:70-102,
+ *             OrthonormalSequence.cpp:189-207), R by a triangular solve -- O(n k) per iteration, k = elements ever made; the
+ *             workspace is sized by max_iter and options.max_iter must not exceed it;
+ *   C9        no Q: the sparse columns B = L^-1 N of the active constraints and S = R^-1, r and y = Q2 Q2^T b from the corrected
+ *             semi-normal equations -- O(q^2) per iteration, q = active constraints; workspace independent of
+ *             max_iter.  Same decisions as SEQUENCE on every tested problem, x / u to 1e-9 (tests/test_oracle_blockgi_literal.py);
+ *   AUTO      C9 for the arrows, SEQUENCE for the tridiagonal shape (whose columns of B are dense); what jrlqp_blockgi_create
+ *             chooses.  The environment variable JRLQP_BLOCKGI_FORM=sequence|c9 overrides AUTO (diagnostic).
+ * jrlqp_blockgi_form says which one a plan runs (the oracle to compare with: orc_blockgi_solve / orc_blockgi_solve_c9). */
+#define JRLQP_BLOCKGI_FORM_AUTO (-1)
+#define JRLQP_BLOCKGI_FORM_SEQUENCE 0
+#define JRLQP_BLOCKGI_FORM_C9 1
+int jrlqp_blockgi_create_form(int kind, int nblk, const int * block_sizes, int ncb, const int * cvar, const int * ccstr, int use_bounds,
+                              int nprob, int max_iter, int form, jrlqp_blockgi ** out);
+int jrlqp_blockgi_form(const jrlqp_blockgi * plan);
 void jrlqp_blockgi_destroy(jrlqp_blockgi * plan);
 long long jrlqp_blockgi_workspace_bytes(const jrlqp_blockgi * plan);
 /* ddiag [nprob*nblk], doff [nprob*(nblk-1)], dcblk [nprob*ncb]: HOST arrays of DEVICE pointers (problem-major) */

@@ -59,6 +59,8 @@ EXPORTED = [
     "jrlqp_blocks_result",
     "jrlqp_blocks_solve",
     "jrlqp_blockgi_create",
+    "jrlqp_blockgi_create_form",
+    "jrlqp_blockgi_form",
     "jrlqp_blockgi_destroy",
     "jrlqp_blockgi_workspace_bytes",
     "jrlqp_blockgi_bind",
@@ -175,6 +177,11 @@ def load_library() -> ct.CDLL:
     lib.jrlqp_blockgi_create.restype = ct.c_int
     lib.jrlqp_blockgi_create.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_int), ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int),
                                          ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p)]
+    lib.jrlqp_blockgi_create_form.restype = ct.c_int
+    lib.jrlqp_blockgi_create_form.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_int), ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int),
+                                              ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p)]
+    lib.jrlqp_blockgi_form.restype = ct.c_int
+    lib.jrlqp_blockgi_form.argtypes = [ct.c_void_p]
     lib.jrlqp_blockgi_destroy.restype = None
     lib.jrlqp_blockgi_destroy.argtypes = [ct.c_void_p]
     lib.jrlqp_blockgi_workspace_bytes.restype = ct.c_longlong
@@ -544,9 +551,14 @@ class BlockGISolver:
     solve(H, a, Cb, bl, bu, xl, xu):
       H   (nprob, N, N) float64 CUDA tensor, H[b].T = G (column-major, leading dimension N); FACTORISED IN PLACE
       Cb  (nprob, ctot) float64 CUDA tensor: the blocks of C back to back, block i stored column-major n_i x m_i
-      a (nprob, N); bl, bu (nprob, m); xl, xu (nprob, N) or None."""
+      a (nprob, N); bl, bu (nprob, m); xl, xu (nprob, N) or None.
 
-    def __init__(self, kind, block_sizes, c_shapes, use_bounds, nprob, max_iter=500, big_bnd=1e100, device="cuda"):
+    form: "auto" | "sequence" | "c9" (include/jrlqp_hip.h, JRLQP_BLOCKGI_FORM_*); `self.form` says what the plan runs (0 sequence, 1 C9:
+    the oracle to compare with is orc_blockgi_solve / orc_blockgi_solve_c9)."""
+
+    FORMS = {"auto": -1, "sequence": 0, "c9": 1}
+
+    def __init__(self, kind, block_sizes, c_shapes, use_bounds, nprob, max_iter=500, big_bnd=1e100, device="cuda", form="auto"):
         import torch
 
         self.lib = load_library()
@@ -565,8 +577,10 @@ class BlockGISolver:
         ncb = len(self.cshapes)
         cv = (ct.c_int * max(ncb, 1))(*[r for r, _ in self.cshapes])
         cc = (ct.c_int * max(ncb, 1))(*[c for _, c in self.cshapes])
-        check(self.lib.jrlqp_blockgi_create(self.kind, self.nblk, bs, ncb, cv, cc, int(bool(use_bounds)), nprob, max_iter, ct.byref(h)))
+        check(self.lib.jrlqp_blockgi_create_form(self.kind, self.nblk, bs, ncb, cv, cc, int(bool(use_bounds)), nprob, max_iter,
+                                                 self.FORMS[form], ct.byref(h)))
         self.h = h
+        self.form = self.lib.jrlqp_blockgi_form(self.h)
         self.workspace_bytes = self.lib.jrlqp_blockgi_workspace_bytes(self.h)
         B, N, m, nb = nprob, self.N, self.m, self.nb
         dev = self.device

@@ -56,6 +56,21 @@ struct BgiArgs
   double * f;
   jrlqp_trace_rec * trace;
   int trace_cap;
+  // ---- contract C9 (blockgi_c9.hip): no orthonormal sequence; workspace per problem ----
+  int form;        // 0: the reference's orthonormal sequence (blockgi.hip), 1: contract C9
+  int ngrp;        // groups of constraints: ncb blocks of C, then (bounds) one per Hessian block in block order
+  const int * greach;   // [2 ngrp] first / last off-head block (block-order index) under the group's window (first > last: none)
+  const int * tk;       // [4 nblk] per block (block order): range of general groups and range of bound groups that reach it
+  const int * kap_prow; // [n] block-order index of the block that holds PERMUTED row i
+  const int * kap_row;  // [n] the same for ORIGINAL row e
+  const int * off_perm; // [nblk] first permuted row of block-order block k
+  const int * kap_phys; // [nblk] physical block index of block-order block k
+  const int * goff;     // [ngrp] first entry of group g in the per-problem active lists
+  double * Bc;     // [nprob * qcap * n_pad]  columns L^-1 n_k of the active constraints, by SLOT, permuted coordinates
+  double * Sm;     // [nprob * qcap * qcap]   S = R^-1: S(row of slot s, column of position j) at s + j qcap
+  double * St;     // [nprob * qcap * qcap]   the same transposed: at s qcap + j
+  int * sgrp;      // [nprob * qcap]  slot -> group
+  int * freel;     // [nprob * qcap]  stack of free slots
   long long * prof; // diagnostic only (jrlqp_debug_set_profile): prof_stride >= 32 int64 per problem (16 used), 100 MHz ticks per phase; or nullptr
   int prof_stride;
 };
@@ -66,4 +81,7 @@ constexpr int kBgiMaxN = 4096; // unknowns per structured QP (vectors live in LD
 // brings a 3000-unknown problem under half a CU's LDS
 long blockgi_lds_bytes(int n, int m, int nb, int nblk, int xu_global = 0);
 hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t stream);
+// contract C9 (blockgi_c9.hip)
+long blockgi_c9_lds_bytes(int n, int m, int nb, int nblk, int ncb, int xu_global = 0);
+hipError_t launch_blockgi_c9(const BgiArgs & a, int nprob, hipStream_t stream);
 } // namespace jrlqp

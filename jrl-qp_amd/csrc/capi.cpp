@@ -107,6 +107,11 @@ struct jrlqp_blockgi
   int * d_active = nullptr;
   size_t ws_bytes = 0;
   bool bound = false;
+  // contract C9 (blockgi_c9.hip): form 1
+  int form = 0, ngrp = 0;
+  int *d_greach = nullptr, *d_tk = nullptr, *d_kap_prow = nullptr, *d_kap_row = nullptr, *d_off_perm = nullptr, *d_kap_phys = nullptr, *d_goff = nullptr;
+  double *d_Bc = nullptr, *d_Sm = nullptr, *d_St = nullptr;
+  int *d_sgrp = nullptr, *d_freel = nullptr;
 };
 
 #define HIP_TRY(x)                      \
@@ -656,6 +661,18 @@ int jrlqp_selftest_mfma_f64(const double * dA, const double * dB, const double *
 int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, const int * cvar, const int * ccstr, int use_bounds,
                          int nprob, int max_iter, jrlqp_blockgi ** out)
 {
+  return jrlqp_blockgi_create_form(kind, nblk, block_sizes, ncb, cvar, ccstr, use_bounds, nprob, max_iter, JRLQP_BLOCKGI_FORM_AUTO, out);
+}
+
+int jrlqp_blockgi_form(const jrlqp_blockgi * h)
+{
+  return h ? h->form : -1;
+}
+
+int jrlqp_blockgi_create_form(int kind, int nblk, const int * block_sizes, int ncb, const int * cvar, const int * ccstr, int use_bounds,
+                              int nprob, int max_iter, int form, jrlqp_blockgi ** out)
+{
+  if(form < JRLQP_BLOCKGI_FORM_AUTO || form > JRLQP_BLOCKGI_FORM_C9) return JRLQP_ERR_INVALID_ARGUMENT;
   if(!out || !block_sizes || kind < 0 || kind > 2 || nblk < 1 || ncb < 0 || nprob < 1 || max_iter < 1) return JRLQP_ERR_INVALID_ARGUMENT;
   if(ncb > 0 && (!cvar || !ccstr)) return JRLQP_ERR_INVALID_ARGUMENT;
   int n = 0, nv = 0, m = 0;
@@ -674,9 +691,21 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   if(ncb > 0 && nv != n) return JRLQP_ERR_INVALID_ARGUMENT; // StructuredC::nbVar() == G.nbVar() (BlockGISolver.cpp:35)
   if(n > jrlqp::kBgiMaxN) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const int nb = use_bounds ? n : 0;
-  if(jrlqp::blockgi_lds_bytes(n, m, nb, nblk) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  // Which form of the QR factors the loop keeps: the reference's orthonormal sequence (blockgi.hip, oracle
+  // orc_blockgi_solve) or contract C9 (blockgi_c9.hip, oracle orc_blockgi_solve_c9: sparse B = L^-1 N and S = R^-1).  AUTO: C9 for the
+  // arrows -- there a column of B is two blocks long --, the sequence for the tridiagonal shape (its columns of B are dense from the
+  // window on, and the reference's fixtures of that shape take four iterations).  JRLQP_BLOCKGI_FORM=sequence|c9 overrides AUTO.
+  const bool c9_fits = jrlqp::blockgi_c9_lds_bytes(n, m, nb, nblk, ncb) <= jrlqp::kLdsPerCU && nblk < 65535;
+  if(form == JRLQP_BLOCKGI_FORM_AUTO)
+  {
+    form = (kind != 2 && c9_fits) ? JRLQP_BLOCKGI_FORM_C9 : JRLQP_BLOCKGI_FORM_SEQUENCE;
+    if(const char * e = std::getenv("JRLQP_BLOCKGI_FORM"))
+      form = (e[0] == 'c' && c9_fits) ? JRLQP_BLOCKGI_FORM_C9 : (e[0] == 's') ? JRLQP_BLOCKGI_FORM_SEQUENCE : form;
+  }
+  if(form == JRLQP_BLOCKGI_FORM_C9 ? !c9_fits : jrlqp::blockgi_lds_bytes(n, m, nb, nblk) > jrlqp::kLdsPerCU) return JRLQP_ERR_UNSUPPORTED_SIZE;
   jrlqp_blockgi * h = new(std::nothrow) jrlqp_blockgi;
   if(!h) return JRLQP_ERR_WORKSPACE;
+  h->form = form;
   int rc = jrlqp_blocks_create(kind, nblk, block_sizes, nprob, 1, &h->blocks);
   if(rc != JRLQP_OK)
   {
@@ -709,8 +738,10 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
     cumc[ncb] = cc;
   }
   const size_t nc = ncb > 0 ? ncb : 1;
-  const size_t pool_b = sizeof(double) * (size_t)nprob * max_iter * h->row_len;
-  const size_t r_b = sizeof(double) * (size_t)nprob * h->rlen;
+  const bool c9 = form == JRLQP_BLOCKGI_FORM_C9;
+  const size_t pool_b = c9 ? 8 : sizeof(double) * (size_t)nprob * max_iter * h->row_len;
+  const size_t r_b = c9 ? 8 : sizeof(double) * (size_t)nprob * h->rlen;
+  const size_t desc_b = c9 ? 8 : sizeof(jrlqp::SeqRec) * (size_t)nprob * max_iter;
   hipError_t e = hipMalloc(&h->d_boff, sizeof(int) * nblk);
   if(e == hipSuccess) e = hipMalloc(&h->d_cvar, sizeof(int) * nc);
   if(e == hipSuccess) e = hipMalloc(&h->d_ccstr, sizeof(int) * nc);
@@ -721,11 +752,11 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
   if(e == hipSuccess) e = hipMalloc(&h->d_cblk, sizeof(double *) * (size_t)nprob * nc);
   if(e == hipSuccess) e = hipMalloc(&h->d_pool, pool_b);
   if(e == hipSuccess) e = hipMalloc(&h->d_Rp, r_b);
-  if(e == hipSuccess) e = hipMalloc(&h->d_desc, sizeof(jrlqp::SeqRec) * (size_t)nprob * max_iter);
+  if(e == hipSuccess) e = hipMalloc(&h->d_desc, desc_b);
   if(e == hipSuccess) e = hipMalloc(&h->d_active, sizeof(int) * (size_t)nprob * h->qcap);
   // throughput layout: large problems (n > 1024) in batches of at least half the CUs keep x and u in HBM so that two
   // problems share a CU (same results: the layout does not enter the arithmetic)
-  h->xu_global = (n > 1024 && nprob >= 128 && 2 * jrlqp::blockgi_lds_bytes(n, m, nb, nblk, 1) <= jrlqp::kLdsPerCU) ? 1 : 0;
+  h->xu_global = (n > 1024 && nprob >= 128 && 2 * (c9 ? jrlqp::blockgi_c9_lds_bytes(n, m, nb, nblk, ncb, 1) : jrlqp::blockgi_lds_bytes(n, m, nb, nblk, 1)) <= jrlqp::kLdsPerCU) ? 1 : 0;
   if(const char * lay = std::getenv("JRLQP_BLOCKGI_LAYOUT")) // diagnostic override: "throughput" | "latency"
     if(n > 1024) h->xu_global = (lay[0] == 't') ? 1 : 0;
   if(e == hipSuccess) e = hipMalloc(&h->d_xu, sizeof(double) * (size_t)nprob * (h->n_pad + h->qcap));
@@ -741,7 +772,104 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
     jrlqp_blockgi_destroy(h);
     return hip_fail(e);
   }
-  h->ws_bytes = pool_b + r_b + sizeof(jrlqp::SeqRec) * (size_t)nprob * max_iter + sizeof(int) * (size_t)nprob * h->qcap;
+  h->ws_bytes = pool_b + r_b + desc_b + sizeof(int) * (size_t)nprob * h->qcap;
+  if(c9)
+  {
+    // static structure of contract C9: block order (off-head blocks in logical order, head last; natural for the tridiagonal shape),
+    // groups (blocks of C, then one group of bounds per Hessian block) and which groups reach which block (oracle: reach_of / reaches)
+    const int up = kind == 1, tri = kind == 2;
+    const int ngrp = ncb + (nb ? nblk : 0);
+    h->ngrp = ngrp;
+    std::vector<int> kap_phys(nblk), off_perm(nblk), kap_of_phys(nblk), kap_prow(n > 0 ? n : 1), kap_row(n > 0 ? n : 1), greach(2 * (size_t)(ngrp > 0 ? ngrp : 1)),
+        tk(4 * (size_t)nblk), goff(ngrp > 0 ? ngrp : 1);
+    for(int k = 0, o = 0; k < nblk; ++k)
+    {
+      const int pbk = up ? (k + 1) % nblk : k;
+      kap_phys[k] = pbk;
+      kap_of_phys[pbk] = k;
+      off_perm[k] = o;
+      for(int i = 0; i < block_sizes[pbk]; ++i)
+      {
+        kap_prow[o + i] = k;
+        kap_row[boff[pbk] + i] = k;
+      }
+      o += block_sizes[pbk];
+    }
+    const int last = tri ? nblk : nblk - 1; // arrows: the head is not an off-head block
+    auto reach_of = [&](int wst, int wen, int & lo, int & hi) {
+      lo = nblk;
+      hi = -1;
+      for(int k = 0; k < last; ++k)
+      {
+        const int o = boff[kap_phys[k]], len = block_sizes[kap_phys[k]];
+        if(o < wen && wst < o + len)
+        {
+          if(k < lo) lo = k;
+          hi = k;
+        }
+      }
+      if(tri && lo <= hi) hi = nblk - 1;
+    };
+    for(int g = 0; g < ncb; ++g)
+    {
+      reach_of(cumv[g], cumv[g] + cvar[g], greach[2 * g], greach[2 * g + 1]);
+      goff[g] = cumc[g];
+    }
+    if(nb)
+      for(int k = 0; k < nblk; ++k)
+      {
+        reach_of(boff[kap_phys[k]], boff[kap_phys[k]] + block_sizes[kap_phys[k]], greach[2 * (ncb + k)], greach[2 * (ncb + k) + 1]);
+        goff[ncb + k] = m + boff[kap_phys[k]];
+      }
+    auto reaches = [&](int g, int k) { return (!tri && k == nblk - 1) || (greach[2 * g] <= k && k <= greach[2 * g + 1]); };
+    for(int k = 0; k < nblk; ++k)
+    {
+      int glo = 0, ghi = -1, blo = 0, bhi = -1;
+      bool first = true;
+      for(int g = 0; g < ncb; ++g)
+        if(reaches(g, k))
+        {
+          if(first) glo = g;
+          ghi = g;
+          first = false;
+        }
+      first = true;
+      for(int g = ncb; g < ngrp; ++g)
+        if(reaches(g, k))
+        {
+          if(first) blo = g;
+          bhi = g;
+          first = false;
+        }
+      tk[4 * k] = glo; tk[4 * k + 1] = ghi; tk[4 * k + 2] = blo; tk[4 * k + 3] = bhi;
+    }
+    const size_t bc_b = sizeof(double) * (size_t)nprob * h->qcap * h->n_pad, s_b = sizeof(double) * (size_t)nprob * h->qcap * h->qcap;
+    e = hipMalloc(&h->d_greach, sizeof(int) * greach.size());
+    if(e == hipSuccess) e = hipMalloc(&h->d_tk, sizeof(int) * tk.size());
+    if(e == hipSuccess) e = hipMalloc(&h->d_kap_prow, sizeof(int) * kap_prow.size());
+    if(e == hipSuccess) e = hipMalloc(&h->d_kap_row, sizeof(int) * kap_row.size());
+    if(e == hipSuccess) e = hipMalloc(&h->d_off_perm, sizeof(int) * nblk);
+    if(e == hipSuccess) e = hipMalloc(&h->d_kap_phys, sizeof(int) * nblk);
+    if(e == hipSuccess) e = hipMalloc(&h->d_goff, sizeof(int) * goff.size());
+    if(e == hipSuccess) e = hipMalloc(&h->d_Bc, bc_b);
+    if(e == hipSuccess) e = hipMalloc(&h->d_Sm, s_b);
+    if(e == hipSuccess) e = hipMalloc(&h->d_St, s_b);
+    if(e == hipSuccess) e = hipMalloc(&h->d_sgrp, sizeof(int) * (size_t)nprob * h->qcap);
+    if(e == hipSuccess) e = hipMalloc(&h->d_freel, sizeof(int) * (size_t)nprob * h->qcap);
+    if(e == hipSuccess) e = hipMemcpy(h->d_greach, greach.data(), sizeof(int) * greach.size(), hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_tk, tk.data(), sizeof(int) * tk.size(), hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_kap_prow, kap_prow.data(), sizeof(int) * kap_prow.size(), hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_kap_row, kap_row.data(), sizeof(int) * kap_row.size(), hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_off_perm, off_perm.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_kap_phys, kap_phys.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_goff, goff.data(), sizeof(int) * goff.size(), hipMemcpyHostToDevice);
+    if(e != hipSuccess)
+    {
+      jrlqp_blockgi_destroy(h);
+      return hip_fail(e);
+    }
+    h->ws_bytes += bc_b + 2 * s_b + 2 * sizeof(int) * (size_t)nprob * h->qcap;
+  }
   *out = h;
   return JRLQP_OK;
 }
@@ -753,6 +881,9 @@ void jrlqp_blockgi_destroy(jrlqp_blockgi * h)
   (void)hipFree(h->d_boff); (void)hipFree(h->d_cvar); (void)hipFree(h->d_ccstr); (void)hipFree(h->d_cumv); (void)hipFree(h->d_cumc);
   (void)hipFree(h->d_toblk); (void)hipFree(h->d_cld); (void)hipFree(h->d_cblk); (void)hipFree(h->d_pool); (void)hipFree(h->d_Rp);
   (void)hipFree(h->d_desc); (void)hipFree(h->d_active); (void)hipFree(h->d_xu);
+  (void)hipFree(h->d_greach); (void)hipFree(h->d_tk); (void)hipFree(h->d_kap_prow); (void)hipFree(h->d_kap_row); (void)hipFree(h->d_off_perm);
+  (void)hipFree(h->d_kap_phys); (void)hipFree(h->d_goff); (void)hipFree(h->d_Bc); (void)hipFree(h->d_Sm); (void)hipFree(h->d_St);
+  (void)hipFree(h->d_sgrp); (void)hipFree(h->d_freel);
   h->stage.release();
   delete h;
 }
@@ -799,7 +930,7 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   jrlqp_options o;
   jrlqp_default_options(&o);
   if(opts) o = *opts;
-  if(o.max_iter > h->max_iter) return JRLQP_ERR_WORKSPACE; // the orthonormal sequence grows by one element per iteration
+  if(o.max_iter > h->max_iter && h->form == JRLQP_BLOCKGI_FORM_SEQUENCE) return JRLQP_ERR_WORKSPACE; // the orthonormal sequence grows by one element per iteration
   // lltInPlace (BlockGISolver.cpp:71): the block factorisation kernels of structured.hip, same stream
   int rc = jrlqp_blocks_llt(h->blocks, stream);
   if(rc != JRLQP_OK) return rc;
@@ -822,7 +953,12 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.prof = g_prof[JRLQP_PROFILE_BLOCKGI].p;
   a.prof_stride = g_prof[JRLQP_PROFILE_BLOCKGI].stride;
   if(a.prof && h->nprob > g_prof[JRLQP_PROFILE_BLOCKGI].nprob) return JRLQP_ERR_INVALID_ARGUMENT;
-  hipError_t e = jrlqp::launch_blockgi(a, h->nprob, static_cast<hipStream_t>(stream));
+  a.form = h->form; a.ngrp = h->ngrp;
+  a.greach = h->d_greach; a.tk = h->d_tk; a.kap_prow = h->d_kap_prow; a.kap_row = h->d_kap_row; a.off_perm = h->d_off_perm;
+  a.kap_phys = h->d_kap_phys; a.goff = h->d_goff;
+  a.Bc = h->d_Bc; a.Sm = h->d_Sm; a.St = h->d_St; a.sgrp = h->d_sgrp; a.freel = h->d_freel;
+  hipError_t e = (h->form == JRLQP_BLOCKGI_FORM_C9) ? jrlqp::launch_blockgi_c9(a, h->nprob, static_cast<hipStream_t>(stream))
+                                                    : jrlqp::launch_blockgi(a, h->nprob, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }
 

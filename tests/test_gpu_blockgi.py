@@ -1,6 +1,8 @@
-"""GPU parity of the structured GI solver (jrlqp_blockgi_*, jrl-qp_amd/csrc/blockgi.hip) against the CPU oracle
-(oracle/blockgi_oracle.c): termination status, iteration count, activation-status vector AND x, u, f bit for bit
-(fp64 tolerance: 0 ulp).  Cases: the reference's BlockGISolver tests (tests/BlockGISolverTest.in.cpp:70-351) -- small
+"""GPU parity of the structured GI solver (jrlqp_blockgi_*) against the CPU oracle (oracle/blockgi_oracle.c): termination status,
+iteration count, activation-status vector AND x, u, f bit for bit (fp64 tolerance: 0 ulp).  The solver keeps the QR factors in one of
+two forms (include/jrlqp_hip.h JRLQP_BLOCKGI_FORM_*): the reference's orthonormal sequence (blockgi.hip == orc_blockgi_solve) or contract
+C9 (blockgi_c9.hip == orc_blockgi_solve_c9; the default for the arrows).  Every plan is compared with the oracle of the form it runs,
+and both forms are driven on every shape (test_both_forms_*).  Cases: the reference's BlockGISolver tests (tests/BlockGISolverTest.in.cpp:70-351) -- small
 tri-diagonal / arrow problems, the two MultiIK fixtures -- plus wider shapes, drops, bounds, and BASELINE config c5."""
 import numpy as np
 import pytest
@@ -26,7 +28,10 @@ def capi(pkg):
     return capi
 
 
-def gpu_solve(capi, qps, max_iter=500, trace_cap=0):
+FORM = {"form": None}  # the form the last GPU plan ran (0 sequence, 1 C9): the oracle to compare with
+
+
+def gpu_solve(capi, qps, max_iter=500, trace_cap=0, form="auto"):
     """Solve a batch of identically shaped StructuredQP on the GPU."""
     import torch
 
@@ -41,7 +46,8 @@ def gpu_solve(capi, qps, max_iter=500, trace_cap=0):
     bu = torch.tensor(np.stack([q.bu for q in qps]), device="cuda")
     xl = torch.tensor(np.stack([q.xl for q in qps]), device="cuda") if use_bounds else None
     xu = torch.tensor(np.stack([q.xu for q in qps]), device="cuda") if use_bounds else None
-    s = capi.BlockGISolver(KIND[q0.kind], q0.bs, shapes, use_bounds, B, max_iter=max_iter)
+    s = capi.BlockGISolver(KIND[q0.kind], q0.bs, shapes, use_bounds, B, max_iter=max_iter, form=form)
+    FORM["form"] = s.form
     r = s.solve(H, a, Cb, bl, bu, xl, xu, trace_cap=trace_cap)
     torch.cuda.synchronize()
     out = dict(x=r.x.cpu().numpy(), u=r.u.cpu().numpy()[:, : m + (n if use_bounds else 0)],
@@ -50,15 +56,17 @@ def gpu_solve(capi, qps, max_iter=500, trace_cap=0):
     return out
 
 
-def oracle_solve(oracle, SP, qp, max_iter=500):
+def oracle_solve(oracle, SP, qp, max_iter=500, c9=None):
+    """The oracle of the form the GPU plan ran (c9=None: the last plan's)."""
     Gs = qp.G.copy(order="F")
     diag, off = SP.block_views(Gs, qp.bs, qp.kind)
-    r = oracle.blockgi_solve(qp.kind, diag, off, qp.a, qp.Cblocks, qp.bl, qp.bu, qp.xl, qp.xu, max_iter=max_iter)
+    c9 = bool(FORM["form"]) if c9 is None else c9
+    r = oracle.blockgi_solve(qp.kind, diag, off, qp.a, qp.Cblocks, qp.bl, qp.bu, qp.xl, qp.xu, max_iter=max_iter, c9=c9)
     return r, Gs
 
 
-def check_batch(oracle, SP, capi, qps, max_iter=500, min_iters=0):
-    g = gpu_solve(capi, qps, max_iter=max_iter)
+def check_batch(oracle, SP, capi, qps, max_iter=500, min_iters=0, form="auto"):
+    g = gpu_solve(capi, qps, max_iter=max_iter, form=form)
     tot = 0
     for b, qp in enumerate(qps):
         r, Gs = oracle_solve(oracle, SP, qp, max_iter=max_iter)
@@ -165,9 +173,9 @@ def test_throughput_layout_large_batch(oracle, SP, capi):
     CU): same bits as the latency layout and as the oracle, for every problem of the batch."""
     base = [SP.mpc_arrow_qp(nstage=36, nx=30, mc=4, seed=s, scale_a=1.0) for s in range(2)]
     assert base[0].n > 1024
-    refs = [oracle_solve(oracle, SP, q, max_iter=600)[0] for q in base]
     qps = [base[i % 2] for i in range(128)]
     g = gpu_solve(capi, qps, max_iter=600)
+    refs = [oracle_solve(oracle, SP, q, max_iter=600)[0] for q in base]
     for b in range(128):
         r = refs[b % 2]
         assert g["term"][b] == r.term == 0 and g["iters"][b] == r.iters and r.iters > 40
@@ -225,3 +233,42 @@ def test_beyond_3072_unknowns(oracle, SP, capi):
     assert sum(qp.bs) == 3930
     g = check_batch(oracle, SP, capi, [qp], max_iter=1000, min_iters=100)
     assert g["term"][0] == 0
+
+
+@pytest.mark.parametrize("form", ["sequence", "c9"])
+@pytest.mark.parametrize("kind", ["tri", "arrow_up", "arrow_down"])
+def test_both_forms_bit_exact(oracle, SP, capi, kind, form):
+    """Round 5: each form on each shape, whatever AUTO would choose -- the reference's small problems, wider ones with removals, C blocks
+    on their own partition with box bounds, vertex solutions (q == n) and a medium arrow / tridiagonal chain."""
+    qps = [SP.random_structured_qp(kind, [3, 5, 2, 3], [3, 3, 3, 3], seed) for seed in range(12)]
+    check_batch(oracle, SP, capi, qps, min_iters=12, form=form)
+    assert FORM["form"] == {"sequence": 0, "c9": 1}[form]
+    bs, mc = {"tri": ([7, 4, 9, 6, 5, 8], [4, 6, 3, 5, 7, 2]), "arrow_up": ([6, 9, 4, 7, 5], [5, 3, 6, 4, 2]), "arrow_down": ([8, 5, 7, 6, 9], [3, 6, 4, 5, 0])}[kind]
+    check_batch(oracle, SP, capi, [SP.random_structured_qp(kind, bs, mc, 100 + seed, ridge=0.05) for seed in range(8)], min_iters=50, form=form)
+    qps = [SP.random_structured_qp(kind, [6, 9, 4, 7, 5], [5, 7, 6], 300 + seed, ridge=0.05, cbs=[10, 8, 13], box=1.0) for seed in range(8)]
+    check_batch(oracle, SP, capi, qps, min_iters=40, form=form)
+    qps = []
+    for seed in range(24):
+        qp = SP.random_structured_qp(kind, [2, 1, 2], [4, 3, 4], 900 + seed, ridge=0.05, box=0.3)
+        qp.a *= 30
+        qps.append(qp)
+    check_batch(oracle, SP, capi, qps, form=form)
+    qps = [SP.random_structured_qp(kind, [30] * 12, [6] * 12, 40 + s, ridge=0.05, box=2.0) for s in range(3)]
+    check_batch(oracle, SP, capi, qps, max_iter=800, min_iters=60, form=form)
+
+
+@pytest.mark.parametrize("form", ["sequence", "c9"])
+def test_c5_full_size_both_forms(oracle, SP, capi, form):
+    qp = SP.mpc_arrow_qp(nstage=100, nx=30, mc=10, seed=1, scale_a=1.0)
+    g = check_batch(oracle, SP, capi, [qp], max_iter=1000, min_iters=300, form=form)
+    assert g["term"][0] == 0
+
+
+def test_c9_blocks_of_up_to_128_rows_and_tridiagonal(oracle, SP, capi):
+    """Contract C9 on shapes AUTO gives to the sequence form (tridiagonal) and on blocks of 65 .. 128 rows."""
+    for kind, bs, mc in [("tri", [70, 128, 65, 96], [20, 30, 10, 25]), ("arrow_up", [96, 70, 128, 33], [15, 25, 30, 5]), ("arrow_down", [128, 40, 97, 65], [30, 10, 25, 12])]:
+        qps = [SP.random_structured_qp(kind, bs, mc, 900 + seed, ridge=0.05) for seed in range(3)]
+        check_batch(oracle, SP, capi, qps, min_iters=30, form="c9")
+        n = sum(bs)
+        qps = [SP.random_structured_qp(kind, bs, [40, 35, 20], 950 + seed, ridge=0.05, cbs=[100, n - 230, 130], box=1.0) for seed in range(2)]
+        check_batch(oracle, SP, capi, qps, min_iters=10, form="c9")
