@@ -38,11 +38,14 @@ struct C9
   int ldq;       // leading dimension of Sm / St (= qcap)
   double *ga, *gb; // two q-vectors (LDS)
   int * slot;      // position -> slot (LDS)
+  int * roff;      // position -> slot * ldq: the row's offset in St (LDS)
   unsigned * smeta; // slot -> first | (last + 1) << 16 off-head block of the column's reach (LDS)
   int *glist, *gcount, *goff; // per-group lists of active slots in active-set order (LDS)
   unsigned short * kapr;      // permuted row -> block-order index (LDS)
   int *koff, *klen, *kpho;    // block-order index -> first permuted row, rows, first ORIGINAL row (LDS)
   double * bsum;              // pow2(nblk) doubles (LDS): block sums of a C9 reduction
+  double * hred;              // 8 x 128 doubles (LDS): the waves' subtree roots of the head rows (c9_y_update)
+  const int4 * tkl;           // block-order index -> ranges of groups that reach the block (LDS copy of BgiArgs::tk)
   int *sgrp, *freel;          // slot -> group, free-slot stack (HBM)
   int nfree;
 };
@@ -88,11 +91,30 @@ __device__ __forceinline__ double blk_reduce(Ctx & K, C9 & Q, bool perm, FA fa, 
 }
 
 // ---- g_k = B_k . v for every active position k (v in LDS, permuted coordinates); pass 0: v = b, only the blocks b reaches ----------
+// sum_i col[o + i] v[o + i], i < len, an fma chain from +0; the column entries of a group of 16 rows are requested together
+__device__ __forceinline__ double c9_col_dot(const double * col, const double * v, int o, int len)
+{
+  double acc = 0.0;
+  for(int i0 = 0; i0 < len; i0 += 16)
+  {
+    double cv[16];
+#pragma unroll
+    for(int u = 0; u < 16; ++u) cv[u] = col[o + min(i0 + u, len - 1)];
+#pragma unroll
+    for(int u = 0; u < 16; ++u)
+    {
+      const double t = FMA(cv[u], v[o + min(i0 + u, len - 1)], acc);
+      acc = (i0 + u < len) ? t : acc;
+    }
+  }
+  return acc;
+}
 template<int NT>
 __device__ __forceinline__ void c9_bt_v(Ctx & K, C9 & Q, int q, const double * v, bool lim, int plo, int phi, double * out)
 {
   const int nblk = K.A->nblk, np = K.A->n_pad;
   const bool arrow = K.A->kind != 2;
+  const int oh = Q.koff[nblk - 1], lh = Q.klen[nblk - 1];
   for(int k = K.tid; k < q; k += NT)
   {
     const int s = Q.slot[k];
@@ -105,19 +127,48 @@ __device__ __forceinline__ void c9_bt_v(Ctx & K, C9 & Q, int q, const double * v
     }
     const double * col = Q.Bc + (size_t)s * np;
     double acc = 0.0;
-    bool first = true;
-    for(int kap = lo; kap <= hi; ++kap)
+    if(arrow && lo == hi && lh <= 32 && Q.klen[lo] <= 32)
     {
-      const int o = Q.koff[kap], len = Q.klen[kap];
-      const double val = chain_neg8(o, 1, len, 0.0, [&](int i) { return -col[i]; }, [&](int i) { return v[i]; });
-      acc = first ? val : acc + val;
-      first = false;
+      // the usual arrow column: one off-head block and the head, 2 x 16 entries requested together, twice
+      const int o = Q.koff[lo], len = Q.klen[lo];
+      double va = 0.0, vh = 0.0;
+#pragma unroll
+      for(int h0 = 0; h0 < 32; h0 += 16)
+      {
+        double ca[16], ch[16];
+#pragma unroll
+        for(int u = 0; u < 16; ++u) ca[u] = col[o + min(h0 + u, len - 1)];
+#pragma unroll
+        for(int u = 0; u < 16; ++u) ch[u] = col[oh + min(h0 + u, lh - 1)];
+#pragma unroll
+        for(int u = 0; u < 16; ++u)
+        {
+          const double t = FMA(ca[u], v[o + min(h0 + u, len - 1)], va);
+          va = (h0 + u < len) ? t : va;
+        }
+#pragma unroll
+        for(int u = 0; u < 16; ++u)
+        {
+          const double t = FMA(ch[u], v[oh + min(h0 + u, lh - 1)], vh);
+          vh = (h0 + u < lh) ? t : vh;
+        }
+      }
+      acc = va + vh;
     }
-    if(arrow)
+    else
     {
-      const int o = Q.koff[nblk - 1], len = Q.klen[nblk - 1];
-      const double val = chain_neg8(o, 1, len, 0.0, [&](int i) { return -col[i]; }, [&](int i) { return v[i]; });
-      acc = first ? val : acc + val;
+      bool first = true;
+      for(int kap = lo; kap <= hi; ++kap)
+      {
+        const double val = c9_col_dot(col, v, Q.koff[kap], Q.klen[kap]);
+        acc = first ? val : acc + val;
+        first = false;
+      }
+      if(arrow)
+      {
+        const double val = c9_col_dot(col, v, oh, lh);
+        acc = first ? val : acc + val;
+      }
     }
     out[k] = acc;
   }
@@ -125,29 +176,46 @@ __device__ __forceinline__ void c9_bt_v(Ctx & K, C9 & Q, int q, const double * v
 }
 
 // ---- d1 = S^T g: column j an fma chain over the rows (positions) ascending; lanes = consecutive columns of St -----------------------
+// One wave per 64 columns.  Priced in VALU instructions per term (a wave64 fp64 instruction occupies its SIMD for four cycles): above
+// the chunk's diagonal block every lane takes every term -- one add for the address (row offsets by position staged in LDS: `roff`),
+// one fma --, only the diagonal block selects.  kPf loads are in flight while the previous kPf are consumed.
+constexpr int kPf = 16;
 template<int NT>
 __device__ __forceinline__ void c9_st_g(Ctx & K, C9 & Q, int q, const double * g, double * d1)
 {
-  const int lane = K.lane, ldq = Q.ldq;
+  const int lane = K.lane;
   for(int c0 = 64 * K.wave; c0 < q; c0 += NT)
   {
     const int j = c0 + lane, jc = min(j, q - 1), imax = min(q - 1, c0 + 63);
     const double * base = Q.St + jc;
     double acc = 0.0;
-    for(int i0 = 0; i0 <= imax; i0 += 8)
+    double a0[kPf], a1[kPf];
+    // rows 0 .. c0-1 (c0 is a multiple of 64): no clamp, no select
+    if(c0 > 0)
     {
-      double gv[8], sv[8];
 #pragma unroll
-      for(int u = 0; u < 8; ++u)
+      for(int u = 0; u < kPf; ++u) a0[u] = base[Q.roff[u]];
+      for(int i0 = 0; i0 < c0; i0 += 2 * kPf)
       {
-        const int i = min(i0 + u, imax);
-        gv[u] = g[i];
-        sv[u] = base[(size_t)Q.slot[i] * ldq];
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) a1[u] = base[Q.roff[i0 + kPf + u]];
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], g[i0 + u], acc);
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) a0[u] = base[Q.roff[min(i0 + 2 * kPf + u, c0 - 1)]];
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], g[i0 + kPf + u], acc);
       }
+    }
+    // the diagonal block: rows c0 .. imax, lane j takes rows <= j
+    for(int i0 = c0; i0 <= imax; i0 += kPf)
+    {
 #pragma unroll
-      for(int u = 0; u < 8; ++u)
+      for(int u = 0; u < kPf; ++u) a0[u] = base[Q.roff[min(i0 + u, imax)]];
+#pragma unroll
+      for(int u = 0; u < kPf; ++u)
       {
-        const double t = FMA(sv[u], gv[u], acc);
+        const double t = FMA(a0[u], g[min(i0 + u, imax)], acc);
         acc = (i0 + u <= jc) ? t : acc;
       }
     }
@@ -166,20 +234,35 @@ __device__ __forceinline__ void c9_s_d(Ctx & K, C9 & Q, int q, const double * d1
     const int i = r0 + lane, ic = min(i, q - 1);
     const double * base = Q.Sm + Q.slot[ic];
     double acc = 0.0;
-    for(int j0 = q - 1; j0 >= r0; j0 -= 8)
+    double a0[kPf], a1[kPf];
+    // columns q-1 .. down to the last whole group of 2 kPf above the chunk's diagonal block: every lane takes every term
+    const int nfull = max(q - (r0 + 64), 0) / (2 * kPf) * (2 * kPf);
+    int j0 = q - 1;
+    if(nfull > 0)
     {
-      double dv[8], sv[8];
 #pragma unroll
-      for(int u = 0; u < 8; ++u)
+      for(int u = 0; u < kPf; ++u) a0[u] = base[(size_t)(j0 - u) * ldq];
+      for(int done = 0; done < nfull; done += 2 * kPf, j0 -= 2 * kPf)
       {
-        const int j = max(j0 - u, r0);
-        dv[u] = d1[j];
-        sv[u] = base[(size_t)j * ldq];
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) a1[u] = base[(size_t)(j0 - kPf - u) * ldq];
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], d1[j0 - u], acc);
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) a0[u] = base[(size_t)max(j0 - 2 * kPf - u, r0) * ldq];
+#pragma unroll
+        for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], d1[j0 - kPf - u], acc);
       }
+    }
+    // the rest, down to the chunk's first row: lane i takes columns >= i
+    for(; j0 >= r0; j0 -= kPf)
+    {
 #pragma unroll
-      for(int u = 0; u < 8; ++u)
+      for(int u = 0; u < kPf; ++u) a0[u] = base[(size_t)max(j0 - u, r0) * ldq];
+#pragma unroll
+      for(int u = 0; u < kPf; ++u)
       {
-        const double t = FMA(sv[u], dv[u], acc);
+        const double t = FMA(a0[u], d1[max(j0 - u, r0)], acc);
         acc = (j0 - u >= ic) ? t : acc;
       }
     }
@@ -188,65 +271,40 @@ __device__ __forceinline__ void c9_s_d(Ctx & K, C9 & Q, int q, const double * d1
   __syncthreads();
 }
 
-// ---- y -= B dl: thread per (permuted) row; per group that reaches the row's block an fma chain over the group's active slots in
-// active-set order, the group values combined by the adjacent-first pairwise tree over the static list of groups (general range,
-// then bound range).  dls: dl by SLOT.  The tree is folded as the groups come (binary-counter stack: static register indices).
-template<int NT>
-__device__ __forceinline__ void c9_y_update(Ctx & K, C9 & Q, double * y, const double * dls)
+// ---- y -= B dl.  Per group that reaches a row's block an fma chain over the group's active slots in active-set order, the group
+// values combined by the adjacent-first pairwise tree over the static list of groups (general range, then bound range).  dls: dl by
+// SLOT.  The tree is folded as the groups come (binary-counter stack: static register indices).
+struct TreeStack
 {
-  const int n = K.A->n, np = K.A->n_pad;
-  const int4 * tk = reinterpret_cast<const int4 *>(K.A->tk);
-  for(int i = K.tid; i < n; i += NT)
+  double st[13];
+  int cnt;
+  __device__ __forceinline__ void reset()
   {
-    const int kap = Q.kapr[i];
-    const int4 t = tk[kap];
-    const double * colrow = Q.Bc + i;
-    double st[13];
-    int cnt = 0;
 #pragma unroll
     for(int L = 0; L < 13; ++L) st[L] = 0.0;
-    auto group = [&](int gI) {
-      const int c = Q.gcount[gI], o = Q.goff[gI];
-      double acc = 0.0;
-      for(int e0 = 0; e0 < c; e0 += 4)
+    cnt = 0;
+  }
+  __device__ __forceinline__ void push(double v) // fold with the completed subtrees of equal size
+  {
+    bool placed = false;
+#pragma unroll
+    for(int L = 0; L < 13; ++L)
+    {
+      if(!placed)
       {
-        double bv[4], dv[4];
-#pragma unroll
-        for(int u = 0; u < 4; ++u)
+        if((cnt >> L) & 1)
+          v = st[L] + v;
+        else
         {
-          const int s = Q.glist[o + min(e0 + u, c - 1)];
-          dv[u] = dls[s];
-          bv[u] = colrow[(size_t)s * np];
-        }
-#pragma unroll
-        for(int u = 0; u < 4; ++u)
-        {
-          const double tt = FMA(dv[u], bv[u], acc);
-          acc = (e0 + u < c) ? tt : acc;
+          st[L] = v;
+          placed = true;
         }
       }
-      // push acc: fold with the completed subtrees of equal size
-      double v = acc;
-      bool placed = false;
-#pragma unroll
-      for(int L = 0; L < 13; ++L)
-      {
-        if(!placed)
-        {
-          if((cnt >> L) & 1)
-            v = st[L] + v;
-          else
-          {
-            st[L] = v;
-            placed = true;
-          }
-        }
-      }
-      ++cnt;
-    };
-    for(int gI = t.x; gI <= t.y; ++gI) group(gI);
-    for(int gI = t.z; gI <= t.w; ++gI) group(gI);
-    // flush: the pending subtrees, smallest first (each is the right sibling of what follows: padding with +0 changes no bit)
+    }
+    ++cnt;
+  }
+  __device__ __forceinline__ double flush() const // the pending subtrees, smallest first (padding with +0 changes no bit)
+  {
     double tot = 0.0;
     bool have = false;
 #pragma unroll
@@ -258,7 +316,167 @@ __device__ __forceinline__ void c9_y_update(Ctx & K, C9 & Q, double * y, const d
         have = true;
       }
     }
-    y[i] = y[i] - tot;
+    return tot;
+  }
+};
+
+// entries e0 .. of group gI for one row: acc <- fma(dl, B, acc) in list order
+__device__ __forceinline__ double c9_group_chain(const C9 & Q, const double * dls, const double * colrow, int np, int gI, int e0, double acc)
+{
+  const int c = Q.gcount[gI], o = Q.goff[gI];
+  for(; e0 < c; e0 += 4)
+  {
+    double bv[4], dv[4];
+#pragma unroll
+    for(int u = 0; u < 4; ++u)
+    {
+      const int s = Q.glist[o + min(e0 + u, c - 1)];
+      dv[u] = dls[s];
+      bv[u] = colrow[(size_t)s * np];
+    }
+#pragma unroll
+    for(int u = 0; u < 4; ++u)
+    {
+      const double tt = FMA(dv[u], bv[u], acc);
+      acc = (e0 + u < c) ? tt : acc;
+    }
+  }
+  return acc;
+}
+
+template<int NT, bool BIG>
+__device__ __forceinline__ void c9_y_update(Ctx & K, C9 & Q, double * y, const double * dls)
+{
+  constexpr int NW = NT / 64, RB = 4, EB = 8;
+  const int n = K.A->n, np = K.A->n_pad, nblk = K.A->nblk, qc = K.A->qcap;
+  const bool arrow = K.A->kind != 2;
+  const int oh = Q.koff[nblk - 1], lh = Q.klen[nblk - 1];
+  const int nrow = arrow ? n - lh : n; // (the head is the last block in permuted coordinates)
+  // ---- A: every row but an arrow's head: thread per row, RB rows at a time; the first EB entries of each row's first group are
+  // requested for all RB rows before any is consumed (the usual row has one group of a few entries: one memory round trip per RB rows)
+  for(int i0 = K.tid; i0 < nrow; i0 += RB * NT)
+  {
+    double bv[RB][EB];
+    int sv[RB][EB], g0[RB], c0[RB];
+#pragma unroll
+    for(int rr = 0; rr < RB; ++rr)
+    {
+      const int i = min(i0 + rr * NT, nrow - 1);
+      const int4 t = Q.tkl[Q.kapr[i]];
+      g0[rr] = (t.x <= t.y) ? t.x : t.z; // (a block no group reaches: t.z > t.w too -- c0 = 0 below)
+      const bool any = (t.x <= t.y) || (t.z <= t.w);
+      c0[rr] = any ? Q.gcount[g0[rr]] : 0;
+      const int o = any ? Q.goff[g0[rr]] : 0;
+#pragma unroll
+      for(int u = 0; u < EB; ++u)
+      {
+        int sl = Q.glist[o + min(u, max(c0[rr] - 1, 0))];
+        sl = (u < c0[rr]) ? sl : 0; // (an unused entry may hold anything: slot 0's storage is always there)
+        sv[rr][u] = sl;
+        bv[rr][u] = Q.Bc[(size_t)sl * np + i];
+      }
+    }
+#pragma unroll
+    for(int rr = 0; rr < RB; ++rr)
+    {
+      const int i = i0 + rr * NT;
+      if(i < nrow)
+      {
+        const int4 t = Q.tkl[Q.kapr[i]];
+        const double * colrow = Q.Bc + i;
+        TreeStack T;
+        T.reset();
+        bool firstg = true;
+        auto group = [&](int gI) {
+          double acc = 0.0;
+          int e0 = 0;
+          if(firstg)
+          {
+#pragma unroll
+            for(int u = 0; u < EB; ++u)
+            {
+              const double tt = FMA(dls[sv[rr][u]], bv[rr][u], acc);
+              acc = (u < c0[rr]) ? tt : acc;
+            }
+            e0 = EB;
+            firstg = false;
+          }
+          acc = c9_group_chain(Q, dls, colrow, np, gI, e0, acc);
+          T.push(acc);
+        };
+        for(int gI = t.x; gI <= t.y; ++gI) group(gI);
+        for(int gI = t.z; gI <= t.w; ++gI) group(gI);
+        y[i] = y[i] - T.flush();
+      }
+    }
+  }
+  // ---- B: the head of an arrow -- every group reaches it.  Lanes = head rows, the waves share the (padded) list of groups in aligned
+  // chunks: each folds its chunk into a subtree, the NW subtree roots meet in LDS and one wave finishes the tree.
+  if(arrow)
+  {
+    const int4 t = Q.tkl[nblk - 1];
+    const int ng = max(t.y - t.x + 1, 0), nT = ng + max(t.w - t.z + 1, 0);
+    int P = 1;
+    while(P < nT) P <<= 1;
+    if(P < NW) P = NW;
+    const int G = P / NW, lane = K.lane;
+    const int r0 = lane, r1 = lane + 64;
+    const double * row0 = Q.Bc + oh + min(r0, lh - 1);
+    const double * row1 = Q.Bc + oh + min(r1, lh - 1);
+    TreeStack T0, T1;
+    T0.reset();
+    T1.reset();
+    for(int ts = K.wave * G; ts < (K.wave + 1) * G; ++ts)
+    {
+      double a0 = 0.0, a1 = 0.0;
+      if(ts < nT) // (uniform)
+      {
+        const int gI = (ts < ng) ? t.x + ts : t.z + (ts - ng);
+        const int c = Q.gcount[gI], o = Q.goff[gI];
+        for(int e0 = 0; e0 < c; e0 += EB)
+        {
+          double b0[EB], b1[EB];
+          int sl[EB];
+#pragma unroll
+          for(int u = 0; u < EB; ++u)
+          {
+            sl[u] = Q.glist[o + min(e0 + u, c - 1)];
+            b0[u] = row0[(size_t)sl[u] * np];
+            if(BIG) b1[u] = row1[(size_t)sl[u] * np];
+          }
+#pragma unroll
+          for(int u = 0; u < EB; ++u)
+          {
+            const double dv = dls[sl[u]];
+            const double t0 = FMA(dv, b0[u], a0);
+            a0 = (e0 + u < c) ? t0 : a0;
+            if(BIG)
+            {
+              const double t1 = FMA(dv, b1[u], a1);
+              a1 = (e0 + u < c) ? t1 : a1;
+            }
+          }
+        }
+      }
+      T0.push(a0);
+      if(BIG) T1.push(a1);
+    }
+    __syncthreads(); // (part A's writes of y are done with; hred is free)
+    Q.hred[K.wave * 128 + r0] = T0.flush();
+    if(BIG) Q.hred[K.wave * 128 + r1] = T1.flush();
+    __syncthreads();
+    for(int r = K.tid; r < lh; r += NT)
+    {
+      double w[NW];
+#pragma unroll
+      for(int i = 0; i < NW; ++i) w[i] = Q.hred[i * 128 + r];
+#pragma unroll
+      for(int st = 1; st < NW; st <<= 1)
+#pragma unroll
+        for(int i = 0; i < NW; i += 2 * st) w[i] = w[i] + w[i + st];
+      y[oh + r] = y[oh + r] - w[0];
+    }
+    (void)qc;
   }
   __syncthreads();
 }
@@ -281,7 +499,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
   K.diag = A.diag + (size_t)pb * A.nblk;
   K.side = A.side + (size_t)pb * (A.nblk > 1 ? A.nblk - 1 : 0);
   K.cblk = A.cblk + (size_t)pb * A.ncb;
-  // LDS: d | z | [x | u] | r | ga | gb | bsum | red (32) | ired (32 doubles) | sh (8) | ints: slot, smeta, gcount, goff, glist, koff, klen, kpho | kapr | bm
+  // LDS: d | z | [x | u] | r | ga | gb | bsum | hred | tkl | red (32) | ired (32 doubles) | sh (8) | ints: slot, roff, smeta, gcount, goff, glist, koff, klen, kpho | kapr | bm
   double * p = sm;
   K.d = p; p += A.n_pad;
   K.z = p; p += A.n_pad;
@@ -302,6 +520,12 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
   while(P2 < nblk) P2 <<= 1;
   if(P2 < 64) P2 = 64;
   Q.bsum = p; p += P2;
+  Q.hred = p; p += 8 * 128;
+  {
+    int4 * tl = reinterpret_cast<int4 *>(p); p += 2 * nblk;
+    for(int k = tid; k < nblk; k += NT) tl[k] = reinterpret_cast<const int4 *>(A.tk)[k];
+    Q.tkl = tl;
+  }
   K.red = p; p += 32;
   K.ired = reinterpret_cast<int *>(p); p += 32;
   double * sh = p; p += 8;
@@ -309,6 +533,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
   K.par = 0;
   int * ip = reinterpret_cast<int *>(p);
   Q.slot = ip; ip += A.qcap;
+  Q.roff = ip; ip += A.qcap;
   Q.smeta = reinterpret_cast<unsigned *>(ip); ip += A.qcap;
   Q.gcount = ip; ip += A.ngrp;
   Q.goff = ip; ip += A.ngrp;
@@ -549,7 +774,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           __syncthreads();
           break;
         }
-        c9_y_update<NT>(K, Q, z, Q.gb);
+        c9_y_update<NT, BIG>(K, Q, z, Q.gb);
         stamp(4);
       }
       double nrm2 = 0.0;
@@ -669,6 +894,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           Q.Sm[(size_t)sn + (size_t)q * Q.ldq] = v;
           Q.St[(size_t)sn * Q.ldq + q] = v;
           Q.slot[q] = sn;
+          Q.roff[q] = sn * Q.ldq;
           Q.smeta[sn] = (unsigned)plo | ((unsigned)(phi + 1) << 16);
           Q.sgrp[sn] = pgrp;
           Q.glist[Q.goff[pgrp] + Q.gcount[pgrp]] = sn;
@@ -794,6 +1020,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           {
             K.active[k] = ta;
             Q.slot[k] = ts;
+            Q.roff[k] = ts * Q.ldq;
           }
           __syncthreads();
         }
@@ -871,8 +1098,8 @@ long blockgi_c9_lds_bytes(int n, int m, int nb, int nblk, int ncb, int xu_global
   int P2 = 1;
   while(P2 < nblk) P2 <<= 1;
   if(P2 < 64) P2 = 64;
-  const long dbl = (xu_global ? 2L * n_pad + 3L * qcap : 3L * n_pad + 4L * qcap) + P2 + 32 + 32 + 8;
-  const long ints = 2L * qcap + 2L * ngrp + (m + nb + 1) + 3L * nblk + (n + 2) / 2 + 2;
+  const long dbl = (xu_global ? 2L * n_pad + 3L * qcap : 3L * n_pad + 4L * qcap) + P2 + 8 * 128 + 2L * nblk + 32 + 32 + 8;
+  const long ints = 3L * qcap + 2L * ngrp + (m + nb + 1) + 3L * nblk + (n + 2) / 2 + 2;
   return (long)sizeof(double) * dbl + 4 * ints + (long)sizeof(BlkMeta) * nblk + 8;
 }
 

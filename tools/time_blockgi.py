@@ -12,6 +12,8 @@ from ikdata import read_arrow, read_tri_block_diag
 from test_gpu_blockgi import KIND
 o = get_oracle()
 PROFILE_LINES = []  # printed by the caller behind the timing line they belong to
+FORMS = [0]  # form of the last plan (0: orthonormal sequence, 1: contract C9)
+FORM_NAME = {0: "sequence", 1: "C9"}
 
 
 def flush_profile():
@@ -29,7 +31,8 @@ def gpu_time(qps, max_iter, reps=5):
     bl = torch.tensor(np.stack([q.bl for q in qps]), device="cuda"); bu = torch.tensor(np.stack([q.bu for q in qps]), device="cuda")
     xl = torch.tensor(np.stack([q.xl for q in qps]), device="cuda") if ub else None
     xu = torch.tensor(np.stack([q.xu for q in qps]), device="cuda") if ub else None
-    s = capi.BlockGISolver(KIND[q0.kind], q0.bs, [c.shape for c in q0.Cblocks], ub, B, max_iter=max_iter)
+    s = capi.BlockGISolver(KIND[q0.kind], q0.bs, [c.shape for c in q0.Cblocks], ub, B, max_iter=max_iter, form=os.environ.get("BGI_FORM", "auto"))
+    FORMS[0] = s.form
     H = H0.clone()
     ts = []
     for _ in range(reps):
@@ -46,19 +49,21 @@ def gpu_time(qps, max_iter, reps=5):
         capi.set_profile(capi.PROFILE_BLOCKGI, None)
         pr = prof.cpu().numpy().astype(np.float64)[0] / 100.0  # us
         names = ["init", "scan", "L^-1 n+", "Q^T d", "Q z", "L^-T z", "R solve", "step length", "update", "add", "drop", "(Q: reflectors", "Q: Givens)"]
+        if s.form == 1:
+            names = ["init", "scan", "L^-1 n+", "B^T v, S^T g, S d1", "y -= B dl", "|y|, L^-T y", "-", "step length", "update", "add", "drop", "-", "-"]
         PROFILE_LINES.append("      phase profile of the line above, problem 0 (us total): " + "; ".join(f"{nm} {pr[i]:.0f}" for i, nm in enumerate(names))
               + f"  | sum {pr[:11].sum():.0f} us over {int(r.iters[0])} iterations; core clock {pr[13] / max(pr[14], 1e-9) * 0.1:.2f} GHz")
     return min(ts), r.iters.cpu().numpy(), r.term.cpu().numpy(), s.workspace_bytes
 
 
-def cpu_time(qp, max_iter, dense=False):
+def cpu_time(qp, max_iter, dense=False, c9=False):
     Gs = qp.G.copy(order="F")
     t = time.perf_counter()
     if dense:
         r = o.solve(Gs, qp.a, qp.dense_C(), qp.bl, qp.bu, qp.xl, qp.xu, max_iter=max_iter)
     else:
         d, f = SP.block_views(Gs, qp.bs, qp.kind)
-        r = o.blockgi_solve(qp.kind, d, f, qp.a, qp.Cblocks, qp.bl, qp.bu, qp.xl, qp.xu, max_iter=max_iter)
+        r = o.blockgi_solve(qp.kind, d, f, qp.a, qp.Cblocks, qp.bl, qp.bu, qp.xl, qp.xu, max_iter=max_iter, c9=c9)
     return (time.perf_counter() - t) * 1e3, r.iters
 
 
@@ -80,17 +85,18 @@ if what in ("all", "ik"):
         cs, it = cpu_time(qp, 500); cd, _ = cpu_time(qp, 500, dense=True)
         for B in (1, 256, 1024):
             ms, iters, term, ws = gpu_time([qp] * B, 64)
-            print(f"{name}: batch {B:4d}: GPU {ms:8.3f} ms ({ms / B * 1e3:8.1f} us/problem, {B / ms * 1e3:9.0f} solves/s) iters {iters[0]} term {term[0]};  "
+            print(f"{name}: batch {B:4d} [{FORM_NAME[FORMS[0]]}]: GPU {ms:8.3f} ms ({ms / B * 1e3:8.1f} us/problem, {B / ms * 1e3:9.0f} solves/s) iters {iters[0]} term {term[0]};  "
                   f"CPU oracle structured {cs:.3f} ms, dense {cd:.3f} ms (1 core)", flush=True)
             flush_profile()
-if what in ("all", "c5", "c5b64"):
+if what in ("all", "c5", "c5b64", "c5b512"):
     for sa in (1.0,):
         base = [SP.mpc_arrow_qp(100, 30, 10, seed=s, scale_a=sa) for s in range(2)]
         cs, it = cpu_time(base[0], 1000)
-        print(f"c5 (n=3030, m=1000, scale_a={sa}): CPU oracle structured {cs:.1f} ms, {it} iterations (dense oracle: ~50 s)", flush=True)
-        for B in ((64,) if what == "c5b64" else (1, 16, 64)):
+        c9s, _ = cpu_time(base[0], 1000, c9=True)
+        print(f"c5 (n=3030, m=1000, scale_a={sa}): CPU oracle structured, sequence form {cs:.1f} ms, C9 {c9s:.1f} ms, {it} iterations (dense oracle: ~50 s)", flush=True)
+        for B in ((64,) if what == "c5b64" else (512,) if what == "c5b512" else (1, 16, 64)):
             qps = (base * B)[:B]
             ms, iters, term, ws = gpu_time(qps, 1000, reps=3)
-            print(f"   batch {B:3d}: GPU {ms:9.2f} ms  ({ms / B:8.2f} ms/problem, {B / ms * 1e3:7.1f} solves/s)  iters {iters[:2]} term {term[:2]}  "
+            print(f"   batch {B:3d} [{FORM_NAME[FORMS[0]]}]: GPU {ms:9.2f} ms  ({ms / B:8.2f} ms/problem, {B / ms * 1e3:7.1f} solves/s)  iters {iters[:2]} term {term[:2]}  "
                   f"{ms / iters.mean() * 1e3:7.1f} us/iteration/batch  workspace {ws / 2**20:.0f} MiB", flush=True)
             flush_profile()
