@@ -588,7 +588,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
 
   int q = 0, it = 0, rc = JRLQP_UNKNOWN;
   double f = 0.0;
-  // diagnostic phase timer (thread 0, 100 MHz wall clock): 0 init, 1 scan, 2 L^-1 n+, 3 B^T v + S^T g + S d1, 4 y -= B dl, 5 L^-T y + |y|,
+  // diagnostic phase timer (thread 0, 100 MHz wall clock): 0 init, 1 scan, 2 L^-1 n+, 3 B^T v, 6 S^T g, 11 S d1, 12 r += dl, 4 y -= B dl, 5 L^-T y + |y|,
   // 7 step length, 8 update, 9 add, 10 drop
   long long pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tp = (A.prof && tid == 0) ? wall_clock64() : 0;
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           plo = phi = kap;
       }
       __syncthreads();
-      sg_lsolve<NT, BIG>(K, d, wst, wen);
+      sg_lsolve<NT, BIG>(K, d, wst, wen, true, (A.kind == 2) ? 0 : plo, (A.kind == 2) ? 0x7fffffff : phi);
       if(pst == JRLQP_UPPER)
       {
         for(int i = tid; i < n; i += NT) d[i] = -d[i];
@@ -758,8 +758,11 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
       for(int pass = 0; pass < 2 && q > 0; ++pass)
       {
         c9_bt_v<NT>(K, Q, q, z, pass == 0, plo, phi, Q.ga);
+        stamp(3);
         c9_st_g<NT>(K, Q, q, Q.ga, Q.gb);
+        stamp(6);
         c9_s_d<NT>(K, Q, q, Q.gb, Q.ga);
+        stamp(11);
         for(int k = tid; k < q; k += NT)
         {
           const double dl = Q.ga[k];
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           Q.gb[Q.slot[k]] = dl; // dl by slot (d1 is dead)
         }
         __syncthreads();
-        stamp(3);
+        stamp(12);
         if(q == n) // Q2 is empty: y = 0 by rule, nothing to refine against
         {
           for(int i = tid; i < n; i += NT) z[i] = 0.0;

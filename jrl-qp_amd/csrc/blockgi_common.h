@@ -81,8 +81,11 @@ __device__ __forceinline__ double dot_tree(Ctx & K, int lo, int hi, FA fa, FB fb
 // ---- StructuredG::solveL / solveInPlaceLTranspose on a vector held in LDS --------------------------------------------
 // Block arrow, L v <- v with the non-zero window [start, end) of v (blockArrowLLT.cpp:92-176).  The up variant's row
 // permutation (:163-170) is a change of offsets only: logical block i sits at physical rows boff[dsel(i)].
+// [lo, hi]: the logical off-head blocks that can lie under the window (default: all; the C9 kernel knows the constraint's reach and
+// spares the waves a scan of ~100 block descriptors per call).  Blocks of at most 32 rows take the operands of their substitution --
+// and wave 0 those of the head's, before the barrier -- in one request (wave_fwd_pre): same steps, same bits.
 template<int NT>
-__device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int end)
+__device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int end, int lo = 0, int hi = 0x7fffffff)
 {
   const BgiArgs & A = *K.A;
   constexpr int NW = NT / 64;
@@ -94,7 +97,19 @@ __device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int
     start = max(0, start - shift);
     end = max(0, end - shift);
   }
-  for(int i = K.wave; i < nblk - 1; i += NW)
+  hi = min(hi, nblk - 2);
+  // the head's operands (wave 0), requested before anything else
+  const bool hpre = nbk <= 32;
+  double hl[32], hdg = 1.0;
+  if(K.wave == 0 && hpre)
+  {
+    const double * Dh = K.bm[ib].diag;
+    const int ldh = K.bm[ib].ldd, rl = (lane < nbk) ? lane : 0;
+    hdg = AT(Dh, ldh, rl, rl);
+#pragma unroll
+    for(int j = 0; j < 32; ++j) hl[j] = AT(Dh, ldh, rl, min(j, nbk - 1));
+  }
+  for(int i = lo + ((K.wave - lo) % NW + NW) % NW; i <= hi; i += NW) // (block i on wave i mod NW, as the full loop deals them)
   {
     const int id = dsel(nblk, up, i), ni = K.bm[id].bs, n0 = K.bm[id].boff - shift;
     const int s = max(start - n0, 0);
@@ -103,7 +118,18 @@ __device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int
     const int ldd = K.bm[id].ldd;
     double * vi = v + K.bm[id].boff + s;
     double xi = (lane < ni - s) ? vi[lane] : 0.0;
-    xi = wave_fwd(Dg + s + (size_t)s * ldd, ldd, ni - s, xi, lane);
+    if(ni - s <= 32)
+    {
+      const double * Ls = Dg + s + (size_t)s * ldd;
+      const int nn = ni - s, rl = (lane < nn) ? lane : 0;
+      double lv[32];
+      const double dg = (nn > 0) ? AT(Ls, ldd, rl, rl) : 1.0;
+#pragma unroll
+      for(int j = 0; j < 32; ++j) lv[j] = (nn > 0) ? AT(Ls, ldd, rl, min(j, nn - 1)) : 0.0;
+      xi = wave_fwd_pre<32>(lv, dg, Ls, ldd, nn, xi, lane);
+    }
+    else
+      xi = wave_fwd(Dg + s + (size_t)s * ldd, ldd, ni - s, xi, lane);
     if(lane < ni - s) vi[lane] = xi;
   }
   __syncthreads();
@@ -111,7 +137,7 @@ __device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int
   {
     double * vb = v + K.bm[ib].boff;
     double acc = (lane < nbk) ? vb[lane] : 0.0;
-    for(int i = 0; i < nblk - 1; ++i)
+    for(int i = lo; i <= hi; ++i)
     {
       const int id = dsel(nblk, up, i), ni = K.bm[id].bs, n0 = K.bm[id].boff - shift;
       const int s = max(start - n0, 0);
@@ -125,7 +151,10 @@ __device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int
                          [&](int k) { return Xi[k]; });
       }
     }
-    acc = wave_fwd(K.bm[ib].diag, K.bm[ib].ldd, nbk, acc, lane);
+    if(hpre)
+      acc = wave_fwd_pre<32>(hl, hdg, K.bm[ib].diag, K.bm[ib].ldd, nbk, acc, lane);
+    else
+      acc = wave_fwd(K.bm[ib].diag, K.bm[ib].ldd, nbk, acc, lane);
     if(lane < nbk) vb[lane] = acc;
   }
   __syncthreads();
@@ -505,7 +534,7 @@ __device__ __forceinline__ void permute_up(Ctx & K, double * v, bool forward)
 // StructuredG::solveL (StructuredG.cpp:67-113); permuted = false keeps the result in the original row order (only
 // valid when the matching sg_ltsolve call is told the same: the two permutations of the reference cancel)
 template<int NT, bool BIG>
-__device__ __forceinline__ void sg_lsolve(Ctx & K, double * v, int start, int end, bool permuted = true)
+__device__ __forceinline__ void sg_lsolve(Ctx & K, double * v, int start, int end, bool permuted = true, int lo = 0, int hi = 0x7fffffff)
 {
   constexpr bool big = BIG; // (a kernel of its own for blocks of 65 .. 128 rows: the two-rows-per-lane variants cost the small-block kernel
                             // 5 % when they merely shared its code -- registers and instruction cache)
@@ -521,7 +550,7 @@ __device__ __forceinline__ void sg_lsolve(Ctx & K, double * v, int start, int en
     if(big)
       arrow_lsolve_big<NT>(K, v, start, end);
     else
-      arrow_lsolve<NT>(K, v, start, end);
+      arrow_lsolve<NT>(K, v, start, end, lo, hi);
     if(K.A->kind == 1 && permuted) permute_up<NT>(K, v, true);
   }
 }

@@ -464,6 +464,74 @@ __device__ __forceinline__ double wave_bwd(const double * L, int ldl, int n, dou
   return act ? xi : x0;
 }
 
+// wave_fwd / wave_bwd with the NP operands of each lane supplied by the caller (n <= NP <= 64), who requested them -- all at once, and
+// beside whatever else the block needs -- before anything depended on them: one memory round trip per block instead of one per group
+// of kAhead steps.  Same steps, same bits.  fwd: lv[j] = L(rl, min(j, n-1)); bwd: lv[j] = L(max(n-1-j, 0), rl); dg = L(rl, rl); rl = lane
+// (lanes >= n: 0).
+template<int NP>
+__device__ __forceinline__ double wave_fwd_pre(const double (&lv)[NP], double dg, const double * L, int ldl, int n, double xi, int lane)
+{
+  n = __builtin_amdgcn_readfirstlane(n);
+  const bool act = lane < n;
+  const int rl = act ? lane : 0;
+  const double rinv = recip_refined(dg);
+  const double x0 = xi;
+#pragma unroll
+  for(int j = 0; j < NP; ++j)
+  {
+    const double v = bcast_lane_s(div_pre(xi, dg, rinv), j);
+    const double upd = FMA(-lv[j], v, xi);
+    xi = (lane > j) ? upd : xi;
+  }
+  const double pre = xi;
+  xi = div_pre(pre, dg, rinv);
+  if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
+  {
+    xi = x0;
+    for(int k = 0; k < n; ++k)
+    {
+      const double v = bcast_lane(xi, k) / bcast_lane(dg, k);
+      if(lane == k)
+        xi = v;
+      else if(lane > k && act)
+        xi = FMA(-AT(L, ldl, rl, k), v, xi);
+    }
+  }
+  return act ? xi : x0;
+}
+template<int NP>
+__device__ __forceinline__ double wave_bwd_pre(const double (&lv)[NP], double dg, const double * L, int ldl, int n, double xi, int lane)
+{
+  n = __builtin_amdgcn_readfirstlane(n);
+  const bool act = lane < n;
+  const int rl = act ? lane : 0;
+  const double rinv = recip_refined(dg);
+  const double x0 = xi;
+#pragma unroll
+  for(int j = 0; j < NP; ++j)
+  {
+    const int k = n - 1 - j; // (a step with k < 0 matches no lane)
+    const double v = bcast_lane_s(div_pre(xi, dg, rinv), max(k, 0));
+    const double upd = FMA(-lv[j], v, xi);
+    xi = (lane < k) ? upd : xi;
+  }
+  const double pre = xi;
+  xi = div_pre(pre, dg, rinv);
+  if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
+  {
+    xi = x0;
+    for(int k = n - 1; k >= 0; --k)
+    {
+      const double v = bcast_lane(xi, k) / bcast_lane(dg, k);
+      if(lane == k)
+        xi = v;
+      else if(lane < k)
+        xi = FMA(-AT(L, ldl, k, rl), v, xi);
+    }
+  }
+  return act ? xi : x0;
+}
+
 // acc <- fma(-a(k), b(k), acc) for k = k0, k0 + step, ... (cnt terms, in that order): the a() operands (HBM/L2) are
 // fetched kAhead terms ahead with unconditional loads (the index is clamped into the valid range).  Two operand buffers
 // take turns (no copy between them); a full group is sixteen plain fmas, only the last, partial group selects per term (no

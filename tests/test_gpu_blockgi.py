@@ -31,7 +31,7 @@ def capi(pkg):
 FORM = {"form": None}  # the form the last GPU plan ran (0 sequence, 1 C9): the oracle to compare with
 
 
-def gpu_solve(capi, qps, max_iter=500, trace_cap=0, form="auto"):
+def gpu_solve(capi, qps, max_iter=500, trace_cap=0, form="auto", packed=False):
     """Solve a batch of identically shaped StructuredQP on the GPU."""
     import torch
 
@@ -48,6 +48,8 @@ def gpu_solve(capi, qps, max_iter=500, trace_cap=0, form="auto"):
     xu = torch.tensor(np.stack([q.xu for q in qps]), device="cuda") if use_bounds else None
     s = capi.BlockGISolver(KIND[q0.kind], q0.bs, shapes, use_bounds, B, max_iter=max_iter, form=form)
     FORM["form"] = s.form
+    if packed:  # the blocks back to back, each with its own leading dimension, instead of views into the N x N matrices
+        H = s.pack(H)
     r = s.solve(H, a, Cb, bl, bu, xl, xu, trace_cap=trace_cap)
     torch.cuda.synchronize()
     out = dict(x=r.x.cpu().numpy(), u=r.u.cpu().numpy()[:, : m + (n if use_bounds else 0)],
@@ -65,8 +67,8 @@ def oracle_solve(oracle, SP, qp, max_iter=500, c9=None):
     return r, Gs
 
 
-def check_batch(oracle, SP, capi, qps, max_iter=500, min_iters=0, form="auto"):
-    g = gpu_solve(capi, qps, max_iter=max_iter, form=form)
+def check_batch(oracle, SP, capi, qps, max_iter=500, min_iters=0, form="auto", packed=False):
+    g = gpu_solve(capi, qps, max_iter=max_iter, form=form, packed=packed)
     tot = 0
     for b, qp in enumerate(qps):
         r, Gs = oracle_solve(oracle, SP, qp, max_iter=max_iter)
@@ -272,3 +274,14 @@ def test_c9_blocks_of_up_to_128_rows_and_tridiagonal(oracle, SP, capi):
         n = sum(bs)
         qps = [SP.random_structured_qp(kind, bs, [40, 35, 20], 950 + seed, ridge=0.05, cbs=[100, n - 230, 130], box=1.0) for seed in range(2)]
         check_batch(oracle, SP, capi, qps, min_iters=10, form="c9")
+
+
+@pytest.mark.parametrize("form", ["sequence", "c9"])
+@pytest.mark.parametrize("kind", ["tri", "arrow_up", "arrow_down"])
+def test_packed_block_storage_bit_exact(oracle, SP, capi, kind, form):
+    """The blocks handed over back to back with their own leading dimensions (BlockGISolver.pack) instead of as views into N x N
+    matrices: the same bits (the reference's StructuredG takes any MatrixRef per block)."""
+    bs, mc = {"tri": ([7, 4, 9, 6, 5, 8], [4, 6, 3, 5, 7, 2]), "arrow_up": ([6, 9, 4, 7, 5], [5, 3, 6, 4, 2]), "arrow_down": ([8, 5, 7, 6, 9], [3, 6, 4, 5, 0])}[kind]
+    check_batch(oracle, SP, capi, [SP.random_structured_qp(kind, bs, mc, 100 + seed, ridge=0.05) for seed in range(6)], min_iters=30, form=form, packed=True)
+    qps = [SP.random_structured_qp(kind, [30] * 12, [6] * 12, 40 + s, ridge=0.05, box=2.0) for s in range(2)]
+    check_batch(oracle, SP, capi, qps, max_iter=800, min_iters=40, form=form, packed=True)

@@ -33,6 +33,8 @@ def gpu_time(qps, max_iter, reps=5):
     xu = torch.tensor(np.stack([q.xu for q in qps]), device="cuda") if ub else None
     s = capi.BlockGISolver(KIND[q0.kind], q0.bs, [c.shape for c in q0.Cblocks], ub, B, max_iter=max_iter, form=os.environ.get("BGI_FORM", "auto"))
     FORMS[0] = s.form
+    if os.environ.get("BGI_PACKED", "1") != "0":  # the blocks back to back (ld = block rows) instead of views into N x N matrices
+        H0 = s.pack(H0)
     H = H0.clone()
     ts = []
     for _ in range(reps):
@@ -50,9 +52,9 @@ def gpu_time(qps, max_iter, reps=5):
         pr = prof.cpu().numpy().astype(np.float64)[0] / 100.0  # us
         names = ["init", "scan", "L^-1 n+", "Q^T d", "Q z", "L^-T z", "R solve", "step length", "update", "add", "drop", "(Q: reflectors", "Q: Givens)"]
         if s.form == 1:
-            names = ["init", "scan", "L^-1 n+", "B^T v, S^T g, S d1", "y -= B dl", "|y|, L^-T y", "-", "step length", "update", "add", "drop", "-", "-"]
+            names = ["init", "scan", "L^-1 n+", "B^T v", "y -= B dl", "|y|, L^-T y", "S^T g", "step length", "update", "add", "drop", "S d1", "r += dl"]
         PROFILE_LINES.append("      phase profile of the line above, problem 0 (us total): " + "; ".join(f"{nm} {pr[i]:.0f}" for i, nm in enumerate(names))
-              + f"  | sum {pr[:11].sum():.0f} us over {int(r.iters[0])} iterations; core clock {pr[13] / max(pr[14], 1e-9) * 0.1:.2f} GHz")
+              + f"  | sum {pr[:13].sum() if s.form == 1 else pr[:11].sum():.0f} us over {int(r.iters[0])} iterations; core clock {pr[13] / max(pr[14], 1e-9) * 0.1:.2f} GHz")
     return min(ts), r.iters.cpu().numpy(), r.term.cpu().numpy(), s.workspace_bytes
 
 
