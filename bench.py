@@ -422,26 +422,26 @@ def bench_single_large(args, rank, world, device, jdist, emit=True):
 def bench_structured(args, rank, world, device, jdist, emit=True):
     """Secondary workload (BASELINE config c5): a batch of structured QPs -- block-arrow Hessian (100 stage blocks of 30 +
     head), block-diagonal C with 10 one-sided constraints per stage -- through jrlqp_blockgi_solve (factorisation + the
-    device-resident structured GI loop).  A step = one batch; each rank owns its own shard (weak scaling).  The metric of
-    this line is structured-GI solves/s; roofline: HBM, algorithmic bytes = the reflector rows both Q applications of
-    every iteration read + inputs + outputs."""
+    device-resident structured GI loop, contract C9: DESIGN.md 7.3).  A step = one batch; each rank owns its own shard (weak scaling).
+    32 distinct seeded problems per GPU, tiled to the batch; the blocks in packed storage (1.43 MB per problem).  Beside the batch
+    rate the record carries what SURVEY 8(d) asks of c5: single-problem latency, block factorisation us, block solve us."""
     import numpy as np
     import torch
 
     import jrl_qp_amd.capi as capi
     import jrl_qp_amd.structured_problems as SP
 
-    B = args.batch if args.batch != BATCH else 512  # two problems per CU (throughput layout of jrlqp_blockgi_*)
+    B = args.batch if args.batch != BATCH else 512
     lo, hi = jdist.shard_range(B * world, rank, world)
-    base = [SP.mpc_arrow_qp(100, 30, 10, seed=s, scale_a=1.0) for s in range(2)]
-    q0 = base[0]
-    n, m = q0.n, q0.m
-    idx = torch.tensor([(lo + i) % 2 for i in range(hi - lo)], device=device)  # two distinct problems, tiled on the device
-    dev2 = lambda f: torch.tensor(np.stack([f(q) for q in base]), device=device)[idx].contiguous()
-    H0 = dev2(lambda q: np.ascontiguousarray(q.G.T))
-    Cb = dev2(lambda q: np.concatenate([c.ravel(order="F") for c in q.Cblocks]))
-    a, bl, bu = dev2(lambda q: q.a), dev2(lambda q: q.bl), dev2(lambda q: q.bu)
-    solver = capi.BlockGISolver("arrow_down", q0.bs, [c.shape for c in q0.Cblocks], False, hi - lo, max_iter=1000, device=device)
+    nloc = hi - lo
+    ND = min(32, nloc)  # distinct problems
+    gen = [SP.mpc_arrow_packed(100, 30, 10, seed=s, scale_a=1.0) for s in range(ND)]
+    bs, cshapes = gen[0][5], gen[0][6]
+    n, m = sum(bs), sum(c for _, c in cshapes)
+    idx = torch.tensor([(lo + i) % ND for i in range(nloc)], device=device)
+    dev = lambda k: torch.tensor(np.stack([g[k] for g in gen]), device=device)[idx].contiguous()
+    H0, a, Cb, bl, bu = dev(0), dev(1), dev(2), dev(3), dev(4)
+    solver = capi.BlockGISolver("arrow_down", bs, cshapes, False, nloc, max_iter=1000, device=device)
     H = H0.clone()
     stream = torch.cuda.current_stream(device)
 
@@ -475,49 +475,60 @@ def bench_structured(args, rank, world, device, jdist, emit=True):
     n_ok, sum_it, elapsed = jdist.reduce_stats(int((term == 0).sum()), int(iters.sum()), elapsed, device=device)
     if rank == 0:
         total = B * world
-        # TWO byte models, named as such:
+        # ---- one problem alone (latency layout, a plan of its own), and the factorisation / the two block solves alone ----
+        single = capi.BlockGISolver("arrow_down", bs, cshapes, False, 1, max_iter=1000, device=device)
+        H1 = H0[:1].clone()
+        one_ms = []
+        for rep in range(4):
+            H1.copy_(H0[:1])
+            single._bind(H1, Cb[:1])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            r1 = single.solve(H1, a[:1], Cb[:1], bl[:1], bu[:1])
+            e1.record(stream)
+            torch.cuda.synchronize(device)
+            if rep:
+                one_ms.append(e0.elapsed_time(e1))
+        fact = structured_factor_times(capi, SP, device)
+        # Byte models, named as such:
         #  * compulsory: every input read once, every output written once -- the factor blocks (201 x 900 doubles, in
         #    place: read + written), C, a, bl, bu; x, u, status, {term, iters}, f.  This is `roofline.achieved`: the path's own floor.
-        #  * re-read model: what THIS implementation streams -- iteration k applies the k elements of the orthonormal sequence twice
-        #    (Q^T d and Q z), each element a row of n doubles stored zero outside its support: sum_k 2 k n 8 bytes.  Implementation
-        #    traffic, not a property of the problem; reported as `implementation_model` next to the PMC-measured traffic.
-        nloc = hi - lo
+        #  * implementation model of contract C9: per pass of an iteration with q active constraints the two triangular products read S
+        #    twice (q^2 / 2 doubles each), the sparse columns of B are read twice (60 doubles per column), and L is read once by L^-T
+        #    (201 x 900 doubles) -- two passes per iteration.  Implementation traffic, not a property of the problem.
         blocks = 201 * 900
         compulsory = nloc * (8.0 * (2 * blocks + n + 1000 * 30 + 2 * m) + 8 * (n + m) + 4 * m + 16)
-        rows = float(sum(int(i) * (int(i) - 1) for i in iters))  # 2 * sum_{k<iters} k
-        reread = rows * n * 8 + compulsory
+        qsum2 = float(sum(2 * (0.92 * k) ** 2 for it in iters for k in range(0, int(it), 8)) * 8)  # sum over iterations of 2 q^2 (q ~ 0.92 k), sampled every 8th
+        model = compulsory + 8.0 * (qsum2 + float(sum(int(i) for i in iters)) * (blocks + 4 * 60 * 250))
         avg_s = float(np.mean(kern_ms)) * 1e-3
-        traffic, traffic_source = pmc_traffic(f"r*_blockgi_c5_batch{hi - lo}_traffic.json", "traffic_bytes_per_launch_fetch_x2_plus_write")
+        traffic, traffic_source = pmc_traffic(f"r*_blockgi_c5_batch{nloc}_traffic.json", "traffic_bytes_per_launch_fetch_x2_plus_write")
         out = {
             "metric": "structured GI QP solves/sec, block arrow 100x30+30 (n=3030, m=1000), batch per GPU",
             "value": total * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 1),
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4] (c5) as a batch: {B} structured QPs per GPU, block arrow (down) 100 stage blocks of 30 + head, "
-                                   f"10 one-sided constraints per stage, through jrlqp_blockgi_solve (in-place block LLT + device-resident "
-                                   f"structured GI loop); wall time includes restoring G before each solve",
-                       "batch_per_gpu": B, "mean_iterations": sum_it / total, "solved": n_ok},
+            "config": {"workload": f"BASELINE configs[4] (c5) as a batch: {B} structured QPs per GPU ({ND} distinct seeded problems, tiled), block arrow (down) 100 "
+                                   f"stage blocks of 30 + head, 10 one-sided constraints per stage, blocks in packed storage, through jrlqp_blockgi_solve "
+                                   f"(in-place block LLT + device-resident structured GI loop, contract C9); wall time includes restoring G before each solve",
+                       "batch_per_gpu": B, "distinct_problems": ND, "mean_iterations": sum_it / total, "min_iterations": int(iters.min()),
+                       "max_iterations": int(iters.max()), "solved": n_ok, "form": "C9" if solver.form == 1 else "sequence"},
+            "single_problem_ms": float(np.median(one_ms)), "single_problem_iterations": int(r1.iters[0]), "single_problem_term": int(r1.term[0]),
+            "factor_us": fact["factor_us"], "solve_us": fact["solve_us"], "factor_solve_what": fact["what"],
             "roofline": {"bound": "hbm", "achieved": compulsory / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": compulsory / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "blockgi_kernel", "algorithmic_bytes_per_launch": compulsory, "avg_launch_ms": avg_s * 1e3,
-                         "implementation_model": {"bytes_per_launch": reread, "achieved": reread / avg_s / 1e9, "frac": reread / avg_s / 1e9 / HBM_PEAK_GBS,
-                                                  "what": "compulsory bytes + the reflector rows both Q applications of every iteration re-read "
-                                                          "(sum over iterations of 2 k n 8 bytes): traffic of this data structure, not of the problem"},
-                         "note": "frac is against the COMPULSORY bytes of SURVEY 8(d); the kernel is bandwidth-relevant only through its own re-reads "
-                                 "(implementation_model), and a single CU per problem is instruction-issue/barrier bound (DESIGN.md 7.3)",
-                         "floor_argument": "the re-read rows ARE the reference's data structure: StructuredQR keeps Q as an OrthonormalSequence of "
-                                           "Householder elements applied one after another (src/internal/OrthonormalSequence.cpp:189-226), an iteration applies "
-                                           "every element made so far twice (Q^T d, then Q z, which depends on d), and one problem's elements (iterations x n x 8 "
-                                           "bytes = 14 MB at c5) exceed LDS + registers, a batch's exceed L2 + Infinity Cache: implementation_model is the "
-                                           "floor of this data structure, and against it the kernel runs at implementation_model.frac of the HBM peak (measured "
-                                           "traffic: traffic_over_implementation_model x that; the excess is the zero padding of the rows outside their "
-                                           "support).  Headroom without changing the data structure (and with it the rounding contract): support-only rows "
-                                           "(-17 % bytes) and 0.85 of peak instead of 0.70 => at most 1.45x (DESIGN.md 7.3)"},
+                         "kernel": "blockgi_c9_kernel", "algorithmic_bytes_per_launch": compulsory, "avg_launch_ms": avg_s * 1e3,
+                         "implementation_model": {"bytes_per_launch": model, "achieved": model / avg_s / 1e9, "frac": model / avg_s / 1e9 / HBM_PEAK_GBS,
+                                                  "what": "compulsory bytes + what contract C9 streams per iteration: S twice per pass (q^2 / 2 doubles each), L once "
+                                                          "(L^-T), the sparse columns of B; one problem's working set (L 1.4 MB, S up to 2 x 1.9 MB, B 0.25 MB) is "
+                                                          "L2-resident, a batch of 512 is not (2.6 GB): these are HBM / Infinity Cache bytes only in a batch"},
+                         "note": "frac is against the COMPULSORY bytes of SURVEY 8(d): the kernel is latency- and issue-bound (one workgroup per problem; the "
+                                 "phase profile of tools/time_blockgi.py: L^-T y 38 %, y -= B dl 18 %, the triangular products 22 %), not bandwidth-bound; rounds "
+                                 "1-4 kept the reference's orthonormal sequence and streamed 7.9 GB per solve (0.57 of the HBM peak at batch 512, 560 solves/s)"},
         }
         out["ms_per_step_min"], out["ms_per_step_median"] = float(np.min(kern_ms)), float(np.median(kern_ms))
         if traffic is not None:
             out["roofline"]["traffic_over_compulsory"] = traffic / compulsory
-            out["roofline"]["traffic_over_implementation_model"] = traffic / reread
+            out["roofline"]["traffic_over_implementation_model"] = traffic / model
         if not emit:
             return out
         print(json.dumps(out), flush=True)
@@ -525,6 +536,48 @@ def bench_structured(args, rank, world, device, jdist, emit=True):
         return None
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def structured_factor_times(capi, SP, device):
+    """blockArrowLLT of ONE 101 x 30 arrow (jrlqp_blocks_llt) and one L solve + one L^T solve of a vector
+    (jrlqp_blocks_solve), HIP-event microseconds, median of 5 after a warm-up."""
+    import numpy as np
+    import torch
+
+    bs = [30] * 101
+    qp_blocks = SP.mpc_arrow_packed(100, 30, 10, seed=0, scale_a=1.0)[0]
+    n = sum(bs)
+    # jrlqp_blocks_* take the blocks as views into a full matrix: assemble the arrow once (one problem: 73 MB)
+    G = np.zeros((n, n))
+    o = 0
+    for i in range(101):
+        G[30 * i:30 * i + 30, 30 * i:30 * i + 30] = qp_blocks[o:o + 900].reshape(30, 30, order="F")
+        o += 900
+    for i in range(100):
+        G[3000:, 30 * i:30 * i + 30] = qp_blocks[o:o + 900].reshape(30, 30, order="F")
+        o += 900
+    T0 = torch.tensor(np.ascontiguousarray(np.tril(G).T)[None], device=device)  # T[0].T = lower triangle of G
+    rhs = torch.tensor(np.random.default_rng(5).standard_normal((1, 1, n)), device=device)
+    stream = torch.cuda.current_stream(device)
+    tf, ts = [], []
+    for rep in range(6):
+        T = T0.clone()
+        M = rhs.clone()
+        plan = capi.StructuredBlocks("arrow_down", bs, T, max_nrhs=1)
+        torch.cuda.synchronize(device)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(stream)
+        plan.llt(fetch=False)
+        e1.record(stream)
+        plan.solve(M, False)
+        plan.solve(M, True)
+        e2.record(stream)
+        torch.cuda.synchronize(device)
+        if rep:
+            tf.append(e0.elapsed_time(e1) * 1e3)
+            ts.append(e1.elapsed_time(e2) * 1e3)
+    return {"factor_us": float(np.median(tf)), "solve_us": float(np.median(ts)),
+            "what": "one problem: jrlqp_blocks_llt of the 101 x 30 arrow; jrlqp_blocks_solve L then L^T on one vector (HIP events)"}
 
 
 def main():

@@ -519,9 +519,11 @@ class StructuredBlocks:
 
         return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def llt(self):
-        """In-place factorisation; returns a list of bools (the reference's return value, one per problem)."""
+    def llt(self, fetch=True):
+        """In-place factorisation; returns a list of bools (the reference's return value, one per problem); fetch=False: enqueue only."""
         check(self.lib.jrlqp_blocks_llt(self.h, self._stream()))
+        if not fetch:
+            return None
         ok = (ct.c_int * self.nprob)()
         check(self.lib.jrlqp_blocks_result(self.h, ok, self._stream()))
         return [bool(v) for v in ok]

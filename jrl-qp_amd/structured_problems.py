@@ -134,3 +134,39 @@ def mpc_arrow_qp(nstage=100, nx=30, mc=10, seed=0, scale_a=4.0) -> StructuredQP:
         bu.append(ub)
     Cb.append(np.zeros((nx, 0), order="F"))
     return StructuredQP("arrow_down", bs, G, a, Cb, np.concatenate(bl), np.concatenate(bu), meta=dict(seed=seed))
+
+
+def mpc_arrow_packed(nstage=100, nx=30, mc=10, seed=0, scale_a=4.0):
+    """The problem of mpc_arrow_qp(nstage, nx, mc, seed, scale_a) WITHOUT ever forming the n x n Hessian: the same random factor M (same
+    generator, same draws), the blocks of G = M^T M formed block by block and returned in the packed layout of
+    capi.BlockGISolver.pack (diagonal blocks, then the side blocks G[head, stage i], each column-major with its own leading dimension:
+    1.43 MB instead of 73 MB at c5).  The blocks agree with mpc_arrow_qp's to rounding (a 30-term product summed by another BLAS call),
+    so this is a problem of the same family, not bit for bit the same instance.  Returns (packed, a, Cflat, bl, bu, bs, cshapes)."""
+    rng = np.random.default_rng(0xC5 + seed)
+    k = nstage + 1
+    # the draws of _pattern(rng, bs, "arrow_down"): per block i the diagonal block, then the block in the head's columns
+    Aii, Aih = [], []
+    for i in range(k):
+        Aii.append(rng.uniform(-1, 1, (nx, nx)))
+        Aih.append(rng.uniform(-1, 1, (nx, nx)))  # (for i = k - 1 this draw overwrites the diagonal block of the head: as in _pattern)
+    Aii[k - 1] = Aih[k - 1]
+    diag, side = [], []
+    head = Aii[k - 1].T @ Aii[k - 1]
+    for i in range(nstage):
+        diag.append(Aii[i].T @ Aii[i])
+        side.append(Aih[i].T @ Aii[i])  # G[head, stage i] = A[i, head]^T A[i, i]
+        head = head + Aih[i].T @ Aih[i]
+    diag.append(head)
+    diag = [0.5 * (d + d.T) for d in diag]
+    n = k * nx
+    a = scale_a * rng.uniform(-1, 1, n)
+    Cb, bu = [], []
+    for i in range(nstage):
+        Ci = rng.standard_normal((nx, mc))
+        x0 = rng.uniform(-1, 1, nx)
+        bu.append(Ci.T @ x0 + np.abs(rng.uniform(0, 1, mc)))
+        Cb.append(Ci)
+    packed = np.concatenate([d.ravel(order="F") for d in diag] + [s_.ravel(order="F") for s_ in side])
+    Cflat = np.concatenate([c.ravel(order="F") for c in Cb])
+    bu = np.concatenate(bu)
+    return packed, a, Cflat, np.full(bu.shape, -np.inf), bu, [nx] * k, [(nx, mc)] * nstage + [(nx, 0)]
