@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/jrlqp_hip.h but not exported"
     assert sorted(capi.EXPORTED) == decl
-    assert lib.jrlqp_abi_version() == 3
+    assert lib.jrlqp_abi_version() == 4
 
 
 def test_defaults_and_lds_budget(pkg):
