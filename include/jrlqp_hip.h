@@ -301,6 +301,15 @@ int jrlqp_gi_solve_batch_multi(int warm, int n, int m, int nb, int B_total, int 
                                const jrlqp_shard_buffers * shards, const jrlqp_options * opts, int synchronize);
 int jrlqp_gi_gather_x_multi(int n, int B_total, int ndev, const int * device_ids, const jrlqp_shard_buffers * shards, int root,
                             double * dx_all_on_root, int synchronize);
+/* Which shard failed to enqueue in the last jrlqp_gi_solve_batch_multi call of this process (-1: none).  On such a failure the call
+ * returns the shard's error AFTER waiting for the shards it had already enqueued (every buffer may be released on return); the
+ * shards behind the failing one were not started. */
+int jrlqp_gi_multi_failed_shard(void);
+/* Rehearsal on a box with fewer GPUs than shards (tests): with `on` != 0 (or JRLQP_MULTI_SHARED_DEVICE set in the environment) a
+ * device may appear more than once in device_ids -- two shards, two streams, two workspaces on one device.  No scaling meaning.
+ * jrlqp_debug_multi_inject_failure(r): shard r of the next calls reports an error instead of being enqueued (-1: off). */
+int jrlqp_debug_multi_allow_shared_device(int on);
+int jrlqp_debug_multi_inject_failure(int shard);
 
 /* LDS bytes one workgroup of the batched kernel uses for (n, m, nb), and where the constraint matrix lives during the
  * solve: *c_placement = 2 one column per thread in registers, 1 staged in LDS, 0 streamed from L2/HBM; returns -1 if

@@ -58,6 +58,9 @@ EXPORTED = [
     "jrlqp_blocks_llt",
     "jrlqp_blocks_result",
     "jrlqp_blocks_solve",
+    "jrlqp_gi_multi_failed_shard",
+    "jrlqp_debug_multi_allow_shared_device",
+    "jrlqp_debug_multi_inject_failure",
     "jrlqp_blockgi_create",
     "jrlqp_blockgi_create_form",
     "jrlqp_blockgi_form",
@@ -345,11 +348,14 @@ class MultiDeviceBatchSolver:
     """jrlqp_gi_solve_batch_multi from one process: the batch is cut into contiguous shards, one per device, each solved on its own
     device with no exchange in between; outputs stay on their devices, `gather_x` assembles x on one."""
 
-    def __init__(self, n, m, use_bounds, B_total, devices, max_iter=500, big_bnd=1e100):
+    def __init__(self, n, m, use_bounds, B_total, devices, max_iter=500, big_bnd=1e100, streams=None):
+        """streams: one torch stream per shard (default: each device's current stream) -- a rehearsal with one device listed twice
+        (jrlqp_debug_multi_allow_shared_device) gives each shard a stream of its own."""
         import torch
 
         self.torch = torch
         self.lib = load_library()
+        self.streams = streams
         self.n, self.m, self.nb, self.B = n, m, (n if use_bounds else 0), B_total
         self.devices = [torch.device(d) for d in devices]
         self.ids = (ct.c_int * len(devices))(*[d.index or 0 for d in self.devices])
@@ -378,7 +384,7 @@ class MultiDeviceBatchSolver:
             sh[r].dterm, sh[r].diters, sh[r].df, sh[r].dL = o["term"].data_ptr(), o["iters"].data_ptr(), o["f"].data_ptr(), None
             sh[r].dworkspace = o["ws"].data_ptr() if o["ws"] is not None else None
             sh[r].workspace_bytes = o["wsb"]
-            sh[r].stream = self.torch.cuda.current_stream(dev).cuda_stream
+            sh[r].stream = (self.streams[r] if self.streams else self.torch.cuda.current_stream(dev)).cuda_stream
         return sh
 
     def solve(self, inputs, synchronize=True):

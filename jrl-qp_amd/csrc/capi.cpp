@@ -367,18 +367,60 @@ long long jrlqp_gi_batch_workspace_bytes_on(int device, int n, int m, int nb, in
   return jrlqp_gi_batch_workspace_bytes(n, m, nb, B);
 }
 
-int jrlqp_gi_solve_batch_multi(int warm, int n, int m, int nb, int B_total, int ndev, const int * device_ids,
-                               const jrlqp_shard_buffers * shards, const jrlqp_options * opts, int synchronize)
+// debug state of the multi-device entry (tests only): a device may be listed more than once (two shards, two streams, two workspaces
+// on ONE device: the rehearsal of a multi-GPU run on a one-GPU box), and shard `g_multi_fail_shard` reports a failure instead of
+// being enqueued; g_multi_failed: the shard whose enqueue failed in the last call (-1: none)
+static int g_multi_shared = 0, g_multi_fail_shard = -1, g_multi_failed = -1;
+
+int jrlqp_debug_multi_allow_shared_device(int on)
 {
-  if(ndev < 1 || !device_ids || !shards || B_total < 0) return JRLQP_ERR_INVALID_ARGUMENT;
+  g_multi_shared = on ? 1 : 0;
+  return JRLQP_OK;
+}
+int jrlqp_debug_multi_inject_failure(int shard)
+{
+  g_multi_fail_shard = shard;
+  return JRLQP_OK;
+}
+int jrlqp_gi_multi_failed_shard(void)
+{
+  return g_multi_failed;
+}
+
+static int multi_check_devices(int ndev, const int * device_ids)
+{
   int visible = 0;
   if(hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return JRLQP_ERR_NO_DEVICE;
+  const bool shared = g_multi_shared || std::getenv("JRLQP_MULTI_SHARED_DEVICE");
   for(int r = 0; r < ndev; ++r)
   {
     if(device_ids[r] < 0 || device_ids[r] >= visible) return JRLQP_ERR_INVALID_ARGUMENT;
-    for(int k = 0; k < r; ++k)
+    for(int k = 0; k < r && !shared; ++k)
       if(device_ids[k] == device_ids[r]) return JRLQP_ERR_INVALID_ARGUMENT; // one shard per device
   }
+  return JRLQP_OK;
+}
+
+// wait for the shards [0, upto) that hold problems (a shard without problems was never enqueued: its buffers need not be filled in)
+static int multi_drain(int B_total, int ndev, const int * device_ids, const jrlqp_shard_buffers * shards, int upto)
+{
+  int rc = JRLQP_OK;
+  for(int r = 0; r < upto; ++r)
+  {
+    int first = 0, count = 0;
+    jrlqp_shard_range(B_total, ndev, r, &first, &count);
+    if(count == 0) continue;
+    if(hipSetDevice(device_ids[r]) != hipSuccess || hipStreamSynchronize(static_cast<hipStream_t>(shards[r].stream)) != hipSuccess) rc = JRLQP_ERR_HIP;
+  }
+  return rc;
+}
+
+int jrlqp_gi_solve_batch_multi(int warm, int n, int m, int nb, int B_total, int ndev, const int * device_ids,
+                               const jrlqp_shard_buffers * shards, const jrlqp_options * opts, int synchronize)
+{
+  g_multi_failed = -1;
+  if(ndev < 1 || !device_ids || !shards || B_total < 0) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(int rc = multi_check_devices(ndev, device_ids)) return rc;
   DeviceGuard guard;
   // enqueue every shard before waiting for any: the devices run side by side, the host thread only launches
   for(int r = 0; r < ndev; ++r)
@@ -387,47 +429,50 @@ int jrlqp_gi_solve_batch_multi(int warm, int n, int m, int nb, int B_total, int 
     jrlqp_shard_range(B_total, ndev, r, &first, &count);
     if(count == 0) continue;
     const jrlqp_shard_buffers & b = shards[r];
-    HIP_TRY(hipSetDevice(device_ids[r]));
-    const int rc = gi_batch_common(warm ? 1 : 0, warm ? b.das : nullptr, n, m, nb, count, b.dG, b.da, b.dC, b.dbl, b.dbu, b.dxl, b.dxu, opts,
-                                   b.dx, b.du, b.dstatus, b.dterm, b.diters, b.df, b.dL, nullptr, 0, b.dworkspace, b.workspace_bytes, b.stream);
-    if(rc != JRLQP_OK) return rc;
-  }
-  if(synchronize)
-    for(int r = 0; r < ndev; ++r)
+    int rc = JRLQP_OK;
+    if(hipSetDevice(device_ids[r]) != hipSuccess)
+      rc = JRLQP_ERR_HIP;
+    else if(r == g_multi_fail_shard)
+      rc = JRLQP_ERR_INVALID_ARGUMENT; // (injected: tests/test_gpu_dist.py)
+    else
+      rc = gi_batch_common(warm ? 1 : 0, warm ? b.das : nullptr, n, m, nb, count, b.dG, b.da, b.dC, b.dbl, b.dbu, b.dxl, b.dxu, opts,
+                           b.dx, b.du, b.dstatus, b.dterm, b.diters, b.df, b.dL, nullptr, 0, b.dworkspace, b.workspace_bytes, b.stream);
+    if(rc != JRLQP_OK)
     {
-      HIP_TRY(hipSetDevice(device_ids[r]));
-      HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(shards[r].stream)));
+      // the shards enqueued so far are running: wait for them, so that the caller may release or reuse every buffer on return; the
+      // shards behind the failing one were never started (jrlqp_gi_multi_failed_shard says which one failed)
+      g_multi_failed = r;
+      (void)multi_drain(B_total, ndev, device_ids, shards, r);
+      return rc;
     }
+  }
+  if(synchronize) return multi_drain(B_total, ndev, device_ids, shards, ndev);
   return JRLQP_OK;
 }
 
 int jrlqp_gi_gather_x_multi(int n, int B_total, int ndev, const int * device_ids, const jrlqp_shard_buffers * shards, int root,
                             double * dx_all_on_root, int synchronize)
 {
-  if(n < 1 || ndev < 1 || !device_ids || !shards || root < 0 || root >= ndev || !dx_all_on_root) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(n < 1 || ndev < 1 || B_total < 0 || !device_ids || !shards || root < 0 || root >= ndev || !dx_all_on_root) return JRLQP_ERR_INVALID_ARGUMENT;
+  if(int rc = multi_check_devices(ndev, device_ids)) return rc;
   DeviceGuard guard;
   for(int r = 0; r < ndev; ++r)
   {
     int first = 0, count = 0;
     jrlqp_shard_range(B_total, ndev, r, &first, &count);
     if(count == 0) continue;
-    // every copy is ordered behind its shard's solve on the shard's OWN stream (a device-to-device copy over xGMI; on the root it
-    // is a plain on-device copy), so nothing waits on the host
+    // every copy is ordered behind its shard's solve on the shard's OWN stream (a device-to-device copy over xGMI; on the root's
+    // device it is a plain on-device copy), so nothing waits on the host
     HIP_TRY(hipSetDevice(device_ids[r]));
     const size_t bytes = sizeof(double) * (size_t)n * count;
     double * dst = dx_all_on_root + (size_t)first * n;
     hipStream_t st = static_cast<hipStream_t>(shards[r].stream);
-    if(r == root)
+    if(device_ids[r] == device_ids[root])
       HIP_TRY(hipMemcpyAsync(dst, shards[r].dx, bytes, hipMemcpyDeviceToDevice, st));
     else
       HIP_TRY(hipMemcpyPeerAsync(dst, device_ids[root], shards[r].dx, device_ids[r], bytes, st));
   }
-  if(synchronize)
-    for(int r = 0; r < ndev; ++r)
-    {
-      HIP_TRY(hipSetDevice(device_ids[r]));
-      HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(shards[r].stream)));
-    }
+  if(synchronize) return multi_drain(B_total, ndev, device_ids, shards, ndev);
   return JRLQP_OK;
 }
 

@@ -94,3 +94,59 @@ def test_multi_device_entry_with_one_device(pkg, oracle):
     sh = (capi.ShardBuffers * 2)()
     assert lib.jrlqp_gi_solve_batch_multi(0, 50, 200, 0, 8, 1, (ct.c_int * 1)(torch.cuda.device_count()), sh, None, 1) == -1
     assert lib.jrlqp_gi_solve_batch_multi(0, 50, 200, 0, 8, 2, (ct.c_int * 2)(0, 0), sh, None, 1) == -1
+
+
+def test_two_shards_rehearsed_on_one_device(pkg, oracle):
+    """Round 5: jrlqp_gi_solve_batch_multi with TWO shards on the one GPU this box has (debug switch: the device list [0, 0]) -- two
+    shard offsets, two streams, two workspaces, jrlqp_gi_gather_x_multi assembling x: equal to the single call and to the oracle,
+    with an uneven split (97 = 49 + 48) and a shape that needs a workspace.  Then an injected failure in shard 1: the call must
+    come back with the error AFTER shard 0's stream has drained (shard 0's results complete), and say which shard failed.
+    No scaling meaning: both shards share one device."""
+    import torch
+
+    import jrl_qp_amd.capi as capi
+    import jrl_qp_amd.problems as P
+
+    lib = capi.load_library()
+    lib.jrlqp_debug_multi_allow_shared_device(1)
+    try:
+        for ch, total in ((P.benchmark_characteristics(50, 200), 97), (P.Characteristics(nVar=100, nObj=100, nIneq=120, nStrongActIneq=20), 25)):
+            pb = P.generate_batch(total, ch, first_index=700)
+            dev = capi.to_device(pb, "cuda:0")
+            cuts = [capi.shard_range(total, 2, r) for r in range(2)]
+            assert cuts[0][1] + cuts[1][1] == total and cuts[1][0] == cuts[0][1]
+            shards = [{k: (v[f : f + c].contiguous() if v is not None else None) for k, v in dev.items()} for f, c in cuts]
+            streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+            torch.cuda.synchronize()
+            ms = capi.MultiDeviceBatchSolver(pb.n, pb.m, False, total, ["cuda:0", "cuda:0"], streams=streams)
+            out = ms.solve(shards)
+            x_all = ms.gather_x(1)
+            ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, nthreads=8)
+            for r, (f, c) in enumerate(cuts):
+                for k in ("x", "u", "status", "term", "iters", "f"):
+                    assert np.array_equal(out[r][k].cpu().numpy(), ref[k][f : f + c]), (r, k)
+            assert np.array_equal(x_all.cpu().numpy(), ref["x"])
+            single = capi.BatchSolver(pb.n, pb.m, False, total, device="cuda:0").solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"])
+            torch.cuda.synchronize()
+            assert torch.equal(single.x, x_all)
+            assert lib.jrlqp_gi_multi_failed_shard() == -1
+            # an injected failure in shard 1: error returned, shard 0 finished and correct, shard 1 untouched
+            for r in range(2):
+                out[r]["x"].fill_(float("nan"))
+            torch.cuda.synchronize()
+            lib.jrlqp_debug_multi_inject_failure(1)
+            try:
+                rc = lib.jrlqp_gi_solve_batch_multi(0, pb.n, pb.m, 0, total, 2, ms.ids, ms._shards(shards), ct.byref(ms.opts), 1)
+            finally:
+                lib.jrlqp_debug_multi_inject_failure(-1)
+            assert rc == -1 and lib.jrlqp_gi_multi_failed_shard() == 1
+            # NO synchronisation here: the call itself must have drained shard 0's stream
+            x0 = out[0]["x"].cpu().numpy()
+            assert np.array_equal(x0, ref["x"][: cuts[0][1]])
+            assert np.isnan(out[1]["x"].cpu().numpy()).all()
+    finally:
+        lib.jrlqp_debug_multi_allow_shared_device(0)
+    # without the switch a device listed twice is still refused
+    sh = (capi.ShardBuffers * 2)()
+    assert lib.jrlqp_gi_solve_batch_multi(0, 50, 200, 0, 8, 2, (ct.c_int * 2)(0, 0), sh, None, 1) == -1
+    assert lib.jrlqp_gi_gather_x_multi(50, 8, 2, (ct.c_int * 2)(0, 0), sh, 0, ct.c_void_p(8), 1) == -1

@@ -88,3 +88,20 @@ def test_wait_states_are_counted_along_branch_edges():
     # enough wait states in front of the branch: clean either way
     ok = listing(["v_readfirstlane_b32 s6, v3", "s_nop 4", "s_cbranch_scc1 L2"] + skipped) + "0000000000001100 <L2>:\n\tv_readlane_b32 s8, v10, s6\n\ts_endpgm\n"
     assert rules(ok) == []
+
+
+def test_r2_across_a_label_on_the_fall_through_path():
+    """A loop head or branch target between the VALU write and the v_readlane does not add a wait state on the fall-through path
+    (llvm-objdump --symbolize-operands prints every such target as a label)."""
+    r2 = listing(["v_add_f64 v[10:11], v[2:3], v[4:5]", "<L7>:", "v_readlane_b32 s8, v10, 3", "s_cbranch_scc1 L7", "s_endpgm"])
+    assert rules(r2) == ["R2"]
+    assert rules(fixed(r2).replace("; isa_lint R2", "")) == []
+    ok = listing(["v_add_f64 v[10:11], v[2:3], v[4:5]", "<L7>:", "s_nop 0", "v_readlane_b32 s8, v10, 3", "s_cbranch_scc1 L7", "s_endpgm"])
+    assert rules(ok) == []
+
+
+def test_r1_age_carried_over_two_branch_edges():
+    """write -> branch A -> label A: branch B -> label B: consumer.  The SGPR's age is imported at label A and must still be counted at B."""
+    chain = listing(["v_readfirstlane_b32 s6, v3", "s_branch L1", "s_nop 7", "<L1>:", "s_branch L2", "s_nop 7", "<L2>:", "v_readlane_b32 s8, v10, s6", "s_endpgm"])
+    assert rules(chain) == ["R1"]  # three wait states: the two branches and nothing else
+    assert rules(fixed(chain).replace("; isa_lint R1", "")) == []

@@ -78,9 +78,21 @@ LABEL = re.compile(r"^(?:<(L\d+)>|(\.L[\w$.]+)):")  # llvm-objdump --symbolize-o
 
 def lint_listing(text, min_states, name, fix_out=None):
     """fix_out: a list that receives the lines of the listing with the missing wait states inserted (then nothing is a finding)."""
-    # pass 1: the age of every pending VALU-written SGPR at each branch, per target label; pass 2: the lint proper
+    # pass 1: the age of every pending VALU-written SGPR at each branch, per target label -- repeated with the ages of the previous round
+    # imported at the labels until nothing changes, so that an age carried over one edge is carried over the next one too
+    # (write -> branch A -> label A: branch B -> label B: consumer); pass 2: the lint proper
     ages = {}
-    _lint_pass(text, min_states, name, None, ages, None, fix_out is not None)
+    for _ in range(8):
+        nxt = {}
+        _lint_pass(text, min_states, name, None, nxt, ages, fix_out is not None)
+        for key, regs in ages.items():  # ages only ever get younger: keep the youngest seen
+            tgt = nxt.setdefault(key, {})
+            for sreg, v in regs.items():
+                if sreg not in tgt or v[0] < tgt[sreg][0]:
+                    tgt[sreg] = v
+        if nxt == ages:
+            break
+        ages = nxt
     return _lint_pass(text, min_states, name, fix_out, None, ages, fix_out is not None)
 
 
@@ -119,8 +131,8 @@ def _lint_pass(text, min_states, name, fix_out, collect, label_ages, s_listing):
                 for sreg, (age, txt) in label_ages.get(key, {}).items():
                     w = clock - age
                     if sreg not in sgpr_valu_write or sgpr_valu_write[sreg][0] < w:
-                        sgpr_valu_write[sreg] = (w, txt + " (via a branch)")
-            prev_vgpr_writes = set()
+                        sgpr_valu_write[sreg] = (w, txt if txt.endswith("(via a branch)") else txt + " (via a branch)")
+            # (prev_vgpr_writes stays: the fall-through predecessor still immediately precedes the label's first instruction -- rule R2)
             continue
         m = INSN.match(line)
         if not m or line.lstrip().startswith((".", ";", "//", "#")):
