@@ -468,8 +468,8 @@ int jrlqp_blockgi_create(int kind, int nblk, const int * block_sizes, int ncb, c
  *   C9        no Q: the sparse columns B = L^-1 N of the active constraints and S = R^-1, r and y = Q2 Q2^T b from the corrected
  *             semi-normal equations -- O(q^2) per iteration, q = active constraints; workspace independent of
  *             max_iter.  Same decisions as SEQUENCE on every tested problem, x / u to 1e-9 (tests/test_oracle_blockgi_literal.py);
- *   AUTO      C9 for the arrows, SEQUENCE for the tridiagonal shape (whose columns of B are dense); what jrlqp_blockgi_create
- *             chooses.  The environment variable JRLQP_BLOCKGI_FORM=sequence|c9 overrides AUTO (diagnostic).
+ *   AUTO      C9 for the arrows of more than 1024 unknowns, SEQUENCE otherwise (the tridiagonal shape's columns of B are dense; small
+ *             problems with few iterations batch better in the sequence kernel); what jrlqp_blockgi_create chooses.  The environment variable JRLQP_BLOCKGI_FORM=sequence|c9 overrides AUTO (diagnostic).
  * jrlqp_blockgi_form says which one a plan runs (the oracle to compare with: orc_blockgi_solve / orc_blockgi_solve_c9). */
 #define JRLQP_BLOCKGI_FORM_AUTO (-1)
 #define JRLQP_BLOCKGI_FORM_SEQUENCE 0

@@ -56,6 +56,13 @@ struct BgiArgs
   double * f;
   jrlqp_trace_rec * trace;
   int trace_cap;
+  // ---- transposed copies of the factor's blocks (both forms; bgi_pack_kernel, behind the factorisation): a backward substitution and
+  // the couplings that walk a block by rows read them with consecutive addresses across the lanes
+  double * Tw;          // [nprob * tw_len]  per problem: diagT_b (bs_b x bs_b, ld bs_b) for every block, then sideT_i (cols_i x rows_i, ld cols_i)
+  const int * tw_doff;  // [nblk]    offset of diagT_b
+  const int * tw_soff;  // [nblk-1]  offset of sideT_i
+  const int * tw_sc;    // [nblk-1]  columns of side block i (= leading dimension of its transposed copy)
+  long tw_len;
   // ---- contract C9 (blockgi_c9.hip): no orthonormal sequence; workspace per problem ----
   int form;        // 0: the reference's orthonormal sequence (blockgi.hip), 1: contract C9
   int ngrp;        // groups of constraints: ncb blocks of C, then (bounds) one per Hessian block in block order
@@ -71,6 +78,7 @@ struct BgiArgs
   double * St;     // [nprob * qcap * qcap]   the same transposed: at s qcap + j
   int * sgrp;      // [nprob * qcap]  slot -> group
   int * freel;     // [nprob * qcap]  stack of free slots
+  int tune;        // diagnostic only (JRLQP_BGI_TUNE): bits that switch parts of the kernels off for timing experiments; 0 in production
   long long * prof; // diagnostic only (jrlqp_debug_set_profile): prof_stride >= 32 int64 per problem (16 used), 100 MHz ticks per phase; or nullptr
   int prof_stride;
 };
@@ -84,4 +92,6 @@ hipError_t launch_blockgi(const BgiArgs & a, int nprob, hipStream_t stream);
 // contract C9 (blockgi_c9.hip)
 long blockgi_c9_lds_bytes(int n, int m, int nb, int nblk, int ncb, int xu_global = 0);
 hipError_t launch_blockgi_c9(const BgiArgs & a, int nprob, hipStream_t stream);
+// transposed copies of the (factorised) blocks into BgiArgs::Tw: enqueue behind the factorisation, before either kernel
+hipError_t launch_blockgi_pack(const BgiArgs & a, int nprob, hipStream_t stream);
 } // namespace jrlqp

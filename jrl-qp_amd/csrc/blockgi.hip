@@ -413,15 +413,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && NCH == 1) ? 3 : (NT == 256) ? 2 :
   K.par = 0;
   {
     BlkMeta * bm = reinterpret_cast<BlkMeta *>(K.red + 32 + 32 + 8);
-    for(int b = tid; b < A.nblk; b += NT)
-    {
-      bm[b].diag = K.diag[b];
-      bm[b].side = (b < A.nblk - 1) ? K.side[b] : nullptr;
-      bm[b].bs = A.bs[b];
-      bm[b].boff = A.boff[b];
-      bm[b].ldd = A.ldd[b];
-      bm[b].lds = (b < A.nblk - 1) ? A.lds[b] : 0;
-    }
+    fill_block_table<NT>(A, pb, tid, K.diag, K.side, bm);
     K.bm = bm;
   }
   K.pool = A.pool + (size_t)pb * A.max_iter * A.row_len;

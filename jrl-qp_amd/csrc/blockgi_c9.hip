@@ -545,15 +545,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
   ip += (reinterpret_cast<size_t>(ip) & 7) ? 1 : 0; // (8-byte alignment of the block table)
   {
     BlkMeta * bm = reinterpret_cast<BlkMeta *>(ip);
-    for(int b = tid; b < A.nblk; b += NT)
-    {
-      bm[b].diag = K.diag[b];
-      bm[b].side = (b < A.nblk - 1) ? K.side[b] : nullptr;
-      bm[b].bs = A.bs[b];
-      bm[b].boff = A.boff[b];
-      bm[b].ldd = A.ldd[b];
-      bm[b].lds = (b < A.nblk - 1) ? A.lds[b] : 0;
-    }
+    fill_block_table<NT>(A, pb, tid, K.diag, K.side, bm);
     K.bm = bm;
   }
   for(int k = tid; k < nblk; k += NT)
@@ -781,7 +773,8 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
         stamp(4);
       }
       double nrm2 = 0.0;
-      if(q != n) nrm2 = blk_reduce<NT, BIG>(K, Q, true, [&](int e) { return z[e]; }, [&](int e) { return z[e]; });
+      if(q != n && !(A.tune & 2)) nrm2 = blk_reduce<NT, BIG>(K, Q, true, [&](int e) { return z[e]; }, [&](int e) { return z[e]; });
+      if(A.tune & 2) nrm2 = 1.0;
       // z = L^-T y  (StructuredJ.cpp:32-41)
       sg_ltsolve<NT, BIG>(K, z);
       stamp(5);
@@ -1077,6 +1070,37 @@ done:
   }
 }
 
+// transposed copies of one problem's blocks (BgiArgs::Tw): workgroup = (problem, block); reads walk the source's columns
+__global__ __launch_bounds__(256) void bgi_pack_kernel(const BgiArgs A)
+{
+  const int per = 2 * A.nblk - 1, pb = blockIdx.x / per, t = blockIdx.x % per;
+  const double * src;
+  int ld, rows, cols;
+  double * dst = A.Tw + (size_t)pb * A.tw_len;
+  if(t < A.nblk)
+  {
+    src = A.diag[(size_t)pb * A.nblk + t];
+    ld = A.ldd[t];
+    rows = cols = A.bs[t];
+    dst += A.tw_doff[t];
+  }
+  else
+  {
+    const int i = t - A.nblk;
+    src = A.side[(size_t)pb * (A.nblk - 1) + i];
+    ld = A.lds[i];
+    cols = A.tw_sc[i];
+    // rows of side block i: arrow down: the head's; arrow up / tridiagonal: block i + 1's
+    rows = (A.kind == 0) ? A.bs[A.nblk - 1] : A.bs[i + 1];
+    dst += A.tw_soff[i];
+  }
+  for(int e = threadIdx.x; e < rows * cols; e += 256)
+  {
+    const int r = e % rows, c = e / rows;
+    dst[c + (size_t)r * cols] = src[r + (size_t)c * ld];
+  }
+}
+
 template<int NT, bool BIG>
 hipError_t launch_c9_b(const BgiArgs & a, int nprob, size_t lds, hipStream_t st)
 {
@@ -1104,6 +1128,12 @@ long blockgi_c9_lds_bytes(int n, int m, int nb, int nblk, int ncb, int xu_global
   const long dbl = (xu_global ? 2L * n_pad + 3L * qcap : 3L * n_pad + 4L * qcap) + P2 + 8 * 128 + 2L * nblk + 32 + 32 + 8;
   const long ints = 3L * qcap + 2L * ngrp + (m + nb + 1) + 3L * nblk + (n + 2) / 2 + 2;
   return (long)sizeof(double) * dbl + 4 * ints + (long)sizeof(BlkMeta) * nblk + 8;
+}
+
+hipError_t launch_blockgi_pack(const BgiArgs & a, int nprob, hipStream_t st)
+{
+  hipLaunchKernelGGL(bgi_pack_kernel, dim3(nprob * (2 * a.nblk - 1)), dim3(256), 0, st, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_blockgi_c9(const BgiArgs & a, int nprob, hipStream_t st)

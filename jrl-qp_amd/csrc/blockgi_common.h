@@ -14,7 +14,225 @@ struct BlkMeta
   double * diag; // diagonal block b
   double * side; // side / sub-diagonal block b (b < nblk - 1)
   int bs, boff, ldd, lds;
+  const double * diagT; // transposed copy of diag (ld bs): element (i, j) holds L(j, i)
+  const double * sideT; // transposed copy of side (ld sct = columns of side): element (c, r) holds side(r, c)
+  int sct, pad;
 };
+
+// fills the block table of one problem (LDS) -- shared by both kernels
+template<int NT>
+__device__ __forceinline__ void fill_block_table(const BgiArgs & A, int pb, int tid, double * const * diag, double * const * side, BlkMeta * bm)
+{
+  const double * tw = A.Tw + (size_t)pb * A.tw_len;
+  for(int b = tid; b < A.nblk; b += NT)
+  {
+    bm[b].diag = diag[b];
+    bm[b].side = (b < A.nblk - 1) ? side[b] : nullptr;
+    bm[b].bs = A.bs[b];
+    bm[b].boff = A.boff[b];
+    bm[b].ldd = A.ldd[b];
+    bm[b].lds = (b < A.nblk - 1) ? A.lds[b] : 0;
+    bm[b].diagT = tw + A.tw_doff[b];
+    bm[b].sideT = (b < A.nblk - 1) ? tw + A.tw_soff[b] : nullptr;
+    bm[b].sct = (b < A.nblk - 1) ? A.tw_sc[b] : 0;
+    bm[b].pad = 0;
+  }
+}
+
+// wave_bwd (device_common.h) on the TRANSPOSED copy of the block: Lt(i, j) = L(j, i), so lane rl's operands L(k, rl) are Lt(rl, k) --
+// consecutive addresses across the lanes (the original walks a column per lane: one cache line per lane and request).  Same steps.
+__device__ __forceinline__ double wave_bwd_t(const double * Lt, int ldl, int n, double xi, int lane)
+{
+  n = __builtin_amdgcn_readfirstlane(n);
+  const bool act = lane < n;
+  const int rl = act ? lane : 0;
+  const double dg = (n > 0) ? AT(Lt, ldl, rl, rl) : 1.0;
+  const double rinv = recip_refined(dg);
+  const double x0 = xi;
+  double lv[kAhead], ln[kAhead];
+#pragma unroll
+  for(int j = 0; j < kAhead; ++j) ln[j] = (n > 0) ? AT(Lt, ldl, rl, max(n - 1 - j, 0)) : 0.0;
+  for(int k0 = n - 1; k0 >= 0; k0 -= kAhead)
+  {
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j) lv[j] = ln[j];
+    if(k0 - kAhead >= 0)
+    {
+#pragma unroll
+      for(int j = 0; j < kAhead; ++j) ln[j] = AT(Lt, ldl, rl, max(k0 - kAhead - j, 0));
+    }
+#pragma unroll
+    for(int j = 0; j < kAhead; ++j)
+    {
+      const int k = k0 - j;
+      const double v = bcast_lane_s(div_pre(xi, dg, rinv), max(k, 0));
+      const double upd = FMA(-lv[j], v, xi);
+      xi = (lane < k) ? upd : xi;
+    }
+  }
+  const double pre = xi;
+  xi = div_pre(pre, dg, rinv);
+  if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
+  {
+    xi = x0;
+    for(int k = n - 1; k >= 0; --k)
+    {
+      const double v = bcast_lane(xi, k) / bcast_lane(dg, k);
+      if(lane == k)
+        xi = v;
+      else if(lane < k)
+        xi = FMA(-AT(Lt, ldl, rl, k), v, xi);
+    }
+  }
+  return act ? xi : x0;
+}
+
+// One off-head block of an arrow's L^-T pass when the block and the head have at most 32 rows: acc_i = v_i - sum_k S(k, i) zh_k
+// (k descending), then the backward substitution with the block (wave_bwd_t's steps) -- with the operands of BOTH requested up front:
+// the coupling's 32 and the first 16 of the substitution go out together, the last 16 as soon as the coupling's registers are free, so
+// a block costs about one memory round trip instead of four.  Sc(i, k) / Lt(i, k): transposed copies (consecutive lanes, consecutive
+// addresses).  Same operations in the same order as chain_neg8 + wave_bwd_t: same bits.
+__device__ __forceinline__ double arrow_block_bwd32(const double * Sc, int lds_, int nbk, const double * Lt, int ldl, int ni, const double * zh,
+                                                    double acc, int lane)
+{
+  ni = __builtin_amdgcn_readfirstlane(ni);
+  nbk = __builtin_amdgcn_readfirstlane(nbk);
+  const bool act = lane < ni;
+  const int rl = act ? lane : 0;
+  double s0[16], s1[16], l0[16], l1[16];
+#pragma unroll
+  for(int j = 0; j < 16; ++j) s0[j] = AT(Sc, lds_, rl, max(nbk - 1 - j, 0));
+#pragma unroll
+  for(int j = 0; j < 16; ++j) s1[j] = AT(Sc, lds_, rl, max(nbk - 17 - j, 0));
+  const double dg = AT(Lt, ldl, rl, rl);
+#pragma unroll
+  for(int j = 0; j < 16; ++j) l0[j] = AT(Lt, ldl, rl, max(ni - 1 - j, 0));
+#pragma unroll
+  for(int j = 0; j < 16; ++j)
+  {
+    const int k = nbk - 1 - j;
+    const double t = FMA(-s0[j], zh[max(k, 0)], acc);
+    acc = (k >= 0) ? t : acc;
+  }
+#pragma unroll
+  for(int j = 0; j < 16; ++j)
+  {
+    const int k = nbk - 17 - j;
+    const double t = FMA(-s1[j], zh[max(k, 0)], acc);
+    acc = (k >= 0) ? t : acc;
+  }
+#pragma unroll
+  for(int j = 0; j < 16; ++j) l1[j] = AT(Lt, ldl, rl, max(ni - 17 - j, 0));
+  const double rinv = recip_refined(dg);
+  const double x0 = acc;
+  double xi = acc;
+#pragma unroll
+  for(int j = 0; j < 16; ++j)
+  {
+    const int k = ni - 1 - j; // (a step with k < 0 matches no lane)
+    const double v = bcast_lane_s(div_pre(xi, dg, rinv), max(k, 0));
+    const double upd = FMA(-l0[j], v, xi);
+    xi = (lane < k) ? upd : xi;
+  }
+#pragma unroll
+  for(int j = 0; j < 16; ++j)
+  {
+    const int k = ni - 17 - j;
+    const double v = bcast_lane_s(div_pre(xi, dg, rinv), max(k, 0));
+    const double upd = FMA(-l1[j], v, xi);
+    xi = (lane < k) ? upd : xi;
+  }
+  const double pre = xi;
+  xi = div_pre(pre, dg, rinv);
+  if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
+  {
+    xi = x0;
+    for(int k = ni - 1; k >= 0; --k)
+    {
+      const double v = bcast_lane(xi, k) / bcast_lane(dg, k);
+      if(lane == k)
+        xi = v;
+      else if(lane < k)
+        xi = FMA(-AT(Lt, ldl, rl, k), v, xi);
+    }
+  }
+  return act ? xi : x0;
+}
+
+// arrow_block_bwd32 on TWO blocks at once: lanes 0 .. 31 work on block A, lanes 32 .. 63 on block B (niB = 0: no second block).  Half as
+// many rounds per L^-T pass, and every request covers two blocks; a step's pivot comes from one v_readlane per half.  Per lane the
+// operations are arrow_block_bwd32's: same bits.
+__device__ __forceinline__ double arrow_block_bwd32x2(const double * ScA, int ldsA, const double * LtA, int niA, const double * ScB, int ldsB,
+                                                      const double * LtB, int niB, int nbk, const double * zh, double acc, int lane)
+{
+  niA = __builtin_amdgcn_readfirstlane(niA);
+  niB = __builtin_amdgcn_readfirstlane(niB);
+  nbk = __builtin_amdgcn_readfirstlane(nbk);
+  const bool hb = lane >= 32;
+  const int l5 = lane & 31;
+  const int ni = hb ? niB : niA;
+  const bool act = l5 < ni;
+  const int rl = act ? l5 : 0;
+  const double * Sc = (hb && niB > 0) ? ScB : ScA;
+  const double * Lt = (hb && niB > 0) ? LtB : LtA;
+  const int lds_ = (hb && niB > 0) ? ldsB : ldsA, ldl = (hb && niB > 0) ? niB : niA, nl = (hb && niB > 0) ? niB : niA;
+  double s0[16], s1[16], l0[16], l1[16];
+#pragma unroll
+  for(int j = 0; j < 16; ++j) s0[j] = AT(Sc, lds_, rl, max(nbk - 1 - j, 0));
+#pragma unroll
+  for(int j = 0; j < 16; ++j) s1[j] = AT(Sc, lds_, rl, max(nbk - 17 - j, 0));
+  const double dg = AT(Lt, ldl, rl, rl);
+#pragma unroll
+  for(int j = 0; j < 16; ++j) l0[j] = AT(Lt, ldl, rl, max(nl - 1 - j, 0));
+#pragma unroll
+  for(int j = 0; j < 16; ++j)
+  {
+    const int k = nbk - 1 - j;
+    const double t = FMA(-s0[j], zh[max(k, 0)], acc);
+    acc = (k >= 0) ? t : acc;
+  }
+#pragma unroll
+  for(int j = 0; j < 16; ++j)
+  {
+    const int k = nbk - 17 - j;
+    const double t = FMA(-s1[j], zh[max(k, 0)], acc);
+    acc = (k >= 0) ? t : acc;
+  }
+#pragma unroll
+  for(int j = 0; j < 16; ++j) l1[j] = AT(Lt, ldl, rl, max(nl - 17 - j, 0));
+  const double rinv = recip_refined(dg);
+  const double x0 = acc;
+  double xi = acc;
+#pragma unroll
+  for(int j = 0; j < 32; ++j)
+  {
+    const int kA = niA - 1 - j, kB = niB - 1 - j; // (a step with k < 0 matches no lane)
+    const double qv = div_pre(xi, dg, rinv);
+    const double vA = bcast_lane_s(qv, max(kA, 0)), vB = bcast_lane_s(qv, 32 + max(kB, 0));
+    const double v = hb ? vB : vA;
+    const double upd = FMA(-(j < 16 ? l0[j & 15] : l1[j & 15]), v, xi);
+    xi = (l5 < (hb ? kB : kA)) ? upd : xi;
+  }
+  const double pre = xi;
+  xi = div_pre(pre, dg, rinv);
+  if(!__all(!act || (div_safe_den(dg) && div_safe_num(pre))))
+  {
+    xi = x0;
+    for(int k = 31; k >= 0; --k)
+    {
+      const double vA = bcast_lane(xi, k) / bcast_lane(dg, k), vB = bcast_lane(xi, 32 + k) / bcast_lane(dg, 32 + k);
+      const double v = hb ? vB : vA;
+      if(k < ni)
+      {
+        if(l5 == k)
+          xi = v;
+        else if(l5 < k)
+          xi = FMA(-AT(Lt, ldl, rl, k), v, xi);
+      }
+    }
+  }
+  return act ? xi : x0;
+}
 
 struct Ctx
 {
@@ -146,8 +364,10 @@ __device__ __forceinline__ void arrow_lsolve(Ctx & K, double * v, int start, int
       {
         const double * Sg = K.bm[i].side;
         const int ldsg = K.bm[i].lds;
+        const double * SgT = K.bm[i].sideT;
+        const int sct = K.bm[i].sct;
         const double * Xi = v + K.bm[id].boff;
-        acc = chain_neg8(s, 1, ni - s, acc, [&](int k) { return up ? AT(Sg, ldsg, k, lane) : AT(Sg, ldsg, lane, k); },
+        acc = chain_neg8(s, 1, ni - s, acc, [&](int k) { return up ? AT(SgT, sct, lane, k) : AT(Sg, ldsg, lane, k); },
                          [&](int k) { return Xi[k]; });
       }
     }
@@ -172,23 +392,54 @@ __device__ __forceinline__ void arrow_ltsolve(Ctx & K, double * v)
   if(K.wave == 0)
   {
     double xi = (lane < nbk) ? vb[lane] : 0.0;
-    xi = wave_bwd(K.bm[ib].diag, K.bm[ib].ldd, nbk, xi, lane);
+    xi = wave_bwd_t(K.bm[ib].diagT, nbk, nbk, xi, lane);
     if(lane < nbk) vb[lane] = xi;
   }
   __syncthreads();
+  if(A.maxb <= 32 && !(A.tune & 4))
+  {
+    // every block has at most 32 rows: two blocks per wave and round (arrow_block_bwd32x2)
+    const int hb = lane >> 5, l5 = lane & 31;
+    for(int p = K.wave; 2 * p < nblk - 1; p += NW)
+    {
+      const int iA = 2 * p, iB = min(2 * p + 1, nblk - 2);
+      const bool hasB = 2 * p + 1 < nblk - 1;
+      const int idA = dsel(nblk, up, iA), idB = dsel(nblk, up, iB);
+      const int niA = K.bm[idA].bs, niB = hasB ? K.bm[idB].bs : 0;
+      const int i = hb ? iB : iA, id = hb ? idB : idA, ni = hb ? niB : niA;
+      double * vi = v + K.bm[id].boff;
+      const double acc = (l5 < ni) ? vi[l5] : 0.0;
+      const double solved = (A.tune & 1) ? acc
+                                         : arrow_block_bwd32x2(up ? K.bm[iA].side : K.bm[iA].sideT, up ? K.bm[iA].lds : K.bm[iA].sct, K.bm[idA].diagT, niA,
+                                                               up ? K.bm[iB].side : K.bm[iB].sideT, up ? K.bm[iB].lds : K.bm[iB].sct, K.bm[idB].diagT, niB,
+                                                               nbk, vb, acc, lane);
+      (void)i;
+      if(l5 < ni) vi[l5] = solved;
+    }
+    __syncthreads();
+    return;
+  }
   for(int i = K.wave; i < nblk - 1; i += NW)
   {
     const int id = dsel(nblk, up, i), ni = K.bm[id].bs;
     const double * Sg = K.bm[i].side;
     const int ldsg = K.bm[i].lds;
+    const double * SgT = K.bm[i].sideT;
+    const int sct = K.bm[i].sct;
     double * vi = v + K.bm[id].boff;
     double acc = (lane < ni) ? vi[lane] : 0.0;
+    double solved;
+    if(A.tune & 1)
+      solved = acc; // (timing experiment: no coupling, no substitution)
+    else if(ni <= 32 && nbk <= 32)
+      solved = arrow_block_bwd32(up ? Sg : SgT, up ? ldsg : sct, nbk, K.bm[id].diagT, ni, ni, vb, acc, lane);
+    else
     {
       const int rl = (lane < ni) ? lane : 0; // idle lanes run the same (discarded) chain: no divergent loads
-      acc = chain_neg8(nbk - 1, -1, nbk, acc, [&](int k) { return up ? AT(Sg, ldsg, rl, k) : AT(Sg, ldsg, k, rl); },
+      acc = chain_neg8(nbk - 1, -1, nbk, acc, [&](int k) { return up ? AT(Sg, ldsg, rl, k) : AT(SgT, sct, rl, k); },
                        [&](int k) { return vb[k]; });
+      solved = wave_bwd_t(K.bm[id].diagT, ni, ni, acc, lane);
     }
-    const double solved = wave_bwd(K.bm[id].diag, K.bm[id].ldd, ni, acc, lane);
     if(lane < ni) vi[lane] = solved;
   }
   __syncthreads();
@@ -252,25 +503,25 @@ __device__ __forceinline__ void tri_ltsolve(Ctx & K, double * v)
     for(int i = A.nblk - 1; i >= 0; --i)
     {
       const int ni = K.bm[i].bs;
-      const double * Li = K.bm[i].diag;
-      const int ldd = K.bm[i].ldd;
+      const double * Li = K.bm[i].diagT; // (the transposed copy: wave_bwd_t)
+      const int ldd = ni;
       if(zero)
       {
         double xi = (lane < ni) ? v[n - ni + lane] : 0.0;
-        xi = wave_bwd(Li, ldd, ni, xi, lane);
+        xi = wave_bwd_t(Li, ldd, ni, xi, lane);
         if(lane < ni) v[n - ni + lane] = xi;
         zero = false;
       }
       else
       {
-        const double * Sg = K.bm[i].side;
-        const int ldsg = K.bm[i].lds;
+        const double * Sg = K.bm[i].sideT;
+        const int ldsg = K.bm[i].sct;
         double acc = (lane < ni) ? v[n - ni + lane] : 0.0;
         {
           const int rl = (lane < ni) ? lane : 0;
-          acc = chain_neg8(li - 1, -1, li, acc, [&](int k) { return AT(Sg, ldsg, k, rl); }, [&](int k) { return v[(l - li) + k]; });
+          acc = chain_neg8(li - 1, -1, li, acc, [&](int k) { return AT(Sg, ldsg, rl, k); }, [&](int k) { return v[(l - li) + k]; });
         }
-        acc = wave_bwd(Li, ldd, ni, acc, lane);
+        acc = wave_bwd_t(Li, ldd, ni, acc, lane);
         if(lane < ni) v[n - ni + lane] = acc;
       }
       wave_sync();

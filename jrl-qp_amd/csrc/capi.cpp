@@ -112,6 +112,10 @@ struct jrlqp_blockgi
   int *d_greach = nullptr, *d_tk = nullptr, *d_kap_prow = nullptr, *d_kap_row = nullptr, *d_off_perm = nullptr, *d_kap_phys = nullptr, *d_goff = nullptr;
   double *d_Bc = nullptr, *d_Sm = nullptr, *d_St = nullptr;
   int *d_sgrp = nullptr, *d_freel = nullptr;
+  // transposed copies of the factor's blocks (both forms)
+  double * d_Tw = nullptr;
+  int *d_tw_doff = nullptr, *d_tw_soff = nullptr, *d_tw_sc = nullptr;
+  long tw_len = 0;
 };
 
 #define HIP_TRY(x)                      \
@@ -743,7 +747,7 @@ int jrlqp_blockgi_create_form(int kind, int nblk, const int * block_sizes, int n
   const bool c9_fits = jrlqp::blockgi_c9_lds_bytes(n, m, nb, nblk, ncb) <= jrlqp::kLdsPerCU && nblk < 65535;
   if(form == JRLQP_BLOCKGI_FORM_AUTO)
   {
-    form = (kind != 2 && c9_fits) ? JRLQP_BLOCKGI_FORM_C9 : JRLQP_BLOCKGI_FORM_SEQUENCE;
+    form = (kind != 2 && n > 1024 && c9_fits) ? JRLQP_BLOCKGI_FORM_C9 : JRLQP_BLOCKGI_FORM_SEQUENCE;
     if(const char * e = std::getenv("JRLQP_BLOCKGI_FORM"))
       form = (e[0] == 'c' && c9_fits) ? JRLQP_BLOCKGI_FORM_C9 : (e[0] == 's') ? JRLQP_BLOCKGI_FORM_SEQUENCE : form;
   }
@@ -818,6 +822,39 @@ int jrlqp_blockgi_create_form(int kind, int nblk, const int * block_sizes, int n
     return hip_fail(e);
   }
   h->ws_bytes = pool_b + r_b + desc_b + sizeof(int) * (size_t)nprob * h->qcap;
+  {
+    // transposed copies of the blocks: diagT_b for every block, sideT_i for every side / sub-diagonal block
+    std::vector<int> doff(nblk), soff(nblk > 1 ? nblk - 1 : 1), sc(nblk > 1 ? nblk - 1 : 1);
+    long o = 0;
+    for(int b = 0; b < nblk; ++b)
+    {
+      doff[b] = (int)o;
+      o += (long)block_sizes[b] * block_sizes[b];
+    }
+    for(int i = 0; i + 1 < nblk; ++i)
+    {
+      // side block i: arrow down: G[head, block i] (head x bs_i); arrow up: G[block i+1, head] (bs_{i+1} x bs_0); tri: G[i+1, i]
+      const int rows = (kind == 0) ? block_sizes[nblk - 1] : block_sizes[i + 1];
+      const int cols = (kind == 0) ? block_sizes[i] : (kind == 1) ? block_sizes[0] : block_sizes[i];
+      soff[i] = (int)o;
+      sc[i] = cols;
+      o += (long)rows * cols;
+    }
+    h->tw_len = (o + 3) & ~3L;
+    e = hipMalloc(&h->d_Tw, sizeof(double) * (size_t)nprob * h->tw_len);
+    if(e == hipSuccess) e = hipMalloc(&h->d_tw_doff, sizeof(int) * nblk);
+    if(e == hipSuccess) e = hipMalloc(&h->d_tw_soff, sizeof(int) * soff.size());
+    if(e == hipSuccess) e = hipMalloc(&h->d_tw_sc, sizeof(int) * sc.size());
+    if(e == hipSuccess) e = hipMemcpy(h->d_tw_doff, doff.data(), sizeof(int) * nblk, hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_tw_soff, soff.data(), sizeof(int) * soff.size(), hipMemcpyHostToDevice);
+    if(e == hipSuccess) e = hipMemcpy(h->d_tw_sc, sc.data(), sizeof(int) * sc.size(), hipMemcpyHostToDevice);
+    if(e != hipSuccess)
+    {
+      jrlqp_blockgi_destroy(h);
+      return hip_fail(e);
+    }
+    h->ws_bytes += sizeof(double) * (size_t)nprob * h->tw_len;
+  }
   if(c9)
   {
     // static structure of contract C9: block order (off-head blocks in logical order, head last; natural for the tridiagonal shape),
@@ -929,6 +966,7 @@ void jrlqp_blockgi_destroy(jrlqp_blockgi * h)
   (void)hipFree(h->d_greach); (void)hipFree(h->d_tk); (void)hipFree(h->d_kap_prow); (void)hipFree(h->d_kap_row); (void)hipFree(h->d_off_perm);
   (void)hipFree(h->d_kap_phys); (void)hipFree(h->d_goff); (void)hipFree(h->d_Bc); (void)hipFree(h->d_Sm); (void)hipFree(h->d_St);
   (void)hipFree(h->d_sgrp); (void)hipFree(h->d_freel);
+  (void)hipFree(h->d_Tw); (void)hipFree(h->d_tw_doff); (void)hipFree(h->d_tw_soff); (void)hipFree(h->d_tw_sc);
   h->stage.release();
   delete h;
 }
@@ -995,6 +1033,8 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.xu_ws = h->d_xu; a.xu_global = h->xu_global;
   a.x = dx; a.u = du; a.status = dstatus; a.term = dterm; a.iters = diters; a.f = df;
   a.trace = dtrace; a.trace_cap = dtrace ? trace_cap : 0;
+  a.tune = 0;
+  if(const char * e = std::getenv("JRLQP_BGI_TUNE")) a.tune = std::atoi(e);
   a.prof = g_prof[JRLQP_PROFILE_BLOCKGI].p;
   a.prof_stride = g_prof[JRLQP_PROFILE_BLOCKGI].stride;
   if(a.prof && h->nprob > g_prof[JRLQP_PROFILE_BLOCKGI].nprob) return JRLQP_ERR_INVALID_ARGUMENT;
@@ -1002,7 +1042,10 @@ int jrlqp_blockgi_solve(jrlqp_blockgi * h, const double * da, const double * dbl
   a.greach = h->d_greach; a.tk = h->d_tk; a.kap_prow = h->d_kap_prow; a.kap_row = h->d_kap_row; a.off_perm = h->d_off_perm;
   a.kap_phys = h->d_kap_phys; a.goff = h->d_goff;
   a.Bc = h->d_Bc; a.Sm = h->d_Sm; a.St = h->d_St; a.sgrp = h->d_sgrp; a.freel = h->d_freel;
-  hipError_t e = (h->form == JRLQP_BLOCKGI_FORM_C9) ? jrlqp::launch_blockgi_c9(a, h->nprob, static_cast<hipStream_t>(stream))
+  a.Tw = h->d_Tw; a.tw_doff = h->d_tw_doff; a.tw_soff = h->d_tw_soff; a.tw_sc = h->d_tw_sc; a.tw_len = h->tw_len;
+  hipError_t e = jrlqp::launch_blockgi_pack(a, h->nprob, static_cast<hipStream_t>(stream));
+  if(e != hipSuccess) return hip_fail(e);
+  e = (h->form == JRLQP_BLOCKGI_FORM_C9) ? jrlqp::launch_blockgi_c9(a, h->nprob, static_cast<hipStream_t>(stream))
                                                     : jrlqp::launch_blockgi(a, h->nprob, static_cast<hipStream_t>(stream));
   return e == hipSuccess ? JRLQP_OK : hip_fail(e);
 }
