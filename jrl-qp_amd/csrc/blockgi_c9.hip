@@ -38,7 +38,7 @@ struct C9
   int ldq;       // leading dimension of Sm / St (= qcap)
   double *ga, *gb; // two q-vectors (LDS)
   int * slot;      // position -> slot (LDS)
-  int * roff;      // position -> slot * ldq: the row's offset in St (LDS)
+  int * roff;      // position -> 8 * slot * ldq: the row's BYTE offset in St (LDS; read as unsigned)
   unsigned * smeta; // slot -> first | (last + 1) << 16 off-head block of the column's reach (LDS)
   int *glist, *gcount, *goff; // per-group lists of active slots in active-set order (LDS)
   unsigned short * kapr;      // permuted row -> block-order index (LDS)
@@ -184,39 +184,95 @@ template<int NT>
 __device__ __forceinline__ void c9_st_g(Ctx & K, C9 & Q, int q, const double * g, double * d1)
 {
   const int lane = K.lane;
+  const char * sbase = reinterpret_cast<const char *>(Q.St);
+  // row offsets in BYTES by position (uniform base + 32-bit offset: one add per term); the array is zero beyond position q - 1 (row 0
+  // of St: always there), so a request that runs past the last row needs no clamp and the offsets are read four at a time
+  const uint4 * roff4 = reinterpret_cast<const uint4 *>(Q.roff);
+  auto ld = [&](unsigned off) { return *reinterpret_cast<const double *>(sbase + off); };
+  auto request = [&](int i0, unsigned lo, double(&a)[kPf]) { // rows i0 .. i0 + kPf - 1 (i0 a multiple of 4)
+    uint4 o[kPf / 4];
+#pragma unroll
+    for(int v = 0; v < kPf / 4; ++v) o[v] = roff4[i0 / 4 + v];
+#pragma unroll
+    for(int v = 0; v < kPf / 4; ++v)
+    {
+      a[4 * v + 0] = ld(o[v].x + lo);
+      a[4 * v + 1] = ld(o[v].y + lo);
+      a[4 * v + 2] = ld(o[v].z + lo);
+      a[4 * v + 3] = ld(o[v].w + lo);
+    }
+  };
+  auto operands = [&](int i0, double(&gv)[kPf]) { // g[i0 .. i0 + kPf - 1] (i0 even: two per LDS read)
+    const double2 * g2 = reinterpret_cast<const double2 *>(g + i0);
+#pragma unroll
+    for(int v = 0; v < kPf / 2; ++v)
+    {
+      const double2 t = g2[v];
+      gv[2 * v] = t.x;
+      gv[2 * v + 1] = t.y;
+    }
+  };
+  // A wave keeps 4 kPf = 64 loads in flight: all of a group of 64 rows are requested, then consumed in order (the wait counts of
+  // straight-line code are exact; a load carried over the loop's back edge makes hipcc wait for EVERYTHING in flight at its first use).
   for(int c0 = 64 * K.wave; c0 < q; c0 += NT)
   {
-    const int j = c0 + lane, jc = min(j, q - 1), imax = min(q - 1, c0 + 63);
-    const double * base = Q.St + jc;
+    const int j = c0 + lane, jc = min(j, q - 1);
+    const unsigned lo = 8u * (unsigned)jc;
     double acc = 0.0;
-    double a0[kPf], a1[kPf];
-    // rows 0 .. c0-1 (c0 is a multiple of 64): no clamp, no select
-    if(c0 > 0)
+    double a0[kPf], a1[kPf], a2[kPf], a3[kPf], gv[kPf];
+    // rows 0 .. c0-1 (c0 is a multiple of 64): no select
+    for(int i0 = 0; i0 < c0; i0 += 4 * kPf)
     {
+      request(i0, lo, a0);
+      request(i0 + kPf, lo, a1);
+      request(i0 + 2 * kPf, lo, a2);
+      request(i0 + 3 * kPf, lo, a3);
+      operands(i0, gv);
 #pragma unroll
-      for(int u = 0; u < kPf; ++u) a0[u] = base[Q.roff[u]];
-      for(int i0 = 0; i0 < c0; i0 += 2 * kPf)
-      {
+      for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], gv[u], acc);
+      operands(i0 + kPf, gv);
 #pragma unroll
-        for(int u = 0; u < kPf; ++u) a1[u] = base[Q.roff[i0 + kPf + u]];
+      for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], gv[u], acc);
+      operands(i0 + 2 * kPf, gv);
 #pragma unroll
-        for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], g[i0 + u], acc);
+      for(int u = 0; u < kPf; ++u) acc = FMA(a2[u], gv[u], acc);
+      operands(i0 + 3 * kPf, gv);
 #pragma unroll
-        for(int u = 0; u < kPf; ++u) a0[u] = base[Q.roff[min(i0 + 2 * kPf + u, c0 - 1)]];
-#pragma unroll
-        for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], g[i0 + kPf + u], acc);
-      }
+      for(int u = 0; u < kPf; ++u) acc = FMA(a3[u], gv[u], acc);
     }
-    // the diagonal block: rows c0 .. imax, lane j takes rows <= j
-    for(int i0 = c0; i0 <= imax; i0 += kPf)
+    // the diagonal block: rows c0 .. c0 + 63, lane j takes rows <= j (rows beyond q - 1 read row 0 and are dropped by the select)
     {
-#pragma unroll
-      for(int u = 0; u < kPf; ++u) a0[u] = base[Q.roff[min(i0 + u, imax)]];
+      request(c0, lo, a0);
+      request(c0 + kPf, lo, a1);
+      request(c0 + 2 * kPf, lo, a2);
+      request(c0 + 3 * kPf, lo, a3);
+      operands(c0, gv);
 #pragma unroll
       for(int u = 0; u < kPf; ++u)
       {
-        const double t = FMA(a0[u], g[min(i0 + u, imax)], acc);
-        acc = (i0 + u <= jc) ? t : acc;
+        const double t = FMA(a0[u], gv[u], acc);
+        acc = (c0 + u <= jc) ? t : acc;
+      }
+      operands(c0 + kPf, gv);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u)
+      {
+        const double t = FMA(a1[u], gv[u], acc);
+        acc = (c0 + kPf + u <= jc) ? t : acc;
+      }
+      operands(c0 + 2 * kPf, gv);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u)
+      {
+        const double t = FMA(a2[u], gv[u], acc);
+        acc = (c0 + 2 * kPf + u <= jc) ? t : acc;
+      }
+      operands(c0 + 3 * kPf, gv);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u)
+      {
+        const double t = FMA(a3[u], gv[u], acc);
+        acc = (c0 + 3 * kPf + u <= jc) ? t : acc;
       }
     }
     if(j < q) d1[j] = acc;
@@ -228,42 +284,56 @@ __device__ __forceinline__ void c9_st_g(Ctx & K, C9 & Q, int q, const double * g
 template<int NT>
 __device__ __forceinline__ void c9_s_d(Ctx & K, C9 & Q, int q, const double * d1, double * dl)
 {
-  const int lane = K.lane, ldq = Q.ldq;
+  const int lane = K.lane;
+  const size_t cstride = (size_t)Q.ldq * 8; // bytes per column
   for(int r0 = 64 * K.wave; r0 < q; r0 += NT)
   {
     const int i = r0 + lane, ic = min(i, q - 1);
-    const double * base = Q.Sm + Q.slot[ic];
+    const unsigned ro = 8u * (unsigned)Q.slot[ic]; // the lane's row: a 32-bit offset against the (uniform) column base
+    const char * sbase = reinterpret_cast<const char *>(Q.Sm);
+    auto ld = [&](int j) { return *reinterpret_cast<const double *>(sbase + (size_t)j * cstride + ro); };
     double acc = 0.0;
-    double a0[kPf], a1[kPf];
-    // columns q-1 .. down to the last whole group of 2 kPf above the chunk's diagonal block: every lane takes every term
-    const int nfull = max(q - (r0 + 64), 0) / (2 * kPf) * (2 * kPf);
+    double a0[kPf], a1[kPf], a2[kPf], a3[kPf];
+    // columns q-1 .. down to the last whole group of 64 above the chunk's diagonal block: every lane takes every term
+    const int nfull = max(q - (r0 + 64), 0) / (4 * kPf) * (4 * kPf);
     int j0 = q - 1;
-    if(nfull > 0)
+    for(int done = 0; done < nfull; done += 4 * kPf, j0 -= 4 * kPf)
     {
 #pragma unroll
-      for(int u = 0; u < kPf; ++u) a0[u] = base[(size_t)(j0 - u) * ldq];
-      for(int done = 0; done < nfull; done += 2 * kPf, j0 -= 2 * kPf)
-      {
+      for(int u = 0; u < kPf; ++u) a0[u] = ld(j0 - u);
 #pragma unroll
-        for(int u = 0; u < kPf; ++u) a1[u] = base[(size_t)(j0 - kPf - u) * ldq];
+      for(int u = 0; u < kPf; ++u) a1[u] = ld(j0 - kPf - u);
 #pragma unroll
-        for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], d1[j0 - u], acc);
+      for(int u = 0; u < kPf; ++u) a2[u] = ld(j0 - 2 * kPf - u);
 #pragma unroll
-        for(int u = 0; u < kPf; ++u) a0[u] = base[(size_t)max(j0 - 2 * kPf - u, r0) * ldq];
+      for(int u = 0; u < kPf; ++u) a3[u] = ld(j0 - 3 * kPf - u);
 #pragma unroll
-        for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], d1[j0 - kPf - u], acc);
-      }
+      for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], d1[j0 - u], acc);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], d1[j0 - kPf - u], acc);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) acc = FMA(a2[u], d1[j0 - 2 * kPf - u], acc);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) acc = FMA(a3[u], d1[j0 - 3 * kPf - u], acc);
     }
-    // the rest, down to the chunk's first row: lane i takes columns >= i
-    for(; j0 >= r0; j0 -= kPf)
+    // the rest, down to the chunk's first row (fewer than 128 columns): lane i takes columns >= i
+    for(; j0 >= r0; j0 -= 2 * kPf)
     {
 #pragma unroll
-      for(int u = 0; u < kPf; ++u) a0[u] = base[(size_t)max(j0 - u, r0) * ldq];
+      for(int u = 0; u < kPf; ++u) a0[u] = ld(max(j0 - u, r0));
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) a1[u] = ld(max(j0 - kPf - u, r0));
 #pragma unroll
       for(int u = 0; u < kPf; ++u)
       {
         const double t = FMA(a0[u], d1[max(j0 - u, r0)], acc);
         acc = (j0 - u >= ic) ? t : acc;
+      }
+#pragma unroll
+      for(int u = 0; u < kPf; ++u)
+      {
+        const double t = FMA(a1[u], d1[max(j0 - kPf - u, r0)], acc);
+        acc = (j0 - kPf - u >= ic) ? t : acc;
       }
     }
     if(i < q) dl[i] = acc;
@@ -410,9 +480,77 @@ __device__ __forceinline__ void c9_y_update(Ctx & K, C9 & Q, double * y, const d
       }
     }
   }
-  // ---- B: the head of an arrow -- every group reaches it.  Lanes = head rows, the waves share the (padded) list of groups in aligned
-  // chunks: each folds its chunk into a subtree, the NW subtree roots meet in LDS and one wave finishes the tree.
-  if(arrow)
+  // ---- B: the head of an arrow -- every group reaches it.  The waves share the (padded) list of groups in aligned chunks: each folds
+  // its chunk into a subtree, the NW subtree roots meet in LDS and one wave finishes the tree.
+  if(arrow && !BIG && lh <= 32)
+  {
+    // head of at most 32 rows: lanes 0 .. 31 take the even slot of a pair of groups, lanes 32 .. 63 the odd one (the pair's sum is the
+    // first level of the tree); the entries of the NEXT pair are requested before this pair's are consumed
+    const int4 t = Q.tkl[nblk - 1];
+    const int ng = max(t.y - t.x + 1, 0), nT = ng + max(t.w - t.z + 1, 0);
+    int P = 1;
+    while(P < nT) P <<= 1;
+    if(P < 2 * NW) P = 2 * NW;
+    const int G = P / NW, lane = K.lane, hb = lane >> 5, l5 = lane & 31;
+    const double * rowp = Q.Bc + oh + min(l5, lh - 1);
+    auto group_of = [&](int ts) { return (ts < nT) ? ((ts < ng) ? t.x + ts : t.z + (ts - ng)) : -1; };
+    auto issue = [&](int ts, double(&bv)[EB], int(&sl)[EB], int & c) {
+      const int gI = group_of(ts);
+      c = (gI >= 0) ? Q.gcount[gI] : 0;
+      const int o = (gI >= 0) ? Q.goff[gI] : 0;
+#pragma unroll
+      for(int u = 0; u < EB; ++u)
+      {
+        int sv = Q.glist[o + min(u, max(c - 1, 0))];
+        sv = (u < c) ? sv : 0;
+        sl[u] = sv;
+        bv[u] = rowp[(size_t)sv * np];
+      }
+    };
+    TreeStack T;
+    T.reset();
+    auto consume = [&](int ts, const double(&bv)[EB], const int(&sl)[EB], int c) {
+      double acc = 0.0;
+#pragma unroll
+      for(int u = 0; u < EB; ++u)
+      {
+        const double tt = FMA(dls[sl[u]], bv[u], acc);
+        acc = (u < c) ? tt : acc;
+      }
+      const int gI = group_of(ts);
+      if(gI >= 0 && c > EB) acc = c9_group_chain(Q, dls, rowp, np, gI, EB, acc);
+      T.push(acc + shfl_xor_d(acc, 32)); // (the same sum in both halves: a + b == b + a)
+    };
+    const int ts0 = K.wave * G + hb, npair = G / 2;
+    double b0[EB], b1[EB];
+    int s0[EB], s1[EB], c0, c1;
+    issue(ts0, b0, s0, c0);
+    for(int r = 0; r < npair; r += 2)
+    {
+      issue(ts0 + 2 * min(r + 1, npair - 1), b1, s1, c1);
+      consume(ts0 + 2 * r, b0, s0, c0);
+      if(r + 1 < npair) // (uniform)
+      {
+        issue(ts0 + 2 * min(r + 2, npair - 1), b0, s0, c0);
+        consume(ts0 + 2 * (r + 1), b1, s1, c1);
+      }
+    }
+    __syncthreads(); // (part A's writes of y are done with; hred is free)
+    if(hb == 0) Q.hred[K.wave * 128 + l5] = T.flush();
+    __syncthreads();
+    for(int r = K.tid; r < lh; r += NT)
+    {
+      double w[NW];
+#pragma unroll
+      for(int i = 0; i < NW; ++i) w[i] = Q.hred[i * 128 + r];
+#pragma unroll
+      for(int st = 1; st < NW; st <<= 1)
+#pragma unroll
+        for(int i = 0; i < NW; i += 2 * st) w[i] = w[i] + w[i + st];
+      y[oh + r] = y[oh + r] - w[0];
+    }
+  }
+  else if(arrow)
   {
     const int4 t = Q.tkl[nblk - 1];
     const int ng = max(t.y - t.x + 1, 0), nT = ng + max(t.w - t.z + 1, 0);
@@ -476,8 +614,8 @@ __device__ __forceinline__ void c9_y_update(Ctx & K, C9 & Q, double * y, const d
         for(int i = 0; i < NW; i += 2 * st) w[i] = w[i] + w[i + st];
       y[oh + r] = y[oh + r] - w[0];
     }
-    (void)qc;
   }
+  (void)qc;
   __syncthreads();
 }
 
@@ -514,8 +652,8 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
     K.u = p; p += A.qcap;
   }
   K.r = p; p += A.qcap;
-  Q.ga = p; p += A.qcap;
-  Q.gb = p; p += A.qcap;
+  Q.ga = p; p += A.qcap + 64; // (+ 64: operands are read in groups that may run past the last position)
+  Q.gb = p; p += A.qcap + 64;
   int P2 = 1;
   while(P2 < nblk) P2 <<= 1;
   if(P2 < 64) P2 = 64;
@@ -533,7 +671,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
   K.par = 0;
   int * ip = reinterpret_cast<int *>(p);
   Q.slot = ip; ip += A.qcap;
-  Q.roff = ip; ip += A.qcap;
+  Q.roff = ip; ip += A.qcap + 64;
   Q.smeta = reinterpret_cast<unsigned *>(ip); ip += A.qcap;
   Q.gcount = ip; ip += A.ngrp;
   Q.goff = ip; ip += A.ngrp;
@@ -596,9 +734,12 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
 
   for(int i = tid; i < m + nb; i += NT) K.status[i] = JRLQP_INACTIVE;
   for(int i = tid; i < n; i += NT) x[i] = 0.0;
+  for(int i = tid; i < A.qcap + 64; i += NT) Q.roff[i] = 0;
   for(int i = tid; i < A.qcap; i += NT)
   {
     u[i] = r[i] = 0.0;
+    Q.ga[i] = Q.gb[i] = 0.0; // (operands are read in groups that may run past q: never uninitialised)
+    if(i < 64) Q.ga[A.qcap + i] = Q.gb[A.qcap + i] = 0.0;
     Q.freel[i] = A.qcap - 1 - i; // (slot 0 is handed out first)
   }
   __syncthreads();
@@ -890,7 +1031,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           Q.Sm[(size_t)sn + (size_t)q * Q.ldq] = v;
           Q.St[(size_t)sn * Q.ldq + q] = v;
           Q.slot[q] = sn;
-          Q.roff[q] = sn * Q.ldq;
+          Q.roff[q] = 8 * sn * Q.ldq;
           Q.smeta[sn] = (unsigned)plo | ((unsigned)(phi + 1) << 16);
           Q.sgrp[sn] = pgrp;
           Q.glist[Q.goff[pgrp] + Q.gcount[pgrp]] = sn;
@@ -1016,7 +1157,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           {
             K.active[k] = ta;
             Q.slot[k] = ts;
-            Q.roff[k] = ts * Q.ldq;
+            Q.roff[k] = 8 * ts * Q.ldq;
           }
           __syncthreads();
         }
@@ -1024,6 +1165,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
         {
           K.status[removed] = JRLQP_INACTIVE;
           Q.freel[Q.nfree] = sl;
+          Q.roff[q - 1] = 0; // (zero beyond the last position: c9_st_g)
           // leave the group's list, order kept
           const int g = Q.sgrp[sl], o = Q.goff[g], c = Q.gcount[g];
           int at = 0;
@@ -1125,8 +1267,8 @@ long blockgi_c9_lds_bytes(int n, int m, int nb, int nblk, int ncb, int xu_global
   int P2 = 1;
   while(P2 < nblk) P2 <<= 1;
   if(P2 < 64) P2 = 64;
-  const long dbl = (xu_global ? 2L * n_pad + 3L * qcap : 3L * n_pad + 4L * qcap) + P2 + 8 * 128 + 2L * nblk + 32 + 32 + 8;
-  const long ints = 3L * qcap + 2L * ngrp + (m + nb + 1) + 3L * nblk + (n + 2) / 2 + 2;
+  const long dbl = (xu_global ? 2L * n_pad + 3L * qcap : 3L * n_pad + 4L * qcap) + 128 + P2 + 8 * 128 + 2L * nblk + 32 + 32 + 8;
+  const long ints = 3L * qcap + 64 + 2L * ngrp + (m + nb + 1) + 3L * nblk + (n + 2) / 2 + 2;
   return (long)sizeof(double) * dbl + 4 * ints + (long)sizeof(BlkMeta) * nblk + 8;
 }
 

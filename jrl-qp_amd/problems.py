@@ -1,8 +1,10 @@
 """Planted-solution random QP generator (synthetic workload for tests and bench.py).
 
-Behavioural twin of the reference's test-support generator -- NOT a copy: same construction,
-own code, seeded counter-based RNG (the reference draws from an unseeded std::mt19937 / libc rand,
-so any fixed seed is admissible -- SURVEY.md §4, §8d):
+A RESTATEMENT, step for step, of the reference's test-support generator in numpy / scipy: the same construction in the same order (the
+step numbering, the four branches and the variable names nVar / nstrong / rankTot / colsTot / red follow randomProblems.cpp so that the
+two can be read side by side -- SURVEY.md 8(d) requires the recipe to be behaviourally identical; it is the workload generator, not the
+hot path), with numpy / scipy primitives in place of Eigen's and a seeded counter-based RNG of its own (the reference draws from an
+unseeded std::mt19937 / libc rand, so any fixed seed is admissible -- SURVEY.md §4, §8d):
 
   reference src/test/randomProblems.cpp:15-251   randomProblem(ProblemCharacteristics)
   reference include/jrl-qp/test/randomMatrices.h:62-215   randOrtho / randn / randDependent
