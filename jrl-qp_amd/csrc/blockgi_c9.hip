@@ -299,6 +299,7 @@ __device__ __forceinline__ void c9_s_d(Ctx & K, C9 & Q, int q, const double * d1
     int j0 = q - 1;
     for(int done = 0; done < nfull; done += 4 * kPf, j0 -= 4 * kPf)
     {
+      double dv[kPf];
 #pragma unroll
       for(int u = 0; u < kPf; ++u) a0[u] = ld(j0 - u);
 #pragma unroll
@@ -308,13 +309,21 @@ __device__ __forceinline__ void c9_s_d(Ctx & K, C9 & Q, int q, const double * d1
 #pragma unroll
       for(int u = 0; u < kPf; ++u) a3[u] = ld(j0 - 3 * kPf - u);
 #pragma unroll
-      for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], d1[j0 - u], acc);
+      for(int u = 0; u < kPf; ++u) dv[u] = d1[j0 - u];
 #pragma unroll
-      for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], d1[j0 - kPf - u], acc);
+      for(int u = 0; u < kPf; ++u) acc = FMA(a0[u], dv[u], acc);
 #pragma unroll
-      for(int u = 0; u < kPf; ++u) acc = FMA(a2[u], d1[j0 - 2 * kPf - u], acc);
+      for(int u = 0; u < kPf; ++u) dv[u] = d1[j0 - kPf - u];
 #pragma unroll
-      for(int u = 0; u < kPf; ++u) acc = FMA(a3[u], d1[j0 - 3 * kPf - u], acc);
+      for(int u = 0; u < kPf; ++u) acc = FMA(a1[u], dv[u], acc);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) dv[u] = d1[j0 - 2 * kPf - u];
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) acc = FMA(a2[u], dv[u], acc);
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) dv[u] = d1[j0 - 3 * kPf - u];
+#pragma unroll
+      for(int u = 0; u < kPf; ++u) acc = FMA(a3[u], dv[u], acc);
     }
     // the rest, down to the chunk's first row (fewer than 128 columns): lane i takes columns >= i
     for(; j0 >= r0; j0 -= 2 * kPf)
@@ -522,18 +531,20 @@ __device__ __forceinline__ void c9_y_update(Ctx & K, C9 & Q, double * y, const d
       T.push(acc + shfl_xor_d(acc, 32)); // (the same sum in both halves: a + b == b + a)
     };
     const int ts0 = K.wave * G + hb, npair = G / 2;
-    double b0[EB], b1[EB];
-    int s0[EB], s1[EB], c0, c1;
-    issue(ts0, b0, s0, c0);
-    for(int r = 0; r < npair; r += 2)
+    // four pairs per trip: their entries are all requested, then consumed in order (no load is carried over the loop's back edge:
+    // hipcc would wait for everything in flight at its first use)
+    for(int r = 0; r < npair; r += 4)
     {
-      issue(ts0 + 2 * min(r + 1, npair - 1), b1, s1, c1);
+      double b0[EB], b1[EB], b2[EB], b3[EB];
+      int s0[EB], s1[EB], s2[EB], s3[EB], c0, c1, c2, c3;
+      issue(ts0 + 2 * r, b0, s0, c0);
+      issue(ts0 + 2 * (r + 1), b1, s1, c1); // (a slot beyond the padded list has no group: no entries)
+      issue(ts0 + 2 * (r + 2), b2, s2, c2);
+      issue(ts0 + 2 * (r + 3), b3, s3, c3);
       consume(ts0 + 2 * r, b0, s0, c0);
-      if(r + 1 < npair) // (uniform)
-      {
-        issue(ts0 + 2 * min(r + 2, npair - 1), b0, s0, c0);
-        consume(ts0 + 2 * (r + 1), b1, s1, c1);
-      }
+      if(r + 1 < npair) consume(ts0 + 2 * (r + 1), b1, s1, c1); // (uniform)
+      if(r + 2 < npair) consume(ts0 + 2 * (r + 2), b2, s2, c2);
+      if(r + 3 < npair) consume(ts0 + 2 * (r + 3), b3, s3, c3);
     }
     __syncthreads(); // (part A's writes of y are done with; hred is free)
     if(hb == 0) Q.hred[K.wave * 128 + l5] = T.flush();

@@ -22,6 +22,8 @@
 #include "device_common.h"
 #include "structured.h"
 
+#include <cstdlib>
+
 namespace jrlqp
 {
 namespace
@@ -300,6 +302,117 @@ __global__ __launch_bounds__(256) void arrow_head_kernel(const BlockDesc D)
     const int e = tid + 256 * s;
     const int r = e % nbk, c = e / nbk;
     if(e < nbk * nbk && r >= c) AT(Ls, ldl, r, c) = acc[s];
+  }
+  __syncthreads();
+  if(tid < 64)
+  {
+    int ret = wave_llt(Ls, ldl, nbk, tid);
+    if(ret > 0 && tid == 0) atomicExch(&D.fail[pb], 1); // (:80) ret <= 0 is success
+  }
+  __syncthreads();
+  for(int e = tid; e < nbk * nbk; e += 256)
+  {
+    int r = e % nbk, c = e / nbk;
+    if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+  }
+}
+
+// The head block on the matrix cores (round 5; heads of at most 64 rows): D_b -= sum_i B_i B_i^T with v_mfma_f64_16x16x4_f64, one wave
+// per 16 x 16 tile of the lower triangle, the blocks in order and k ascending inside a block (4 per instruction: the instruction
+// accumulates in k order, tests/test_gpu_arith.py) -- per element the SAME single fma chain as arrow_head_kernel's, which walked the
+// blocks with two barriers and an LDS round trip each (550 us for 100 blocks of 30 rows; one problem's whole factorisation was 600 us).
+// Four blocks' operands (64 loads per lane) are requested before their 32 instructions run; nothing is carried over the loop's edge.
+typedef double double4_h __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void arrow_head_mfma_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[]; // Ls (nbk x ldl)
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
+  const int pb = blockIdx.x;
+  const int ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int nbk = D.bs[ib];
+  double * Dg = D.diag[(size_t)pb * D.nblk + ib];
+  const int ldd = D.ldd[ib];
+  const int ldl = nbk | 1;
+  double * Ls = sm;
+  if(D.fail[pb]) return; // a block already failed: the reference returns false before touching D_b further
+  const int nt = (nbk + 15) >> 4, ntile = nt * (nt + 1) / 2;
+  for(int t = wave; t < ntile; t += 4)
+  {
+    int ti = 0, rem = t;
+    while(rem > ti) // tile (ti, tj), tj <= ti, numbered row by row
+    {
+      rem -= ti + 1;
+      ++ti;
+    }
+    const int tj = rem;
+    const int i0 = ti * 16, c0 = tj * 16;
+    const int col = c0 + (l & 15);
+    double4_h acc;
+#pragma unroll
+    for(int r = 0; r < 4; ++r)
+    {
+      const int row = i0 + (l >> 4) + 4 * r;
+      acc[r] = (row < nbk && col < nbk && row >= col) ? AT(Dg, ldd, row, col) : 0.0;
+    }
+    const int arow = i0 + (l & 15), brow = c0 + (l & 15), kk = l >> 4;
+    const int ar = min(arow, nbk - 1), br = min(brow, nbk - 1);
+    const bool ain = arow < nbk, bin = brow < nbk;
+    constexpr int GB = 4; // blocks per trip
+    for(int g0 = 0; g0 < D.nblk - 1; g0 += GB)
+    {
+      double av[GB][8], bv[GB][8];
+      int nis[GB];
+#pragma unroll
+      for(int g = 0; g < GB; ++g)
+      {
+        const int i = min(g0 + g, D.nblk - 2);
+        const int ni = D.bs[dsel(D.nblk, D.up, i)];
+        nis[g] = (g0 + g < D.nblk - 1) ? ni : 0;
+        const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+        const int ldsg = D.lds[i];
+#pragma unroll
+        for(int k8 = 0; k8 < 8; ++k8)
+        {
+          const int kq = min(4 * k8 + kk, ni - 1);
+          av[g][k8] = D.up ? AT(Sg, ldsg, kq, ar) : AT(Sg, ldsg, ar, kq);
+          bv[g][k8] = D.up ? AT(Sg, ldsg, kq, br) : AT(Sg, ldsg, br, kq);
+        }
+      }
+#pragma unroll
+      for(int g = 0; g < GB; ++g)
+      {
+        const int ni = nis[g];
+#pragma unroll
+        for(int k8 = 0; k8 < 8; ++k8)
+        {
+          if(4 * k8 < ni) // (uniform)
+          {
+            const bool kin = 4 * k8 + kk < ni;
+            const double a = (kin && ain) ? -av[g][k8] : 0.0;
+            const double b = (kin && bin) ? bv[g][k8] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
+        }
+        // a block of more than 32 columns: the rest, 4 at a time
+        for(int k = 32; k < ni; k += 4)
+        {
+          const int i = g0 + g;
+          const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+          const int ldsg = D.lds[i];
+          const int kq = min(k + kk, ni - 1);
+          const bool kin = k + kk < ni;
+          const double a0 = D.up ? AT(Sg, ldsg, kq, ar) : AT(Sg, ldsg, ar, kq);
+          const double b0 = D.up ? AT(Sg, ldsg, kq, br) : AT(Sg, ldsg, br, kq);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64((kin && ain) ? -a0 : 0.0, (kin && bin) ? b0 : 0.0, acc, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for(int r = 0; r < 4; ++r)
+    {
+      const int row = i0 + (l >> 4) + 4 * r;
+      if(row < nbk && col < nbk && row >= col) AT(Ls, ldl, row, col) = acc[r];
+    }
   }
   __syncthreads();
   if(tid < 64)
@@ -1213,10 +1326,20 @@ hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipS
   if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(kTriThreads), lds_blk, st, dd);
   if(maxb <= 64)
   {
-    const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + 64 * 65);
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
-    if(e != hipSuccess) return e;
-    hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), lds_head, st, dd);
+    const bool mfma = std::getenv("JRLQP_ARROW_HEAD_LDS") == nullptr; // (diagnostic: the round 1-4 kernel that staged every block in LDS)
+    const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + (mfma ? 0 : 64 * 65));
+    if(mfma)
+    {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
+      if(e != hipSuccess) return e;
+      hipLaunchKernelGGL(arrow_head_mfma_kernel, dim3(nprob), dim3(256), lds_head, st, dd);
+    }
+    else
+    {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
+      if(e != hipSuccess) return e;
+      hipLaunchKernelGGL(arrow_head_kernel, dim3(nprob), dim3(256), lds_head, st, dd);
+    }
   }
   else
   {
