@@ -578,6 +578,92 @@ __global__ __launch_bounds__(64) void arrow_lsolve_head_kernel(const BlockDesc D
   }
 }
 
+// phase 2 for blocks of at most 64 rows (round 5): the chain of a head row runs over every entry of every side block in order --
+// 3000 dependent fmas at c5 -- and arrow_lsolve_head_kernel fed it one global load per term (433 us).  Here wave 0 only chains, out
+// of LDS; waves 1 .. 3 stage the NEXT group of side blocks (and the solved X_i that go with them) while it does: one memory round
+// trip per GROUP of blocks.  Same terms in the same order: same bits.
+__global__ __launch_bounds__(256) void arrow_lsolve_head_staged_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start, int end, int gb,
+                                                                         int bcap)
+{
+  extern __shared__ double sm[]; // [2][gb][bcap] side blocks | [2][gb][64] X_i
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pb = blockIdx.x;
+  const int ib = dsel(D.nblk, D.up, D.nblk - 1);
+  const int nbk = D.bs[ib];
+  int ntot = 0;
+  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  double * Mp = M + (size_t)pb * D.mstride;
+  const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
+  double * Bs = sm;
+  double * Xs = sm + 2 * (size_t)gb * bcap;
+  const int nside = D.nblk - 1, ngroup = (nside + gb - 1) / gb;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mb = Mp + (ntot - nbk) + (size_t)c * ldm;
+    double acc = (wave == 0 && lane < nbk) ? Mb[lane] : 0.0;
+    // stage group g into buffer g & 1 (threads t0 .. 255 step nthr)
+    auto stage = [&](int g, int t0, int nthr) {
+      double * Bg = Bs + (size_t)(g & 1) * gb * bcap;
+      double * Xg = Xs + (size_t)(g & 1) * gb * 64;
+      int n0 = 0;
+      for(int i = 0; i < g * gb; ++i) n0 += D.bs[dsel(D.nblk, D.up, i)];
+      for(int j = 0; j < gb; ++j)
+      {
+        const int i = g * gb + j;
+        if(i >= nside) break;
+        const int id = dsel(D.nblk, D.up, i), ni = D.bs[id];
+        const double * Sg = D.side[(size_t)pb * nside + i];
+        const int ldsg = D.lds[i];
+        const int rows = D.up ? ni : nbk, cols = D.up ? nbk : ni, ldb = rows | 1;
+        for(int e = tid - t0; e < rows * cols; e += nthr) Bg[(size_t)j * bcap + (e % rows) + (e / rows) * ldb] = AT(Sg, ldsg, e % rows, e / rows);
+        const double * Xi = Mp + n0 + (size_t)c * ldm;
+        for(int e = tid - t0; e < ni; e += nthr) Xg[j * 64 + e] = Xi[e];
+        n0 += ni;
+      }
+    };
+    if(ngroup > 0) stage(0, 0, 256);
+    __syncthreads();
+    int n0 = 0;
+    for(int g = 0; g < ngroup; ++g)
+    {
+      if(wave != 0)
+      {
+        if(g + 1 < ngroup) stage(g + 1, 64, 192);
+      }
+      else
+      {
+        const double * Bg = Bs + (size_t)(g & 1) * gb * bcap;
+        const double * Xg = Xs + (size_t)(g & 1) * gb * 64;
+        for(int j = 0; j < gb; ++j)
+        {
+          const int i = g * gb + j;
+          if(i >= nside) break;
+          const int id = dsel(D.nblk, D.up, i), ni = D.bs[id];
+          const int s = max(start - n0, 0);
+          if(!(ni < s || end <= n0) && lane < nbk)
+          {
+            const int rows = D.up ? ni : nbk, ldb = rows | 1;
+            const double * B = Bg + (size_t)j * bcap;
+            for(int k = s; k < ni; ++k)
+            {
+              const double bv = D.up ? B[k + lane * ldb] : B[lane + k * ldb];
+              acc = FMA(-bv, Xg[j * 64 + k], acc);
+            }
+          }
+          n0 += ni;
+        }
+      }
+      __syncthreads();
+    }
+    if(wave == 0)
+    {
+      double a1 = 0.0;
+      wave_fwd2(Lb, D.ldd[ib], nbk, acc, a1, lane);
+      if(lane < nbk) Mb[lane] = acc;
+    }
+    __syncthreads();
+  }
+}
+
 // L^T X = M, phase 1: head block X_b = L_b(0:r,0:r)^-T M_b(0:r) when end reaches into it (:203-212)
 __global__ __launch_bounds__(64) void arrow_ltsolve_head_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start, int end)
 {
@@ -1367,7 +1453,21 @@ hipError_t launch_block_arrow_solve(const BlockDesc & d, int nprob, bool transpo
       end = end - n0 > 0 ? end - n0 : 0;
     }
     if(d.nblk > 1) hipLaunchKernelGGL(arrow_lsolve_blocks_kernel, dim3(d.nblk - 1, nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
-    hipLaunchKernelGGL(arrow_lsolve_head_kernel, dim3(nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
+    int maxb = 0;
+    for(int k = 0; k < d.nblk; ++k) maxb = d.h_bs[k] > maxb ? d.h_bs[k] : maxb;
+    if(maxb <= 64 && d.nblk > 1)
+    {
+      // side blocks staged through LDS in groups (arrow_lsolve_head_staged_kernel): as many blocks per group as 2 x gb x bcap doubles allow
+      const int bcap = maxb * (maxb | 1);
+      int gb = (int)((96 * 1024 / sizeof(double)) / (2 * (size_t)(bcap + 64)));
+      gb = gb < 1 ? 1 : (gb > 16 ? 16 : gb);
+      const size_t lds = sizeof(double) * 2 * (size_t)gb * (bcap + 64);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_lsolve_head_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if(e != hipSuccess) return e;
+      hipLaunchKernelGGL(arrow_lsolve_head_staged_kernel, dim3(nprob), dim3(256), lds, st, d, M, ldm, nrhs, start, end, gb, bcap);
+    }
+    else
+      hipLaunchKernelGGL(arrow_lsolve_head_kernel, dim3(nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
   }
   else
   {
