@@ -42,6 +42,7 @@ struct C9
   unsigned * smeta; // slot -> first | (last + 1) << 16 off-head block of the column's reach (LDS)
   int *glist, *gcount, *goff; // per-group lists of active slots in active-set order (LDS)
   unsigned short * kapr;      // permuted row -> block-order index (LDS)
+  unsigned char * lstat;      // activation status of every constraint (LDS copy of the output array: the scan reads it every pass)
   int *koff, *klen, *kpho;    // block-order index -> first permuted row, rows, first ORIGINAL row (LDS)
   double * bsum;              // pow2(nblk) doubles (LDS): block sums of a C9 reduction
   double * hred;              // 8 x 128 doubles (LDS): the waves' subtree roots of the head rows (c9_y_update)
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
   Q.klen = ip; ip += nblk;
   Q.kpho = ip; ip += nblk;
   Q.kapr = reinterpret_cast<unsigned short *>(ip); ip += (n + 2) / 2;
+  Q.lstat = reinterpret_cast<unsigned char *>(ip); ip += (m + nb + 4) / 4;
   ip += (reinterpret_cast<size_t>(ip) & 7) ? 1 : 0; // (8-byte alignment of the block table)
   {
     BlkMeta * bm = reinterpret_cast<BlkMeta *>(ip);
@@ -743,7 +745,11 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
     }
   };
 
-  for(int i = tid; i < m + nb; i += NT) K.status[i] = JRLQP_INACTIVE;
+  for(int i = tid; i < m + nb; i += NT)
+  {
+    K.status[i] = JRLQP_INACTIVE;
+    Q.lstat[i] = JRLQP_INACTIVE;
+  }
   for(int i = tid; i < n; i += NT) x[i] = 0.0;
   for(int i = tid; i < A.qcap + 64; i += NT) Q.roff[i] = 0;
   for(int i = tid; i < A.qcap; i += NT)
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
         int bidx = 0x7fffffff, btag = JRLQP_INACTIVE;
         for(int j = tid; j < m; j += NT)
         {
-          if(K.status[j] != JRLQP_INACTIVE) continue;
+          if(Q.lstat[j] != JRLQP_INACTIVE) continue; // (the LDS copy of the status: no memory round trip in front of the chain)
           const int b = A.to_block[j], len = A.cvar[b];
           const double * c = K.cblk[b] + (size_t)(j - A.cum_cstr[b]) * A.cld[b];
           const double * w = x + A.cum_var[b];
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
         }
         for(int i = tid; i < nb; i += NT)
         {
-          if(K.status[m + i] != JRLQP_INACTIVE) continue;
+          if(Q.lstat[m + i] != JRLQP_INACTIVE) continue;
           const double sl = x[i] - xl[i];
           if(sl < bval)
           {
@@ -1048,6 +1054,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
           Q.glist[Q.goff[pgrp] + Q.gcount[pgrp]] = sn;
           Q.gcount[pgrp] += 1;
           K.status[p] = pst;
+          Q.lstat[p] = (unsigned char)pst;
           K.active[q] = p;
         }
         ++q;
@@ -1175,6 +1182,7 @@ __global__ __launch_bounds__(NT) void blockgi_c9_kernel(const BgiArgs A)
         if(tid == 0)
         {
           K.status[removed] = JRLQP_INACTIVE;
+          Q.lstat[removed] = JRLQP_INACTIVE;
           Q.freel[Q.nfree] = sl;
           Q.roff[q - 1] = 0; // (zero beyond the last position: c9_st_g)
           // leave the group's list, order kept
@@ -1279,7 +1287,7 @@ long blockgi_c9_lds_bytes(int n, int m, int nb, int nblk, int ncb, int xu_global
   while(P2 < nblk) P2 <<= 1;
   if(P2 < 64) P2 = 64;
   const long dbl = (xu_global ? 2L * n_pad + 3L * qcap : 3L * n_pad + 4L * qcap) + 128 + P2 + 8 * 128 + 2L * nblk + 32 + 32 + 8;
-  const long ints = 3L * qcap + 64 + 2L * ngrp + (m + nb + 1) + 3L * nblk + (n + 2) / 2 + 2;
+  const long ints = 3L * qcap + 64 + 2L * ngrp + (m + nb + 1) + 3L * nblk + (n + 2) / 2 + (m + nb + 4) / 4 + 2;
   return (long)sizeof(double) * dbl + 4 * ints + (long)sizeof(BlkMeta) * nblk + 8;
 }
 
