@@ -476,10 +476,13 @@ def bench_structured(args, rank, world, device, jdist, emit=True):
     if rank == 0:
         total = B * world
         # ---- one problem alone (latency layout, a plan of its own), and the factorisation / the two block solves alone ----
-        single = capi.BlockGISolver("arrow_down", bs, cshapes, False, 1, max_iter=1000, device=device)
+        # (--no-secondary: skipped, so that a profiler's per-kernel averages see the batch launches only)
+        extras = not getattr(args, "no_secondary", False)
+        single = capi.BlockGISolver("arrow_down", bs, cshapes, False, 1, max_iter=1000, device=device) if extras else None
         H1 = H0[:1].clone()
         one_ms = []
-        for rep in range(4):
+        r1 = None
+        for rep in range(4 if extras else 0):
             H1.copy_(H0[:1])
             single._bind(H1, Cb[:1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -489,7 +492,7 @@ def bench_structured(args, rank, world, device, jdist, emit=True):
             torch.cuda.synchronize(device)
             if rep:
                 one_ms.append(e0.elapsed_time(e1))
-        fact = structured_factor_times(capi, SP, device)
+        fact = structured_factor_times(capi, SP, device) if extras else {"factor_us": None, "solve_us": None, "what": "skipped (--no-secondary)"}
         # Byte models, named as such:
         #  * compulsory: every input read once, every output written once -- the factor blocks (201 x 900 doubles, in
         #    place: read + written), C, a, bl, bu; x, u, status, {term, iters}, f.  This is `roofline.achieved`: the path's own floor.
@@ -512,7 +515,8 @@ def bench_structured(args, rank, world, device, jdist, emit=True):
                                    f"(in-place block LLT + device-resident structured GI loop, contract C9); wall time includes restoring G before each solve",
                        "batch_per_gpu": B, "distinct_problems": ND, "mean_iterations": sum_it / total, "min_iterations": int(iters.min()),
                        "max_iterations": int(iters.max()), "solved": n_ok, "form": "C9" if solver.form == 1 else "sequence"},
-            "single_problem_ms": float(np.median(one_ms)), "single_problem_iterations": int(r1.iters[0]), "single_problem_term": int(r1.term[0]),
+            "single_problem_ms": float(np.median(one_ms)) if one_ms else None, "single_problem_iterations": int(r1.iters[0]) if r1 is not None else None,
+            "single_problem_term": int(r1.term[0]) if r1 is not None else None,
             "factor_us": fact["factor_us"], "solve_us": fact["solve_us"], "factor_solve_what": fact["what"],
             "roofline": {"bound": "hbm", "achieved": compulsory / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": compulsory / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r5"
 sys.path.insert(0, ROOT)
 import subprocess
 
@@ -87,11 +87,12 @@ def main():
     shutil.copy(os.path.join(SRC, "p_bgi", "bgi_kernel_stats.csv"), os.path.join(DST, f"{TAG}_blockgi_c5_batch{nb}_kernel_stats.csv"))
     shutil.copy(os.path.join(SRC, "p_bgi_fetch", "fetch_counter_collection.csv"), os.path.join(DST, f"{TAG}_blockgi_c5_batch{nb}_pmc_fetch_size.csv"))
     shutil.copy(os.path.join(SRC, "p_bgi_write", "write_counter_collection.csv"), os.path.join(DST, f"{TAG}_blockgi_c5_batch{nb}_pmc_write_size.csv"))
-    ks5 = kernel_stats(os.path.join(SRC, "p_bgi", "bgi_kernel_stats.csv"), "blockgi_kernel")
-    f5, _ = pmc_per_launch(os.path.join(SRC, "p_bgi_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE", "blockgi_kernel")
-    w5, _ = pmc_per_launch(os.path.join(SRC, "p_bgi_write", "write_counter_collection.csv"), "WRITE_SIZE", "blockgi_kernel")
+    BGK = "blockgi_c9_kernel" if "blockgi_c9_kernel" in open(os.path.join(SRC, "p_bgi", "bgi_kernel_stats.csv")).read() else "blockgi_kernel"
+    ks5 = kernel_stats(os.path.join(SRC, "p_bgi", "bgi_kernel_stats.csv"), BGK)
+    f5, _ = pmc_per_launch(os.path.join(SRC, "p_bgi_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE", BGK)
+    w5, _ = pmc_per_launch(os.path.join(SRC, "p_bgi_write", "write_counter_collection.csv"), "WRITE_SIZE", BGK)
     json.dump({
-        "kernel": "blockgi_kernel", "batch": nb, "kernel_source_sha16": SHA, "commit": COMMIT,
+        "kernel": BGK, "batch": nb, "kernel_source_sha16": SHA, "commit": COMMIT,
         "FETCH_SIZE_KB_per_launch": round(f5, 1), "WRITE_SIZE_KB_per_launch": round(w5, 1),
         "traffic_bytes_per_launch_fetch_x2_plus_write": int(round((2.0 * f5 + w5) * 1024)),
         "algorithmic_bytes_per_launch": b5["roofline"].get("algorithmic_bytes_per_launch"),

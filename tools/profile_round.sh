@@ -9,9 +9,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o bench -- p
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -o fetch -- python3 bench.py --no-cpu-baseline --no-secondary --steps 5 --warmup 1 > /dev/null 2> $O/p_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_write -o write -- python3 bench.py --no-cpu-baseline --no-secondary --steps 5 --warmup 1 > /dev/null 2> $O/p_write.err
 python bench.py --workload c5 --steps 2 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bgi -o bgi -- python3 bench.py --workload c5 --steps 2 --warmup 1 > /dev/null 2> $O/p_bgi.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_bgi_fetch -o fetch -- python3 bench.py --workload c5 --steps 1 --warmup 1 > /dev/null 2> $O/p_bgi_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_bgi_write -o write -- python3 bench.py --workload c5 --steps 1 --warmup 1 > /dev/null 2> $O/p_bgi_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_bgi -o bgi -- python3 bench.py --workload c5 --steps 2 --warmup 1 --no-secondary > /dev/null 2> $O/p_bgi.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_bgi_fetch -o fetch -- python3 bench.py --workload c5 --steps 1 --warmup 1 --no-secondary > /dev/null 2> $O/p_bgi_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p_bgi_write -o write -- python3 bench.py --workload c5 --steps 1 --warmup 1 --no-secondary > /dev/null 2> $O/p_bgi_write.err
 python bench.py --workload c2 --steps 3 > $O/bench_c2.json 2> $O/bench_c2.err
 # Mode A (c2): kernel stats and HBM traffic of ALL launches of a solve (two solves per pass: one warm-up + one step; --no-secondary
 # also skips the init-only probes, so every dispatch of the run belongs to one of the two solves)
