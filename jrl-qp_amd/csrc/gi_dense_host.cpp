@@ -475,9 +475,9 @@ int jrlqp_debug_dense_inject_sync_fault(jrlqp_dense * h, int pass)
 }
 
 // ---- the complete solve: DualSolver::solve (src/DualSolver.cpp:91-168) on the host ----------------------------
-static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
-                            const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term_out,
-                            void * stream, bool warm, const int * as_host)
+static int dense_solve_attempts(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                                const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term_out,
+                                void * stream, bool warm, const int * as_host)
 {
   int rc = jrlqp_dense_bind(h, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu);
   if(rc != JRLQP_OK) return rc;
@@ -785,8 +785,20 @@ attempt:
       const int kind = (t >= big) ? kKindInfeasible : ((t2 >= big) ? kKindDual : ((t == t2) ? kKindAdd : kKindDrop));
       if(h->h_mb->dkind != kind)
       {
-        h->last_hip = (int)hipErrorAssert;
-        return JRLQP_ERR_HIP;
+        // void the attempt like a starved hand-off: drain, switch to event edges (no speculation there), repeat from the factor
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(h->spec);
+        (void)hipStreamSynchronize(h->side);
+        h->chain_pending = 0;
+        if(h->use_events || rerun)
+        {
+          h->last_hip = (int)hipErrorAssert;
+          return JRLQP_ERR_HIP;
+        }
+        h->use_events = true;
+        ++h->event_reruns;
+        rerun = true;
+        goto attempt;
       }
     }
     if(t >= big) return finish(JRLQP_INFEASIBLE);
@@ -849,6 +861,25 @@ attempt:
     }
   }
   return finish(JRLQP_MAX_ITER_REACHED);
+}
+
+// Every exit of the loop above that is NOT a termination status (a HIP error, a starved rerun that failed too) leaves through here:
+// the caller's stream and the handle's two side streams are drained and the pending-chain flag is cleared, exactly as finish() does
+// for a regular end -- a speculative sweep or a gated scan may still be running on x / u / J / psel, and the exported hooks,
+// jrlqp_dense_results and the next solve touch the same buffers.
+static int dense_solve_impl(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,
+                            const double * dbu, const double * dxl, const double * dxu, const jrlqp_options * opts, int * term_out,
+                            void * stream, bool warm, const int * as_host)
+{
+  const int rc = dense_solve_attempts(h, dG, ldg, da, dC, ldc, dbl, dbu, dxl, dxu, opts, term_out, stream, warm, as_host);
+  if(rc != JRLQP_OK && h)
+  {
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    (void)hipStreamSynchronize(h->spec);
+    (void)hipStreamSynchronize(h->side);
+    h->chain_pending = 0;
+  }
+  return rc;
 }
 
 int jrlqp_dense_solve(jrlqp_dense * h, double * dG, int ldg, const double * da, const double * dC, int ldc, const double * dbl,

@@ -121,6 +121,16 @@ def test_blockgi_plan_validation_without_gpu(pkg):
     assert lib.jrlqp_blockgi_create(2, 70, I(*([60] * 70)), 1, I(4200), I(1), 0, 1, 10, ct.byref(h)) == -2  # n > 4096
     assert lib.jrlqp_blockgi_workspace_bytes(None) == -1
     assert lib.jrlqp_blockgi_solve(None, *([None] * 12), None, 0, None) == -1
+    # ABI 4: the form of the QR factors is AUTO (-1), SEQUENCE (0) or C9 (1); anything else is refused before the device is touched,
+    # and so are the same inconsistent shapes through the new entry point
+    for bad in (-2, 2, 7):
+        assert lib.jrlqp_blockgi_create_form(0, 2, I(3, 4), 2, I(3, 4), I(2, 2), 0, 1, 100, bad, ct.byref(h)) == -1
+    assert lib.jrlqp_blockgi_create_form(0, 2, I(3, 4), 2, I(3, 3), I(2, 2), 0, 1, 100, 1, ct.byref(h)) == -1
+    assert lib.jrlqp_blockgi_create_form(0, 2, I(3, 130), 2, I(3, 130), I(2, 2), 0, 1, 10, 1, ct.byref(h)) == -2
+    assert lib.jrlqp_blockgi_form(None) == -1
+    # the multi-device debug switches answer without a device
+    assert lib.jrlqp_debug_multi_allow_shared_device(0) == 0 and lib.jrlqp_debug_multi_inject_failure(-1) == 0
+    assert lib.jrlqp_gi_multi_failed_shard() == -1
 
 
 def test_product_does_not_touch_the_oracle():

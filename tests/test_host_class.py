@@ -146,3 +146,45 @@ def test_multiple_uses_no_allocation_and_parity(pkg, oracle, tmp_path):
     out = subprocess.run([exe, str(tmp_path / "problems.bin"), str(tmp_path / "results.bin")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "multiple uses OK" in out.stdout, out.stdout + out.stderr
     _check_results(open(tmp_path / "results.bin", "rb").read(), pbs, oracle)
+
+
+SRC_EIGEN = os.path.join(ROOT, "tests", "cpp", "test_eigen_adapter.cpp")
+
+
+def _eigen_include():
+    """-I flags of an installed Eigen (pkg-config, or the usual directories); [] where Eigen is absent -- no stand-in is ever written."""
+    try:
+        out = subprocess.run(["pkg-config", "--cflags-only-I", "eigen3"], capture_output=True, text=True)
+        if out.returncode == 0 and out.stdout.strip():
+            return out.stdout.split()
+    except OSError:
+        pass
+    for d in ("/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/homebrew/include/eigen3"):
+        if os.path.isfile(os.path.join(d, "Eigen", "Core")):
+            return ["-I" + d]
+    return []
+
+
+def test_eigen_adapter_header_is_inert_without_eigen(pkg, tmp_path):
+    """include/jrlqp/EigenAdapter.hpp must compile to nothing where Eigen is absent (guarded by __has_include) -- and to the front end
+    where it is present: the test program then links (CPU box) and, on a GPU box, solves the GI paper's example through it."""
+    import jrl_qp_amd.capi as capi
+
+    capi.load_library()
+    exe = str(tmp_path / "eigen_adapter")
+    inc = _eigen_include()
+    _build(exe, SRC_EIGEN, inc)
+    if not inc:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 77 and "SKIP" in out.stdout  # the header declared nothing: the program is the skip stub
+
+
+@pytest.mark.gpu
+def test_eigen_adapter_paper_example(pkg, tmp_path):
+    inc = _eigen_include()
+    if not inc:
+        pytest.skip("Eigen is not installed on this box")
+    exe = str(tmp_path / "eigen_adapter")
+    _build(exe, SRC_EIGEN, inc)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
