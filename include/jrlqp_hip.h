@@ -392,6 +392,14 @@ int jrlqp_dense_results(jrlqp_dense * h, double * x_host, double * u_host, int *
  * 128-129, 138, 153, 159): record `it` of trace_host (HOST memory, caller-owned, trace_cap records; NULL / 0 switches it off)
  * is written by pass `it` of the loop, exactly like dtrace of the batched entry points. */
 int jrlqp_dense_set_trace(jrlqp_dense * h, jrlqp_trace_rec * trace_host, int trace_cap);
+/* The VECTORS of the reference's per-pass log (LogFlags::ITERATION_BASIC_DETAILS: x, u, f at the top of a pass, DualSolver.cpp:108; z, r
+ * behind the step computation, :128-129), round 5.  Record `it` of vectors_host (HOST memory, caller-owned, `cap` records of
+ * jrlqp_dense_trace_vectors_stride(h) doubles; NULL / 0 switches it off) holds
+ *     x [n] | u [m+nb+1] (q + 1 entries valid, by POSITION in the active set) | z [n] | r [m+nb+1] (q valid) | f | q
+ * as they stand when pass `it` has computed its step and applied nothing yet.  A debugging aid: while it is on, every pass is
+ * synchronised and copied (no sweep or scan runs ahead of the decision); results are unchanged. */
+int jrlqp_dense_trace_vectors_stride(const jrlqp_dense * h);
+int jrlqp_dense_set_trace_vectors(jrlqp_dense * h, double * vectors_host, int cap);
 /* How the handle orders the kernels of a pass that run on different streams: 0 = device-side tags, 1 = events.  Decided at
  * creation (JRLQP_DENSE_SYNC=events|tags overrides) and switched to events for good by a solve whose tag
  * hand-off starved (the solve is then repeated with events and returns its normal result); *event_reruns counts those. */

@@ -61,6 +61,8 @@ EXPORTED = [
     "jrlqp_gi_multi_failed_shard",
     "jrlqp_debug_multi_allow_shared_device",
     "jrlqp_debug_multi_inject_failure",
+    "jrlqp_dense_trace_vectors_stride",
+    "jrlqp_dense_set_trace_vectors",
     "jrlqp_blockgi_create",
     "jrlqp_blockgi_create_form",
     "jrlqp_blockgi_form",
@@ -420,6 +422,26 @@ class DenseSolver:
 
     def trace_numpy(self, iters):
         return [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in self._trace[: min(iters, len(self._trace))]]
+
+    def set_trace_vectors(self, cap):
+        """x, u, z, r, f, q of every pass of the next solves (jrlqp_dense_set_trace_vectors): read back with trace_vectors(iters)."""
+        self.lib.jrlqp_dense_trace_vectors_stride.restype = ct.c_int
+        self.lib.jrlqp_dense_trace_vectors_stride.argtypes = [ct.c_void_p]
+        self.lib.jrlqp_dense_set_trace_vectors.restype = ct.c_int
+        self.lib.jrlqp_dense_set_trace_vectors.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int]
+        self._vstride = self.lib.jrlqp_dense_trace_vectors_stride(self.h)
+        self._vtrace = np.zeros((max(cap, 1), self._vstride)) if cap else None
+        check(self.lib.jrlqp_dense_set_trace_vectors(self.h, self._vtrace.ctypes.data_as(ct.c_void_p) if cap else None, cap))
+
+    def trace_vectors(self, iters):
+        """[dict(x, u, z, r, f, q)] per pass; u has q + 1 entries and r has q, by position in the active set."""
+        n, mt1 = self.n, self.m + self.nb + 1
+        out = []
+        for rec in self._vtrace[: min(iters, len(self._vtrace))]:
+            q = int(rec[2 * n + 2 * mt1 + 1])
+            out.append(dict(x=rec[:n].copy(), u=rec[n : n + q + 1].copy(), z=rec[n + mt1 : 2 * n + mt1].copy(),
+                            r=rec[2 * n + mt1 : 2 * n + mt1 + q].copy(), f=float(rec[2 * n + 2 * mt1]), q=q))
+        return out
 
     def sync_mode(self):
         """(mode, reruns): mode 0 = device-side tags, 1 = events; reruns = solves repeated with events after a starved hand-off."""

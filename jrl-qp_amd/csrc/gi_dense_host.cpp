@@ -47,6 +47,8 @@ struct jrlqp_dense
   int tag = 0;                         // pass counter: the step kernel echoes it into the mailbox when its scalars are out
   jrlqp_trace_rec * trace = nullptr;   // jrlqp_dense_set_trace: one record per pass of the library's loop (host memory, caller-owned)
   int trace_cap = 0;
+  double * vtrace = nullptr;           // jrlqp_dense_set_trace_vectors: x, u, z, r, f, q of every pass (host memory, caller-owned)
+  int vtrace_cap = 0;
   bool speculate_scan = true;          // ... and the next pass's constraint scan with it (blocked scan only)
   bool speculate = true;               // enqueue the sweep of an addition ahead of the decision (StepDev; JRLQP_DENSE_SPECULATE=0 switches it off)
   int inject_fault_pass = -1;          // jrlqp_debug_dense_inject_sync_fault: the pass whose first kernel waits for a tag nobody posts
@@ -452,6 +454,19 @@ int jrlqp_dense_init_active_set(jrlqp_dense * h, double big_bnd, int * term, int
   return JRLQP_OK;
 }
 
+int jrlqp_dense_trace_vectors_stride(const jrlqp_dense * h)
+{
+  return h ? 2 * h->n + 2 * (h->m + h->nb + 1) + 2 : -1;
+}
+
+int jrlqp_dense_set_trace_vectors(jrlqp_dense * h, double * vectors_host, int cap)
+{
+  if(!h || cap < 0 || (cap > 0 && !vectors_host)) return JRLQP_ERR_INVALID_ARGUMENT;
+  h->vtrace = cap ? vectors_host : nullptr;
+  h->vtrace_cap = cap;
+  return JRLQP_OK;
+}
+
 int jrlqp_dense_set_trace(jrlqp_dense * h, jrlqp_trace_rec * trace_host, int trace_cap)
 {
   if(!h || trace_cap < 0 || (trace_cap > 0 && !trace_host)) return JRLQP_ERR_INVALID_ARGUMENT;
@@ -727,7 +742,7 @@ attempt:
       // The sweep of an addition -- most passes add -- goes into the stream NOW, behind the step kernel and ahead of the decision:
       // it runs only if the device's own decision for this pass (StepDev) is "add", and then also advances x and u.  The GPU no
       // longer idles while the scalars travel to the host and the launches travel back.
-      speculated = h->speculate && !h->use_events && spec && q < n - 1;
+      speculated = h->speculate && !h->use_events && spec && q < n - 1 && !h->vtrace; // (a vector trace reads x and u of THIS pass: nothing may run ahead)
       if(speculated)
       {
         const bool more = h->it + 1 < o.max_iter;
@@ -778,6 +793,22 @@ attempt:
     const double t = (t2 < t1) ? t2 : t1;
     if(h->trace && h->it < h->trace_cap) // the reference logs every pass (DualSolver.cpp:116,128-129,138,153,159)
       h->trace[h->it] = jrlqp_trace_rec{p, pstat, l, (t2 >= big) ? 2 : ((t == t2) ? 0 : 1), t1, t2};
+    if(h->vtrace && h->it < h->vtrace_cap)
+    {
+      // the vectors the reference logs under ITERATION_BASIC_DETAILS: x, u, f at the top of the pass (DualSolver.cpp:108) and z, r
+      // behind the step computation (:128-129).  Nothing of this pass has been applied yet (no speculation while this trace is on).
+      const int mt1 = m + nb + 1, stride = 2 * n + 2 * mt1 + 2;
+      double * rec = h->vtrace + (size_t)h->it * stride;
+      TRY(hipStreamSynchronize(st));
+      TRY(hipMemcpy(rec, h->s.x, sizeof(double) * n, hipMemcpyDeviceToHost));
+      std::fill(rec + n, rec + n + mt1, 0.0);
+      TRY(hipMemcpy(rec + n, h->s.u, sizeof(double) * (q + 1), hipMemcpyDeviceToHost));
+      TRY(hipMemcpy(rec + n + mt1, h->s.z, sizeof(double) * n, hipMemcpyDeviceToHost));
+      std::fill(rec + 2 * n + mt1, rec + 2 * n + 2 * mt1, 0.0);
+      if(q) TRY(hipMemcpy(rec + 2 * n + mt1, h->s.r, sizeof(double) * q, hipMemcpyDeviceToHost));
+      rec[2 * n + 2 * mt1] = h->f;
+      rec[2 * n + 2 * mt1 + 1] = (double)q;
+    }
     if(speculated)
     {
       // the device took the same decision from the same scalars with the same operations; a disagreement would mean that the sweep in

@@ -74,6 +74,15 @@ static double zdot(int n, const double * a, const double * b)
 /* ------------------------------------------------------------------------------------------- */
 
 /* C1 dot product (Eigen dot/GEMV call sites: GoldfarbIdnaniSolver.cpp:73,97,183-190, ConstraintNormal.h:87-113) */
+/* optional per-pass vector trace of the NEXT orc_gi_solve calls of this thread (tests only; NULL / 0: off) */
+static __thread double * g_vtrace = NULL;
+static __thread int g_vtrace_cap = 0;
+void orc_set_vector_trace(double * buf, int cap)
+{
+  g_vtrace = cap > 0 ? buf : NULL;
+  g_vtrace_cap = cap > 0 ? cap : 0;
+}
+
 double orc_dot(int n, const double * a, const double * b)
 {
   double acc = 0.0;
@@ -1101,6 +1110,19 @@ main_loop:
       }
       double t = (t2 < t1) ? t2 : t1; /* std::min(t1, t2) (DualSolver.cpp:127) */
 
+      if(g_vtrace && it < g_vtrace_cap)
+      {
+        /* the vectors the reference logs per pass (DualSolver.cpp:108: x, u, f_; :128-129: z, r): as they stand behind the step
+         * computation, nothing of this pass applied yet -- the layout of jrlqp_dense_set_trace_vectors */
+        const int mt1 = m + nb + 1;
+        double * rec = g_vtrace + (long)it * (2 * n + 2 * mt1 + 2);
+        for(int i = 0; i < n; ++i) rec[i] = S.x[i];
+        for(int k = 0; k < mt1; ++k) rec[n + k] = (k <= q) ? S.u[k] : 0.0;
+        for(int i = 0; i < n; ++i) rec[n + mt1 + i] = S.z[i];
+        for(int k = 0; k < mt1; ++k) rec[2 * n + mt1 + k] = (k < q) ? S.r[k] : 0.0;
+        rec[2 * n + 2 * mt1] = S.f;
+        rec[2 * n + 2 * mt1 + 1] = (double)q;
+      }
       if(trace && it < trace_cap)
       {
         trace[it].p = p; trace[it].status = pstatus; trace[it].l = l; trace[it].t1 = t1; trace[it].t2 = t2;

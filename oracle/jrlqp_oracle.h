@@ -273,6 +273,10 @@ int orc_blockgi_solve(int type, int nblk, const int * bs, double ** diag, const 
                       double big_bnd, double * x, double * u, int * status, int * active, int * nactive, int * iters,
                       double * f, orc_trace_rec * trace, int trace_cap);
 
+/* per-pass vector trace of the calling thread's next orc_gi_solve calls: record `it` = x [n] | u [m+nb+1] | z [n] | r [m+nb+1] | f | q
+ * (the layout of jrlqp_dense_set_trace_vectors; the values the reference logs at DualSolver.cpp:108, :128-129).  NULL / 0: off. */
+void orc_set_vector_trace(double * buf, int cap);
+
 /* The same solver under contract C9 (round 5; blockgi_oracle.c): no orthonormal sequence -- the sparse columns B = L^-1 N of the active
  * constraints and S = R^-1 (inverse Cholesky factor of N^T G^-1 N), r and y = b - B r by the corrected semi-normal equations, S updated
  * by a bordered-inverse column on add and by C7 rotations of its columns on remove; reductions over whole vectors by structural block.

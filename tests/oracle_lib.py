@@ -116,6 +116,8 @@ class Oracle:
         L.orc_blockgi_solve.argtypes = [ct.c_int] + blk + [c_dp, ct.c_int, c_ip, c_ip, pp, c_ip, c_dp, c_dp, c_dp, c_dp, ct.c_int,
                                                            ct.c_int, ct.c_double, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp,
                                                            ct.POINTER(TraceRec), ct.c_int]
+        L.orc_set_vector_trace.restype = None
+        L.orc_set_vector_trace.argtypes = [ct.c_void_p, ct.c_int]
         L.orc_blockgi_solve_c9.restype = ct.c_int
         L.orc_blockgi_solve_c9.argtypes = L.orc_blockgi_solve.argtypes
         L.orc_dot_tree.restype = ct.c_double
@@ -165,6 +167,26 @@ class Oracle:
                                          ct.byref(f), tr, trace_cap, None)
         trace = [(t.p, t.status, t.l, t.kind, t.t1, t.t2) for t in tr[: min(trace_cap, iters.value)]]
         return OracleResult(term, x, u, status, active[: nact.value].copy(), iters.value, f.value, trace, Gf)
+
+    def solve_with_vectors(self, G, a, C, bl, bu, xl=None, xu=None, cap=64, **kw):
+        """solve() with the per-pass vector trace on: returns (result, [dict(x, u, z, r, f, q)] per pass) -- the values the reference
+        logs under ITERATION_BASIC_DETAILS (DualSolver.cpp:108, :128-129), in the layout of jrlqp_dense_set_trace_vectors."""
+        C = np.asarray(C)
+        n, m = np.asarray(G).shape[0], (C.shape[1] if C.ndim == 2 and C.size else 0)  # C is n x m: one constraint per column
+        nb = 0 if xl is None else len(xl)
+        mt1 = m + nb + 1
+        buf = np.zeros((cap, 2 * n + 2 * mt1 + 2))
+        self.lib.orc_set_vector_trace(buf.ctypes.data_as(ct.c_void_p), cap)
+        try:
+            r = self.solve(G, a, C, bl, bu, xl, xu, **kw)
+        finally:
+            self.lib.orc_set_vector_trace(None, 0)
+        out = []
+        for rec in buf[: min(cap, r.iters)]:
+            q = int(rec[2 * n + 2 * mt1 + 1])
+            out.append(dict(x=rec[:n].copy(), u=rec[n : n + q + 1].copy(), z=rec[n + mt1 : 2 * n + mt1].copy(),
+                            r=rec[2 * n + mt1 : 2 * n + mt1 + q].copy(), f=float(rec[2 * n + 2 * mt1]), q=q))
+        return r, out
 
     def box_solve(self, x0, c, bl, xl, xu, max_iter=500, big_bnd=1e100, trace_cap=0) -> OracleResult:
         """experimental::BoxAndSingleConstraintSolver::solve(x0, c, bl, xl, xu): closed-form init_, then the GI loop."""

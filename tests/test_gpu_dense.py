@@ -329,6 +329,45 @@ def test_dense_trace_matches_oracle(capi, P, oracle):
         check(r2, ref, f"problem {b}, trace off")
 
 
+def test_dense_vector_trace_matches_oracle(capi, P, oracle):
+    """jrlqp_dense_set_trace_vectors (round 5): x, u, f at the top of every pass and z, r behind its step computation -- what the
+    reference logs under LogFlags::ITERATION_BASIC_DETAILS (DualSolver.cpp:108, :128-129) -- bit for bit the oracle's, pass by pass; and
+    the solve's results are those of an untraced solve (the trace only synchronises)."""
+    import jrl_qp_amd.trace as T
+
+    ch = P.Characteristics(nVar=60, nObj=60, nEq=4, nIneq=120, nStrongActIneq=18, bounds=True, nStrongActBounds=5, doubleSidedIneq=True)
+    pb = P.generate_batch(1, ch, first_index=5150)
+    ref, vec = oracle.solve_with_vectors(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], pb.xl[0], pb.xu[0], cap=400, trace_cap=400)
+    s = capi.DenseSolver(pb.n, pb.m, True)
+    s.set_trace(400)
+    s.set_trace_vectors(400)
+    r = s.solve(*_torch_problem(pb, 0, True))
+    check(r, ref, "vector trace on")
+    got = s.trace_vectors(r["iters"])
+    assert len(got) == len(vec) == ref.iters > 10
+    for it, (g, o) in enumerate(zip(got, vec)):
+        assert g["q"] == o["q"] and g["f"] == o["f"], it
+        for k in ("x", "u", "z", "r"):
+            assert np.array_equal(g[k], o[k]), (it, k)
+    txt = T.to_matlab(s.trace_numpy(r["iters"]), name="gi", vectors=got)
+    assert "gi(1).x = [" in txt and "gi(3).z = [" in txt and "gi(3).r = [" in txt and txt.count(".f = ") == ref.iters
+    s.set_trace_vectors(0)
+    check(s.solve(*_torch_problem(pb, 0, True)), ref, "vector trace off")
+    # beyond 256 unknowns (the blocked scan that otherwise runs ahead of the decision)
+    ch = P.Characteristics(nVar=300, nObj=300, nIneq=330, nStrongActIneq=40)
+    pb = P.generate_batch(1, ch, first_index=77)
+    ref, vec = oracle.solve_with_vectors(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], cap=8)
+    s = capi.DenseSolver(pb.n, pb.m, False)
+    s.set_trace_vectors(8)
+    r = s.solve(*_torch_problem(pb, 0, False))
+    check(r, ref, "vector trace, n = 300")
+    got = s.trace_vectors(r["iters"])
+    assert len(got) == 8
+    for it, (g, o) in enumerate(zip(got, vec)):
+        for k in ("x", "u", "z", "r"):
+            assert np.array_equal(g[k], o[k]), (it, k)
+
+
 def test_dense_no_constraint_twice_on_one_handle(capi, P, oracle):
     """m = 0 and nb = 0 beyond the batched sizes: nothing is selected, so no kernel of a pass may be left waiting for a tag nobody
     posts (round 3's review: the side-stream chain and z spun for a second and poisoned the next solve).  Two solves in a row."""
