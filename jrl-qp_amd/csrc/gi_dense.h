@@ -67,6 +67,9 @@ struct DenseViews
 struct DenseState
 {
   double *J, *R, *d, *z, *x, *u, *r, *cc, *ss;
+  double * Ptri;  // CANON C10: the tile sums of r = S d1 when they do not fit in LDS (nseg (nseg + 1) / 2 tiles of 64)
+  double *S, *S2; // CANON C10 (capacity of more than 256 unknowns): S = R^-1 beside R (ld n, like R), and the buffer a removal writes the
+                  // new S into (the two swap roles); nullptr otherwise
   double *cc2, *ss2, *rfin; // output of a coefficient chain run ahead of the add/drop decision (its own buffers: a drop
                             // writes cc/ss on the main stream while a discarded chain may still be running)
   unsigned char * st; // activation status per constraint / bound

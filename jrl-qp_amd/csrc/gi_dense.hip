@@ -56,9 +56,11 @@ __device__ __forceinline__ void wave_argmin(double & val, int & idx, int & aux)
 __device__ unsigned long long g_rotprof[32];
 #define ROTP(slot, expr) do { if(blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_rotprof[slot], (unsigned long long)(expr)); } while(0)
 #define ROTT() wall_clock64()
+#define ROTQ(slot, expr) do { if(threadIdx.x == 0) atomicAdd(&g_rotprof[slot], (unsigned long long)(expr)); } while(0)
 #else
 #define ROTP(slot, expr) do { (void)sizeof(expr); } while(0)
 #define ROTT() 0ull
+#define ROTQ(slot, expr) do { (void)sizeof(expr); } while(0)
 #endif
 // ---- pass hand-off tags (PassSync, gi_dense.h) -----------------------------------------------------------------------------
 // Whole workgroup.  The wait gives up after ~1 s (a producer that never ran: a dead stream), says so in the host-visible mailbox
@@ -834,12 +836,52 @@ __device__ __forceinline__ double blk_tree_n(const double * P, int ldp, int nseg
     for(int i = 0; i < SL; i += 2 * h) p[i] = p[i] + p[i + h];
   return p[0];
 }
+// The C8 tree over the segment sums of row-chunk c of a triangular product (CANON C10: step_tail_kernel): slot s holds Pc[64 s] for
+// c <= s < nseg and +0 otherwise
+template<int SL>
+__device__ __forceinline__ double tri_tree(const double * Pc, int c, int nseg)
+{
+  double p[SL];
+#pragma unroll
+  for(int t = 0; t < SL; ++t) p[t] = Pc[(size_t)min(max(t, c), nseg - 1) * 64];
+#pragma unroll
+  for(int t = 0; t < SL; ++t) p[t] = (t >= c && t < nseg) ? p[t] : 0.0;
+#pragma unroll
+  for(int h = 1; h < SL; h <<= 1)
+#pragma unroll
+    for(int i = 0; i < SL; i += 2 * h) p[i] = p[i] + p[i + h];
+  return p[0];
+}
 __device__ __forceinline__ double blk_tree(const double * P, int ldp, int nseg, int o)
 {
   if(nseg <= 8) return blk_tree_n<8>(P, ldp, nseg, o);
   if(nseg <= 16) return blk_tree_n<16>(P, ldp, nseg, o);
   if(nseg <= 32) return blk_tree_n<32>(P, ldp, nseg, o);
   return blk_tree_n<64>(P, ldp, nseg, o);
+}
+// two outputs at once, the loads of both in flight together (the step kernel's z: one latency instead of two)
+template<int SL>
+__device__ __forceinline__ void blk_tree2_n(const double * P, int ldp, int nseg, int o0, int o1, double & r0, double & r1)
+{
+  double p[SL], w[SL];
+#pragma unroll
+  for(int t = 0; t < SL; ++t) p[t] = P[(size_t)min(t, nseg - 1) * ldp + o0];
+#pragma unroll
+  for(int t = 0; t < SL; ++t) w[t] = P[(size_t)min(t, nseg - 1) * ldp + o1];
+#pragma unroll
+  for(int t = 0; t < SL; ++t) p[t] = (t < nseg) ? p[t] : 0.0;
+#pragma unroll
+  for(int t = 0; t < SL; ++t) w[t] = (t < nseg) ? w[t] : 0.0;
+#pragma unroll
+  for(int h = 1; h < SL; h <<= 1)
+#pragma unroll
+    for(int i = 0; i < SL; i += 2 * h)
+    {
+      p[i] = p[i] + p[i + h];
+      w[i] = w[i] + w[i + h];
+    }
+  r0 = p[0];
+  r1 = w[0];
 }
 // d = +-(tree of the segment sums), 64 outputs per workgroup (one wave); psel != nullptr: sign and "is there a general constraint at
 // all" from the selection on the device; publishes d_tag like jtn_kernel.  Also the combine of z (plain: sign 1, no psel).
@@ -1198,7 +1240,8 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
                                                         int m = 0, int tag = 0, const PassSync * zsync = nullptr, int wait_z = 0,
                                                         StepDev * sd = nullptr, const double * gbl = nullptr, const double * gbu = nullptr,
                                                         const double * gxl = nullptr, const double * gxu = nullptr, const double * Pz = nullptr,
-                                                        int ldpz = 0, int nsegz = 0, double * zout = nullptr, PassSync * dsync = nullptr, int post_d = 0)
+                                                        int ldpz = 0, int nsegz = 0, double * zout = nullptr, PassSync * dsync = nullptr, int post_d = 0,
+                                                        const double * __restrict__ Sinv = nullptr, double * Pg = nullptr)
 {
   extern __shared__ double rs[]; // block 0: the running right-hand side (q) ; block 1: z | x | n+ (3 n)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1241,6 +1284,20 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
   // The decision on the device (StepDev, gi_dense.h): called by the ONE thread of each workgroup that has just written that
   // workgroup's scalars; the second to arrive has both halves and forms t2, t and the kind of step exactly as the host does
   // (gi_dense_host.cpp; DualSolver.cpp:127-151; GoldfarbIdnaniSolver.cpp:174-218).
+  // (the bound the decision compares with: fetched by the deciding lanes while the workgroup computes, not behind the hand-shake)
+  double bsel = 0.0;
+  if(sd && psel && tid == 0)
+  {
+    const int p = psel[0], ps = psel[1];
+    if(ps == LOWER || ps == EQUALITY)
+      bsel = gbl[p];
+    else if(ps == UPPER)
+      bsel = gbu[p];
+    else if(ps == LOWER_BOUND || ps == FIXED)
+      bsel = gxl[p - m];
+    else
+      bsel = gxu[p - m];
+  }
   auto decide = [&]() {
     if(!sd || !psel) return;
     __threadfence();
@@ -1248,18 +1305,9 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
     if(old != 1) return;
     __hip_atomic_store(&sd->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const int p = psel[0], ps = psel[1];
     const volatile StepDev * sv = sd; // (behind the acquire fence: the other workgroup's half, out of L2)
     const double t1v = sv->t1, zzv = sv->zz, czv = sv->cz, cxv = sv->cx;
-    double b;
-    if(ps == LOWER || ps == EQUALITY)
-      b = gbl[p];
-    else if(ps == UPPER)
-      b = gbu[p];
-    else if(ps == LOWER_BOUND || ps == FIXED)
-      b = gxl[p - m];
-    else
-      b = gxu[p - m];
+    const double b = bsel;
     double t2v = big;
     if(__builtin_sqrt(zzv) > 1e-14) t2v = (b - cxv) / czv;
     const double tv = (t2v < t1v) ? t2v : t1v;
@@ -1279,6 +1327,7 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
     double * zl = rs;
     double * xl = rs + n;
     double * cl = xl + npad;
+    const unsigned long long tb0 = ROTT();
     for(int i = tid; i < n; i += 512)
     {
       xl[pd(i)] = x[i];
@@ -1347,19 +1396,43 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
       if(sd) sd->cx = acc;
     }
     if(zsync && wait_z) flag_wait(&zsync->z_tag, wait_z, mb);
+    const unsigned long long tb1 = ROTT();
     if(Pz)
     {
       // CANON C8: z_blk_kernel (ahead of this kernel in the stream) left the segment sums of z: the tree here, z itself for the update
-      for(int i = tid; i < n; i += 512)
+      if(nsegz <= 32)
       {
-        const double zi = blk_tree(Pz, ldpz, nsegz, i);
-        zl[i] = zi;
-        zout[i] = zi;
+        // (two rows per thread and trip, their 2 nseg loads in flight together: the segment sums come from the other XCDs' kernel --
+        // memory, not L2 -- and a trip costs one such latency; measured 7.7 us of the 15 us of this workgroup with one row per trip)
+        for(int i0 = tid; i0 < n; i0 += 1024)
+        {
+          const int i1 = i0 + 512, i1c = min(i1, n - 1);
+          double z0, z1;
+          if(nsegz <= 16)
+            blk_tree2_n<16>(Pz, ldpz, nsegz, i0, i1c, z0, z1);
+          else
+            blk_tree2_n<32>(Pz, ldpz, nsegz, i0, i1c, z0, z1);
+          zl[i0] = z0;
+          zout[i0] = z0;
+          if(i1 < n)
+          {
+            zl[i1] = z1;
+            zout[i1] = z1;
+          }
+        }
       }
+      else
+        for(int i = tid; i < n; i += 512)
+        {
+          const double zi = blk_tree(Pz, ldpz, nsegz, i);
+          zl[i] = zi;
+          zout[i] = zi;
+        }
     }
     else
       for(int i = tid; i < n; i += 512) zl[i] = z[i];
     __syncthreads();
+    const unsigned long long tb2 = ROTT();
     // z.z and n+.z: C4 trees (CANON C5, oracle orc_dot_tree): element e joins chain e mod 1024, thread t owns chains 2t and
     // 2t + 1 (ascending e), then the adjacent-first pairwise tree -- the two chains of a thread, the lanes of a wave
     // (wave_sum_tree), the eight waves.
@@ -1402,13 +1475,112 @@ __global__ __launch_bounds__(512) void step_tail_kernel(const double * __restric
         sd->zz = zzv;
         sd->cz = czv;
       }
+      const unsigned long long tb3 = ROTT();
       decide();
+      ROTQ(27, ROTT() - tb3);
     }
+    const unsigned long long tb4 = ROTT();
     post_tag(); // (wave 0 of block 1 wrote the three scalars; thread 0 is one of its lanes)
+    ROTQ(24, 1);
+    ROTQ(25, tb1 - tb0);
+    ROTQ(26, tb2 - tb1);
+    ROTQ(28, tb4 - tb2);
+    ROTQ(29, ROTT() - tb4);
     return;
   }
 
+  const unsigned long long ta0 = ROTT();
   for(int i = tid; i < q; i += 512) rs[i] = d[i];
+  if(Sinv)
+  {
+    // CANON C10 (more than kBlockN unknowns; oracle compute_step): r = S d1 with S = R^-1 kept beside R.  Row i is a blocked product in
+    // the manner of C8 over its terms k = i .. q-1: the columns in segments of 64 by absolute index, a segment's chain ascending from
+    // max(64 s, i), the segment sums combined by the tree.  The blocked substitution below is q dependent steps behind two barriers
+    // per 64 columns (21.7 us of a 78 us pass at c2, q ~ 300); here a (row chunk c, segment s >= c) tile is 64 independent chains of 64
+    // terms, lane = row, its 64 loads in flight at once, and the tiles go round the eight waves.  The tile sums: P[tile][lane], tiles
+    // numbered row chunk by row chunk -- in LDS while they fit, in the workspace Pg beyond (q > ~1100: generic pointer).
+    const int nsg = (q + 63) >> 6, ntile = nsg * (nsg + 1) / 2;
+    double * ro = rs + 64 * nsg; // (the result; d padded to whole segments: the entries beyond q are read and never used)
+    double * P = Pg ? Pg : ro + q;
+    lds_barrier();
+    {
+      int c = 0, off = 0; // tile t = off(c) + (s - c), off(c) = the tiles of the row chunks above c
+      for(int t = wave; t < ntile; t += 8)
+      {
+        while(t >= off + nsg - c)
+        {
+          off += nsg - c;
+          ++c;
+        }
+        const int sg = c + (t - off);
+        const int i = 64 * c + lane, ic = min(i, q - 1), k0 = 64 * sg, kmax = min(64, q - k0);
+        const double * base = Sinv + ic + (size_t)k0 * ld;
+        double a[64];
+#pragma unroll
+        for(int e = 0; e < 64; ++e) a[e] = base[(size_t)min(e, kmax - 1) * ld]; // (clamped, not predicated: every load in flight at once)
+        double acc = 0.0;
+        if(sg > c && kmax == 64)
+        {
+#pragma unroll
+          for(int e = 0; e < 64; ++e) acc = FMA(a[e], rs[k0 + e], acc);
+        }
+        else
+        {
+#pragma unroll
+          for(int e = 0; e < 64; ++e)
+          {
+            const double nx = FMA(a[e], rs[k0 + e], acc);
+            acc = (k0 + e >= i && e < kmax) ? nx : acc;
+          }
+        }
+        P[(size_t)t * 64 + lane] = acc;
+      }
+    }
+    if(Pg) __threadfence();
+    lds_barrier();
+    for(int i = tid; i < q; i += 512)
+    {
+      const int c = i >> 6;
+      const double * Pc = P + ((size_t)(c * nsg - c * (c - 1) / 2) - c) * 64 + (i & 63); // + 64 s: the sum of tile (c, s)
+      ro[i] = (nsg <= 8) ? tri_tree<8>(Pc, c, nsg) : (nsg <= 16) ? tri_tree<16>(Pc, c, nsg) : (nsg <= 32) ? tri_tree<32>(Pc, c, nsg) : tri_tree<64>(Pc, c, nsg);
+    }
+    lds_barrier();
+    if(wave != 0) return;
+    const unsigned long long ta1 = ROTT();
+    double tk = big;
+    int kk = NONE, dummy = 0;
+    for(int k = lane; k < q; k += 64)
+    {
+      double rv = ro[k];
+      r[k] = rv;
+      int sk = st[k];
+      if(sk != EQUALITY && sk != FIXED && rv > 0.0)
+      {
+        double tt = u[k] / rv;
+        if(tt < tk)
+        {
+          tk = tt;
+          kk = k;
+        }
+      }
+    }
+    wave_argmin(tk, kk, dummy);
+    if(lane == 0)
+    {
+      const double t1v = (kk == NONE) ? big : tk;
+      mb->t1 = t1v;
+      mb->l = (kk == NONE) ? 0 : kk;
+      mb->uq = u[q];
+      if(sd) sd->t1 = t1v;
+      decide();
+    }
+    const unsigned long long ta2 = ROTT();
+    post_tag();
+    ROTQ(21, ta1 - ta0);
+    ROTQ(22, ta2 - ta1);
+    ROTQ(23, ROTT() - ta2);
+    return;
+  }
   const int nblk = (q + 63) >> 6;
   // One block of R per wave in 64 statically indexed registers, lane = row.  wave 0: the diagonal block it solves next,
   // blk[k] = R(kb + lane, kb + k), and dg = its pivot; waves 1-7: the tile they advance their row block through
@@ -1662,14 +1834,17 @@ __global__ __launch_bounds__(CHAIN_THREADS) void add_chain_kernel(int n, int q, 
 
 // K10 part 1b: R(:, q) = d(0:q) with the new diagonal; status byte of the activated constraint (GoldfarbIdnaniSolver.cpp:233)
 __global__ __launch_bounds__(256) void add_commit_kernel(int q, const double * d, const double * rfin, double * R, int ld, unsigned char * st, int p,
-                                                         int pstat, const PassSync * sync = nullptr, int wait_chain = 0, Mailbox * mb = nullptr)
+                                                         int pstat, const PassSync * sync = nullptr, int wait_chain = 0, Mailbox * mb = nullptr,
+                                                         double * S = nullptr, const double * r = nullptr)
 {
   if(sync && wait_chain) flag_wait(&sync->chain_tag, wait_chain, mb); // rfin comes from the chain on the side stream
   const int k = blockIdx.x * 256 + threadIdx.x;
   if(k < q) AT(R, ld, k, q) = d[k];
+  if(S && k < q) AT(S, ld, k, q) = -(r[k] / *rfin); // CANON C10
   if(k == q)
   {
     AT(R, ld, q, q) = *rfin;
+    if(S) AT(S, ld, q, q) = 1.0 / *rfin;
     st[p] = (unsigned char)pstat;
   }
 }
@@ -1892,6 +2067,8 @@ struct CommitArgs
   const PassSync * sync; // wait_chain != 0: (c_i, s_i) and rfin come from the chain on the side stream (PassSync::chain_tag)
   int wait_chain;
   Mailbox * mb;
+  double * S = nullptr;       // CANON C10: S = R^-1 gets the column [-r / rho; 1 / rho] (r: this pass's S d1)
+  const double * r = nullptr;
 };
 // The sweep enqueued AHEAD of the add / drop decision (StepDev, gi_dense.h): it runs only if the device's decision for pass `tag` is
 // "add", takes (p, status) from psel and t from StepDev, and does the primal / dual update itself -- workgroup g advances its 64
@@ -1934,6 +2111,12 @@ __global__ __launch_bounds__(ROT_THREADS) void rot_apply_kernel(double * J, int 
   if(cm.d && blockIdx.x == 0)
   {
     for(int k = threadIdx.x; k < cm.q; k += ROT_THREADS) AT(cm.R, cm.ld, k, cm.q) = cm.d[k];
+    if(cm.S)
+    {
+      const double rho = *cm.rfin;
+      for(int k = threadIdx.x; k < cm.q; k += ROT_THREADS) AT(cm.S, cm.ld, k, cm.q) = -(cm.r[k] / rho);
+      if(threadIdx.x == 0) AT(cm.S, cm.ld, cm.q, cm.q) = 1.0 / rho;
+    }
     if(threadIdx.x == 0)
     {
       AT(cm.R, cm.ld, cm.q, cm.q) = *cm.rfin;
@@ -1959,6 +2142,91 @@ __global__ __launch_bounds__(ROT_THREADS) void rot_apply_kernel(double * J, int 
     ROTP(2, ROTT() - tk2); // the sweep, as the chain wave sees it
     ROTP(3, 1);            // launches
   }
+}
+
+// CANON C10, removal: S' = (S G) without row l and without its last column, G the rotations remove_r_kernel has just generated
+// (cc[i], ss[i], i = l .. q-2, on columns (i, i + 1): the rotation J takes too -- (G^T R)^-1 = S G).  Every row is a chain of its own:
+// lane = NEW row r' (old row r = r' + (r' >= l)), carried value x = S(r, i), next y = S(r, i + 1); a row below l meets its first
+// rotation, i = r - 1, with a structural zero for x.  The new S is written into the OTHER buffer (a row below l moves up by one: in
+// place it would overwrite what the lane of the row above still reads); the host swaps the two buffers afterwards.
+// grid (row groups of 64, 2): y = 0 rotates -- the (c, s) pairs staged in LDS, 64 entries of the row requested together (a chain of q - l
+// steps with one memory round trip per 64) --, y = 1 copies the columns left of l, which no rotation touches.
+__global__ __launch_bounds__(64) void remove_s_kernel(const double * __restrict__ S, double * __restrict__ S2, int ld, int q, int l,
+                                                      const double * __restrict__ cc, const double * __restrict__ ss)
+{
+  extern __shared__ double2 cs_l[]; // (c, s) of rotation l + t
+  const int lane = threadIdx.x;
+  const int r2 = blockIdx.x * 64 + lane; // new row
+  if(blockIdx.y == 1)
+  {
+    // rows above l: columns r .. l - 1 as they are
+    if((int)blockIdx.x * 64 >= l) return;
+    const int r = min(r2, l - 1);
+    for(int j0 = blockIdx.x * 64; j0 < l; j0 += 32)
+    {
+      double v[32];
+#pragma unroll
+      for(int e = 0; e < 32; ++e) v[e] = AT(S, ld, r, min(j0 + e, l - 1));
+#pragma unroll
+      for(int e = 0; e < 32; ++e)
+        if(r2 < l && j0 + e >= r2 && j0 + e < l) AT(S2, ld, r2, j0 + e) = v[e];
+    }
+    return;
+  }
+  const int nrot = q - l - 1;
+  for(int t = lane; t < nrot; t += 64) cs_l[t] = make_double2(cc[l + t], ss[l + t]);
+  wave_sync();
+  if(nrot <= 0) return;
+  const bool live = r2 < q - 1;
+  const int r2c = min(r2, q - 2);
+  const int r = r2c + (r2c >= l ? 1 : 0); // old row
+  const int t0 = (r < l) ? 0 : r - l - 1;
+  double carry = (r < l) ? AT(S, ld, r, l) : 0.0;
+  const double * yrow = S + r + (size_t)(l + 1) * ld; // y of rotation t: yrow[t * ld]
+  double * orow = S2 + r2c + (size_t)l * ld;          // its output: orow[t * ld]
+  for(int tb = __builtin_amdgcn_readfirstlane(t0); tb < nrot; tb += 64) // (t0 grows with the lane: lane 0 starts first)
+  {
+    double y[64];
+#pragma unroll
+    for(int e = 0; e < 64; ++e) y[e] = yrow[(size_t)min(tb + e, nrot - 1) * ld];
+#pragma unroll
+    for(int e = 0; e < 64; ++e)
+    {
+      const int tt = tb + e;
+      const double2 cs = cs_l[min(tt, nrot - 1)];
+      const double out = FMA(-cs.y, y[e], cs.x * carry);
+      const double nc = FMA(cs.y, carry, cs.x * y[e]);
+      const bool on = live && tt >= t0 && tt < nrot;
+      if(on) orow[(size_t)tt * ld] = out;
+      carry = on ? nc : carry;
+    }
+  }
+}
+
+// CANON C10, warm start: S = R^-1 of the QR factor (oracle gi_solve_impl).  One workgroup per column j solves R s = e_j by column-oriented
+// back substitution in LDS: s_j = 1 / R(j,j); once s_k is final every row above adds its term, acc_i = fma(R(i,k), s_k, acc_i) (row i's
+// chain runs over k = j .. i + 1, descending, from +0 -- the oracle's order), and s_{k-1} = -acc_{k-1} / R(k-1,k-1).  Column k of R is
+// read coalesced; one barrier per step, the q columns side by side on q workgroups.
+__global__ __launch_bounds__(256) void invert_upper_kernel(const double * __restrict__ R, double * __restrict__ S, int ld, int q)
+{
+  extern __shared__ double col[]; // acc_i until row i is final, s_i afterwards
+  const int j = blockIdx.x, tid = threadIdx.x;
+  if(j >= q) return;
+  for(int i = tid; i < j; i += 256) col[i] = 0.0;
+  if(tid == 0) col[j] = 1.0 / AT(R, ld, j, j);
+  __syncthreads();
+  for(int k = j; k >= 1; --k)
+  {
+    const double sk = col[k];
+    for(int i = tid; i < k; i += 256)
+    {
+      double a = FMA(AT(R, ld, i, k), sk, col[i]);
+      if(i == k - 1) a = (-a) / AT(R, ld, k - 1, k - 1);
+      col[i] = a;
+    }
+    __syncthreads();
+  }
+  for(int i = tid; i <= j; i += 256) AT(S, ld, i, j) = col[i];
 }
 
 // K11 part 1 (one workgroup; thread tid owns the NEW columns tid + u * blockDim.x, u < NC, of R): delete column l of R,
@@ -2002,13 +2270,21 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
     // (16 entries of the row requested together, then stored one column to the left: one memory round trip per 16
     // columns instead of one per column; across threads every access is coalesced)
     int k = l;
-    for(; k + 16 <= qn; k += 16)
+    for(; k + 24 <= qn; k += 24)
     {
-      double v[16];
+      double v[24];
 #pragma unroll
-      for(int e = 0; e < 16; ++e) v[e] = AT(R, ld, rr, k + 1 + e);
+      for(int e = 0; e < 24; ++e) v[e] = AT(R, ld, rr, k + 1 + e);
 #pragma unroll
-      for(int e = 0; e < 16; ++e) AT(R, ld, rr, k + e) = v[e];
+      for(int e = 0; e < 24; ++e) AT(R, ld, rr, k + e) = v[e];
+    }
+    for(; k + 8 <= qn; k += 8)
+    {
+      double v[8];
+#pragma unroll
+      for(int e = 0; e < 8; ++e) v[e] = AT(R, ld, rr, k + 1 + e);
+#pragma unroll
+      for(int e = 0; e < 8; ++e) AT(R, ld, rr, k + e) = v[e];
     }
     for(; k < qn; ++k) AT(R, ld, rr, k) = AT(R, ld, rr, k + 1);
   }
@@ -2017,7 +2293,9 @@ __global__ __launch_bounds__(1024) void remove_r_kernel(double * R, int ld, int 
   // rotations are requested ahead -- clamped addresses, no predicate -- and the per-rotation hand-off of (c, s) goes
   // through LDS behind LDS-only barriers (a __syncthreads() would drain the prefetches at every step).  A thread only
   // ever rewrites entries of its own columns that it has already consumed.
-  constexpr int PF = 4;
+  // (round 5: 12 rows ahead with one column per thread -- a rotation's store is in the same in-order queue as the prefetches, the row
+  // requested four rotations ago was only there once the stores of the rotations between had been acknowledged: ~0.4 us a rotation)
+  constexpr int PF = (NC == 1) ? 12 : 4;
   int colr[NC]; // old column read for slot w (clamped for the slots without a column)
   double yq[NC][PF];
 #pragma unroll
@@ -2298,10 +2576,23 @@ static size_t tile_lds(int n)
 {
   return sizeof(double) * (size_t)(n + (n & 1) + TS_NS * TS_SLOT); // the vector | the tile slots (jtn, select_partial)
 }
+// CANON C10: do the tile sums of r = S d1 fit in LDS beside d1 and r?  (otherwise: DenseState::Ptri)
+static bool tail_tiles_in_lds(int q)
+{
+  const size_t nsg = (size_t)(q + 63) >> 6;
+  return sizeof(double) * (64 * nsg + q + 2 + nsg * (nsg + 1) / 2 * 64) <= 96 * 1024;
+}
 static size_t tail_lds(int n, int q)
 {
   const int b1 = 3 * n + 2 * ((n >> 6) + 1) + 16; // block 1: z | x | n+ (the two padded, one entry per 64) | the per-wave partial sums of the two C4 trees
-  return sizeof(double) * (size_t)((b1 > q + 2) ? b1 : q + 2);
+  size_t b0 = (size_t)q + 2;
+  if(n > kBlockN) // CANON C10: d1 padded to whole segments | r | the tile sums while they fit
+  {
+    const size_t nsg = (size_t)(q + 63) >> 6;
+    b0 = 64 * nsg + q + 2;
+    if(tail_tiles_in_lds(q)) b0 += nsg * (nsg + 1) / 2 * 64;
+  }
+  return sizeof(double) * ((size_t)b1 > b0 ? (size_t)b1 : b0);
 }
 // Dynamic LDS beyond the default 64 KiB (step_tail: three n-vectors, n > 2730; rot_apply: the (c, s) pairs of a sweep,
 // more than ~1900 rotations; add_chain: the third vector of the seeded recurrence): the limit is raised once, to the
@@ -2330,7 +2621,8 @@ static hipError_t raise_lds(K kernel, LdsRaised & done, size_t need)
 static hipError_t tail_attr(int n)
 {
   static LdsRaised done;
-  return raise_lds(&step_tail_kernel, done, tail_lds(n, 0));
+  const size_t need = tail_lds(n, 0); // (block 1; block 0 of CANON C10 takes up to 96 KiB: tail_tiles_in_lds)
+  return raise_lds(&step_tail_kernel, done, (n > kBlockN && need < 96 * 1024) ? 96 * 1024 : need);
 }
 static hipError_t tile_attr(int n) // (n > ~1800: the vector and six slots pass the default 64 KiB)
 {
@@ -2462,6 +2754,8 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   const bool zs = zside && tag && !events && !no_producer && !(v.n > kBlockN); // z = J2 d2 on its own stream, beside the substitution (both only need d)
   const bool blk_early = v.n > kBlockN;
   // d_tag is published for whoever runs beside the main stream; blocked d (n > 256): by the step kernel, once z_blk_kernel has combined d
+  // (round 5: posted by the row-group-0 workgroups of z_blk_kernel itself, one kernel earlier -- their 16 agent-scope releases made that
+  // kernel 4.2 -> 8.1 us and the sweep waited no less: the chain was never late)
   const int dpost_any = (!events && (chain || zs)) ? tag : 0;
   const int dpost = blk_early ? 0 : dpost_any;
   if(events) wait_sel_tag = wait_chain_tag = 0;
@@ -2554,11 +2848,13 @@ hipError_t dense_step(const DenseViews & v, DenseState & s, int p, int pstat, in
   if(dev_p)
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x,
                        nullptr, 0, s.mb, s.psel, v.C, v.ldc, v.m, tag, s.sync, zs ? tag : 0, s.sd, v.bl, v.bu, v.xl, v.xu, blk ? s.partZ : nullptr, s.ldpJ, nseg,
-                       s.z, blk ? s.sync : nullptr, blk ? dpost_any : 0);
+                       s.z, blk ? s.sync : nullptr, blk ? dpost_any : 0, (n > kBlockN) ? s.S : nullptr,
+                       (n > kBlockN && !tail_tiles_in_lds(q)) ? s.Ptri : nullptr);
   else
     hipLaunchKernelGGL(step_tail_kernel, dim3(2), dim3(512), tail_lds(n, q), st, s.R, n, n, q, s.d, s.r, s.u, s.st, big, s.z, s.x, cp,
                        p - v.m, s.mb, nullptr, nullptr, 0, 0, tag, s.sync, zs ? tag : 0, nullptr, nullptr, nullptr, nullptr, nullptr, blk ? s.partZ : nullptr,
-                       s.ldpJ, nseg, s.z, blk ? s.sync : nullptr, blk ? dpost_any : 0);
+                       s.ldpJ, nseg, s.z, blk ? s.sync : nullptr, blk ? dpost_any : 0, (n > kBlockN) ? s.S : nullptr,
+                       (n > kBlockN && !tail_tiles_in_lds(q)) ? s.Ptri : nullptr);
   return hipGetLastError();
 }
 
@@ -2586,9 +2882,10 @@ hipError_t dense_add(const DenseViews & v, DenseState & s, int p, int pstat, int
   }
   if(n - 2 >= q)
     hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(ROT_THREADS), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
-                       CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat, s.sync, wait_chain_tag, s.mb});
+                       CommitArgs{s.d, s.rfin, s.R, s.st, q, n, p, pstat, s.sync, wait_chain_tag, s.mb, (n > kBlockN) ? s.S : nullptr, s.r});
   else // q = n - 1: nothing to rotate
-    hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat, s.sync, wait_chain_tag, s.mb);
+    hipLaunchKernelGGL(add_commit_kernel, dim3(q / 256 + 1), dim3(256), 0, st, q, s.d, s.rfin, s.R, n, s.st, p, pstat, s.sync, wait_chain_tag, s.mb,
+                       (n > kBlockN) ? s.S : nullptr, s.r);
   return hipGetLastError();
 }
 
@@ -2599,7 +2896,7 @@ hipError_t dense_add_speculative(const DenseViews & v, DenseState & s, int q, hi
   hipError_t e = rot_attr(n);
   if(e != hipSuccess) return e;
   hipLaunchKernelGGL(rot_apply_kernel, dim3((n + 63) / 64), dim3(ROT_THREADS), rot_lds(n - 1 - q), st, s.J, n, n, q, n - 2, 1, s.cc2, s.ss2,
-                     CommitArgs{s.d, s.rfin, s.R, s.st, q, n, -1, 0, s.sync, wait_chain_tag, s.mb},
+                     CommitArgs{s.d, s.rfin, s.R, s.st, q, n, -1, 0, s.sync, wait_chain_tag, s.mb, (n > kBlockN) ? s.S : nullptr, s.r},
                      SpecArgs{s.sd, tag, s.psel, s.z, s.r, s.x, s.u, s.sync, post_x_tag});
   return hipGetLastError();
 }
@@ -2608,10 +2905,13 @@ void dense_rot_profile_dump()
 {
 #ifdef JRLQP_ROT_PROF
   unsigned long long h[32] = {0};
-  if(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rotprof), sizeof(h)) != hipSuccess || h[3] == 0) return;
+  if(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rotprof), sizeof(h)) != hipSuccess || (h[3] == 0 && h[24] == 0)) return;
   const double L = (double)h[3], us = 0.01;
   std::fprintf(stderr, "[rot prof] %llu launches, %.1f chunks each; per launch (us): wait chain tag %.2f, commit+stage %.2f, sweep %.2f | loader: wait data %.2f, at barriers %.2f | chain: wait B_0 %.2f, other barriers %.2f | storer A at barriers %.2f\n",
                h[3], h[8] / L, h[0] * us / L, h[1] * us / L, h[2] * us / L, h[4] * us / L, h[5] * us / L, h[6] * us / L, h[7] * us / L, h[9] * us / L);
+  if(h[24])
+    std::fprintf(stderr, "[tail prof] %llu launches; per launch (us): block 0: r = S d1 %.2f, ratio test + decision %.2f, pass tag %.2f | block 1: stage x, n+ and n+.x %.2f, z tree %.2f, dots %.2f, decision %.2f, pass tag %.2f\n",
+                 h[24], h[21] * us / h[24], h[22] * us / h[24], h[23] * us / h[24], h[25] * us / h[24], h[26] * us / h[24], h[28] * us / h[24], h[27] * us / h[24], h[29] * us / h[24]);
   if(h[20])
     std::fprintf(stderr, "[jtn prof] %llu launches (workgroup 0); per launch (us): wait tags %.2f, stage the column %.2f, tiles %.2f, publish d %.2f\n", h[20],
                  h[16] * us / h[20], h[17] * us / h[20], h[18] * us / h[20], h[19] * us / h[20]);
@@ -2665,6 +2965,15 @@ hipError_t dense_remove(const DenseViews & v, DenseState & s, int l, int q, int 
   else // four columns per thread (q <= 4096 = JRLQP_DENSE_MAX_N)
     hipLaunchKernelGGL(remove_r_kernel<4>, dim3(1), dim3(1024), 0, st, s.R, n, q, l, s.cc, s.ss, s.u, s.st, gone);
   const int qn = q - 1;
+  if(n > kBlockN && s.S)
+  {
+    // CANON C10: S follows R with the rotations just generated; the new S lands in the other buffer and the two swap roles
+    if(q > 1)
+      hipLaunchKernelGGL(remove_s_kernel, dim3((q - 1 + 63) / 64, 2), dim3(64), sizeof(double2) * (size_t)(q - l), st, s.S, s.S2, n, q, l, s.cc, s.ss);
+    double * t = s.S;
+    s.S = s.S2;
+    s.S2 = t;
+  }
   {
     hipError_t e = rot_attr(n);
     if(e != hipSuccess) return e;
@@ -2691,6 +3000,8 @@ hipError_t dense_warm_factor(const DenseViews & v, DenseState & s, int q, hipStr
       if(k + 1 < q) hipLaunchKernelGGL(warm_hh_apply_kernel, dim3(q - k - 1), dim3(64), sizeof(double) * 2 * n, st, s.R, n, n, k, s.hco);
     }
   }
+  if(q > 0 && n > kBlockN && s.S) // CANON C10: S = R^-1 of the factor just made
+    hipLaunchKernelGGL(invert_upper_kernel, dim3(q), dim3(256), sizeof(double) * (size_t)q, st, s.R, s.S, n, q);
   hipError_t e = dense_jinv(v.G, v.ldg, s.J, n, st);
   if(e != hipSuccess) return e;
   if(q > 0) hipLaunchKernelGGL(warm_jq_kernel, dim3((n + 63) / 64), dim3(64), 0, st, s.J, n, n, s.R, n, q, s.hco);

@@ -116,6 +116,13 @@ int jrlqp_dense_create(int n, int m, int nb, jrlqp_dense ** out)
   DenseState & s = h->s;
   hipError_t e = dmalloc(s.J, (size_t)n * n + 2); // (+2: the sweep's 16-byte loads may read one double past the last column, gi_dense.hip rot_sweep)
   if(e == hipSuccess) e = dmalloc(s.R, (size_t)n * n);
+  s.S = s.S2 = s.Ptri = nullptr;
+  // CANON C10 (gi_dense.hip kBlockN).  JRLQP_DENSE_C10=0 (diagnostic): no S -- r by back substitution on R, the oracle's ORC_LIT_R_SOLVE
+  const char * c10env = std::getenv("JRLQP_DENSE_C10");
+  const bool c10 = n > 256 && !(c10env && c10env[0] == '0');
+  if(e == hipSuccess && c10) e = dmalloc(s.S, (size_t)n * n);
+  if(e == hipSuccess && c10) e = dmalloc(s.S2, (size_t)n * n);
+  if(e == hipSuccess && c10) e = dmalloc(s.Ptri, (size_t)((n + 63) / 64) * ((n + 63) / 64 + 1) / 2 * 64);
   if(e == hipSuccess) e = dmalloc(s.d, n);
   if(e == hipSuccess) e = dmalloc(s.z, n);
   if(e == hipSuccess) e = dmalloc(s.x, n);
@@ -208,6 +215,7 @@ void jrlqp_dense_destroy(jrlqp_dense * h)
   if(h->spec) (void)hipStreamSynchronize(h->spec);
   if(h->side) (void)hipStreamSynchronize(h->side);
   dense_rot_profile_dump();
+  (void)hipFree(s.S); (void)hipFree(s.S2); (void)hipFree(s.Ptri);
   (void)hipFree(s.J); (void)hipFree(s.R); (void)hipFree(s.d); (void)hipFree(s.z); (void)hipFree(s.x);
   (void)hipFree(s.u); (void)hipFree(s.r); (void)hipFree(s.cc); (void)hipFree(s.ss); (void)hipFree(s.st);
   (void)hipFree(s.cc2); (void)hipFree(s.ss2); (void)hipFree(s.rfin);

@@ -429,6 +429,7 @@ typedef struct
   const double *C, *bl, *bu, *xl, *xu;
   int ldc;
   double *J, *R, *d, *z, *x, *u, *r; /* J,R: n x n, ld n (GoldfarbIdnaniSolver.cpp:140-141) */
+  double * Si; /* CANON C10 (more than ORC_BLOCK_N unknowns): S = R^-1, n x n, ld n, kept beside R; NULL otherwise */
   double f;
   orc_active_set A;
 } gi_state;
@@ -517,6 +518,33 @@ static void compute_step(gi_state * S, int p, int status)
     const double dj = d[j];
     for(int i = 0; i < n; ++i) z[i] = FMA(cj[i], dj, z[i]);
   }
+  }
+  if(S->Si)
+  {
+    /* CANON C10: r = S d1 with S = R^-1 kept explicitly.  Row i is a blocked product in the manner of C8 over its terms k = i .. q-1:
+     * the columns in segments of 64 by absolute index, a segment's fma chain ascending from max(64 s, i) and from +0, the segment sums
+     * combined by the adjacent-first pairwise tree over 64 slots (empty slots +0).  The substitution below is q dependent steps; this
+     * is q (q + 64) / 128 independent chains of at most 64 terms. */
+    const int nseg = (q + 63) >> 6;
+    for(int i = 0; i < q; ++i)
+    {
+      double p[64];
+      const double * row = S->Si + i;
+      for(int sg = 0; sg < 64; ++sg)
+      {
+        double acc = 0.0;
+        if(sg < nseg)
+        {
+          const int k0 = (64 * sg > i) ? 64 * sg : i, k1 = (64 * sg + 64 < q) ? 64 * sg + 64 : q;
+          for(int k = k0; k < k1; ++k) acc = FMA(row[(long)k * n], d[k], acc);
+        }
+        p[sg] = acc;
+      }
+      for(int h = 1; h < 64; h <<= 1)
+        for(int t = 0; t < 64; t += 2 * h) p[t] = p[t] + p[t + h];
+      r[i] = p[0];
+    }
+    return;
   }
   /* r = R^-1 d1 (:146), upper triangular back substitution */
   for(int k = 0; k < q; ++k) r[k] = d[k];
@@ -622,6 +650,12 @@ static void add_constraint(gi_state * S, int p, int status)
   }
   d[q - 1] = rfin;
   for(int k = 0; k < q; ++k) S->R[k + (long)(q - 1) * n] = d[k];
+  if(S->Si)
+  {
+    /* C10: the bordered inverse of [R d1; 0 rho]: S gets the column [-r / rho; 1 / rho], r = S d1 of this pass (still in S->r) */
+    for(int k = 0; k < q - 1; ++k) S->Si[k + (long)(q - 1) * n] = -(S->r[k] / rfin);
+    S->Si[(q - 1) + (long)(q - 1) * n] = 1.0 / rfin;
+  }
   if(cc != cs_small) free(cc);
 }
 
@@ -640,6 +674,25 @@ static void remove_constraint_raw(gi_state * S, int l)
     for(int k = i + 2; k <= q; ++k) rot(c, s, &R[i + (long)k * n], &R[(i + 1) + (long)k * n]);
     double *ci = J + (long)i * n, *cj = J + (long)(i + 1) * n;
     for(int rr = 0; rr < n; ++rr) rot(c, s, &ci[rr], &cj[rr]);
+    if(S->Si)
+    {
+      /* C10: S <- S G (the same rotation of columns i, i + 1 as J's: (G^T R)^-1 = S G); rows below i + 1 hold structural zeros */
+      double *si = S->Si + (long)i * n, *sj = S->Si + (long)(i + 1) * n;
+      for(int rr = 0; rr <= i + 1; ++rr)
+      {
+        if(rr == l) continue; /* (the row that leaves) */
+        double xv = (rr <= i) ? si[rr] : 0.0, yv = sj[rr]; /* (row i + 1 meets its first rotation with a structural zero in column i) */
+        rot(c, s, &xv, &yv);
+        si[rr] = xv;
+        sj[rr] = yv;
+      }
+    }
+  }
+  if(S->Si)
+  {
+    /* row l and the last column leave: rows l + 1 .. q move up by one (q: the new count; S had q + 1 rows and columns) */
+    for(int j = l; j < q; ++j)
+      for(int rr = l; rr <= j; ++rr) S->Si[rr + (long)j * n] = S->Si[(rr + 1) + (long)j * n];
   }
 }
 
@@ -913,6 +966,9 @@ static int gi_solve_impl(int warm,
   S.u = S.x + n; S.r = S.u + (m + nb + 2);
   double * cxs = S.r + (m + nb + 2); /* C^T x, all m columns (active ones are computed and ignored) */
   S.f = 0.0;
+  /* CANON C10: beyond ORC_BLOCK_N unknowns S = R^-1 is kept beside R (cold and warm start of the dense solver; the closed-form box
+   * start is a batched-size path) */
+  S.Si = (n > ORC_BLOCK_N && warm != 2 && !(g_lit & ORC_LIT_R_SOLVE)) ? (double *)calloc((size_t)n * (size_t)n, sizeof(double)) : NULL;
   S.A.ncstr = m; S.A.nbnd = nb;
   S.A.status = (int *)malloc(sizeof(int) * (size_t)(m + nb + 1));
   S.A.active = (int *)malloc(sizeof(int) * (size_t)(m + nb + 1));
@@ -932,6 +988,25 @@ static int gi_solve_impl(int warm,
     if(rc != ORC_SUCCESS) goto done;
     if(orc_llt(n, G, ldg) >= 0) { rc = ORC_NON_POS_HESSIAN; goto done; }
     initialize_computation_data(&S, G, ldg, b_act, hco);
+    if(S.Si)
+    {
+      /* C10: S = R^-1 of the QR factor just made.  Column j solves R s = e_j by column-oriented back substitution: s_j = 1 / R(j,j); once
+       * s_k is final every row above adds its term, acc_i = fma(R(i,k), s_k, acc_i) (acc from +0: row i's chain runs over k = j .. i + 1,
+       * descending), and s_{k-1} = -acc_{k-1} / R(k-1,k-1). */
+      const int q0 = S.A.nact;
+      for(int j = 0; j < q0; ++j)
+      {
+        double * sc = S.Si + (long)j * n;
+        for(int i = 0; i < j; ++i) sc[i] = 0.0;
+        sc[j] = 1.0 / S.R[j + (long)j * n];
+        for(int k = j; k >= 1; --k)
+        {
+          const double sk = sc[k];
+          for(int i = 0; i < k; ++i) sc[i] = FMA(S.R[i + (long)k * n], sk, sc[i]);
+          sc[k - 1] = (-sc[k - 1]) / S.R[(k - 1) + (long)(k - 1) * n];
+        }
+      }
+    }
     initialize_primal_dual(&S, a, b_act, alpha, beta);
     for(;;) /* constraints activated with u < 0 are deactivated (:78-109) */
     {
@@ -1176,6 +1251,7 @@ done:
   if(nactive_out) *nactive_out = S.A.nact;
   if(iters_out) *iters_out = it;
   if(f_out) *f_out = S.f;
+  free(S.Si);
   free(S.A.status);
   free(S.A.active);
   free(own);

@@ -136,7 +136,8 @@ enum
   ORC_LIT_SERIAL_GIVENS = 4, /* makeGivens(d_i, d_{i+1}), i = n-2 .. q, radius in d_i (GoldfarbIdnaniSolver.cpp:225-232) instead of C7 */
   ORC_LIT_NO_FMA = 8,        /* those dots and rotations with every product and sum rounded separately */
   ORC_LIT_CHAIN_GEMV = 16,   /* d = J^T n+, C^T x, n+.x and z = J2 d2 as in-order chains at every size instead of C8 (blocked beyond 256 unknowns) */
-  ORC_LIT_ALL = 23
+  ORC_LIT_R_SOLVE = 32,      /* r = R^-1 d1 by back substitution with R at every size (GoldfarbIdnaniSolver.cpp:146) instead of C10 (S = R^-1 kept explicitly beyond 256 unknowns) */
+  ORC_LIT_ALL = 55
 };
 int orc_gi_solve_literal(int flags, int n, int m, int nb, double * G, int ldg, const double * a, const double * C, int ldc,
                          const double * bl, const double * bu, const double * xl, const double * xu, int max_iter,

@@ -248,7 +248,7 @@ class Oracle:
                                         _dp(x), _dp(u), _ip(status), _ip(term), _ip(iters), _dp(f), nthreads)
         return dict(x=x, u=u, status=status, term=term, iters=iters, f=f, L=Gc)
 
-    LIT_CHAIN_DOTS, LIT_ROT_C3, LIT_SERIAL_GIVENS, LIT_NO_FMA, LIT_CHAIN_GEMV, LIT_ALL = 1, 2, 4, 8, 16, 23
+    LIT_CHAIN_DOTS, LIT_ROT_C3, LIT_SERIAL_GIVENS, LIT_NO_FMA, LIT_CHAIN_GEMV, LIT_R_SOLVE, LIT_ALL = 1, 2, 4, 8, 16, 32, 55
 
     def solve_batch_literal(self, flags, G, a, C, bl, bu, xl=None, xu=None, max_iter=500, big_bnd=1e100, nthreads=1):
         """Cold packed batch with some of CANON C5 / C6 / C7 switched off (orc_gi_solve_batch_literal; flags = 0 is the canonical
