@@ -127,6 +127,28 @@ def test_dense_stream_handoff_modes(capi, P, oracle, monkeypatch, mode):
     check(solve_gpu(capi, pb, 0, True, max_iter=3000), ref, f"hand-off by {mode}")
 
 
+def test_dense_c10_on_and_off(capi, P, oracle, monkeypatch):
+    """CANON C10 (beyond 256 unknowns S = R^-1 is kept beside R and r = S d1 is a blocked product) against the literal form (r by back
+    substitution on R) ON THE GPU: with JRLQP_DENSE_C10=0 the handle keeps no S and equals the oracle with ORC_LIT_R_SOLVE bit for bit;
+    by default it equals the canonical oracle bit for bit; and the two agree in every decision (termination, iteration count,
+    statuses) with x and u to rounding -- the same comparison tests/test_oracle_literal.py makes on 6942 problems on the CPU."""
+    ch = P.Characteristics(nVar=300, nObj=300, nEq=6, nIneq=420, nStrongActIneq=80, bounds=True, nStrongActBounds=20, doubleSidedIneq=True)
+    pb = P.generate_batch(1, ch, first_index=9100)
+    canon = oracle.solve(pb.G[0], pb.a[0], pb.C[0].T, pb.bl[0], pb.bu[0], pb.xl[0], pb.xu[0], max_iter=5000)
+    lit = oracle.solve_batch_literal(oracle.LIT_R_SOLVE, pb.G[:1], pb.a[:1], pb.C[:1], pb.bl[:1], pb.bu[:1], pb.xl[:1], pb.xu[:1], max_iter=5000)
+    assert canon.term == 0 and canon.iters > 100
+    on = solve_gpu(capi, pb, 0, True, max_iter=5000)
+    check(on, canon, "C10 on")
+    monkeypatch.setenv("JRLQP_DENSE_C10", "0")
+    off = solve_gpu(capi, pb, 0, True, max_iter=5000)
+    assert off["term"] == lit["term"][0] and off["iters"] == lit["iters"][0]
+    assert np.array_equal(off["status"], lit["status"][0])
+    assert np.array_equal(off["x"], lit["x"][0]) and np.array_equal(off["u"], lit["u"][0]) and off["f"] == lit["f"][0]
+    # the decision: same verdict, same path, same set -- values to rounding
+    assert off["term"] == on["term"] and off["iters"] == on["iters"] and np.array_equal(off["status"], on["status"])
+    assert np.max(np.abs(off["x"] - on["x"])) <= 1e-11 * max(1.0, np.max(np.abs(on["x"])))
+
+
 def test_c2_full_size(capi, P, oracle):
     """BASELINE configs[1] (c2) at full size: n = 1024, m = 2048, 307 strongly active, through jrlqp_dense_solve --
     termination status, iteration count, activation statuses, x, u, f and the Cholesky factor left in G, bit for bit
