@@ -187,7 +187,7 @@ static int big_grid(int n, int m, int nb, int B)
     return 0;
   const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr);
   const int per_cu = ldsb > 0 ? (int)(jrlqp::kLdsPerCU / ldsb) : 1;
-  const int cap = (n > JRLQP_BATCH_LDS_N) ? 3 : 2; // (J in the workspace: more workgroups per CU hide its L2 latency; gi_batch_big.hip launch bounds)
+  const int cap = jrlqp::batch_big_is_wide(n) ? 3 : 2; // (J in the workspace: more workgroups per CU hide its L2 latency; gi_batch_big.hip launch bounds)
   const int slots = ncu * (per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu));
   return B < slots ? B : slots;
 }

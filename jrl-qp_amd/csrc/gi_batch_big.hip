@@ -26,6 +26,7 @@
 // between the phases.  This kernel is the coverage path for large n: it is written for exactness and simplicity, not for
 // the latency engineering of gi_batch_kernel.h.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "device_common.h"
 #include "gi_batch.h"
@@ -1517,21 +1518,47 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
   }
 }
 
+// J in the workgroup's workspace slice instead of LDS (the WIDE instantiations): always beyond 128 unknowns; JRLQP_BIG_WIDE_FROM=<n>
+// (experiment) lowers the threshold
+static int wide_from()
+{
+  static const int v = [] {
+    const char * e = std::getenv("JRLQP_BIG_WIDE_FROM");
+    const int t = e ? std::atoi(e) : 129;
+    return (t >= 65 && t <= 129) ? t : 129;
+  }();
+  return v;
+}
+static bool is_wide(int n) { return n >= wide_from(); }
 long big_lds_doubles(int n, int r_in_lds)
 {
   const long ld = n | 1;
   long dbl = 4L * n + 2L * (n + 2) + 3L * n + (n + 2);
-  if(n <= 128) dbl += (long)n * ld; // J (beyond 128 unknowns it lives in the workspace: WIDE)
+  if(!is_wide(n)) dbl += (long)n * ld; // J (beyond 128 unknowns it lives in the workspace: WIDE)
   if(r_in_lds) dbl += (long)n * (n + 1) / 2;
   return dbl;
 }
 } // namespace
 
+bool batch_big_is_wide(int n) { return is_wide(n); }
+
 long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds)
 {
-  for(int rl = (n <= 128) ? 1 : 0; rl >= 0; --rl)
+  auto bytes_of = [&](int rl) { return ((big_lds_doubles(n, rl) * 8 + (long)sizeof(CtlB) + 4L * (n + 2) + (long)(m + nb)) + 15) & ~15L; };
+  if(!is_wide(n) && !std::getenv("JRLQP_BIG_R_IN_LDS"))
   {
-    const long bytes = ((big_lds_doubles(n, rl) * 8 + (long)sizeof(CtlB) + 4L * (n + 2) + (long)(m + nb)) + 15) & ~15L;
+    // (round 5) where J and the packed R fit once but not twice beside each other and J alone fits twice -- n = 79 .. 95 -- the packed R
+    // goes to the workspace: two workgroups per CU with R behind L2 against one with R in LDS
+    const long b1 = bytes_of(1), b0 = bytes_of(0);
+    if(b1 <= kLdsPerCU && 2 * b1 > kLdsPerCU && 2 * b0 <= kLdsPerCU)
+    {
+      if(r_in_lds) *r_in_lds = 0;
+      return b0;
+    }
+  }
+  for(int rl = !is_wide(n) ? 1 : 0; rl >= 0; --rl)
+  {
+    const long bytes = bytes_of(rl);
     if(bytes <= kLdsPerCU)
     {
       if(r_in_lds) *r_in_lds = rl;
@@ -1547,7 +1574,7 @@ long batch_big_ws_doubles_per_wg(int n, int r_in_lds, int warm)
 {
   long d = r_in_lds ? 0 : (((long)n * (n + 1) / 2 + 1) & ~1L);
   if(warm) d += (long)n * n;
-  if(n > 128) d += (long)n * (n | 1) + 1; // WIDE: L / J
+  if(is_wide(n)) d += (long)n * (n | 1) + 1; // WIDE: L / J
   return d;
 }
 
@@ -1565,13 +1592,15 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
   };
   if(a.box) // experimental::BoxAndSingleConstraintSolver beyond 64 variables (cold start only)
   {
-    if(a.n > 128) return go(&gi_batch_big_kernel<false, false, true, false, 1, true>);
+    if(is_wide(a.n)) return go(&gi_batch_big_kernel<false, false, true, false, 1, true>);
     return r_in_lds ? go(&gi_batch_big_kernel<true, false, false, false, 1, true>) : go(&gi_batch_big_kernel<false, false, false, false, 1, true>);
   }
-  if(a.n > 128) return a.warm ? go(&gi_batch_big_kernel<false, true, true>) : go(&gi_batch_big_kernel<false, false, true>);
+  if(is_wide(a.n)) return a.warm ? go(&gi_batch_big_kernel<false, true, true>) : go(&gi_batch_big_kernel<false, false, true>);
   if(a.prof && !a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, false, false, true>) : go(&gi_batch_big_kernel<false, false, false, true>);
   if(2 * lds <= kLdsPerCU && r_in_lds) // two workgroups per CU: the instantiations held to 256 VGPRs
     return a.warm ? go(&gi_batch_big_kernel<true, true, false, false, 2>) : go(&gi_batch_big_kernel<true, false, false, false, 2>);
+  if(2 * lds <= kLdsPerCU && !is_wide(a.n)) // ... with the packed R in the workspace (batch_big_lds_bytes)
+    return a.warm ? go(&gi_batch_big_kernel<false, true, false, false, 2>) : go(&gi_batch_big_kernel<false, false, false, false, 2>);
   if(a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, true>) : go(&gi_batch_big_kernel<false, true>);
   return r_in_lds ? go(&gi_batch_big_kernel<true, false>) : go(&gi_batch_big_kernel<false, false>);
 }

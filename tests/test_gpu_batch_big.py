@@ -148,6 +148,7 @@ def test_big_n_status_codes_and_trace(capi, P, oracle):
 BIG_WARM = [
     dict(nVar=70, nObj=70, nIneq=140, nStrongActIneq=20),
     dict(nVar=70, nObj=70, nEq=6, nIneq=60, nStrongActIneq=14, bounds=True, nStrongActBounds=6, doubleSidedIneq=True),
+    dict(nVar=88, nObj=88, nEq=5, nIneq=120, nStrongActIneq=25, bounds=True, nStrongActBounds=7),  # 79 .. 95: two workgroups per CU, the packed R in the workspace
     dict(nVar=100, nObj=100, nIneq=200, nStrongActIneq=30),
     dict(nVar=100, nObj=100, nEq=10, nIneq=90, nStrongActIneq=20, bounds=True, nStrongActBounds=8),
     dict(nVar=128, nObj=128, nIneq=160, nStrongActIneq=36),  # R and B = L^-1 N both in the caller's workspace
