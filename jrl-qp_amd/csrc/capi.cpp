@@ -180,12 +180,12 @@ long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds)
 }
 
 // grid of the persistent kernel of gi_batch_big.hip on the current device (0: no device)
-static int big_grid(int n, int m, int nb, int B)
+static int big_grid(int n, int m, int nb, int B, int have_ws = 1)
 {
   int dev = 0, ncu = 0;
   if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
     return 0;
-  const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr);
+  const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr, have_ws);
   const int per_cu = ldsb > 0 ? (int)(jrlqp::kLdsPerCU / ldsb) : 1;
   const int cap = jrlqp::batch_big_is_wide(n) ? 3 : 2; // (J in the workspace: more workgroups per CU hide its L2 latency; gi_batch_big.hip launch bounds)
   const int slots = ncu * (per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu));
@@ -244,7 +244,9 @@ static int gi_batch_common(int warm,
   if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const bool bign = n > JRLQP_BATCH_WAVE_N; // more rows than one lane-per-row wavefront: gi_batch_big.hip
   int r_in_lds = 0;
-  if(bign && jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  // (a cold solve without a workspace keeps R in LDS wherever it fits: one workgroup per CU for n = 79 .. 95 instead of two)
+  const int have_ws = (dws != nullptr || warm) ? 1 : 0;
+  if(bign && jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds, have_ws) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const int cmode = bign ? 0 : jrlqp::batch_pick_cmode(n, m, nb, warm);
   if(cmode < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
 
@@ -274,7 +276,7 @@ static int gi_batch_common(int warm,
   {
     // persistent grid: as many workgroups per CU as their LDS allows (two up to n = 88, one beyond), each looping over its
     // share of the batch
-    const int nwg = big_grid(n, m, nb, B);
+    const int nwg = big_grid(n, m, nb, B, have_ws);
     if(nwg < 1) return JRLQP_ERR_NO_DEVICE;
     double * ws = nullptr;
     const long per_wg = jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, warm);
@@ -518,8 +520,9 @@ static int box_common(int n, int B, const double * dx0, const double * dc, const
   // beyond one wavefront of variables (round 4): the large-n batched kernel with the same closed form, thread = variable
   // (gi_batch_big.hip, BOX); R (past n = 104) and J (past n = 128) live in the caller's workspace like a cold dense solve's
   int r_in_lds = 0;
-  if(jrlqp::batch_big_lds_bytes(n, 1, n, &r_in_lds) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
-  const int nwg = big_grid(n, 1, n, B);
+  // (the box instantiations run one workgroup per CU: R stays in LDS wherever it fits, whatever the caller passed)
+  if(jrlqp::batch_big_lds_bytes(n, 1, n, &r_in_lds, 0) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
+  const int nwg = big_grid(n, 1, n, B, 0);
   if(nwg < 1) return JRLQP_ERR_NO_DEVICE;
   double * ws = nullptr;
   const long per_wg = jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, 0);

@@ -37,7 +37,7 @@ int batch_pick_cmode(int n, int m, int nb, int warm = 0); // -1 if unsupported
 hipError_t launch_gi_batch_box(const BatchArgs & a, hipStream_t stream);
 // 64 < n <= JRLQP_BATCH_MAX_N (gi_batch_big.hip): persistent grid of nwg workgroups; ws: nwg * batch_big_ws_doubles_per_wg(...)
 // doubles of global workspace: R when it does not fit in LDS beside J (*r_in_lds == 0), B = L^-1 N of a warm start
-long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds);
+long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds, int have_ws = 1);
 bool batch_big_is_wide(int n); // J in the workspace (always beyond JRLQP_BATCH_LDS_N unknowns)
 long batch_big_ws_doubles_per_wg(int n, int r_in_lds, int warm);
 hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStream_t stream);
