@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     // 6 scalar products, 7 step, 8 addition (sweep of J), 9 removal, 10 #additions, 11 #removals, 12-15 what waves 0-3 each needed of slot 5
     // (0: R^-1 d and the ratio test, 1: the coefficient chain, 2-3: z) -- into prof[b * stride + slot]
     const bool profb = PROFB && A.prof != nullptr && tid == 0; // (PROFB: a build of its own -- the accumulators cost the production kernel 5 %)
-    long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long pacc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // (16-22: the phases of a warm start's init)
     long long plast = profb ? clock64() : 0;
     auto stamp = [&](int slot) {
       if(profb)
@@ -458,35 +458,64 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         st[i] = (unsigned char)sdec;
       }
       __syncthreads();
+      // the order and the trimming (round 5: a ballot scan over the constraints IN ACTIVATION ORDER -- bounds first -- 256 at a time; one
+      // thread walked all m + nb status bytes twice before: 380 k cycles at m + nb = 1100).  rank = inequality entries in front of this
+      // one, kept while rank < n - #eq; pos = kept entries in front of it.
       if(tid == 0)
       {
-        int neq = 0;
-        for(int i = 0; i < mt; ++i) neq += (st[i] == B_EQUALITY || st[i] == B_FIXED) ? 1 : 0;
-        const int budget = n - neq;
-        int pos = 0, rank = 0;
-        if(budget >= 0)
-          for(int part = 0; part < 2; ++part)
-          {
-            const int lo = (part == 0) ? m : 0, hi = (part == 0) ? mt : m;
-            for(int i = lo; i < hi; ++i)
-            {
-              const int sv = st[i];
-              if(sv == B_INACTIVE) continue;
-              const bool iseq = (sv == B_EQUALITY || sv == B_FIXED);
-              const bool keep = iseq || rank < budget;
-              if(!iseq) ++rank;
-              if(keep)
-                act[pos++] = i;
-              else
-                st[i] = B_INACTIVE;
-            }
-          }
-        ctl->pad0 = (neq > n) ? 1 : 0;
-        ctl->pad1 = pos;
+        ctl->pad0 = 0;
+        ctl->pad1 = 0;
+        ctl->l = 0;
       }
+      __syncthreads();
+      {
+        int c = 0;
+        for(int i = tid; i < mt; i += WGB) c += (st[i] == B_EQUALITY || st[i] == B_FIXED) ? 1 : 0;
+        if(c) atomicAdd(&ctl->pad0, c);
+      }
+      __syncthreads();
+      const int neq0 = ctl->pad0;
+      const int budget = n - neq0;
+      __syncthreads();
+      if(budget >= 0)
+        for(int base = 0; base < mt; base += WGB)
+        {
+          const int o = base + tid;
+          const int i = (o < nb) ? m + o : o - nb;
+          const int sv = (o < mt) ? st[i] : B_INACTIVE;
+          const bool iseq = (sv == B_EQUALITY || sv == B_FIXED);
+          const bool ineq = (sv != B_INACTIVE) && !iseq;
+          const unsigned long long lt = (1ull << lane) - 1ull;
+          const unsigned long long m1 = __ballot(ineq);
+          if(lane == 0) ctl->red_idx[wave] = __popcll(m1);
+          __syncthreads();
+          int rank = ctl->l;
+          for(int w = 0; w < wave; ++w) rank += ctl->red_idx[w];
+          rank += __popcll(m1 & lt);
+          const bool keep = iseq || (ineq && rank < budget);
+          const unsigned long long m2 = __ballot(keep);
+          if(lane == 0) ctl->red_stat[wave] = __popcll(m2);
+          __syncthreads();
+          int pos = ctl->pad1;
+          for(int w = 0; w < wave; ++w) pos += ctl->red_stat[w];
+          pos += __popcll(m2 & lt);
+          if(keep)
+            act[pos] = i;
+          else if(ineq)
+            st[i] = B_INACTIVE;
+          __syncthreads();
+          if(tid == 0)
+          {
+            ctl->l += ctl->red_idx[0] + ctl->red_idx[1] + ctl->red_idx[2] + ctl->red_idx[3];
+            ctl->pad1 += ctl->red_stat[0] + ctl->red_stat[1] + ctl->red_stat[2] + ctl->red_stat[3];
+          }
+          __syncthreads();
+        }
+      if(tid == 0) ctl->pad0 = (neq0 > n) ? 1 : 0;
       __syncthreads();
       over = ctl->pad0 != 0;
       nact0 = ctl->pad1;
+      stamp(16); // processInitialActiveSet
     }
     // ---------------------------------------------------------------- LLT, left-looking column by column (orc_llt)
     int info = -1;
@@ -559,6 +588,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           dgl[tid] = M[tid + (long)tid * ld];
         }
         __syncthreads();
+        stamp(17); // N, b_act
         // B = L^-1 N (:426): wave w takes columns w, w + 4, ...; two rows per lane; per element the terms in ascending k, then
         // one division (the oracle's forward substitution)
         for(int j = wave; j < q; j += 4)
@@ -568,6 +598,22 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
 #pragma unroll
           for(int h = 0; h < EPL; ++h) bv[h] = (lane + 64 * h < n) ? col[lane + 64 * h] : 0.0;
           const int ns = __builtin_amdgcn_readfirstlane(n);
+          if constexpr(!WIDE)
+          {
+            // (round 5) the lean step of x0's substitution -- hoisted reciprocals, coefficients requested ahead, no division in a step:
+            // 520 cycles a step with the plain division below, 782 k of a warm start's 3.2 M cycles at n = 100 -- licensed by its own
+            // range check; the plain loop stays as the fall-back
+            const int nl = n - 1;
+            if(wave_tri_lean<EPL, true>(bv, n, lane, [&](int e, int k) { return M[min(e, nl) + (long)k * ld]; }, [&](int e) { return dgl[e]; }))
+            {
+#pragma unroll
+              for(int h = 0; h < EPL; ++h)
+                if(lane + 64 * h < n) col[lane + 64 * h] = bv[h];
+              continue;
+            }
+#pragma unroll
+            for(int h = 0; h < EPL; ++h) bv[h] = (lane + 64 * h < n) ? col[lane + 64 * h] : 0.0;
+          }
           for(int k = 0; k < ns; ++k)
           {
             const double v = vec_bcast(bv, k) / M[k + (long)k * ld];
@@ -585,14 +631,23 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             if(lane + 64 * h < n) col[lane + 64 * h] = bv[h];
         }
         __syncthreads();
-        // B = Q R, Householder, column by column (:432-440; Eigen makeHouseholder / applyHouseholderOnTheLeft), in place
+        stamp(18); // B = L^-1 N
+        // B = Q R, Householder, column by column (:432-440; Eigen makeHouseholder / applyHouseholderOnTheLeft), in place.
+        // B lives in the workspace (global memory).  Round 5: the reflector of a step is staged in LDS (zs: free until the loop) -- its
+        // norm is a chain over LDS instead of n dependent-by-eight global round trips, and the trailing columns read it from there;
+        // a trailing column comes 16 entries per round trip, in the chain as in the update.  Per element the operations are unchanged.
         for(int k = 0; k < q; ++k)
         {
           double * vk = Bw + (long)k * n;
+          double * vl = zs;
           if(wave == 0)
           {
-            const double tailsq = chain_asc<false>(vk, 1, vk, 1, k + 1, n, 0.0); // (every lane the same chain)
-            const double c0 = vk[k];
+#pragma unroll
+            for(int h = 0; h < EPL; ++h)
+              if(lane + 64 * h < n) vl[lane + 64 * h] = vk[lane + 64 * h];
+            wave_sync();
+            const double tailsq = chain_asc<false>(vl, 1, vl, 1, k + 1, n, 0.0); // (every lane the same chain)
+            const double c0 = vl[k];
             const bool zero = tailsq <= 2.2250738585072014e-308;
             double beta = __builtin_sqrt(FMA(c0, c0, tailsq));
             beta = (c0 >= 0.0) ? -beta : beta;
@@ -602,11 +657,16 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             beta = zero ? c0 : beta;
             double mv[EPL];
 #pragma unroll
-            for(int h = 0; h < EPL; ++h) mv[h] = (lane + 64 * h > k && lane + 64 * h < n) ? vk[lane + 64 * h] : 0.0;
+            for(int h = 0; h < EPL; ++h) mv[h] = (lane + 64 * h > k && lane + 64 * h < n) ? vl[lane + 64 * h] : 0.0;
             wave_sync();
 #pragma unroll
             for(int h = 0; h < EPL; ++h)
-              if(lane + 64 * h > k && lane + 64 * h < n) vk[lane + 64 * h] = zero ? 0.0 : mv[h] / den;
+              if(lane + 64 * h > k && lane + 64 * h < n)
+              {
+                const double sv = zero ? 0.0 : mv[h] / den;
+                vk[lane + 64 * h] = sv;
+                vl[lane + 64 * h] = sv;
+              }
             if(lane == 0)
             {
               vk[k] = beta;
@@ -621,16 +681,25 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             if(j < q)
             {
               double * cj = Bw + (long)j * n;
-              double t = chain_asc<false>(vk, 1, cj, 1, k + 1, n, 0.0);
+              double t = chain_asc<false, 16>(vl, 1, cj, 1, k + 1, n, 0.0);
               const double top = cj[k];
               t = t + top;
               cj[k] = FMA(-tau, t, top);
               const double stt = tau * t;
-              for(int i = k + 1; i < n; ++i) cj[i] = FMA(-stt, vk[i], cj[i]);
+              for(int i0 = k + 1; i0 < n; i0 += 16)
+              {
+                double cv[16];
+#pragma unroll
+                for(int e = 0; e < 16; ++e) cv[e] = cj[min(i0 + e, n - 1)];
+#pragma unroll
+                for(int e = 0; e < 16; ++e)
+                  if(i0 + e < n) cj[i0 + e] = FMA(-stt, vl[i0 + e], cv[e]);
+              }
             }
           }
           __syncthreads();
         }
+        stamp(19); // QR
       }
       else if constexpr(BOX)
       {
@@ -806,20 +875,30 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       __syncthreads();
       if constexpr(WARM)
       {
-        // J = J Q, Q = H_0 H_1 ... (:443-444): one row of J per thread, reflector after reflector (a row only meets itself)
-        if(tid < n)
+        stamp(20); // J = L^-T
+        // J = J Q, Q = H_0 H_1 ... (:443-444): one row of J per thread, reflector after reflector (a row only meets itself).  Round 5:
+        // the reflector (a column of B in the workspace) is staged in LDS -- zs and ds take turns, one barrier per reflector, the next
+        // one requested before the current one is applied -- instead of every thread reading it from memory eight entries per round trip.
+        {
+          double vnext = (tid < n && q > 0) ? Bw[tid] : 0.0;
           for(int k = 0; k < q; ++k)
           {
+            double * v = (k & 1) ? ds : zs;
+            if(tid < n) v[tid] = vnext;
+            if(k + 1 < q && tid < n) vnext = Bw[(long)(k + 1) * n + tid];
+            __syncthreads();
             const double tau = sss[k];
-            if(tau == 0.0 || k + 1 >= n) continue;
-            const double * v = Bw + (long)k * n;
-            double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
-            const double jk = M[tid + (long)k * ld];
-            t = t + jk;
-            M[tid + (long)k * ld] = FMA(-tau, t, jk);
-            const double stt = tau * t;
-            for(int j = k + 1; j < n; ++j) M[tid + (long)j * ld] = FMA(-stt, v[j], M[tid + (long)j * ld]);
+            if(tid < n && tau != 0.0 && k + 1 < n)
+            {
+              double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
+              const double jk = M[tid + (long)k * ld];
+              t = t + jk;
+              M[tid + (long)k * ld] = FMA(-tau, t, jk);
+              const double stt = tau * t;
+              for(int j = k + 1; j < n; ++j) M[tid + (long)j * ld] = FMA(-stt, v[j], M[tid + (long)j * ld]);
+            }
           }
+        }
         // R = upper triangle of the factored B
         for(int e = tid; e < q * q; e += WGB)
         {
@@ -827,6 +906,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           if(i <= j) RP(i, j) = Bw[i + (long)j * n];
         }
         __syncthreads();
+        stamp(21); // J = J Q, R
       }
     }
     double * J = M;
@@ -1230,6 +1310,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       }
       if(tid == 0) us[q] = 0.0;
       __syncthreads();
+      stamp(22); // the start point and the purge
     }
     else if(term == BT_SUCCESS && !BOX) // (the box solver's init_ replaces initActiveSet as well: no pre-activation of xl == xu)
     {
@@ -1514,7 +1595,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       A.f[b] = ctl->f;
     }
     if(profb)
-      for(int k = 0; k < 16; ++k) A.prof[(size_t)b * A.prof_stride + k] = pacc[k];
+      for(int k = 0; k < 24; ++k) A.prof[(size_t)b * A.prof_stride + k] = pacc[k];
   }
 }
 
@@ -1598,6 +1679,9 @@ hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStr
   }
   if(is_wide(a.n)) return a.warm ? go(&gi_batch_big_kernel<false, true, true>) : go(&gi_batch_big_kernel<false, false, true>);
   if(a.prof && !a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, false, false, true>) : go(&gi_batch_big_kernel<false, false, false, true>);
+#ifdef JRLQP_BIG_WARM_PROF // (diagnostic build: the phase profile of a warm start, tools/time_big_family.py warm ...)
+  if(a.prof && a.warm) return r_in_lds ? go(&gi_batch_big_kernel<true, true, false, true>) : go(&gi_batch_big_kernel<false, true, false, true>);
+#endif
   if(2 * lds <= kLdsPerCU && r_in_lds) // two workgroups per CU: the instantiations held to 256 VGPRs
     return a.warm ? go(&gi_batch_big_kernel<true, true, false, false, 2>) : go(&gi_batch_big_kernel<true, false, false, false, 2>);
   if(2 * lds <= kLdsPerCU && !is_wide(a.n)) // ... with the packed R in the workspace (batch_big_lds_bytes)

@@ -9,6 +9,9 @@ import jrl_qp_amd.capi as capi, jrl_qp_amd.problems as P
 fam = sys.argv[1] if len(sys.argv) > 1 else "test3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+warm = fam.startswith("warm")  # warm1 / warm3: the family re-solved from its own optimal active set (0 iterations: the warm init alone); needs a build with -DJRLQP_BIG_WARM_PROF for the phases
+if warm:
+    fam = "test" + fam[4:]
 if fam == "test1":
     ch = P.Characteristics(nVar=n, nObj=n, nEq=int(0.4 * n))
 else:
@@ -25,6 +28,10 @@ args = (dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"]) + ((dev["xl"], dev["
 for _ in range(2):
     r = s.solve(*args)
 torch.cuda.synchronize()
+if warm:
+    guess = r.status.clone()
+    cold_solve = s.solve
+    s.solve = lambda *a: s.solve_warm(*a, guess=guess)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ts = []
 for _ in range(8):
@@ -42,4 +49,8 @@ tot = pr[:, :10].sum(axis=1).mean()
 print(f"cycles per solve {tot:.0f}; additions {pr[:, 10].mean():.1f}, removals {pr[:, 11].mean():.1f}")
 for i, nm in enumerate(names):
     print(f"  {nm:26s} {pr[:, i].mean():12.0f} ({100 * pr[:, i].mean() / tot:5.1f} %)")
+if warm:
+    wn = ["processInitialActiveSet", "N, b_act", "B = L^-1 N", "QR", "J = L^-T", "J = J Q, R", "start point + purge"]
+    for i, nm in enumerate(wn):
+        print(f"  warm: {nm:24s} {pr[:, 16 + i].mean():12.0f}")
 print("  of 'z || R^-1 d || chain', per wave: " + ", ".join(f"w{w} {pr[:, 12 + w].mean():.0f}" for w in range(4)) + "  (0: substitution + ratio test, 1: coefficient chain, 2-3: z)")
