@@ -888,14 +888,48 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             if(k + 1 < q && tid < n) vnext = Bw[(long)(k + 1) * n + tid];
             __syncthreads();
             const double tau = sss[k];
-            if(tid < n && tau != 0.0 && k + 1 < n)
+            if(tau != 0.0 && k + 1 < n) // (uniform)
             {
-              double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
-              const double jk = M[tid + (long)k * ld];
-              t = t + jk;
-              M[tid + (long)k * ld] = FMA(-tau, t, jk);
-              const double stt = tau * t;
-              for(int j = k + 1; j < n; ++j) M[tid + (long)j * ld] = FMA(-stt, v[j], M[tid + (long)j * ld]);
+              if constexpr(WIDE)
+              {
+                if(tid < n)
+                {
+                  double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
+                  const double jk = M[tid + (long)k * ld];
+                  t = t + jk;
+                  M[tid + (long)k * ld] = FMA(-tau, t, jk);
+                  const double stt = tau * t;
+                  for(int j = k + 1; j < n; ++j) M[tid + (long)j * ld] = FMA(-stt, v[j], M[tid + (long)j * ld]);
+                }
+              }
+              else
+              {
+                // the row's scalar product is a chain (its thread's); the update J(i, j) -= (tau t_i) v_j is not: the n rows leave
+                // tau t_i in LDS and ALL 256 threads share the (n - k - 1) n entries -- with a thread per row two of the four
+                // waves did 100 LDS-fed updates each, the other two nothing
+                if(tid < n)
+                {
+                  double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
+                  const double jk = M[tid + (long)k * ld];
+                  t = t + jk;
+                  M[tid + (long)k * ld] = FMA(-tau, t, jk);
+                  rs[tid] = tau * t;
+                }
+                __syncthreads();
+                double sv[EPL];
+#pragma unroll
+                for(int h = 0; h < EPL; ++h) sv[h] = rs[min(lane + 64 * h, n - 1)];
+                for(int j = k + 1 + wave; j < n; j += WGB / 64) // a wave per column, lane = row
+                {
+                  const double vj = v[j];
+#pragma unroll
+                  for(int h = 0; h < EPL; ++h)
+                  {
+                    const int i = lane + 64 * h;
+                    if(i < n) M[i + (long)j * ld] = FMA(-sv[h], vj, M[i + (long)j * ld]);
+                  }
+                }
+              }
             }
           }
         }
