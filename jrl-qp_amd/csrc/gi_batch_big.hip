@@ -675,8 +675,10 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           }
           __syncthreads();
           const double tau = hco[k];
-          if(tau != 0.0 && k + 1 < n)
+          if(tau != 0.0 && k + 1 < n) // (uniform)
           {
+            // the scalar product of a trailing column with the reflector is a chain -- its thread's --; the update of the column is not:
+            // the threads leave tau t_j in LDS and all four waves share the columns (lane = row: a column's entries are contiguous)
             const int j = k + 1 + tid; // trailing column
             if(j < q)
             {
@@ -685,15 +687,18 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
               const double top = cj[k];
               t = t + top;
               cj[k] = FMA(-tau, t, top);
-              const double stt = tau * t;
-              for(int i0 = k + 1; i0 < n; i0 += 16)
+              rs[tid] = tau * t;
+            }
+            __syncthreads();
+            for(int jj = k + 1 + wave; jj < q; jj += WGB / 64)
+            {
+              double * cj = Bw + (long)jj * n;
+              const double stt = rs[jj - k - 1];
+#pragma unroll
+              for(int h = 0; h < EPL; ++h)
               {
-                double cv[16];
-#pragma unroll
-                for(int e = 0; e < 16; ++e) cv[e] = cj[min(i0 + e, n - 1)];
-#pragma unroll
-                for(int e = 0; e < 16; ++e)
-                  if(i0 + e < n) cj[i0 + e] = FMA(-stt, vl[i0 + e], cv[e]);
+                const int i = lane + 64 * h;
+                if(i > k && i < n) cj[i] = FMA(-stt, vl[i], cj[i]);
               }
             }
           }
