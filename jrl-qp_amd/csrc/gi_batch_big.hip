@@ -421,6 +421,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
     stamp(0);
     bool over = false;
     int nact0 = 0;
+    int jnext = -2; // WARM, n <= 128: the next row of this thread's column of J = L^-T (built beside the QR by waves 2-3); -2: not started
     if constexpr(WARM)
     {
       // processInitialActiveSet (experimental/GoldfarbIdnaniSolver.cpp:309-386; oracle process_initial_active_set): the decision per
@@ -636,10 +637,28 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         // B lives in the workspace (global memory).  Round 5: the reflector of a step is staged in LDS (zs: free until the loop) -- its
         // norm is a chain over LDS instead of n dependent-by-eight global round trips, and the trailing columns read it from there;
         // a trailing column comes 16 entries per round trip, in the chain as in the update.  Per element the operations are unchanged.
+        // Beside it (round 5, n <= 128): J = L^-T needs L alone -- B = L^-1 N is complete -- and the QR never touches M; waves 2-3 have
+        // no trailing column (q <= n <= 128) and idle through the reflector's norm and the columns' chains.  Thread 128 + c runs
+        // column c of J, a few rows per reflector (a column is a back substitution of its own: nobody else's entries); what is left
+        // when the QR ends is finished where J = L^-T stands for a cold start.
+        const int jrows = WIDE ? 0 : (n + q - 1) / max(q, 1) + 1;
+        auto j_rows = [&](int rows) {
+          if(WIDE || tid < 128 || tid - 128 >= n) return;
+          const int c = tid - 128;
+          if(jnext == -2) jnext = c;
+          for(int r = 0; r < rows && jnext >= 0; ++r, --jnext)
+          {
+            const int i = jnext;
+            double acc = (c == i) ? 1.0 : 0.0;
+            acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
+            M[i + (long)c * ld] = acc / dgl[i];
+          }
+        };
         for(int k = 0; k < q; ++k)
         {
           double * vk = Bw + (long)k * n;
           double * vl = zs;
+          j_rows(jrows);
           if(wave == 0)
           {
 #pragma unroll
@@ -817,10 +836,11 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         // nobody else's entries, so there is no barrier between the rows (round 3 dealt the columns of a row to the lowest threads and
         // paid a barrier per row); waves 0-1 hold the columns.  Beside them wave 2 computes x0 with the lean wave-level substitutions
         // (two entries per lane, no barrier either: round 3 spent 2 n barrier steps with a division each on it).
-        if(tid < n)
+        if(WARM ? (tid >= 128 && tid - 128 < n) : (tid < n))
         {
-          const int c = tid;
-          for(int i = c; i >= 0; --i)
+          // (a warm start: waves 2-3 hold the columns and have done most of their rows beside the QR)
+          const int c = WARM ? tid - 128 : tid;
+          for(int i = (WARM && jnext != -2) ? jnext : c; i >= 0; --i)
           {
             double acc = (c == i) ? 1.0 : 0.0;
             acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
