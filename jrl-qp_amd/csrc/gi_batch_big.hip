@@ -590,10 +590,39 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         }
         __syncthreads();
         stamp(17); // N, b_act
-        // B = L^-1 N (:426): wave w takes columns w, w + 4, ...; two rows per lane; per element the terms in ascending k, then
-        // one division (the oracle's forward substitution)
-        for(int j = wave; j < q; j += 4)
+        // J = L^-T for a warm start of at most 128 unknowns (round 5): it needs L alone, so waves 2-3 -- thread 128 + c runs column c, a
+        // back substitution of its own that meets nobody else's entries -- build it NOW, beside the first columns of B = L^-1 N, and
+        // the reflectors below are applied to J as they are made (one loop instead of a QR followed by a sweep over J).
+        auto j_rows = [&](int rows) {
+          if(WIDE || tid < 128 || tid - 128 >= n) return;
+          const int c = tid - 128;
+          if(jnext == -2) jnext = c;
+          for(int r = 0; r < rows && jnext >= 0; ++r, --jnext)
+          {
+            const int i = jnext;
+            double acc = (c == i) ? 1.0 : 0.0;
+            acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
+            M[i + (long)c * ld] = acc / dgl[i];
+          }
+        };
+        if constexpr(!WIDE)
         {
+          if(tid == 0) ctl->pad0 = 0; // the next column of B nobody has taken yet
+          __syncthreads();
+          if(wave >= 2) j_rows(n);
+        }
+        // B = L^-1 N (:426): a wave per column, two rows per lane; per element the terms in ascending k, then one division (the oracle's
+        // forward substitution).  Beyond 128 unknowns wave w takes columns w, w + 4, ...; up to 128 the waves draw columns from a
+        // counter (waves 2-3 join when their columns of J are done).  L's diagonal comes from dgl: J's has replaced it in M.
+        for(int j = WIDE ? wave : 0;; j += 4)
+        {
+          if constexpr(!WIDE)
+          {
+            int jj = 0;
+            if(lane == 0) jj = atomicAdd(&ctl->pad0, 1);
+            j = __builtin_amdgcn_readfirstlane(jj);
+          }
+          if(j >= q) break;
           double * col = Bw + (long)j * n;
           double bv[EPL];
 #pragma unroll
@@ -617,7 +646,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           }
           for(int k = 0; k < ns; ++k)
           {
-            const double v = vec_bcast(bv, k) / M[k + (long)k * ld];
+            const double v = vec_bcast(bv, k) / dgl[k];
             const double * lk = M + (long)k * ld;
 #pragma unroll
             for(int h = 0; h < EPL; ++h)
@@ -632,33 +661,29 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             if(lane + 64 * h < n) col[lane + 64 * h] = bv[h];
         }
         __syncthreads();
-        stamp(18); // B = L^-1 N
+        if constexpr(!WIDE)
+        {
+          // (L is dead: the strictly lower part of J is zero -- the reflectors' scalar products below run over whole rows)
+          for(int e = tid; e < n * n; e += WGB)
+          {
+            const int i = e % n, j = e / n;
+            if(i > j) M[i + (long)j * ld] = 0.0;
+          }
+          __syncthreads();
+        }
+        stamp(18); // B = L^-1 N (and J = L^-T)
         // B = Q R, Householder, column by column (:432-440; Eigen makeHouseholder / applyHouseholderOnTheLeft), in place.
         // B lives in the workspace (global memory).  Round 5: the reflector of a step is staged in LDS (zs: free until the loop) -- its
         // norm is a chain over LDS instead of n dependent-by-eight global round trips, and the trailing columns read it from there;
-        // a trailing column comes 16 entries per round trip, in the chain as in the update.  Per element the operations are unchanged.
-        // Beside it (round 5, n <= 128): J = L^-T needs L alone -- B = L^-1 N is complete -- and the QR never touches M; waves 2-3 have
-        // no trailing column (q <= n <= 128) and idle through the reflector's norm and the columns' chains.  Thread 128 + c runs
-        // column c of J, a few rows per reflector (a column is a back substitution of its own: nobody else's entries); what is left
-        // when the QR ends is finished where J = L^-T stands for a cold start.
-        const int jrows = WIDE ? 0 : (n + q - 1) / max(q, 1) + 1;
-        auto j_rows = [&](int rows) {
-          if(WIDE || tid < 128 || tid - 128 >= n) return;
-          const int c = tid - 128;
-          if(jnext == -2) jnext = c;
-          for(int r = 0; r < rows && jnext >= 0; ++r, --jnext)
-          {
-            const int i = jnext;
-            double acc = (c == i) ? 1.0 : 0.0;
-            acc = chain_desc_neg(M + (long)i * ld, 1, M + (long)c * ld, 1, i + 1, c + 1, acc); // L(k,i) * J(k,c), k = c .. i+1
-            M[i + (long)c * ld] = acc / dgl[i];
-          }
-        };
+        // a trailing column comes 16 entries per round trip.  The scalar product of a column with the reflector is a chain -- its
+        // thread's --; the update of the column is not: the threads leave tau t_j in LDS and all four waves share the columns (lane =
+        // row: a column's entries are contiguous).  Up to 128 unknowns the same reflector is applied to J = J Q (:443-444) in the same
+        // step: threads 128 + i run row i's scalar product beside the trailing columns' (threads 0 .. q - k - 2 <= 127), and the
+        // updates of both share the waves.  Per element the operations are unchanged.
         for(int k = 0; k < q; ++k)
         {
           double * vk = Bw + (long)k * n;
           double * vl = zs;
-          j_rows(jrows);
           if(wave == 0)
           {
 #pragma unroll
@@ -696,10 +721,8 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
           const double tau = hco[k];
           if(tau != 0.0 && k + 1 < n) // (uniform)
           {
-            // the scalar product of a trailing column with the reflector is a chain -- its thread's --; the update of the column is not:
-            // the threads leave tau t_j in LDS and all four waves share the columns (lane = row: a column's entries are contiguous)
             const int j = k + 1 + tid; // trailing column
-            if(j < q)
+            if(j < q && (WIDE || tid < 128))
             {
               double * cj = Bw + (long)j * n;
               double t = chain_asc<false, 16>(vl, 1, cj, 1, k + 1, n, 0.0);
@@ -707,6 +730,15 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
               t = t + top;
               cj[k] = FMA(-tau, t, top);
               rs[tid] = tau * t;
+            }
+            if(!WIDE && tid >= 128 && tid - 128 < n)
+            {
+              const int i = tid - 128; // row of J
+              double t = chain_asc<false>(M + i, ld, vl, 1, k + 1, n, 0.0);
+              const double jk = M[i + (long)k * ld];
+              t = t + jk;
+              M[i + (long)k * ld] = FMA(-tau, t, jk);
+              ds[i] = tau * t;
             }
             __syncthreads();
             for(int jj = k + 1 + wave; jj < q; jj += WGB / 64)
@@ -718,6 +750,22 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
               {
                 const int i = lane + 64 * h;
                 if(i > k && i < n) cj[i] = FMA(-stt, vl[i], cj[i]);
+              }
+            }
+            if constexpr(!WIDE)
+            {
+              double sv[EPL];
+#pragma unroll
+              for(int h = 0; h < EPL; ++h) sv[h] = ds[min(lane + 64 * h, n - 1)];
+              for(int jj = k + 1 + wave; jj < n; jj += WGB / 64) // a wave per column of J, lane = row
+              {
+                const double vj = vl[jj];
+#pragma unroll
+                for(int h = 0; h < EPL; ++h)
+                {
+                  const int i = lane + 64 * h;
+                  if(i < n) M[i + (long)jj * ld] = FMA(-sv[h], vj, M[i + (long)jj * ld]);
+                }
               }
             }
           }
@@ -891,6 +939,7 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
         }
         __syncthreads();
       }
+      if(!(WARM && !WIDE)) // (a warm start of at most 128 unknowns has done it, and has applied Q to J since)
       for(int e = tid; e < n * n; e += WGB) // the strictly lower part of J is zero
       {
         const int i = e % n, j = e / n;
@@ -901,9 +950,10 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
       if constexpr(WARM)
       {
         stamp(20); // J = L^-T
-        // J = J Q, Q = H_0 H_1 ... (:443-444): one row of J per thread, reflector after reflector (a row only meets itself).  Round 5:
-        // the reflector (a column of B in the workspace) is staged in LDS -- zs and ds take turns, one barrier per reflector, the next
-        // one requested before the current one is applied -- instead of every thread reading it from memory eight entries per round trip.
+        // J = J Q, Q = H_0 H_1 ... (:443-444) beyond 128 unknowns: one row of J per thread, reflector after reflector (a row only meets
+        // itself); the reflector (a column of B in the workspace) is staged in LDS -- zs and ds take turns, one barrier per reflector,
+        // the next one requested before the current one is applied.  (Up to 128 unknowns the QR loop above has applied them.)
+        if constexpr(WIDE)
         {
           double vnext = (tid < n && q > 0) ? Bw[tid] : 0.0;
           for(int k = 0; k < q; ++k)
@@ -913,48 +963,14 @@ __global__ __launch_bounds__(WGB, WIDE ? 3 : OCC) void gi_batch_big_kernel(const
             if(k + 1 < q && tid < n) vnext = Bw[(long)(k + 1) * n + tid];
             __syncthreads();
             const double tau = sss[k];
-            if(tau != 0.0 && k + 1 < n) // (uniform)
+            if(tau != 0.0 && k + 1 < n && tid < n)
             {
-              if constexpr(WIDE)
-              {
-                if(tid < n)
-                {
-                  double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
-                  const double jk = M[tid + (long)k * ld];
-                  t = t + jk;
-                  M[tid + (long)k * ld] = FMA(-tau, t, jk);
-                  const double stt = tau * t;
-                  for(int j = k + 1; j < n; ++j) M[tid + (long)j * ld] = FMA(-stt, v[j], M[tid + (long)j * ld]);
-                }
-              }
-              else
-              {
-                // the row's scalar product is a chain (its thread's); the update J(i, j) -= (tau t_i) v_j is not: the n rows leave
-                // tau t_i in LDS and ALL 256 threads share the (n - k - 1) n entries -- with a thread per row two of the four
-                // waves did 100 LDS-fed updates each, the other two nothing
-                if(tid < n)
-                {
-                  double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
-                  const double jk = M[tid + (long)k * ld];
-                  t = t + jk;
-                  M[tid + (long)k * ld] = FMA(-tau, t, jk);
-                  rs[tid] = tau * t;
-                }
-                __syncthreads();
-                double sv[EPL];
-#pragma unroll
-                for(int h = 0; h < EPL; ++h) sv[h] = rs[min(lane + 64 * h, n - 1)];
-                for(int j = k + 1 + wave; j < n; j += WGB / 64) // a wave per column, lane = row
-                {
-                  const double vj = v[j];
-#pragma unroll
-                  for(int h = 0; h < EPL; ++h)
-                  {
-                    const int i = lane + 64 * h;
-                    if(i < n) M[i + (long)j * ld] = FMA(-sv[h], vj, M[i + (long)j * ld]);
-                  }
-                }
-              }
+              double t = chain_asc<false>(M + tid, ld, v, 1, k + 1, n, 0.0);
+              const double jk = M[tid + (long)k * ld];
+              t = t + jk;
+              M[tid + (long)k * ld] = FMA(-tau, t, jk);
+              const double stt = tau * t;
+              for(int j = k + 1; j < n; ++j) M[tid + (long)j * ld] = FMA(-stt, v[j], M[tid + (long)j * ld]);
             }
           }
         }
