@@ -17,6 +17,7 @@
 // Blocks are at most 64 x 64 (one wavefront row-per-lane); the substitutions keep the running column in
 // registers and move pivots with v_readlane, like the dense kernel.  -ffp-contract=off; every fma explicit.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <climits>
 
 #include "device_common.h"
@@ -162,9 +163,8 @@ __device__ void block_trsm_left(const double * L, int ldl, const double * diagL,
 // block arrow LLT, phase 1: one 256-thread workgroup per off-head block, right-looking out of LDS (see the comment on
 // the block-tridiagonal kernel: same bits as the column-by-column order, one barrier + one division per column)
 // =========================================================================================================
-__global__ __launch_bounds__(kTriThreads) void arrow_block_kernel(const BlockDesc D)
+__device__ void arrow_block_body(const BlockDesc & D, double * sm)
 {
-  extern __shared__ double sm[];
   const int tid = threadIdx.x;
   const int i = blockIdx.x; // logical block index < nblk - 1
   const int pb = blockIdx.y; // problem in the batch
@@ -222,6 +222,12 @@ __global__ __launch_bounds__(kTriThreads) void arrow_block_kernel(const BlockDes
       for(int e = tid; e < ni * cols; e += kTriThreads) AT(Sg, ldsg, e % ni, c0 + e / ni) = AT(Xs, ldx, e % ni, e / ni);
     }
   }
+}
+
+__global__ __launch_bounds__(kTriThreads) void arrow_block_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  arrow_block_body(D, sm);
 }
 
 // =========================================================================================================
@@ -323,6 +329,9 @@ __global__ __launch_bounds__(256) void arrow_head_kernel(const BlockDesc D)
 // blocks with two barriers and an LDS round trip each (550 us for 100 blocks of 30 rows; one problem's whole factorisation was 600 us).
 // Four blocks' operands (64 loads per lane) are requested before their 32 instructions run; nothing is carried over the loop's edge.
 typedef double double4_h __attribute__((ext_vector_type(4)));
+template<int J, int NB>
+__device__ __forceinline__ void llt_columns(double (&a)[NB], int & ret, int lane, double * Ls, int * ready, int base, double piv, double ljj, double lq); // (below)
+constexpr int kHeadRingMaxBlocks = 2048; // side blocks whose descriptors the ring-fed head kernel keeps in LDS (16 bytes each)
 __global__ __launch_bounds__(256) void arrow_head_mfma_kernel(const BlockDesc D)
 {
   extern __shared__ double sm[]; // Ls (nbk x ldl)
@@ -336,6 +345,162 @@ __global__ __launch_bounds__(256) void arrow_head_mfma_kernel(const BlockDesc D)
   double * Ls = sm;
   if(D.fail[pb]) return; // a block already failed: the reference returns false before touching D_b further
   const int nt = (nbk + 15) >> 4, ntile = nt * (nt + 1) / 2;
+  // ---- the side blocks through an LDS ring (round 5): arrow pointing down, blocks of at most 32 rows with an even number of rows,
+  // even leading dimensions and 16-byte aligned blocks -- packed storage and the reference's views into an even-sized matrix alike.
+  // The loop below asks for four blocks' operands, waits for them (~3 us), runs 32 instructions (0.7 us), 25 times over: 100 of the
+  // kernel's 135 us at c5.  Here wave 3 -- no tile of its own: a head of at most 32 rows has three -- streams the blocks into a
+  // ring of four slots of two blocks with LDS-direct loads (16 bytes per lane, eight instructions per block whatever its size: the
+  // s_waitcnt constants count them), three slots in flight; waves 0-2 take their operands out of LDS.  One LDS-only barrier per
+  // slot.  Per element still the one fma chain: the blocks in order, k ascending.
+  __shared__ int s_ring_ok;
+  {
+    if(tid == 0) s_ring_ok = (!D.up && nbk <= 32 && (nbk & 1) == 0 && ntile <= 3 && D.nblk > 1 && D.nblk - 1 <= kHeadRingMaxBlocks) ? 1 : 0;
+    __syncthreads();
+    if(s_ring_ok)
+    {
+      int bad = 0;
+      for(int i = tid; i < D.nblk - 1; i += 256)
+      {
+        const int ni = D.bs[dsel(D.nblk, D.up, i)];
+        const size_t ad = reinterpret_cast<size_t>(D.side[(size_t)pb * (D.nblk - 1) + i]);
+        bad |= (ni > 32) || (D.lds[i] & 1) || (ad & 15);
+      }
+      if(bad) s_ring_ok = 0; // (benign race: every writer stores 0)
+    }
+    __syncthreads();
+    if(s_ring_ok)
+    {
+      constexpr int HB = 2, HSLOTS = 4, HNI = 8;          // blocks per slot, slots, load instructions per block
+      constexpr int HIMG = HNI * 128;                     // doubles per block image (8 KiB: pieces of 16 bytes, 64 per instruction)
+      constexpr int HSLOT = HB * HIMG;
+      double * ring = sm + (size_t)nbk * ldl + ((nbk * ldl) & 1); // (16-byte aligned behind Ls)
+      const int nside = D.nblk - 1, nchunk = (nside + HB - 1) / HB;
+      // the blocks' descriptors in LDS: fetched inside the loader's loop they are vector loads -- in the same in-order queue as the
+      // ring's, so every slot would wait for everything in flight
+      const double ** m_ptr = reinterpret_cast<const double **>(ring + HSLOTS * HSLOT);
+      int * m_ni = reinterpret_cast<int *>(m_ptr + nside);
+      int * m_ld = m_ni + nside;
+      for(int i = tid; i < nside; i += 256)
+      {
+        m_ptr[i] = D.side[(size_t)pb * nside + i];
+        m_ni[i] = D.bs[dsel(D.nblk, D.up, i)];
+        m_ld[i] = D.lds[i];
+      }
+      __syncthreads();
+      const int ppc = nbk >> 1, ldi = nbk; // 16-byte pieces per column of a block; leading dimension of its image
+      if(wave == 3)
+      {
+        // piece e = lane + 64 s of a block: column e / ppc, piece e % ppc of that column (the same for every block)
+        int pcol[HNI], poff[HNI];
+#pragma unroll
+        for(int q = 0; q < HNI; ++q)
+        {
+          const int e = l + 64 * q;
+          pcol[q] = e / ppc;
+          poff[q] = 2 * (e - pcol[q] * ppc);
+        }
+        auto issue = [&](int k) {
+          double * slot = ring + (k % HSLOTS) * HSLOT;
+#pragma unroll
+          for(int g = 0; g < HB; ++g)
+          {
+            const int i = min(k * HB + g, nside - 1);
+            const int ni = m_ni[i];
+            const double * Sg = m_ptr[i];
+            const int ldsg = m_ld[i];
+#pragma unroll
+            for(int q = 0; q < HNI; ++q)
+            {
+              const double * p = Sg + (size_t)min(pcol[q], ni - 1) * ldsg + poff[q]; // (columns past the block: its last one, never read)
+              __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)(slot + g * HIMG + q * 128), 16, 0, 0);
+            }
+          }
+        };
+        for(int k = 0; k < 3 && k < nchunk; ++k) issue(k);
+        for(int k = 0; k < nchunk; ++k)
+        {
+          // slot k has landed when at most the loads of the slots behind it are outstanding (HB * HNI = 16 each, in order)
+          if(k + 2 < nchunk)
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+          else if(k + 1 < nchunk)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          lds_barrier(); // B_k
+          if(k + 3 < nchunk) issue(k + 3); // (slot (k + 3) mod 4 was last read for slot k - 1: everybody has passed B_k)
+        }
+      }
+      else
+      {
+        const int t = wave; // (ntile <= 3)
+        const bool work = t < ntile;
+        int ti = 0, rem = t;
+        while(rem > ti)
+        {
+          rem -= ti + 1;
+          ++ti;
+        }
+        const int tj = rem;
+        const int i0 = ti * 16, c0 = tj * 16;
+        const int col = c0 + (l & 15);
+        double4_h acc;
+#pragma unroll
+        for(int r = 0; r < 4; ++r)
+        {
+          const int row = i0 + (l >> 4) + 4 * r;
+          acc[r] = (work && row < nbk && col < nbk && row >= col) ? AT(Dg, ldd, row, col) : 0.0;
+        }
+        const int arow = i0 + (l & 15), brow = c0 + (l & 15), kk = l >> 4;
+        const int ar = min(arow, nbk - 1), br = min(brow, nbk - 1);
+        const bool ain = arow < nbk, bin = brow < nbk;
+        for(int k = 0; k < nchunk; ++k)
+        {
+          lds_barrier(); // B_k: slot k is in LDS
+          if(!work) continue;
+          const double * slot = ring + (k % HSLOTS) * HSLOT;
+#pragma unroll
+          for(int g = 0; g < HB; ++g)
+          {
+            const int i = k * HB + g;
+            if(i < nside) // (uniform)
+            {
+              const int ni = m_ni[i];
+              const double * img = slot + g * HIMG;
+              double av[8], bv[8];
+#pragma unroll
+              for(int k8 = 0; k8 < 8; ++k8)
+              {
+                const int kq = min(4 * k8 + kk, ni - 1);
+                av[k8] = img[ar + kq * ldi];
+                bv[k8] = img[br + kq * ldi];
+              }
+#pragma unroll
+              for(int k8 = 0; k8 < 8; ++k8)
+              {
+                if(4 * k8 < ni) // (uniform)
+                {
+                  const bool kin = 4 * k8 + kk < ni;
+                  const double a = (kin && ain) ? -av[k8] : 0.0;
+                  const double b = (kin && bin) ? bv[k8] : 0.0;
+                  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+        if(work)
+        {
+#pragma unroll
+          for(int r = 0; r < 4; ++r)
+          {
+            const int row = i0 + (l >> 4) + 4 * r;
+            if(row < nbk && col < nbk && row >= col) AT(Ls, ldl, row, col) = acc[r];
+          }
+        }
+      }
+    }
+  }
+  if(!s_ring_ok) // (uniform; the ring needs no barrier of its own here: the one below orders Ls)
   for(int t = wave; t < ntile; t += 4)
   {
     int ti = 0, rem = t;
@@ -415,6 +580,41 @@ __global__ __launch_bounds__(256) void arrow_head_mfma_kernel(const BlockDesc D)
     }
   }
   __syncthreads();
+  if(s_ring_ok)
+  {
+    // (heads of at most 32 rows: the factorisation in registers, as arrow_block_fast_kernel's -- the padded 32 x 33 factor goes to the
+    // ring, which is free now; a pivot failure leaves Ls as it was and wave_llt below reproduces what the reference leaves behind)
+    __shared__ int s_rdy, s_ret2;
+    double * L2 = sm + (size_t)nbk * ldl + ((nbk * ldl) & 1);
+    if(tid == 0) s_rdy = 0;
+    if(wave == 0)
+    {
+      const bool row = l < nbk;
+      const int rl = row ? l : 0;
+      double a[32];
+#pragma unroll
+      for(int c = 0; c < 32; ++c)
+      {
+        const int cc = (c < nbk) ? c : 0;
+        const double v = (rl >= cc) ? AT(Ls, ldl, rl, cc) : AT(Ls, ldl, cc, rl); // (Ls holds the lower triangle: a row's upper part by symmetry)
+        a[c] = (row && c < nbk) ? v : ((l == c) ? 1.0 : 0.0); // identity padding
+      }
+      int ret = -1;
+      const double p0 = bcast_lane(a[0], 0), l0 = __builtin_sqrt(p0);
+      llt_columns<0, 32>(a, ret, l, L2, &s_rdy, 0, p0, l0, a[0] / l0);
+      if(l == 0) s_ret2 = ret;
+    }
+    __syncthreads();
+    if(s_ret2 < 0)
+    {
+      for(int e = tid; e < nbk * nbk; e += 256)
+      {
+        const int r = e % nbk, c = e / nbk;
+        if(r >= c) AT(Dg, ldd, r, c) = L2[r + c * 33];
+      }
+      return;
+    }
+  }
   if(tid < 64)
   {
     int ret = wave_llt(Ls, ldl, nbk, tid);
@@ -1273,6 +1473,91 @@ __global__ __launch_bounds__(kTriThreads) void tri_llt_fast_kernel(const BlockDe
 #endif
 }
 
+// Block arrow (pointing down), phase 1 for blocks and a head of at most NB rows (round 5): ONE step of the chain above -- wave 0
+// factorises the diagonal block in registers (llt_columns), wave 1 follows one column behind with B_i = side[i] L_i^-T
+// (trsm_columns), no barrier and no LDS round trip per column -- instead of block_llt / block_trsm_right_lt with their barrier per
+// column (40 us per block; 15 us here).  Per element the operations and their order are the same.  A pivot failure (any column) or
+// a lost hand-off: nothing has been stored yet, and the barrier kernel's body redoes the block from memory with the reference's
+// failure semantics.
+template<int NB>
+__global__ __launch_bounds__(kTriThreads) void arrow_block_fast_kernel(const BlockDesc D)
+{
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x, pb = blockIdx.y;
+  const int ni = D.bs[i], nbk = D.bs[D.nblk - 1]; // (down arrow: logical = physical)
+  double * Dg = D.diag[(size_t)pb * D.nblk + i];
+  double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
+  const int ldd = D.ldd[i], ldsg = D.lds[i];
+  constexpr int ldl = NB | 1;
+  double * Ls = sm;
+  double * Xs = Ls + NB * ldl;
+  __shared__ int s_ret, s_ready, s_lost;
+  if(tid == 0)
+  {
+    s_ready = 0;
+    s_lost = 0;
+    s_ret = -1;
+  }
+  if(wave < 2)
+    load_block(Ls, ldl, Dg, ldd, ni, ni, tid, 128);
+  else if(wave == 2)
+    load_rows<NB>(Xs, Sg, ldsg, nbk, ni, lane);
+  __syncthreads();
+  if(wave == 0)
+  {
+    const bool row = lane < ni;
+    const int rl = row ? lane : 0;
+    double a[NB];
+#pragma unroll
+    for(int c = 0; c < NB; ++c)
+    {
+      const double v = AT(Ls, ldl, rl, (c < ni) ? c : 0);
+      a[c] = (row && c < ni) ? v : ((lane == c) ? 1.0 : 0.0); // identity padding
+    }
+    int ret = -1;
+    const double p0 = bcast_lane(a[0], 0), l0 = __builtin_sqrt(p0);
+    llt_columns<0, NB>(a, ret, lane, Ls, &s_ready, 0, p0, l0, a[0] / l0);
+    if(lane == 0) s_ret = ret;
+    if(ret >= 0) tri_post(&s_ready, NB + 1, lane); // releases the wave behind
+  }
+  else if(wave == 1)
+  {
+    const bool srow = lane < nbk;
+    const int sl = srow ? lane : 0;
+    double x[NB];
+#pragma unroll
+    for(int c = 0; c < NB; ++c)
+    {
+      const double v = AT(Xs, ldl, sl, (c < ni) ? c : 0);
+      x[c] = (srow && c < ni) ? v : 0.0;
+    }
+    bool dead = false;
+    trsm_columns<0, NB>(x, Ls, &s_ready, 0, dead);
+    if(!dead)
+    {
+#pragma unroll
+      for(int c = 0; c < NB; ++c)
+        if(lane < NB) AT(Xs, ldl, lane, c) = x[c];
+    }
+    else if(lane == 0)
+      s_lost = 1; // the factorisation failed, or a hand-off never came: the barrier kernel's body takes over
+  }
+  __syncthreads();
+  if(s_lost || s_ret >= 0)
+  {
+    __syncthreads();
+    arrow_block_body(D, sm); // (nothing of this attempt has reached memory)
+    return;
+  }
+  for(int e = tid; e < ni * ni; e += kTriThreads)
+  {
+    const int r = e % ni, c = e / ni;
+    if(r >= c) AT(Dg, ldd, r, c) = AT(Ls, ldl, r, c);
+  }
+  for(int e = tid; e < nbk * ni; e += kTriThreads) AT(Sg, ldsg, e % nbk, e / nbk) = AT(Xs, ldl, e % nbk, e / nbk);
+}
+
 // triBlockDiagLSolve (triBlockDiagLLT.cpp:37-96): forward block substitution with the zero-window `start`
 __global__ __launch_bounds__(64) void tri_lsolve_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start)
 {
@@ -1409,11 +1694,22 @@ hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipS
   dd.xs_cap = panel_doubles(maxb, lds_blk);
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk);
   if(e != hipSuccess) return e;
-  if(d.nblk > 1) hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(kTriThreads), lds_blk, st, dd);
+  static const bool slow_blocks = std::getenv("JRLQP_ARROW_BLOCKS_BARRIER") != nullptr; // (diagnostic: the barrier-per-column kernel)
+  if(d.nblk > 1 && !d.up && maxb <= 32 && !slow_blocks)
+  {
+    // (the register kernel: two padded 32 x 33 blocks in LDS, or what its fall-back -- the barrier kernel's body -- needs)
+    const size_t lds_fast = std::max(lds_blk, sizeof(double) * 2 * 32 * 33);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_block_fast_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(arrow_block_fast_kernel<32>, dim3(d.nblk - 1, nprob), dim3(kTriThreads), lds_fast, st, dd);
+  }
+  else if(d.nblk > 1)
+    hipLaunchKernelGGL(arrow_block_kernel, dim3(d.nblk - 1, nprob), dim3(kTriThreads), lds_blk, st, dd);
   if(maxb <= 64)
   {
     const bool mfma = std::getenv("JRLQP_ARROW_HEAD_LDS") == nullptr; // (diagnostic: the round 1-4 kernel that staged every block in LDS)
-    const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + (mfma ? 0 : 64 * 65));
+    // (the matrix-core kernel: Ls and, for heads of at most 32 rows, the ring of side blocks -- 4 slots x 2 blocks x 8 KiB)
+    const size_t lds_head = sizeof(double) * ((size_t)maxb * (maxb | 1) + (mfma ? ((maxb <= 32 && d.nblk - 1 <= kHeadRingMaxBlocks) ? 1 + 4 * 2 * 8 * 128 + 2 * (size_t)d.nblk : 0) : 64 * 65));
     if(mfma)
     {
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_head_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_head);
