@@ -1,6 +1,6 @@
 """Extended fuzz of the host-driven dense path (Mode A, jrlqp_dense_solve) against the oracle: random n in 1 .. 260 with
 random mixes of equalities, bounds, double-sided constraints; bit-identical results required.  Not part of the suite.
-   python tools/fuzz_dense.py [trials (default 80)] [seed] [first trial]
+   python tools/fuzz_dense.py [trials (default 80)] [seed] [first trial] [n lowest] [n highest]
 
 Observed once per ~3000 trials on the GPU box (twice in 6000): the ORACLE's result array carried a NaN multiplier for an
 inactive constraint while the GPU result was the correct 0 and x, f, status, iterations agreed.  It did not reproduce on
@@ -26,11 +26,13 @@ from test_gpu_dense import check, solve_gpu
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # (earlier trials only consume the random stream)
+NLO = int(sys.argv[4]) if len(sys.argv) > 4 else 1    # range of n (default 1 .. 260; e.g. 257 420: the sizes that keep S = R^-1, CANON C10)
+NHI = int(sys.argv[5]) if len(sys.argv) > 5 else 260
 rng = np.random.default_rng(seed)
 oracle = get_oracle()
 terms = {}
 for trial in range(trials):
-    n = int(rng.integers(1, 261))
+    n = int(rng.integers(NLO, NHI + 1))
     nEq = int(rng.integers(0, max(1, n // 4) + 1)) if rng.random() < 0.4 else 0
     bounds = bool(rng.random() < 0.4)
     nIneq = int(rng.integers(0, 3 * n + 8))
