@@ -180,12 +180,19 @@ long jrlqp_gi_batch_lds_bytes(int n, int m, int nb, int * c_in_lds)
 }
 
 // grid of the persistent kernel of gi_batch_big.hip on the current device (0: no device)
-static int big_grid(int n, int m, int nb, int B, int have_ws = 1)
+static int device_cus()
 {
   int dev = 0, ncu = 0;
   if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
     return 0;
-  const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr, have_ws);
+  return ncu;
+}
+
+static int big_grid(int n, int m, int nb, int B, int two_per_cu = 1)
+{
+  const int ncu = device_cus();
+  if(ncu < 1) return 0;
+  const long ldsb = jrlqp::batch_big_lds_bytes(n, m, nb, nullptr, two_per_cu);
   const int per_cu = ldsb > 0 ? (int)(jrlqp::kLdsPerCU / ldsb) : 1;
   const int cap = jrlqp::batch_big_is_wide(n) ? 3 : 2; // (J in the workspace: more workgroups per CU hide its L2 latency; gi_batch_big.hip launch bounds)
   const int slots = ncu * (per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu));
@@ -199,12 +206,13 @@ long long jrlqp_gi_batch_workspace_bytes(int n, int m, int nb, int B)
   int r_in_lds = 0;
   if(jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds) < 0) return -1;
   if(B == 0) return 0;
-  int dev = 0, ncu = 0;
-  if(hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
-    return -1;
+  const int ncu = device_cus();
+  if(ncu < 1) return -1;
+  const int two = B > ncu ? 1 : 0; // (n = 79 .. 95: two workgroups per CU only pay when the batch has more problems than CUs)
+  if(jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds, two) < 0) return -1;
   // sized by the machine (one slice per resident workgroup of the persistent grid), not by the batch; the figure covers a
   // warm start (B = L^-1 N, n x n) as well as a cold one (R alone, and only beyond n = 104)
-  return (long long)sizeof(double) * big_grid(n, m, nb, B) * jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, 1);
+  return (long long)sizeof(double) * big_grid(n, m, nb, B, two) * jrlqp::batch_big_ws_doubles_per_wg(n, r_in_lds, 1);
 }
 
 static int gi_batch_common(int warm,
@@ -244,8 +252,9 @@ static int gi_batch_common(int warm,
   if(n > JRLQP_BATCH_MAX_N) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const bool bign = n > JRLQP_BATCH_WAVE_N; // more rows than one lane-per-row wavefront: gi_batch_big.hip
   int r_in_lds = 0;
-  // (a cold solve without a workspace keeps R in LDS wherever it fits: one workgroup per CU for n = 79 .. 95 instead of two)
-  const int have_ws = (dws != nullptr || warm) ? 1 : 0;
+  // (n = 79 .. 95: two workgroups per CU with the packed R in the workspace -- when there is a workspace and the batch has more
+  // problems than the device has CUs; a cold solve without a workspace keeps R in LDS wherever it fits)
+  const int have_ws = ((dws != nullptr || warm) && bign && B > device_cus()) ? 1 : 0;
   if(bign && jrlqp::batch_big_lds_bytes(n, m, nb, &r_in_lds, have_ws) < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
   const int cmode = bign ? 0 : jrlqp::batch_pick_cmode(n, m, nb, warm);
   if(cmode < 0) return JRLQP_ERR_UNSUPPORTED_SIZE;
@@ -271,6 +280,7 @@ static int gi_batch_common(int warm,
   a.box = 0;
   a.as_in = das;
   a.tune = env_tune();
+  a.two_per_cu = have_ws;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if(bign)
   {

@@ -25,6 +25,8 @@ struct BatchArgs
   const int * as_in;  // B x (m+nb) guesses, or nullptr ("no guess"); may alias `status`
   int box;            // 1: experimental::BoxAndSingleConstraintSolver (G = I implicit, a = x0, m == 1, nb == n, bu = +inf); n > 64: gi_batch_big.hip
   int tune;           // experiment bits (JRLQP_TUNE in the environment, capi.cpp env_tune; 0 in production)
+  int two_per_cu = 0; // gi_batch_big, n = 79 .. 95: the packed R in the workspace so that two workgroups share a CU (batches of more
+                      // problems than CUs, a workspace at hand: capi.cpp decides, batch_big_lds_bytes and the launcher follow)
 };
 
 constexpr long kLdsPerCU = 163840; // 160 KiB (MI355X_MICROARCH.md)
@@ -37,7 +39,7 @@ int batch_pick_cmode(int n, int m, int nb, int warm = 0); // -1 if unsupported
 hipError_t launch_gi_batch_box(const BatchArgs & a, hipStream_t stream);
 // 64 < n <= JRLQP_BATCH_MAX_N (gi_batch_big.hip): persistent grid of nwg workgroups; ws: nwg * batch_big_ws_doubles_per_wg(...)
 // doubles of global workspace: R when it does not fit in LDS beside J (*r_in_lds == 0), B = L^-1 N of a warm start
-long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds, int have_ws = 1);
+long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds, int two_per_cu = 1);
 bool batch_big_is_wide(int n); // J in the workspace (always beyond JRLQP_BATCH_LDS_N unknowns)
 long batch_big_ws_doubles_per_wg(int n, int r_in_lds, int warm);
 hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStream_t stream);

@@ -1698,11 +1698,12 @@ long big_lds_doubles(int n, int r_in_lds)
 
 bool batch_big_is_wide(int n) { return is_wide(n); }
 
-// have_ws == 0: the caller passed no workspace -- R stays in LDS wherever it fits (the contract of the entries without `_ws`)
-long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds, int have_ws)
+// two_per_cu == 0: R stays in LDS wherever it fits -- the caller passed no workspace (the contract of the entries without `_ws`), or the
+// batch has no more problems than the device has CUs (a workgroup alone on its CU: R in LDS is the faster place)
+long batch_big_lds_bytes(int n, int m, int nb, int * r_in_lds, int two_per_cu)
 {
   auto bytes_of = [&](int rl) { return ((big_lds_doubles(n, rl) * 8 + (long)sizeof(CtlB) + 4L * (n + 2) + (long)(m + nb)) + 15) & ~15L; };
-  if(have_ws && !is_wide(n) && !std::getenv("JRLQP_BIG_R_IN_LDS"))
+  if(two_per_cu && !is_wide(n) && !std::getenv("JRLQP_BIG_R_IN_LDS"))
   {
     // (round 5) where J and the packed R fit once but not twice beside each other and J alone fits twice -- n = 79 .. 95 -- the packed R
     // goes to the workspace: two workgroups per CU with R behind L2 against one with R in LDS
@@ -1738,7 +1739,7 @@ long batch_big_ws_doubles_per_wg(int n, int r_in_lds, int warm)
 hipError_t launch_gi_batch_big(const BatchArgs & a, int nwg, double * ws, hipStream_t stream)
 {
   int r_in_lds = 0;
-  const long lds = batch_big_lds_bytes(a.n, a.m, a.nb, &r_in_lds, ws != nullptr);
+  const long lds = batch_big_lds_bytes(a.n, a.m, a.nb, &r_in_lds, a.two_per_cu);
   if(lds < 0) return hipErrorInvalidValue;
   const long stride = batch_big_ws_doubles_per_wg(a.n, r_in_lds, a.warm);
   auto go = [&](auto kern) {

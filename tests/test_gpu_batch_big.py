@@ -95,26 +95,32 @@ def test_wide_n_grid_and_limits(capi, P, oracle):
 
 
 def test_big_n_between_79_and_95_with_and_without_a_workspace(capi, P, oracle):
-    """n = 79 .. 95: J and the packed R fit once in a CU's LDS, J alone twice.  With the caller's workspace (what
-    jrlqp_gi_batch_workspace_bytes asks for since round 5) R goes there and two workgroups share a CU; a caller that passes no
-    workspace -- the contract of the entries without `_ws`: none is needed while R fits in LDS -- still gets its solve, R in LDS, one
-    workgroup per CU.  Same bits either way."""
+    """n = 79 .. 95: J and the packed R fit once in a CU's LDS, J alone twice.  A batch of more problems than the device has CUs, with
+    the caller's workspace (what jrlqp_gi_batch_workspace_bytes asks for since round 5), keeps R there and two workgroups share a CU;
+    a smaller batch, or a caller that passes no workspace -- the contract of the entries without `_ws`: none is needed while R fits
+    in LDS -- runs with R in LDS, one workgroup per CU.  Same bits every way."""
     import torch
 
     ch = P.Characteristics(nVar=84, nObj=84, nEq=3, nIneq=130, nStrongActIneq=22, bounds=True, nStrongActBounds=6, doubleSidedIneq=True)
-    pb = P.generate_batch(5, ch, first_index=9300)
-    ref = oracle.solve_batch(pb.G, pb.a, pb.C, pb.bl, pb.bu, pb.xl, pb.xu, nthreads=5)
-    assert np.all(ref["term"] == 0) and int(ref["iters"].max()) > 10
-    assert_bit_identical(run_gpu(capi, pb, use_bounds=True), ref, "n = 84 with the workspace")
+    base = P.generate_batch(5, ch, first_index=9300)
+    ref5 = oracle.solve_batch(base.G, base.a, base.C, base.bl, base.bu, base.xl, base.xu, nthreads=5)
+    assert np.all(ref5["term"] == 0) and int(ref5["iters"].max()) > 10
+    assert_bit_identical(run_gpu(capi, base, use_bounds=True), ref5, "n = 84, five problems")
+    B = 5 * 120  # more problems than CUs: two workgroups per CU
+    tile = lambda a: np.ascontiguousarray(np.concatenate([a] * 120))
+    pb = P.PackedBatch(n=base.n, m=base.m, nb=base.nb, G=tile(base.G), a=tile(base.a), C=tile(base.C), bl=tile(base.bl), bu=tile(base.bu),
+                       xl=tile(base.xl), xu=tile(base.xu), x_star=tile(base.x_star), lam_star=tile(base.lam_star))
+    ref = {k: np.concatenate([v] * 120) for k, v in ref5.items() if k != "L"}
+    assert_bit_identical(run_gpu(capi, pb, use_bounds=True), ref, "n = 84 x 600 with the workspace")
     dev = capi.to_device(pb, "cuda:0")
-    s = capi.BatchSolver(pb.n, pb.m, True, pb.B, device="cuda:0")
+    s = capi.BatchSolver(pb.n, pb.m, True, B, device="cuda:0")
     assert s.workspace_bytes > 0
     s.workspace, s.workspace_bytes = None, 0
     r = s.solve(dev["G"], dev["a"], dev["C"], dev["bl"], dev["bu"], dev["xl"], dev["xu"])
     torch.cuda.synchronize()
     out = dict(x=r.x.cpu().numpy(), u=r.u.cpu().numpy(), status=r.status.cpu().numpy(), term=r.term.cpu().numpy(), iters=r.iters.cpu().numpy(),
                f=r.f.cpu().numpy())
-    assert_bit_identical(out, ref, "n = 84 without a workspace")
+    assert_bit_identical(out, ref, "n = 84 x 600 without a workspace")
 
 
 def test_big_n_persistent_grid_more_problems_than_cus(capi, P, oracle):
