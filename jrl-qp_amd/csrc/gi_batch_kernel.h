@@ -1626,40 +1626,17 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
       // (experimental/GoldfarbIdnaniSolver.cpp:388-487, 78-109); J = L^-T and N are in place
       // ==================================================================================================
       q = uniform(ctl->nact);
-      // ---- B = L^-1 N (:426): wave w takes columns w, w+4, ...; lane = row, forward substitution as for x0
+      // ---- B = L^-1 N (:426): wave w takes columns w, w+4, ...; lane = row, x0's forward substitution (wave_fwd: hoisted reciprocals,
+      // the column entries of L requested a group of steps ahead, no branch in a group, its own range check and plain-division
+      // fall-back -- round 5; the loop here took 325 cycles a step where wave_fwd takes ~60: 78 k of a warm start's 310 k cycles at n = 40)
+      for(int j = wave; j < q; j += 4)
       {
-        const int rl = (lane < n) ? lane : 0;
-        double dg = L[rl + rl * ld];
-        dg = (lane < n) ? dg : 1.0;
-        const double rinv = recip_refined(dg);
-        const bool den_safe = __all(div_safe_den(dg));
-        for(int j = wave; j < q; j += 4)
-        {
-          const double b0 = (lane < n) ? Bw[lane + j * ld] : 0.0;
-          double xi = b0;
-          for(int pass = 0; pass < 2; ++pass)
-          {
-            bool safe = den_safe;
-            xi = b0;
-            double col = L[rl];
-            for(int k = 0; k < n; ++k)
-            {
-              const double coln = L[rl + ((k + 1 < n) ? (k + 1) : k) * ld];
-              const double num = opaque_v(bcast_lane(xi, k));
-              const double den = bcast_lane(dg, k);
-              const double v = (pass == 0) ? div_pre(num, den, bcast_lane(rinv, k)) : num / opaque_v(den);
-              safe = safe && div_safe_num(num);
-              const double upd = FMA(-col, v, xi);
-              xi = (lane > k && lane < n) ? upd : xi;
-              xi = (lane == k) ? v : xi;
-              col = coln;
-            }
-            if(safe) break;
-          }
-          if(lane < n) Bw[lane + j * ld] = xi;
-        }
+        const double b0 = (lane < n) ? Bw[lane + j * ld] : 0.0;
+        const double xi = wave_fwd(L, ld, n, b0, lane);
+        if(lane < n) Bw[lane + j * ld] = xi;
       }
       __syncthreads();
+      STAMP(24) // B = L^-1 N
       // ---- B = Q R, Householder, column by column (:432-440; Eigen makeHouseholder / applyHouseholderOnTheLeft) on
       // wave 0; wave 1 applies each reflector to J from the right as soon as it exists (J = J Q, :443-444)
       for(int k = 0; k < q; ++k)
@@ -1719,6 +1696,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         }
       }
       __syncthreads();
+      STAMP(25) // QR and J = J Q
       // ---- R = upper triangle of the factored B (L is dead)
       for(int e = tid; e < q * q; e += WG)
       {
@@ -1726,6 +1704,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         if(i <= j) R[i + j * ld] = Bw[i + j * ld];
       }
       __syncthreads();
+      STAMP(26) // R
       // ---- initializePrimalDualPoints (:462-487), repeated after every purge (:78-109)
       for(;;)
       {
@@ -1811,6 +1790,7 @@ __global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2
         q = uniform(q - 1);
         __syncthreads();
       }
+      STAMP(27) // start point + purge
     }
     else if(ctl->eq_next != NONE)
     {
@@ -2805,6 +2785,10 @@ hipError_t launch_prof(const BatchArgs & a, long lds, hipStream_t stream)
 #else
   if(NT > 0 && a.n != NT) // a smaller problem, embedded (no phase-profile build of these)
     return a.warm ? launch_one<NT, CMODE, false, true, true>(a, lds, stream) : launch_one<NT, CMODE, false, false, true>(a, lds, stream);
+#ifdef JRLQP_WARM_PROF // (diagnostic build: the phases of a warm start in the generic kernel -- slots 24 .. 27, tools/time_big_family.py warm3 <n>)
+  if constexpr(NT == 0)
+    if(a.warm && a.prof) return launch_one<NT, CMODE, true, true>(a, lds, stream);
+#endif
   if(a.warm) return launch_one<NT, CMODE, false, true>(a, lds, stream); // the phase profile covers the cold path only
   return a.prof ? launch_one<NT, CMODE, true, false>(a, lds, stream) : launch_one<NT, CMODE, false, false>(a, lds, stream);
 #endif

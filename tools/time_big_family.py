@@ -12,7 +12,9 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 warm = fam.startswith("warm")  # warm1 / warm3: the family re-solved from its own optimal active set (0 iterations: the warm init alone); needs a build with -DJRLQP_BIG_WARM_PROF for the phases
 if warm:
     fam = "test" + fam[4:]
-if fam == "test1":
+if fam == "testF":  # (the warm family's shape: 10 n inequalities and a box -- too many for the register-resident instantiations)
+    ch = P.Characteristics(nVar=n, nObj=n, nIneq=10 * n, nStrongActIneq=int(0.35 * n), bounds=True, nStrongActBounds=int(0.1 * n), doubleSidedIneq=True)
+elif fam == "test1":
     ch = P.Characteristics(nVar=n, nObj=n, nEq=int(0.4 * n))
 else:
     ch = P.Characteristics(nVar=n, nObj=n, nEq=int(0.2 * n), nIneq=n, nStrongActIneq=int(0.3 * n), bounds=True, nStrongActBounds=int(0.1 * n), doubleSidedIneq=True)
@@ -44,6 +46,8 @@ capi.set_profile(capi.PROFILE_GI_BATCH, prof)
 s.solve(*args); torch.cuda.synchronize()
 capi.set_profile(capi.PROFILE_GI_BATCH, None)
 pr = prof.cpu().numpy().astype(np.float64)
+if os.environ.get("JRLQP_RAW_PROF"):
+    print("raw slots: " + ", ".join(f"{i}: {pr[:, i].mean():.0f}" for i in range(32)))
 names = ["load", "LLT", "x0 / J / initActiveSet", "scan + selection", "d = J^T n+", "z || R^-1 d || chain", "scalar products", "step", "addition (sweep)", "removal"]
 tot = pr[:, :10].sum(axis=1).mean()
 print(f"cycles per solve {tot:.0f}; additions {pr[:, 10].mean():.1f}, removals {pr[:, 11].mean():.1f}")
