@@ -1,6 +1,7 @@
 // gi_batch.hip -- host-side helpers and dispatch of the batched kernel (gi_batch_kernel.h); the instantiations for n <= 32, the
 // generic kernels and the box solver are compiled here, those for n = 40 .. 64 in gi_batch_wide.hip (two translation units: the
 // kernel template unrolls over n, and one unit took six minutes to compile)
+#include <cstdlib>
 #include "gi_batch_kernel.h"
 
 namespace jrlqp
@@ -57,7 +58,11 @@ hipError_t launch_gi_batch_box(const BatchArgs & a, hipStream_t stream)
 
 hipError_t launch_gi_batch(const BatchArgs & a, int cmode, hipStream_t stream)
 {
-  const long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode, a.warm);
+  long lds = batch_lds_bytes(a.n, a.m, a.nb, cmode, a.warm);
+  // (experiment: JRLQP_EXP_LDS_PAD=<bytes> of unused dynamic LDS per workgroup -- fewer workgroups per CU with the same kernel: the
+  // slope of throughput against occupancy)
+  static const long pad = [] { const char * e = std::getenv("JRLQP_EXP_LDS_PAD"); return e ? std::atol(e) : 0L; }();
+  if(pad > 0 && lds + pad <= kLdsPerCU) lds += pad;
   if(cmode == 2)
   {
     switch(batch_pad_size(a.n, a.warm))

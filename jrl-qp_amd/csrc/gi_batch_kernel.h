@@ -410,8 +410,13 @@ __device__ __forceinline__ void jinv_reg_rows(double (&acc)[N], int lane, const 
   }
 }
 
+#ifdef JRLQP_EXP_OCC4 // (experiment, tools/ubench/exp_c3.sh B -DJRLQP_EXP_OCC4: the register side of "four workgroups per CU" -- every role held to 128 VGPRs)
+#define JRLQP_OCC_50 4
+#else
+#define JRLQP_OCC_50 3
+#endif
 template<int NT, int CMODE, bool PROF, bool WARM, bool EMB = false, bool BOX = false>
-__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : (NT <= 16 ? 5 : (NT <= 32 ? 4 : 3))) : 1) void gi_batch_kernel(const BatchArgs A)
+__global__ __launch_bounds__(WG, (NT > 0 && CMODE == 2) ? ((WARM || NT > 50) ? 2 : (NT <= 16 ? 5 : (NT <= 32 ? 4 : JRLQP_OCC_50))) : 1) void gi_batch_kernel(const BatchArgs A)
 {
   long long last_ = 0, wall0_ = 0, last3_ = 0, last2_ = 0;
   if(PROF)

@@ -14,7 +14,7 @@ $L/clang -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $W/wide.s -o $W/wide.dev.o
 $L/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $W/wide.co $W/wide.dev.o
 $L/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$W/wide.co -output=$W/wide.hipfb
 /opt/rocm/bin/hipcc $F --offload-host-only -Xclang -fcuda-include-gpubinary -Xclang $W/wide.hipfb -c $C/gi_batch_wide.hip -o $W/gi_batch_wide.o
-OBJS=""; for o in gi_batch gi_batch_wide2 gi_batch_big gi_dense gi_dense_host structured blockgi selftest capi; do OBJS="$OBJS $C/$o.o"; done
+OBJS=""; for o in gi_batch gi_batch_wide2 gi_batch_big gi_dense gi_dense_host structured blockgi blockgi_c9 selftest capi; do OBJS="$OBJS $C/$o.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ubench/lib$TAG.bin $W/gi_batch_wide.o $OBJS
 grep -c "scratch_" $W/wide.s | sed "s/^/scratch ops in listing: /"
 ls -la $ROOT/tools/ubench/lib$TAG.bin
