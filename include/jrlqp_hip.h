@@ -180,8 +180,8 @@ int jrlqp_gi_solve_batch_warm(int n,
  *   jrlqp_gi_batch_workspace_bytes: device bytes a batch of B problems of shape (n, m, nb) needs beside its inputs and outputs
  *     on the CURRENT device, cold or warm-started: 0 for every shape whose state fits in LDS and registers (all n <= 64); beyond,
  *     per resident workgroup of the persistent grid (sized by the machine, not by B), the n x n array B = L^-1 N of a warm
- *     start, the packed R factor -- from n = 79 to 95 so that two workgroups share a CU (round 5), and past n = 104 .. 112 (it depends on
- *     m + nb too) because it no longer fits in LDS --, and past n = 128 the factors L / J themselves.  A cold solve needs only the R / J
+ *     start, the packed R factor -- from n = 79 to 95 for batches of more problems than the device has CUs, so that two workgroups
+ *     share a CU (round 5), and past n = 104 .. 112 (it depends on m + nb too) because it no longer fits in LDS --, and past n = 128 the factors L / J themselves.  A cold solve needs only the R / J
  *     part and accepts a smaller workspace accordingly; WITHOUT any workspace (NULL) it still runs wherever R fits in LDS (n <= 104 at
  *     least; one workgroup per CU from n = 79); -1 if the shape is unsupported.
  *   jrlqp_gi_solve_batch_ws: jrlqp_gi_solve_batch (warm == 0, das ignored) or jrlqp_gi_solve_batch_warm (warm != 0) with that
