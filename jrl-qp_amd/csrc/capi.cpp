@@ -87,6 +87,7 @@ struct jrlqp_blocks
   double **d_diag = nullptr, **d_side = nullptr;
   double * d_tmp = nullptr;
   bool bound = false;
+  int ring_ok = 0; // (jrlqp_blocks_bind)
 };
 
 // plan object of the structured GI solver: a jrlqp_blocks plan (factorisation of G) + the block-diagonal C description
@@ -637,6 +638,14 @@ int jrlqp_blocks_bind(jrlqp_blocks * p, double * const * ddiag, const int * ldd,
   }
   HIP_TRY(p->stage.submitted(st));
   p->bound = true;
+  // (can the side blocks of a down arrow be streamed into LDS 16 bytes per lane?  structured.hip, arrow_lsolve_head_ring_kernel)
+  p->ring_ok = (p->kind == 0 && ns >= 1 && ns <= 2048 && (p->h_bs[p->nblk - 1] & 1) == 0) ? 1 : 0;
+  for(int i = 0; i < p->nblk && p->ring_ok; ++i)
+    if(p->h_bs[i] > 32) p->ring_ok = 0;
+  for(int i = 0; i < ns && p->ring_ok; ++i)
+    if(lds[i] & 1) p->ring_ok = 0;
+  for(size_t i = 0; ns > 0 && i < (size_t)p->nprob * ns && p->ring_ok; ++i)
+    if(reinterpret_cast<size_t>(dside[i]) & 15) p->ring_ok = 0;
   return JRLQP_OK;
 }
 
@@ -650,6 +659,7 @@ static jrlqp::BlockDesc make_desc(const jrlqp_blocks * p, long mstride)
   d.diag = p->d_diag; d.side = p->d_side; d.fail = p->d_fail;
   d.h_bs = p->h_bs.data();
   d.xs_cap = 0; // (set by the factorisation launch helpers)
+  d.ring_ok = p->ring_ok;
   return d;
 }
 

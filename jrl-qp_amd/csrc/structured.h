@@ -17,6 +17,8 @@ struct BlockDesc
   int * fail;      // [nprob] set to 1 when a factorisation fails
   const int * h_bs; // host copy of bs (launch helpers only)
   int xs_cap;      // doubles of LDS the factorisation kernels may use for a panel of a side block (set by the launch helpers)
+  int ring_ok = 0; // arrow pointing down, every block of at most 32 rows, an even number of rows in the head, even leading dimensions and
+                   // 16-byte aligned side blocks (jrlqp_blocks_bind checks): the side blocks can be streamed into LDS 16 bytes per lane
 };
 
 hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st);

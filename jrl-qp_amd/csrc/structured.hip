@@ -1683,6 +1683,168 @@ inline int panel_doubles(int maxb, size_t & lds_bytes)
   lds_bytes = sizeof(double) * (fixed + panel);
   return (int)panel;
 }
+// The head of the arrow's L solve (pointing down) for blocks of at most 32 rows, round 5: y_b -= sum_i B_i x_i is ONE chain of
+// (number of unknowns) terms per head row -- 3000 at c5 --, and the staged kernel above spent 190 us on it for one problem: a scalar
+// chain out of LDS (33 cycles a term) behind groups of side blocks staged by three waves with plain loads (a round trip per group).
+// Here, as in arrow_head_mfma_kernel: wave 3 streams the side blocks into an LDS ring with LDS-direct loads (three slots of two
+// blocks in flight) and wave 0 runs the chain, lane = head row, every operand of a block requested before the block's terms run.
+// (The matrix cores were tried -- A = [-x_k] in row 0, B = B_i^T, so that D(0, j) is head row j's chain, bit for bit -- and lost:
+// a dependent v_mfma_f64_16x16x4 costs ~170 cycles and one row of sixteen is used; 100 us for the 1400 of c5 against 41 us for the
+// 3000 scalar terms.)  Per element: the staged kernel's chain.
+constexpr int LB = 2, LSLOTS = 4, LNI = 8, LIMG = LNI * 128, LSLOT = LB * LIMG;
+__global__ __launch_bounds__(256) void arrow_lsolve_head_ring_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start, int end)
+{
+  extern __shared__ double sm[]; // ring | x (the unknowns of the off-head blocks) | descriptors
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, pb = blockIdx.x;
+  const int ib = D.nblk - 1, nbk = D.bs[ib], nside = D.nblk - 1, nchunk = (nside + LB - 1) / LB;
+  int ntot = 0;
+  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int nx = ntot - nbk;
+  double * Mp = M + (size_t)pb * D.mstride;
+  const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
+  double * ring = sm;
+  double * xs = ring + LSLOTS * LSLOT;
+  const double ** m_ptr = reinterpret_cast<const double **>(xs + ((nx + 1) & ~1));
+  int * m_ni = reinterpret_cast<int *>(m_ptr + nside);
+  int * m_ld = m_ni + nside;
+  int * m_n0 = m_ld + nside;
+  for(int i = tid; i < nside; i += 256)
+  {
+    m_ptr[i] = D.side[(size_t)pb * nside + i];
+    m_ni[i] = D.bs[i];
+    m_ld[i] = D.lds[i];
+  }
+  __syncthreads();
+  if(tid == 0) // (out of LDS: the same walk over D.bs is a dependent memory round trip per block)
+  {
+    int n0 = 0;
+    for(int i = 0; i < nside; ++i)
+    {
+      m_n0[i] = n0;
+      n0 += m_ni[i];
+    }
+  }
+  const int ppc = nbk >> 1, ldi = nbk; // 16-byte pieces per column of a side block (nbk rows); leading dimension of its image
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mb = Mp + nx + (size_t)c * ldm;
+    __syncthreads(); // (descriptors; the previous right-hand side is done with xs and the ring)
+    for(int e = tid; e < nx; e += 256) xs[e] = Mp[e + (size_t)c * ldm];
+    __syncthreads();
+    if(wave == 3)
+    {
+      int pcol[LNI], poff[LNI];
+#pragma unroll
+      for(int q = 0; q < LNI; ++q)
+      {
+        const int e = l + 64 * q;
+        pcol[q] = e / ppc;
+        poff[q] = 2 * (e - pcol[q] * ppc);
+      }
+      auto issue = [&](int k) {
+        double * slot = ring + (k % LSLOTS) * LSLOT;
+#pragma unroll
+        for(int g = 0; g < LB; ++g)
+        {
+          const int i = min(k * LB + g, nside - 1);
+          const int ni = m_ni[i];
+          const double * Sg = m_ptr[i];
+          const int ldsg = m_ld[i];
+#pragma unroll
+          for(int q = 0; q < LNI; ++q)
+          {
+            const double * p = Sg + (size_t)min(pcol[q], ni - 1) * ldsg + poff[q];
+            __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)(slot + g * LIMG + q * 128), 16, 0, 0);
+          }
+        }
+      };
+#ifdef LRING_PROF
+      long long tw = 0, tb = 0, ti = 0;
+#endif
+      for(int k = 0; k < 3 && k < nchunk; ++k) issue(k);
+      for(int k = 0; k < nchunk; ++k)
+      {
+#ifdef LRING_PROF
+        const long long t0 = wall_clock64();
+#endif
+        if(k + 2 < nchunk)
+          asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if(k + 1 < nchunk)
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LRING_PROF
+        const long long t1 = wall_clock64();
+#endif
+        lds_barrier(); // B_k
+#ifdef LRING_PROF
+        const long long t2 = wall_clock64();
+#endif
+        if(k + 3 < nchunk) issue(k + 3);
+#ifdef LRING_PROF
+        tw += t1 - t0; tb += t2 - t1; ti += wall_clock64() - t2;
+#endif
+      }
+#ifdef LRING_PROF
+      if(pb == 0 && l == 0) printf("lring loader: wait loads %lld, barrier %lld, issue %lld (10 ns ticks)\n", tw, tb, ti);
+#endif
+    }
+    else if(wave == 0)
+    {
+      // lane = head row: its chain over the blocks in order, k ascending -- every operand of a block requested before its chain runs
+      // (clamped addresses, fixed counts; the terms outside [s, ni) are not executed)
+      const int rl = min(l, nbk - 1);
+      double acc = (l < nbk) ? Mb[l] : 0.0;
+#ifdef LRING_PROF
+      long long cb = 0, cc = 0, clast = wall_clock64();
+#endif
+      for(int k = 0; k < nchunk; ++k)
+      {
+#ifdef LRING_PROF
+        { const long long t = wall_clock64(); cc += t - clast; clast = t; }
+#endif
+        lds_barrier(); // B_k: slot k is in LDS
+#ifdef LRING_PROF
+        { const long long t = wall_clock64(); cb += t - clast; clast = t; }
+#endif
+        const double * slot = ring + (k % LSLOTS) * LSLOT;
+#pragma unroll
+        for(int g = 0; g < LB; ++g)
+        {
+          const int i = k * LB + g;
+          if(i >= nside) continue; // (uniform)
+          const int ni = m_ni[i], n0 = m_n0[i];
+          const int s = max(start - n0, 0);
+          if(ni < s || end <= n0) continue; // (the reference's zero-window skipping, blockArrowLLT.cpp:139-151)
+          const double * img = slot + g * LIMG + rl;
+          const double * xi = xs + n0;
+          double bv[32], xv[32];
+#pragma unroll
+          for(int kq = 0; kq < 32; ++kq)
+          {
+            const int kc = min(kq, ni - 1);
+            bv[kq] = img[kc * ldi];
+            xv[kq] = xi[kc];
+          }
+#pragma unroll
+          for(int kq = 0; kq < 32; ++kq)
+            if(kq >= s && kq < ni) acc = FMA(-bv[kq], xv[kq], acc); // (uniform)
+        }
+      }
+#ifdef LRING_PROF
+      if(pb == 0 && l == 0) printf("lring chain: barrier %lld, compute %lld (10 ns ticks)\n", cb, cc);
+#endif
+      double a1 = 0.0;
+      wave_fwd2(Lb, D.ldd[ib], nbk, acc, a1, l);
+      if(l < nbk) Mb[l] = acc;
+    }
+    else
+    {
+      for(int k = 0; k < nchunk; ++k) lds_barrier();
+    }
+  }
+}
+
 } // namespace
 
 hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st)
@@ -1751,7 +1913,16 @@ hipError_t launch_block_arrow_solve(const BlockDesc & d, int nprob, bool transpo
     if(d.nblk > 1) hipLaunchKernelGGL(arrow_lsolve_blocks_kernel, dim3(d.nblk - 1, nprob), dim3(64), 0, st, d, M, ldm, nrhs, start, end);
     int maxb = 0;
     for(int k = 0; k < d.nblk; ++k) maxb = d.h_bs[k] > maxb ? d.h_bs[k] : maxb;
-    if(maxb <= 64 && d.nblk > 1)
+    static const bool no_ring = std::getenv("JRLQP_ARROW_LSOLVE_STAGED") != nullptr; // (diagnostic: the staged scalar chain)
+    if(d.ring_ok && !d.up && maxb <= 32 && d.nblk > 1 && !no_ring)
+    {
+      // (the ring of side blocks | the unknowns of the off-head blocks | 24 bytes of descriptors per block)
+      const size_t lds = sizeof(double) * ((size_t)LSLOTS * LSLOT + (size_t)((ntot + 1) & ~1) + 3 * (size_t)d.nblk + 2);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&arrow_lsolve_head_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if(e != hipSuccess) return e;
+      hipLaunchKernelGGL(arrow_lsolve_head_ring_kernel, dim3(nprob), dim3(256), lds, st, d, M, ldm, nrhs, start, end);
+    }
+    else if(maxb <= 64 && d.nblk > 1)
     {
       // side blocks staged through LDS in groups (arrow_lsolve_head_staged_kernel): as many blocks per group as 2 x gb x bcap doubles allow
       const int bcap = maxb * (maxb | 1);
