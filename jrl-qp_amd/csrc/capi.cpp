@@ -86,6 +86,7 @@ struct jrlqp_blocks
   int *d_bs = nullptr, *d_ldd = nullptr, *d_lds = nullptr, *d_fail = nullptr;
   double **d_diag = nullptr, **d_side = nullptr;
   double * d_tmp = nullptr;
+  int * d_off = nullptr; // logical prefix offsets (nblk + 1)
   bool bound = false;
   int ring_ok = 0; // (jrlqp_blocks_bind)
 };
@@ -588,6 +589,14 @@ int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, 
   if(e == hipSuccess) e = hipMalloc(&p->d_side, sizeof(double *) * (size_t)nprob * ns);
   if(e == hipSuccess) e = hipMalloc(&p->d_tmp, sizeof(double) * (size_t)nprob * ntot * max_nrhs);
   if(e == hipSuccess) e = hipMemcpy(p->d_bs, block_sizes, sizeof(int) * nblk, hipMemcpyHostToDevice);
+  if(e == hipSuccess) e = hipMalloc(&p->d_off, sizeof(int) * (nblk + 1));
+  if(e == hipSuccess)
+  {
+    // (logical order: the up arrow's blocks are rotated by one, structured.hip dsel)
+    std::vector<int> off(nblk + 1, 0);
+    for(int i = 0; i < nblk; ++i) off[i + 1] = off[i] + block_sizes[(kind == 1) ? (i + 1) % nblk : i];
+    e = hipMemcpy(p->d_off, off.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice);
+  }
   if(e == hipSuccess) e = p->stage.init(sizeof(int) * 2 * (size_t)(nblk + ns + 2) + sizeof(double *) * (size_t)nprob * (nblk + ns));
   if(e != hipSuccess)
   {
@@ -601,7 +610,7 @@ int jrlqp_blocks_create(int kind, int nblk, const int * block_sizes, int nprob, 
 void jrlqp_blocks_destroy(jrlqp_blocks * p)
 {
   if(!p) return;
-  (void)hipFree(p->d_bs); (void)hipFree(p->d_ldd); (void)hipFree(p->d_lds); (void)hipFree(p->d_fail);
+  (void)hipFree(p->d_off); (void)hipFree(p->d_bs); (void)hipFree(p->d_ldd); (void)hipFree(p->d_lds); (void)hipFree(p->d_fail);
   (void)hipFree(p->d_diag); (void)hipFree(p->d_side); (void)hipFree(p->d_tmp);
   p->stage.release();
   delete p;
@@ -660,6 +669,8 @@ static jrlqp::BlockDesc make_desc(const jrlqp_blocks * p, long mstride)
   d.h_bs = p->h_bs.data();
   d.xs_cap = 0; // (set by the factorisation launch helpers)
   d.ring_ok = p->ring_ok;
+  d.off = p->d_off;
+  d.ntot = p->ntot;
   return d;
 }
 

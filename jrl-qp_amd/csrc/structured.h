@@ -17,6 +17,8 @@ struct BlockDesc
   int * fail;      // [nprob] set to 1 when a factorisation fails
   const int * h_bs; // host copy of bs (launch helpers only)
   int xs_cap;      // doubles of LDS the factorisation kernels may use for a panel of a side block (set by the launch helpers)
+  const int * off = nullptr; // [nblk + 1] first unknown of LOGICAL block i (device; the kernels summed block sizes from memory before)
+  int ntot = 0;              // number of unknowns
   int ring_ok = 0; // arrow pointing down, every block of at most 32 rows, an even number of rows in the head, even leading dimensions and
                    // 16-byte aligned side blocks (jrlqp_blocks_bind checks): the side blocks can be streamed into LDS 16 bytes per lane
 };

@@ -711,8 +711,7 @@ __global__ __launch_bounds__(64) void arrow_lsolve_blocks_kernel(const BlockDesc
   const int lane = threadIdx.x, i = blockIdx.x, pb = blockIdx.y;
   const int id = dsel(D.nblk, D.up, i);
   const int ni = D.bs[id];
-  int n0 = 0;
-  for(int k = 0; k < i; ++k) n0 += D.bs[dsel(D.nblk, D.up, k)];
+  const int n0 = D.off[i];
   int s = max(start - n0, 0);
   if(ni < s || end <= n0) return; // M_i is zero
   const double * Dg = D.diag[(size_t)pb * D.nblk + id];
@@ -736,8 +735,7 @@ __global__ __launch_bounds__(64) void arrow_lsolve_head_kernel(const BlockDesc D
   const int lane = threadIdx.x, pb = blockIdx.x;
   const int ib = dsel(D.nblk, D.up, D.nblk - 1);
   const int nbk = D.bs[ib];
-  int ntot = 0;
-  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int ntot = D.ntot;
   double * Mp = M + (size_t)pb * D.mstride;
   const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
   for(int c = 0; c < nrhs; ++c)
@@ -789,8 +787,7 @@ __global__ __launch_bounds__(256) void arrow_lsolve_head_staged_kernel(const Blo
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pb = blockIdx.x;
   const int ib = dsel(D.nblk, D.up, D.nblk - 1);
   const int nbk = D.bs[ib];
-  int ntot = 0;
-  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int ntot = D.ntot;
   double * Mp = M + (size_t)pb * D.mstride;
   const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
   double * Bs = sm;
@@ -804,8 +801,7 @@ __global__ __launch_bounds__(256) void arrow_lsolve_head_staged_kernel(const Blo
     auto stage = [&](int g, int t0, int nthr) {
       double * Bg = Bs + (size_t)(g & 1) * gb * bcap;
       double * Xg = Xs + (size_t)(g & 1) * gb * 64;
-      int n0 = 0;
-      for(int i = 0; i < g * gb; ++i) n0 += D.bs[dsel(D.nblk, D.up, i)];
+      int n0 = D.off[min(g * gb, D.nblk)];
       for(int j = 0; j < gb; ++j)
       {
         const int i = g * gb + j;
@@ -870,8 +866,7 @@ __global__ __launch_bounds__(64) void arrow_ltsolve_head_kernel(const BlockDesc 
   const int lane = threadIdx.x, pb = blockIdx.x;
   const int ib = dsel(D.nblk, D.up, D.nblk - 1);
   const int nbk = D.bs[ib];
-  int ntot = 0;
-  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int ntot = D.ntot;
   if(!(end > ntot - nbk)) return;
   const int r = end - ntot + nbk;
   const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
@@ -892,13 +887,11 @@ __global__ __launch_bounds__(64) void arrow_ltsolve_blocks_kernel(const BlockDes
   const int lane = threadIdx.x, i = blockIdx.x, pb = blockIdx.y;
   const int ib = dsel(D.nblk, D.up, D.nblk - 1);
   const int nbk = D.bs[ib];
-  int ntot = 0;
-  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int ntot = D.ntot;
   const bool zero = !(end > ntot - nbk);
   const int id = dsel(D.nblk, D.up, i);
   const int ni = D.bs[id];
-  int n0 = 0;
-  for(int k = 0; k < i; ++k) n0 += D.bs[dsel(D.nblk, D.up, k)];
+  const int n0 = D.off[i];
   if(zero && start >= n0 + ni) return;
   const double * Li = D.diag[(size_t)pb * D.nblk + id];
   const int ldd = D.ldd[id];
@@ -1617,8 +1610,7 @@ __global__ __launch_bounds__(64) void tri_ltsolve_kernel(const BlockDesc D, doub
 {
   const int lane = threadIdx.x, pb = blockIdx.x;
   double * Mp = M + (size_t)pb * D.mstride;
-  int ntot = 0;
-  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int ntot = D.ntot;
   const int end = (end_in < 0) ? ntot : end_in;
   for(int c = 0; c < nrhs; ++c)
   {
@@ -1697,8 +1689,7 @@ __global__ __launch_bounds__(256) void arrow_lsolve_head_ring_kernel(const Block
   extern __shared__ double sm[]; // ring | x (the unknowns of the off-head blocks) | descriptors
   const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, pb = blockIdx.x;
   const int ib = D.nblk - 1, nbk = D.bs[ib], nside = D.nblk - 1, nchunk = (nside + LB - 1) / LB;
-  int ntot = 0;
-  for(int k = 0; k < D.nblk; ++k) ntot += D.bs[k];
+  const int ntot = D.ntot;
   const int nx = ntot - nbk;
   double * Mp = M + (size_t)pb * D.mstride;
   const double * Lb = D.diag[(size_t)pb * D.nblk + ib];
