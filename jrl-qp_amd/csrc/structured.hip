@@ -1559,13 +1559,27 @@ __global__ __launch_bounds__(64) void tri_lsolve_kernel(const BlockDesc D, doubl
   for(int c = 0; c < nrhs; ++c)
   {
     double * Mc = Mp + (size_t)c * ldm;
-    int n = 0, l = 0, li = 0;
+    int n = 0, li = 0;
     bool zero = true;
+    double xp[2] = {0.0, 0.0}; // the solution of the block before (rows lane, lane + 64): its terms below come out of these registers
+    // (round 5) the descriptors of a block are fetched one block ahead; the block before's solution stays in registers (it was stored
+    // and read back through memory behind a fence); S(r, k) is requested 16 columns at a time
+    int ni_n = D.bs[0], ldd_n = D.ldd[0], ldsg_n = 1;
+    const double * Li_n = D.diag[(size_t)pb * D.nblk];
+    const double * Sg_n = nullptr;
     for(int i = 0; i < D.nblk; ++i)
     {
-      const int ni = D.bs[i];
-      const double * Li = D.diag[(size_t)pb * D.nblk + i];
-      const int ldd = D.ldd[i];
+      const int ni = ni_n, ldd = ldd_n, ldsg = ldsg_n;
+      const double * Li = Li_n;
+      const double * Sg = Sg_n;
+      if(i + 1 < D.nblk)
+      {
+        ni_n = D.bs[i + 1];
+        ldd_n = D.ldd[i + 1];
+        Li_n = D.diag[(size_t)pb * D.nblk + i + 1];
+        Sg_n = D.side[(size_t)pb * (D.nblk - 1) + i];
+        ldsg_n = D.lds[i];
+      }
       if(n + ni >= start)
       {
         if(zero)
@@ -1576,29 +1590,48 @@ __global__ __launch_bounds__(64) void tri_lsolve_kernel(const BlockDesc D, doubl
           if(lane < r) Mc[start + lane] = xa;
           if(lane + 64 < r) Mc[start + lane + 64] = xb;
           zero = false;
+          // (the solve above ran on the rows from `off` on, lane e = row off + e: the next block wants row k in lane k mod 64 of xp[k / 64])
+          __threadfence_block();
+          wave_sync();
+          xp[0] = (lane < ni) ? Mc[n + lane] : 0.0; // (rows in front of `start`: whatever zero the caller stored)
+          xp[1] = (lane + 64 < ni) ? Mc[n + lane + 64] : 0.0;
         }
         else
         {
-          const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i - 1];
-          const int ldsg = D.lds[i - 1];
           double acc[2]; // rows lane, lane + 64 of block i
 #pragma unroll
           for(int h = 0; h < 2; ++h)
           {
             const int r = lane + 64 * h;
+            const int rc = min(r, ni - 1);
             acc[h] = (r < ni) ? Mc[n + r] : 0.0;
-            if(r < ni)
-              for(int k = 0; k < li; ++k) acc[h] = FMA(-AT(Sg, ldsg, r, k), Mc[l + k], acc[h]);
+            if(64 * h < ni) // (uniform)
+              for(int k0 = 0; k0 < li; k0 += 16)
+              {
+                double sv[16];
+#pragma unroll
+                for(int e = 0; e < 16; ++e) sv[e] = AT(Sg, ldsg, rc, min(k0 + e, li - 1));
+#pragma unroll
+                for(int e = 0; e < 16; ++e)
+                {
+                  const int k = k0 + e;
+                  if(k < li) // (uniform)
+                  {
+                    const double xk = (k < 64) ? bcast_lane_s(xp[0], k) : bcast_lane_s(xp[1], k - 64);
+                    const double t = FMA(-sv[e], xk, acc[h]);
+                    acc[h] = (r < ni) ? t : acc[h];
+                  }
+                }
+              }
           }
           wave_fwd2(Li, ldd, ni, acc[0], acc[1], lane);
 #pragma unroll
           for(int h = 0; h < 2; ++h)
             if(lane + 64 * h < ni) Mc[n + lane + 64 * h] = acc[h];
+          xp[0] = acc[0];
+          xp[1] = acc[1];
         }
-        __threadfence_block();
-        wave_sync();
       }
-      l = n;
       li = ni;
       n += ni;
     }
@@ -1615,13 +1648,26 @@ __global__ __launch_bounds__(64) void tri_ltsolve_kernel(const BlockDesc D, doub
   for(int c = 0; c < nrhs; ++c)
   {
     double * Mc = Mp + (size_t)c * ldm;
-    int n = ntot, l = 0, li = 0;
+    int n = ntot, li = 0;
     bool zero = true;
-    for(int i = D.nblk - 1; i >= 0; --i)
+    double xp[2] = {0.0, 0.0}; // the solution of the block behind (rows lane, lane + 64); see tri_lsolve_kernel
+    const int last = D.nblk - 1;
+    int ni_n = D.bs[last], ldd_n = D.ldd[last], ldsg_n = 1;
+    const double * Li_n = D.diag[(size_t)pb * D.nblk + last];
+    const double * Sg_n = nullptr;
+    for(int i = last; i >= 0; --i)
     {
-      const int ni = D.bs[i];
-      const double * Li = D.diag[(size_t)pb * D.nblk + i];
-      const int ldd = D.ldd[i];
+      const int ni = ni_n, ldd = ldd_n, ldsg = ldsg_n;
+      const double * Li = Li_n;
+      const double * Sg = Sg_n;
+      if(i > 0)
+      {
+        ni_n = D.bs[i - 1];
+        ldd_n = D.ldd[i - 1];
+        Li_n = D.diag[(size_t)pb * D.nblk + i - 1];
+        Sg_n = D.side[(size_t)pb * (D.nblk - 1) + i - 1];
+        ldsg_n = D.lds[i - 1];
+      }
       if(n - ni < end)
       {
         if(zero)
@@ -1632,29 +1678,47 @@ __global__ __launch_bounds__(64) void tri_ltsolve_kernel(const BlockDesc D, doub
           if(lane < r) Mc[n - ni + lane] = xa;
           if(lane + 64 < r) Mc[n - ni + lane + 64] = xb;
           zero = false;
+          __threadfence_block();
+          wave_sync();
+          xp[0] = (lane < ni) ? Mc[n - ni + lane] : 0.0; // (rows from `end` on: whatever zero the caller stored)
+          xp[1] = (lane + 64 < ni) ? Mc[n - ni + lane + 64] : 0.0;
         }
         else
         {
-          const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
-          const int ldsg = D.lds[i];
           double acc[2]; // rows lane, lane + 64 of block i
 #pragma unroll
           for(int h = 0; h < 2; ++h)
           {
             const int r = lane + 64 * h;
+            const int rc = min(r, ni - 1);
             acc[h] = (r < ni) ? Mc[n - ni + r] : 0.0;
-            if(r < ni)
-              for(int k = li - 1; k >= 0; --k) acc[h] = FMA(-AT(Sg, ldsg, k, r), Mc[(l - li) + k], acc[h]);
+            if(64 * h < ni) // (uniform)
+              for(int k0 = li - 1; k0 >= 0; k0 -= 16)
+              {
+                double sv[16];
+#pragma unroll
+                for(int e = 0; e < 16; ++e) sv[e] = AT(Sg, ldsg, max(k0 - e, 0), rc);
+#pragma unroll
+                for(int e = 0; e < 16; ++e)
+                {
+                  const int k = k0 - e;
+                  if(k >= 0) // (uniform)
+                  {
+                    const double xk = (k < 64) ? bcast_lane_s(xp[0], k) : bcast_lane_s(xp[1], k - 64);
+                    const double t = FMA(-sv[e], xk, acc[h]);
+                    acc[h] = (r < ni) ? t : acc[h];
+                  }
+                }
+              }
           }
           wave_bwd2(Li, ldd, ni, acc[0], acc[1], lane);
 #pragma unroll
           for(int h = 0; h < 2; ++h)
             if(lane + 64 * h < ni) Mc[n - ni + lane + 64 * h] = acc[h];
+          xp[0] = acc[0];
+          xp[1] = acc[1];
         }
-        __threadfence_block();
-        wave_sync();
       }
-      l = n;
       li = ni;
       n -= ni;
     }
@@ -1836,6 +1900,178 @@ __global__ __launch_bounds__(256) void arrow_lsolve_head_ring_kernel(const Block
   }
 }
 
+// The block-tridiagonal solves for blocks of at most 32 rows (round 5): everything block i needs -- its row (column) of L_i, the diagonal
+// entry, its row (column) of the side block and its right-hand side entry -- is requested while block i - 1 (i + 1) is being solved, and
+// the substitution runs on registers (wave_fwd_pre / wave_bwd_pre); the descriptors of all blocks sit in LDS.  The kernels above pay
+// some five dependent memory round trips per block (4.4 us); per element the chains are theirs.
+struct TriMeta
+{
+  const double ** mL;
+  const double ** mS;
+  int *ni, *ldd, *lds, *off;
+};
+__device__ __forceinline__ TriMeta tri_meta(double * sm, const BlockDesc & D, int pb, int tid, int nthr)
+{
+  TriMeta m;
+  m.mL = reinterpret_cast<const double **>(sm);
+  m.mS = m.mL + D.nblk;
+  m.ni = reinterpret_cast<int *>(m.mS + D.nblk);
+  m.ldd = m.ni + D.nblk;
+  m.lds = m.ldd + D.nblk;
+  m.off = m.lds + D.nblk;
+  for(int i = tid; i < D.nblk; i += nthr)
+  {
+    m.mL[i] = D.diag[(size_t)pb * D.nblk + i];
+    m.mS[i] = (i + 1 < D.nblk) ? D.side[(size_t)pb * (D.nblk - 1) + i] : nullptr;
+    m.ni[i] = D.bs[i];
+    m.ldd[i] = D.ldd[i];
+    m.lds[i] = (i + 1 < D.nblk) ? D.lds[i] : 1;
+    m.off[i] = D.off[i];
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(64) void tri_lsolve_pre_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int start)
+{
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x, pb = blockIdx.x;
+  const TriMeta m = tri_meta(sm, D, pb, lane, 64);
+  wave_sync();
+  __threadfence_block();
+  double * Mp = M + (size_t)pb * D.mstride;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mc = Mp + (size_t)c * ldm;
+    // the first block the window reaches: solved on its rows from `start` on (the kernel above's code)
+    int i0 = 0;
+    while(i0 < D.nblk && m.off[i0] + m.ni[i0] < start) ++i0;
+    if(i0 >= D.nblk) continue;
+    double xp;
+    {
+      const int n = m.off[i0], ni = m.ni[i0], ldd = m.ldd[i0];
+      const double * Li = m.mL[i0];
+      const int r = n + ni - start, off = ni - r;
+      double xa = (lane < r) ? Mc[start + lane] : 0.0, xb = 0.0;
+      wave_fwd2(Li + off + (size_t)off * ldd, ldd, r, xa, xb, lane);
+      if(lane < r) Mc[start + lane] = xa;
+      __threadfence_block();
+      wave_sync();
+      xp = (lane < ni) ? Mc[n + lane] : 0.0; // (rows in front of `start`: whatever zero the caller stored)
+    }
+    // operands of block j: lane = row; lv[e] = L_j(row, min(e, n_j - 1)), sv[e] = S_{j-1}(row, min(e, n_{j-1} - 1))
+    double lv[32], sv[32], dg = 1.0, rhs = 0.0;
+    auto fetch = [&](int j, double (&lo)[32], double (&so)[32], double & dgo, double & rho) {
+      const int nj = m.ni[j], lj = m.ni[j - 1], rl = min(lane, nj - 1);
+      const double * Lj = m.mL[j];
+      const double * Sj = m.mS[j - 1];
+      const int ldd = m.ldd[j], ldsg = m.lds[j - 1];
+#pragma unroll
+      for(int e = 0; e < 32; ++e) lo[e] = AT(Lj, ldd, rl, min(e, nj - 1));
+#pragma unroll
+      for(int e = 0; e < 32; ++e) so[e] = AT(Sj, ldsg, rl, min(e, lj - 1));
+      dgo = AT(Lj, ldd, rl, rl);
+      rho = (lane < nj) ? Mc[m.off[j] + lane] : 0.0;
+    };
+    if(i0 + 1 < D.nblk) fetch(i0 + 1, lv, sv, dg, rhs);
+    for(int i = i0 + 1; i < D.nblk; ++i)
+    {
+      double lvn[32], svn[32], dgn = 1.0, rhsn = 0.0;
+      if(i + 1 < D.nblk) fetch(i + 1, lvn, svn, dgn, rhsn);
+      const int ni = m.ni[i], li = m.ni[i - 1];
+      double acc = rhs;
+#pragma unroll
+      for(int k = 0; k < 32; ++k)
+        if(k < li) // (uniform)
+        {
+          const double t = FMA(-sv[k], bcast_lane_s(xp, k), acc);
+          acc = (lane < ni) ? t : acc;
+        }
+      acc = wave_fwd_pre<32>(lv, dg, m.mL[i], m.ldd[i], ni, acc, lane);
+      if(lane < ni) Mc[m.off[i] + lane] = acc;
+      xp = acc;
+#pragma unroll
+      for(int e = 0; e < 32; ++e)
+      {
+        lv[e] = lvn[e];
+        sv[e] = svn[e];
+      }
+      dg = dgn;
+      rhs = rhsn;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void tri_ltsolve_pre_kernel(const BlockDesc D, double * M, int ldm, int nrhs, int end_in)
+{
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x, pb = blockIdx.x;
+  const TriMeta m = tri_meta(sm, D, pb, lane, 64);
+  wave_sync();
+  __threadfence_block();
+  double * Mp = M + (size_t)pb * D.mstride;
+  const int ntot = D.ntot;
+  const int end = (end_in < 0) ? ntot : end_in;
+  for(int c = 0; c < nrhs; ++c)
+  {
+    double * Mc = Mp + (size_t)c * ldm;
+    // the last block the window reaches: solved on its rows in front of `end`
+    int i0 = D.nblk - 1;
+    while(i0 >= 0 && m.off[i0] >= end) --i0;
+    if(i0 < 0) continue;
+    double xp;
+    {
+      const int n0 = m.off[i0], ni = m.ni[i0], ldd = m.ldd[i0];
+      const int r = end - n0 < ni ? end - n0 : ni;
+      double xa = (lane < r) ? Mc[n0 + lane] : 0.0, xb = 0.0;
+      wave_bwd2(m.mL[i0], ldd, r, xa, xb, lane);
+      if(lane < r) Mc[n0 + lane] = xa;
+      __threadfence_block();
+      wave_sync();
+      xp = (lane < ni) ? Mc[n0 + lane] : 0.0; // (rows from `end` on: whatever zero the caller stored)
+    }
+    // operands of block j: lane = row r of the block; lv[e] = L_j(max(n_j - 1 - e, 0), r), sv[e] = S_j(max(n_{j+1} - 1 - e, 0), r)
+    double lv[32], sv[32], dg = 1.0, rhs = 0.0;
+    auto fetch = [&](int j, double (&lo)[32], double (&so)[32], double & dgo, double & rho) {
+      const int nj = m.ni[j], lj = m.ni[j + 1], rl = min(lane, nj - 1);
+      const double * Lj = m.mL[j];
+      const double * Sj = m.mS[j];
+      const int ldd = m.ldd[j], ldsg = m.lds[j];
+#pragma unroll
+      for(int e = 0; e < 32; ++e) lo[e] = AT(Lj, ldd, max(nj - 1 - e, 0), rl);
+#pragma unroll
+      for(int e = 0; e < 32; ++e) so[e] = AT(Sj, ldsg, max(lj - 1 - e, 0), rl);
+      dgo = AT(Lj, ldd, rl, rl);
+      rho = (lane < nj) ? Mc[m.off[j] + lane] : 0.0;
+    };
+    if(i0 > 0) fetch(i0 - 1, lv, sv, dg, rhs);
+    for(int i = i0 - 1; i >= 0; --i)
+    {
+      double lvn[32], svn[32], dgn = 1.0, rhsn = 0.0;
+      if(i > 0) fetch(i - 1, lvn, svn, dgn, rhsn);
+      const int ni = m.ni[i], li = m.ni[i + 1];
+      double acc = rhs;
+#pragma unroll
+      for(int e = 0; e < 32; ++e)
+        if(e < li) // (uniform): the term of k = li - 1 - e
+        {
+          const double t = FMA(-sv[e], bcast_lane_s(xp, max(li - 1 - e, 0)), acc);
+          acc = (lane < ni) ? t : acc;
+        }
+      acc = wave_bwd_pre<32>(lv, dg, m.mL[i], m.ldd[i], ni, acc, lane);
+      if(lane < ni) Mc[m.off[i] + lane] = acc;
+      xp = acc;
+#pragma unroll
+      for(int e = 0; e < 32; ++e)
+      {
+        lv[e] = lvn[e];
+        sv[e] = svn[e];
+      }
+      dg = dgn;
+      rhs = rhsn;
+    }
+  }
+}
+
 } // namespace
 
 hipError_t launch_block_arrow_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t st)
@@ -1978,6 +2214,18 @@ hipError_t launch_tri_llt(const BlockDesc & d, int nprob, int maxb, hipStream_t 
 hipError_t launch_tri_solve(const BlockDesc & d, int nprob, bool transpose, double * M, int ldm, int nrhs, int start_or_end,
                             hipStream_t st)
 {
+  int maxb = 0;
+  for(int k = 0; k < d.nblk; ++k) maxb = d.h_bs[k] > maxb ? d.h_bs[k] : maxb;
+  static const bool plain = std::getenv("JRLQP_TRI_SOLVE_PLAIN") != nullptr; // (diagnostic: the kernels without the one-block-ahead requests)
+  if(maxb <= 32 && d.nblk <= 2048 && !plain)
+  {
+    const size_t lds = (size_t)d.nblk * (2 * sizeof(double *) + 4 * sizeof(int));
+    if(!transpose)
+      hipLaunchKernelGGL(tri_lsolve_pre_kernel, dim3(nprob), dim3(64), lds, st, d, M, ldm, nrhs, start_or_end);
+    else
+      hipLaunchKernelGGL(tri_ltsolve_pre_kernel, dim3(nprob), dim3(64), lds, st, d, M, ldm, nrhs, start_or_end);
+    return hipGetLastError();
+  }
   if(!transpose)
     hipLaunchKernelGGL(tri_lsolve_kernel, dim3(nprob), dim3(64), 0, st, d, M, ldm, nrhs, start_or_end);
   else
