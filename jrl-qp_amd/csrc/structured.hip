@@ -718,6 +718,24 @@ __global__ __launch_bounds__(64) void arrow_lsolve_blocks_kernel(const BlockDesc
   const int ldd = D.ldd[id];
   const double * Lsub = Dg + s + (size_t)s * ldd; // bottomRightCorner(ni - s, ni - s)
   double * Mp = M + (size_t)pb * D.mstride;
+  if(ni - s <= 32)
+  {
+    // (round 5) the lane's row of L, its diagonal entry and its right-hand side entry requested together, the substitution on registers:
+    // one memory round trip instead of one per group of steps
+    const int nr = ni - s, rl = min(lane, max(nr - 1, 0));
+    double lv[32];
+#pragma unroll
+    for(int e = 0; e < 32; ++e) lv[e] = (nr > 0) ? AT(Lsub, ldd, rl, min(e, nr - 1)) : 0.0;
+    const double dg = (nr > 0) ? AT(Lsub, ldd, rl, rl) : 1.0;
+    for(int c = 0; c < nrhs; ++c)
+    {
+      double * Mi = Mp + n0 + s + (size_t)c * ldm;
+      double xa = (lane < nr) ? Mi[lane] : 0.0;
+      xa = wave_fwd_pre<32>(lv, dg, Lsub, ldd, nr, xa, lane);
+      if(lane < nr) Mi[lane] = xa;
+    }
+    return;
+  }
   for(int c = 0; c < nrhs; ++c)
   {
     double * Mi = Mp + n0 + s + (size_t)c * ldm;
@@ -898,6 +916,44 @@ __global__ __launch_bounds__(64) void arrow_ltsolve_blocks_kernel(const BlockDes
   const double * Sg = D.side[(size_t)pb * (D.nblk - 1) + i];
   const int ldsg = D.lds[i];
   double * Mp = M + (size_t)pb * D.mstride;
+  if(ni <= 32 && nbk <= 32 && end >= n0 + ni)
+  {
+    // (round 5, blocks and head of at most 32 rows, the whole block inside the window) the lane's column of L_i and of B_i, the diagonal
+    // entry, the head's solution and the right-hand side entry requested together; the chain and the substitution on registers
+    const int rl = min(lane, ni - 1);
+    double lv[32], bv[32];
+#pragma unroll
+    for(int e = 0; e < 32; ++e) lv[e] = AT(Li, ldd, max(ni - 1 - e, 0), rl);
+#pragma unroll
+    for(int e = 0; e < 32; ++e)
+    {
+      const int k = max(nbk - 1 - e, 0);
+      bv[e] = D.up ? AT(Sg, ldsg, rl, k) : AT(Sg, ldsg, k, rl);
+    }
+    const double dg = AT(Li, ldd, rl, rl);
+    for(int c = 0; c < nrhs; ++c)
+    {
+      double * Mi = Mp + n0 + (size_t)c * ldm;
+      const double * Xb = Mp + (ntot - nbk) + (size_t)c * ldm;
+      double xv[32];
+#pragma unroll
+      for(int e = 0; e < 32; ++e) xv[e] = Xb[max(nbk - 1 - e, 0)];
+      double acc = (lane < ni) ? Mi[lane] : 0.0;
+      if(!zero)
+      {
+#pragma unroll
+        for(int e = 0; e < 32; ++e)
+          if(e < nbk) // (uniform)
+          {
+            const double t = FMA(-bv[e], xv[e], acc);
+            acc = (lane < ni) ? t : acc;
+          }
+      }
+      acc = wave_bwd_pre<32>(lv, dg, Li, ldd, ni, acc, lane);
+      if(lane < ni) Mi[lane] = acc;
+    }
+    return;
+  }
   for(int c = 0; c < nrhs; ++c)
   {
     double * Mi = Mp + n0 + (size_t)c * ldm;
